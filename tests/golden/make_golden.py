@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).
+The reference is imported with stub modules for the packages this image lacks
+(cv2, h5py, torchvision, scipy.misc -- SURVEY App. B); none of its source is
+copied.  Inputs and weights come from seg2eye_amd.synthetic (pure integer-hash
+functions), so a fixture stores only: the state-dict manifest (names + shapes),
+the small inputs, and the reference's outputs.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import argparse
+import os
+import sys
+import types
+
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    cv2 = mod('cv2', INTER_NEAREST=0, INTER_LINEAR=1, INTER_CUBIC=2, FONT_HERSHEY_SIMPLEX=0)
+    cv2.cv2 = cv2
+    mod('h5py')
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+    tv = mod('torchvision')
+    tv.transforms = mod('torchvision.transforms', Normalize=_Dummy, Lambda=_Dummy, Compose=_Dummy,
+                        ToTensor=_Dummy, Resize=_Dummy)
+    tv.utils = mod('torchvision.utils', make_grid=lambda *a, **k: None)
+    import scipy
+    scipy.misc = mod('scipy.misc')
+
+
+def ref_opt(**kw):
+    from seg2eye_amd.options import default_opt
+    kw.setdefault('gpu_ids', [])
+    opt = default_opt(**kw)
+    delattr(opt, 'compute_dtype')
+    return opt
+
+
+def load_filled(net, seed=0):
+    from seg2eye_amd.synthetic import fill_state_dict
+    sd = net.state_dict()
+    manifest = [(k, tuple(v.shape)) for k, v in sd.items()]
+    filled = fill_state_dict(manifest, seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    return manifest
+
+
+def manifest_arrays(prefix, manifest):
+    return {prefix + '_names': np.array([m[0] for m in manifest]),
+            prefix + '_shapes': np.array([list(m[1]) + [0] * (4 - len(m[1])) for m in manifest], np.int64),
+            prefix + '_ndims': np.array([len(m[1]) for m in manifest], np.int64)}
+
+
+def checksum(t):
+    t = t.detach().double().flatten()
+    idx = torch.linspace(0, t.numel() - 1, 16).long()
+    return np.concatenate([[t.sum().item(), t.abs().sum().item()], t[idx].numpy()])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=HERE)
+    ap.add_argument('--full', action='store_true', help='also the ngf=64 256x256 N=8 pin (slow)')
+    args = ap.parse_args()
+    install_stubs()
+    sys.path.insert(0, REF)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    from models.networks.generator import SPADESTYLEGenerator
+    from models.networks.discriminator import MultiscaleDiscriminator
+    from models.networks.encoder import ConvEncoder
+    from models.networks.normalization import SPADE, ApplyStyle, SPADE_STYLE_Block
+    from models.networks.architecture import SPADE_STYLE_ResnetBlock
+    from models.networks.loss import GANLoss
+    from seg2eye_amd import synthetic as syn
+
+    def onehot(label):
+        lab = torch.from_numpy(label.astype(np.int64))
+        return torch.zeros(lab.shape[0], 4, *lab.shape[2:]).scatter_(1, lab, 1.0)
+
+    # ---- G1/G2: generator, ngf=8 (64x64) and ngf=16 (128x128 portrait-ish 128x64) -------
+    for tag, ngf, crop, ar, n in (('g_ngf8_64', 8, 64, 1.0, 2), ('g_ngf16_128x64', 16, 64, 0.5, 2)):
+        opt = ref_opt(ngf=ngf, crop_size=crop, aspect_ratio=ar)
+        netG = SPADESTYLEGenerator(opt)
+        man = load_filled(netG)
+        H, W = netG.sh * 32, netG.sw * 32
+        label = syn.ellipse_labels(n, H, W, seed=7)
+        w = syn.hash_normal('latent_w', (n, opt.w_dim), seed=7)
+        seg = onehot(label)
+        netG.eval()
+        with torch.no_grad():
+            y_eval = netG(seg, torch.from_numpy(w))
+        # gradients of a scalar loss in eval mode (pins backward through every block);
+        # taken BEFORE the train-mode forward, which mutates weight_u / weight_v
+        netG.zero_grad()
+        wt = torch.from_numpy(w).requires_grad_(True)
+        yg = netG(seg, wt)
+        proj = torch.from_numpy(syn.hash_uniform('g_proj', tuple(yg.shape), seed=7))
+        (yg * proj).sum().backward()
+        grads = {('grad_' + k): checksum(p.grad) for k, p in netG.named_parameters()}
+        netG.train()
+        with torch.no_grad():
+            y_train = netG(seg, torch.from_numpy(w))
+        sd_after = netG.state_dict()
+        uv = {('uv_' + k): v.numpy().copy() for k, v in sd_after.items() if k.endswith(('weight_u', 'weight_v'))}
+        np.savez_compressed(os.path.join(args.out, tag + '.npz'), label=label, w=w,
+                            y_eval=y_eval.numpy(), y_train=y_train.numpy(), grad_w=wt.grad.numpy(),
+                            hw=np.array([H, W, netG.sh, netG.sw]), **manifest_arrays('G', man), **uv, **grads)
+        print(tag, 'y std', float(y_eval.std()), 'train-eval maxdiff', float((y_eval - y_train).abs().max()))
+
+    # ---- G3: per-module ------------------------------------------------------------------
+    opt = ref_opt(ngf=8, crop_size=64)
+    n, C, h = 2, 16, 16
+    label = syn.ellipse_labels(n, 64, 64, seed=11)
+    seg = onehot(label)
+    x = torch.from_numpy(syn.hash_normal('mod_x', (n, C, h, h), seed=11))
+    w = torch.from_numpy(syn.hash_normal('mod_w', (n, 16), seed=11))
+    out = {'label': label, 'x': x.numpy(), 'w': w.numpy()}
+    for name, ctor in (('spade', lambda: SPADE('spadeinstance3x3', C, 4)),
+                       ('adain', lambda: ApplyStyle(16, C, False)),
+                       ('ssb', lambda: SPADE_STYLE_Block(C, opt)),
+                       ('res_same', lambda: SPADE_STYLE_ResnetBlock(C, C, opt)),
+                       ('res_diff', lambda: SPADE_STYLE_ResnetBlock(C, C // 2, opt))):
+        m = ctor()
+        man = load_filled(m)
+        m.eval()
+        xi = x.clone().requires_grad_(True)
+        wi = w.clone().requires_grad_(True)
+        if name == 'spade':
+            y = m(xi, seg)
+        elif name == 'adain':
+            y = m(xi, wi)
+        else:
+            y = m(xi, seg, wi)
+        proj = torch.from_numpy(syn.hash_uniform('proj_' + name, tuple(y.shape), seed=11))
+        (y * proj).sum().backward()
+        out.update(manifest_arrays(name, man))
+        out[name + '_y'] = y.detach().numpy()
+        out[name + '_dx'] = xi.grad.numpy()
+        if wi.grad is not None:
+            out[name + '_dw'] = wi.grad.numpy()
+        for k, p in m.named_parameters():
+            out['%s_grad_%s' % (name, k)] = checksum(p.grad)
+    np.savez_compressed(os.path.join(args.out, 'modules.npz'), **out)
+    print('modules ok')
+
+    # ---- D1 + L1: discriminator + losses --------------------------------------------------
+    opt = ref_opt(ndf=8, crop_size=32)
+    netD = MultiscaleDiscriminator(opt)
+    man = load_filled(netD)
+    n2, H = 4, 32
+    label = syn.ellipse_labels(n2 // 2, H, H, seed=13)
+    seg = onehot(label)
+    fake = torch.from_numpy(syn.smooth_images('d_fake', (n2 // 2, 1, H, H), seed=13))
+    real = torch.from_numpy(syn.smooth_images('d_real', (n2 // 2, 1, H, H), seed=13))
+    fake_r = fake.clone().requires_grad_(True)
+    xin = torch.cat([torch.cat([seg, fake_r], 1), torch.cat([seg, real], 1)], 0)
+    netD.eval()
+    pred = netD(xin)
+    crit = GANLoss('hinge', tensor=torch.FloatTensor, opt=opt)
+    pf = [[t[:t.size(0) // 2] for t in p] for p in pred]
+    pr = [[t[t.size(0) // 2:] for t in p] for p in pred]
+    l_g = crit(pf, True, for_discriminator=False)
+    l_df = crit(pf, False, for_discriminator=True)
+    l_dr = crit(pr, True, for_discriminator=True)
+    feat = torch.zeros(1)
+    for i in range(2):
+        for j in range(len(pf[i]) - 1):
+            feat = feat + torch.nn.L1Loss()(pf[i][j], pr[i][j].detach()) * 10.0 / 2
+    (l_g + feat).sum().backward(retain_graph=True)
+    g_fake = fake_r.grad.clone()
+    g_params_G = {('gradG_' + k): checksum(p.grad) for k, p in netD.named_parameters()}
+    netD.zero_grad()
+    (l_df + l_dr).sum().backward()
+    g_params_D = {('gradD_' + k): checksum(p.grad) for k, p in netD.named_parameters()}
+    netD.train()
+    with torch.no_grad():
+        pred_t = netD(xin.detach())
+    uv = {('uv_' + k): v.numpy() for k, v in netD.state_dict().items() if k.endswith(('weight_u', 'weight_v'))}
+    dd = {'label': label, 'fake': fake.numpy(), 'real': real.numpy(),
+          'l_g': l_g.detach().numpy(), 'l_df': l_df.detach().numpy(), 'l_dr': l_dr.detach().numpy(),
+          'l_feat': feat.detach().numpy(), 'grad_fake': g_fake.numpy()}
+    for i in range(2):
+        for j in range(5):
+            dd['pred_%d_%d' % (i, j)] = pred[i][j].detach().numpy() if j in (0, 4) or i == 1 else checksum(pred[i][j])
+            dd['predtrain_%d_%d' % (i, j)] = pred_t[i][j].numpy() if j == 4 else checksum(pred_t[i][j])
+    np.savez_compressed(os.path.join(args.out, 'd_ndf8_32.npz'), **dd, **manifest_arrays('D', man),
+                        **uv, **g_params_G, **g_params_D)
+    print('D ok', [float(x) for x in (l_g, l_df, l_dr, feat)])
+
+    # ---- E1: encoder ----------------------------------------------------------------------
+    opt = ref_opt(ngf=8, crop_size=256)
+    netE = ConvEncoder(opt)
+    man = load_filled(netE)
+    xs = syn.smooth_images('e_style', (3, 1, 64, 96), seed=17)       # exercises the bilinear resize
+    netE.eval()
+    with torch.no_grad():
+        mu, logvar, feats = netE(torch.from_numpy(xs))
+    np.savez_compressed(os.path.join(args.out, 'e_ngf8.npz'), x=xs, mu=mu.numpy(), logvar=logvar.numpy(),
+                        feat_last=feats[-1].numpy(), feat0_ck=checksum(feats[0]), **manifest_arrays('E', man))
+    print('E ok')
+
+    # ---- M1 + T1: full model / trainer, crop 256, ngf=ndf=8, N=2 -----------------------------
+    class FloatAdam(torch.optim.Adam):           # betas=(0, 0.9) mixes int and float
+        def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), **kw):
+            super().__init__(params, lr=lr, betas=(float(betas[0]), float(betas[1])), **kw)
+    torch.optim.Adam = FloatAdam
+    from trainers.pix2pix_trainer import Pix2PixTrainer
+    opt = ref_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, init_type='normal')
+    opt.checkpoints_dir = '/tmp/s2e_golden_ckpt'
+    trainer = Pix2PixTrainer(opt)
+    model = trainer.pix2pix_model
+    mG, mD, mE = load_filled(model.netG), load_filled(model.netD), load_filled(model.netE)
+    batch = syn.make_batch(2, 256, 256, seed=21)
+
+    def tdata():
+        return {'label': torch.from_numpy(batch['label'].astype(np.int64)),
+                'style_image': torch.from_numpy(batch['style_image']),
+                'target': torch.from_numpy(batch['target']), 'filename': batch['filename']}
+    rec = {}
+    for it in range(2):
+        trainer.run_generator_one_step(tdata())
+        for k, v in trainer.g_losses.items():
+            rec['it%d_%s' % (it, k.replace('/', '_'))] = v.detach().numpy()
+        if it == 0:
+            rec['it0_fake_sub'] = trainer.generated.detach()[:, :, ::8, ::8].numpy()
+        trainer.run_discriminator_one_step(tdata())
+        for k, v in trainer.d_losses.items():
+            rec['it%d_%s' % (it, k.replace('/', '_'))] = v.detach().numpy()
+        for tag, net in (('G', model.netG), ('D', model.netD), ('E', model.netE)):
+            for k, v in net.state_dict().items():
+                rec['it%d_ck_%s.%s' % (it, tag, k)] = checksum(v)
+    np.savez_compressed(os.path.join(args.out, 'trainer_ngf8_256.npz'), **rec,
+                        **manifest_arrays('G', mG), **manifest_arrays('D', mD), **manifest_arrays('E', mE))
+    print('trainer ok', {k: float(v) for k, v in rec.items() if k.startswith('it') and v.size == 1})
+
+    # ---- full-size pin (config 2): ngf=64, 256^2, N=8, eval-mode G --------------------------
+    if args.full:
+        opt = ref_opt(ngf=64, crop_size=256, aspect_ratio=1.0)
+        netG = SPADESTYLEGenerator(opt)
+        man = load_filled(netG)
+        label = syn.ellipse_labels(8, 256, 256, seed=1234)
+        w = syn.hash_normal('latent_w', (8, 16), seed=1234)
+        netG.eval()
+        with torch.no_grad():
+            y = netG(onehot(label), torch.from_numpy(w))
+        np.savez_compressed(os.path.join(args.out, 'g_ngf64_256_pin.npz'),
+                            y_sub=y[:, :, ::8, ::8].numpy().astype(np.float32),
+                            stats=np.array([y.mean().item(), y.std().item(), y.norm().item()]),
+                            **manifest_arrays('G', man))
+        print('full pin ok: mean/std', y.mean().item(), y.std().item())
+
+
+if __name__ == '__main__':
+    main()

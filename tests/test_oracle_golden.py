@@ -1,0 +1,149 @@
+"""The CPU oracle against the golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, filled_state, assert_checksum_close
+from oracle import seg2eye_oracle as O
+from seg2eye_amd import synthetic as syn
+from seg2eye_amd.options import default_opt
+
+TOL = 2e-5      # fp32 CPU vs fp32 CPU, different op grouping only
+
+
+def _onehot(label):
+    return O.one_hot_labels(torch.from_numpy(label.astype(np.int64)), 4)
+
+
+@pytest.mark.parametrize('tag', ['g_ngf8_64', 'g_ngf16_128x64'])
+def test_generator_eval_train_and_grads(tag):
+    z = load_golden(tag)
+    sd = filled_state(z, 'G')
+    H, W, sh, sw = [int(v) for v in z['hw']]
+    seg, w = _onehot(z['label']), torch.from_numpy(z['w'])
+    with torch.no_grad():
+        y = O.generator_forward(sd, seg, w, sh, sw, training=False)
+    np.testing.assert_allclose(y.numpy(), z['y_eval'], atol=TOL, rtol=0)
+    upd = {}
+    with torch.no_grad():
+        yt = O.generator_forward(sd, seg, w, sh, sw, training=True, updates=upd)
+    np.testing.assert_allclose(yt.numpy(), z['y_train'], atol=TOL, rtol=0)
+    uv_keys = [k[3:] for k in z.files if k.startswith('uv_')]
+    assert sorted(uv_keys) == sorted(upd)
+    for k in uv_keys:
+        np.testing.assert_allclose(upd[k].numpy(), z['uv_' + k], atol=1e-6, rtol=0)
+    # backward, eval mode
+    leaf = {k: (v.clone().requires_grad_(True) if O.OracleModel.is_param(k) else v) for k, v in sd.items()}
+    wt = w.clone().requires_grad_(True)
+    yg = O.generator_forward(leaf, seg, wt, sh, sw, training=False)
+    proj = torch.from_numpy(syn.hash_uniform('g_proj', tuple(yg.shape), seed=7))
+    (yg * proj).sum().backward()
+    np.testing.assert_allclose(wt.grad.numpy(), z['grad_w'], atol=2e-4 * np.abs(z['grad_w']).max(), rtol=0)
+    for k, p in leaf.items():
+        if O.OracleModel.is_param(k):
+            assert_checksum_close(p.grad, z['grad_' + k], 2e-4, k)
+
+
+def test_modules():
+    z = load_golden('modules')
+    seg = _onehot(z['label'])
+    x0, w0 = torch.from_numpy(z['x']), torch.from_numpy(z['w'])
+    fns = {
+        'spade': lambda sd, x, w: O.spade(sd, '', x, seg) if False else O.spade({('.' + k): v for k, v in sd.items()}, '', x, seg),
+        'adain': lambda sd, x, w: O.apply_style({('p.' + k): v for k, v in sd.items()}, 'p', x, w),
+        'ssb': lambda sd, x, w: O.spade_style_block({('p.' + k): v for k, v in sd.items()}, 'p', x, seg, w),
+        'res_same': lambda sd, x, w: O.spade_style_resblk({('p.' + k): v for k, v in sd.items()}, 'p', x, seg, w, False, None),
+        'res_diff': lambda sd, x, w: O.spade_style_resblk({('p.' + k): v for k, v in sd.items()}, 'p', x, seg, w, False, None),
+    }
+    for name, fn in fns.items():
+        sd = filled_state(z, name)
+        leaf = {k: (v.clone().requires_grad_(True) if O.OracleModel.is_param(k) else v) for k, v in sd.items()}
+        x = x0.clone().requires_grad_(True)
+        w = w0.clone().requires_grad_(True)
+        y = fn(leaf, x, w)
+        np.testing.assert_allclose(y.detach().numpy(), z[name + '_y'], atol=TOL, rtol=0, err_msg=name)
+        proj = torch.from_numpy(syn.hash_uniform('proj_' + name, tuple(y.shape), seed=11))
+        (y * proj).sum().backward()
+        np.testing.assert_allclose(x.grad.numpy(), z[name + '_dx'], atol=5e-5, rtol=0, err_msg=name)
+        if name + '_dw' in z.files:
+            np.testing.assert_allclose(w.grad.numpy(), z[name + '_dw'], atol=2e-4 * np.abs(z[name + '_dw']).max(), rtol=0)
+        for k, p in leaf.items():
+            if O.OracleModel.is_param(k):
+                assert_checksum_close(p.grad, z['%s_grad_%s' % (name, k)], 2e-4, name + ':' + k)
+
+
+def test_discriminator_and_losses():
+    z = load_golden('d_ndf8_32')
+    sd = filled_state(z, 'D')
+    leaf = {k: (v.clone().requires_grad_(True) if O.OracleModel.is_param(k) else v) for k, v in sd.items()}
+    seg = _onehot(z['label'])
+    fake = torch.from_numpy(z['fake']).requires_grad_(True)
+    real = torch.from_numpy(z['real'])
+    xin = torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, real], 1)], 0)
+    pred = O.discriminator_forward(leaf, xin, training=False)
+    for i in range(2):
+        for j in range(5):
+            ref = z['pred_%d_%d' % (i, j)]
+            if ref.ndim == 1 and ref.shape[0] == 18:
+                assert_checksum_close(pred[i][j], ref, 1e-5, 'pred%d%d' % (i, j))
+            else:
+                np.testing.assert_allclose(pred[i][j].detach().numpy(), ref, atol=TOL, rtol=0)
+    pf, pr = O.divide_pred(pred)
+    l_g = O.gan_loss(pf, True, for_discriminator=False)
+    l_df = O.gan_loss(pf, False, True)
+    l_dr = O.gan_loss(pr, True, True)
+    feat = O.feature_matching_loss(pf, pr, 10.0)
+    for got, key in ((l_g, 'l_g'), (l_df, 'l_df'), (l_dr, 'l_dr'), (feat, 'l_feat')):
+        assert got.shape == (1,)
+        np.testing.assert_allclose(got.detach().numpy(), z[key], atol=1e-5, rtol=1e-5)
+    params = [(k, p) for k, p in leaf.items() if O.OracleModel.is_param(k)]
+    grads = torch.autograd.grad((l_g + feat).sum(), [fake] + [p for _, p in params], retain_graph=True)
+    np.testing.assert_allclose(grads[0].numpy(), z['grad_fake'], atol=2e-4 * np.abs(z['grad_fake']).max(), rtol=0)
+    for (k, _), g in zip(params, grads[1:]):
+        assert_checksum_close(g, z['gradG_' + k], 2e-4, k)
+    grads = torch.autograd.grad((l_df + l_dr).sum(), [p for _, p in params])
+    for (k, _), g in zip(params, grads):
+        assert_checksum_close(g, z['gradD_' + k], 2e-4, k)
+    # train mode: one power iteration, post-forward u, v
+    upd = {}
+    with torch.no_grad():
+        pt = O.discriminator_forward(sd, xin.detach(), training=True, updates=upd)
+    for i in range(2):
+        np.testing.assert_allclose(pt[i][4].numpy(), z['predtrain_%d_4' % i], atol=TOL, rtol=0)
+    for k in upd:
+        np.testing.assert_allclose(upd[k].numpy(), z['uv_' + k], atol=1e-6, rtol=0)
+
+
+def test_encoder():
+    z = load_golden('e_ngf8')
+    sd = filled_state(z, 'E')
+    with torch.no_grad():
+        mu, logvar, feats = O.encoder_forward(sd, torch.from_numpy(z['x']), training=False)
+    np.testing.assert_allclose(mu.numpy(), z['mu'], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(logvar.numpy(), z['logvar'], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(feats[-1].numpy(), z['feat_last'], atol=5e-5, rtol=0)
+    assert_checksum_close(feats[0], z['feat0_ck'], 1e-5)
+
+
+def test_trainer_two_iterations():
+    """T1: Pix2PixTrainer G-step, D-step, G-step, D-step (TTUR Adam, double
+    power iteration, G regeneration in the D step)."""
+    z = load_golden('trainer_ngf8_256')
+    opt = default_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2)
+    m = O.OracleModel(filled_state(z, 'G'), filled_state(z, 'D'), filled_state(z, 'E'), opt, 8, 8)
+    b = syn.make_batch(2, 256, 256, seed=21)
+    data = {'label': torch.from_numpy(b['label'].astype(np.int64)),
+            'style_image': torch.from_numpy(b['style_image']), 'target': torch.from_numpy(b['target'])}
+    for it in range(2):
+        gl, fake = m.run_generator_one_step(data)
+        dl = m.run_discriminator_one_step(data)
+        for k, v in list(gl.items()) + list(dl.items()):
+            ref = z['it%d_%s' % (it, k.replace('/', '_'))]
+            np.testing.assert_allclose(v.numpy(), ref, rtol=2e-4, atol=2e-5, err_msg='it%d %s' % (it, k))
+        if it == 0:
+            np.testing.assert_allclose(fake[:, :, ::8, ::8].numpy(), z['it0_fake_sub'], atol=1e-4, rtol=0)
+        for tag, sd in (('G', m.G), ('D', m.D), ('E', m.E)):
+            for k, v in sd.items():
+                assert_checksum_close(v, z['it%d_ck_%s.%s' % (it, tag, k)], 1e-4 if it == 0 else 5e-4,
+                                      'it%d %s.%s' % (it, tag, k))
