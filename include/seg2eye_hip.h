@@ -1,0 +1,156 @@
+/* seg2eye_hip.h -- C ABI of libseg2eye_hip.so (gfx950 / MI355X kernels for the Seg2Eye
+ * G+D train-step hot path).
+ *
+ * The reference (mcbuehler/Seg2Eye) has NO native code and no FFI: every op on
+ * the path is a stock torch call.  Each entry point below therefore replaces a *group of torch
+ * calls* in the reference, cited as file:line under /root/reference.  The host-side mirror of the
+ * reference's plugin boundary (models.networks.define_G/define_D, Pix2PixModel, Pix2PixTrainer)
+ * lives in seg2eye_amd/ and binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and ints; no torch / C++ types.  All pointers are DEVICE pointers
+ *    owned by the caller.  The library never allocates or frees device memory, never synchronises,
+ *    launches only on the given stream (a hipStream_t passed as void*), uses the current device.
+ *  - Every function returns S2E_OK (0) or a negative S2E_ERR_*; s2e_last_error() gives the
+ *    thread-local message.  Re-entrant; no mutable globals.
+ *  - dtype: S2E_F32 or S2E_BF16 = storage type of activations / packed weights and the MFMA input
+ *    type; accumulation, statistics, losses and weight gradients are always fp32 (or fp64 where
+ *    noted).
+ *  - Activations are NHWC contiguous: element (n, y, x, c) at ((n*H + y)*W + x)*C + c.  That is the
+ *    storage of a torch channels_last tensor of logical shape (N, C, H, W).
+ *  - Label maps are uint8 (N, H, W), values < 4.
+ */
+#ifndef SEG2EYE_HIP_H
+#define SEG2EYE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2E_OK 0
+#define S2E_ERR_ARG (-1)
+#define S2E_ERR_LAUNCH (-2)
+#define S2E_ERR_UNSUPPORTED (-3)
+
+enum { S2E_F32 = 0, S2E_BF16 = 1 };
+enum { S2E_ACT_NONE = 0, S2E_ACT_LRELU = 1, S2E_ACT_TANH = 2 };          /* LeakyReLU slope 0.2 */
+enum { S2E_AUX_NONE = 0, S2E_AUX_RELU_MASK = 1, S2E_AUX_LRELU_GRAD = 2 }; /* y *= (aux>0 ? 1 : 0 | 0.2) */
+enum { S2E_NORM_SPADE_STYLE = 0, S2E_NORM_PLAIN_IN = 1 };
+enum { S2E_LOSS_NEG_MEAN = 0, S2E_LOSS_HINGE_REAL = 1, S2E_LOSS_HINGE_FAKE = 2, S2E_LOSS_L1 = 3 };
+
+int s2e_version(void);
+const char* s2e_last_error(void);
+
+/* ------------------------------------------------------------------ convolution (implicit GEMM, MFMA)
+ * Replaces nn.Conv2d forward / backward at: models/networks/generator.py:30,48 (fc, conv_img),
+ * architecture.py:24-27 (conv_0, conv_1, conv_s), normalization.py:85-89 (mlp_gamma, mlp_beta),
+ * discriminator.py:84-96 (4x4 convs), encoder.py:23-28,37-39 (3x3 s2 convs).
+ *
+ * x is (N, Hi, Wi, Cin), y is (N, Ho, Wo, Cout); both NHWC.
+ * transposed = 0:  y[n,oy,ox,co] = sum_{ky,kx,ci} x[n, oy*stride-pad+ky, ox*stride-pad+kx, ci] * W[co][ky][kx][ci]
+ * transposed = 1 (data gradient of a conv with this stride/pad; x plays grad_out, y plays grad_in):
+ *                  y[n,oy,ox,co] = sum x[n, (oy+pad-ky)/stride, (ox+pad-kx)/stride, ci] * W[co][ky][kx][ci]
+ *                  over taps where the division is exact and in range.
+ * W is the packed matrix written by s2e_pack_conv_weight: row co, column (ky*KW+kx)*Cin + ci.
+ * Prologue:  in_act  applied to x as it is loaded (S2E_ACT_NONE | S2E_ACT_LRELU).
+ * Epilogue:  v = acc + bias[co] (bias may be NULL) + residual[n,oy,ox,co] (may be NULL);
+ *            v = out_act(v);  v *= aux-derived mask (aux has y's shape; may be NULL).
+ * stride in {1,2}.  Any Cin / Cout; the 16-byte vector path needs Cin % (16/sizeof(T)) == 0. */
+typedef struct {
+    int N, Hi, Wi, Cin;
+    int Ho, Wo, Cout;
+    int KH, KW, stride, pad;
+    int transposed;
+    int in_act, out_act, aux_mode;
+} s2e_conv_desc;
+
+int s2e_conv_cout_pad(int cout);                 /* rows of a packed weight matrix    */
+int s2e_conv_k_pad(int dtype, int k);            /* columns of a packed weight matrix */
+/* w_oihw: fp32 (cout, cin, kh, kw) contiguous (torch layout).  cin_pad >= cin: channels
+ * cin..cin_pad-1 of the activation are structural zeros (e.g. the 5->8 padded D input).
+ * transposed = 0: packed[co][(ky*kw+kx)*cin_pad + ci]           (cout_pad(cout) x k_pad(kh*kw*cin_pad))
+ * transposed = 1: packed[ci][(ky*kw+kx)*cout + co]              (cout_pad(cin_pad) x k_pad(kh*kw*cout)) */
+int s2e_pack_conv_weight(int dtype, const float* w_oihw, void* packed, int cout, int cin, int kh, int kw,
+                         int cin_pad, int transposed, void* stream);
+int s2e_conv2d(int dtype, const void* x, const void* w_packed, const float* bias, const void* residual,
+               const void* aux, void* y, const s2e_conv_desc* d, void* stream);
+/* Weight gradient of the forward conv described by d (d->transposed must be 0):
+ * dw[co][(ky*KW+kx)*Cin + ci] += sum_{n,oy,ox} gy[n,oy,ox,co] * in_act(x)[n, oy*s-p+ky, ox*s-p+kx, ci]
+ * dw: fp32 (Cout x KH*KW*Cin), row-major, ACCUMULATED into (caller zeroes it); split over pixels
+ * with fp32 atomics. */
+int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, const s2e_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ InstanceNorm statistics
+ * nn.InstanceNorm2d(affine=False) statistics, normalization.py:73 / :41 (biased variance, eps 1e-5).
+ * x (N, HW, C) -> stats (N, C, 2) fp32 = {mean, rstd}.  ws: N*C*2 doubles of scratch (zeroed here). */
+int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, void* stream);
+
+/* ------------------------------------------------------------------ SPADE+Style modulation / IN+LeakyReLU
+ * mode S2E_NORM_SPADE_STYLE (SPADE_STYLE_Block.forward normalization.py:184-192 + SPADE.forward :91-105
+ * + ApplyStyle.forward :163-169, optionally followed by architecture.py:61 LeakyReLU):
+ *     out = 0.5*( (x-mean)*rstd*(1+gamma) + beta + x*(1+s0) + s1 ),  gamma = gb[..., :C], beta = gb[..., C:]
+ *     style (N, 2C) fp32 = {s0 | s1} (already through FC + LeakyReLU, normalization.py:135-141)
+ * mode S2E_NORM_PLAIN_IN (InstanceNorm2d + LeakyReLU of discriminator.py:91-94, encoder.py IN):
+ *     out = (x-mean)*rstd            (gb, style unused; may be NULL)
+ * lrelu != 0 applies LeakyReLU(0.2) to out. */
+int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* gb, const float* stats, const float* style,
+                     void* out, int N, int HW, int C, int lrelu, void* stream);
+/* Backward of the above given g = dL/dout.  Writes dx (N,HW,C), dgb (N,HW,2C) and ACCUMULATES
+ * dstyle (N,2C) fp32 (SPADE_STYLE mode only; dgb/dstyle may be NULL in PLAIN_IN mode).
+ * ws: N*C*4 doubles of scratch (zeroed here). */
+int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
+                     const float* style, void* dx, void* dgb, float* dstyle, double* ws,
+                     int N, int HW, int C, int lrelu, void* stream);
+/* out[c] += sum_m g[m][c]  (conv bias gradient).  g (M, C); out fp32 (C). */
+int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream);
+
+/* ------------------------------------------------------------------ label-map ops
+ * conv3x3(pad 1) of the nearest-downsampled ONE-HOT label map, without materialising the one-hot:
+ * out[n,y,x,co] = bias[co] + sum_{ky,kx in bounds} table[(ky*3+kx)*ncls + label_h[n,y+ky-1,x+kx-1]][co]
+ * with label_h[y][x] = label[y*(H/h)][x*(W/w)] (F.interpolate 'nearest', integer ratio), then ReLU
+ * if relu != 0.  Replaces SPADE.mlp_shared (normalization.py:85-88,97-98) and the generator's
+ * fc conv on the downsampled segmap (generator.py:72-73).  table: fp32 (9*ncls, Cout). */
+int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* table, const float* bias, void* out,
+                      int N, int H, int W, int h, int w, int ncls, int Cout, int relu, void* stream);
+/* out (N,h,w,cpad): channels [0,ncls) one-hot of the nearest-downsampled label, channel ncls =
+ * img[n,y,x] when img != NULL (img is (N,h,w) of T), remaining channels 0.  Builds the
+ * discriminator input cat([seg, image]) (pix2pix_model.py:328-336) and the one-hot operand for
+ * the mlp_shared / fc weight gradients. */
+int s2e_onehot_nhwc(int dtype, const uint8_t* label, const void* img, void* out,
+                    int N, int H, int W, int h, int w, int ncls, int cpad, void* stream);
+/* nn.Upsample(scale_factor=2) nearest (generator.py:50): (N,h,w,C) -> (N,2h,2w,C); bwd sums 2x2. */
+int s2e_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h, int w, int C, void* stream);
+int s2e_upsample2x_bwd(int dtype, const void* gy, void* gx, int N, int h, int w, int C, void* stream);
+/* F.avg_pool2d(k=3, s=2, p=1, count_include_pad=False) (discriminator.py:46-49), NHWC.
+ * Ho = (H+1)/2, Wo = (W+1)/2 (floor((H+2-3)/2)+1). */
+int s2e_avgpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+int s2e_avgpool3x3s2_bwd(int dtype, const void* gy, void* gx, int N, int H, int W, int C, void* stream);
+/* gx = gy * (1 - y*y)   (backward of torch.tanh, generator.py:100). */
+int s2e_tanh_bwd(int dtype, const void* gy, const void* y, void* gx, long n, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * Scalar reductions of GANLoss hinge (loss.py:66-77) and the GAN feature-matching L1
+ * (pix2pix_model.py:231-241).  out[0] += scale * sum_i f(a_i, b_i):
+ *   NEG_MEAN: -a      HINGE_REAL: -min(a-1,0)      HINGE_FAKE: -min(-a-1,0)      L1: |a-b|
+ * (pass scale = coefficient / n for a mean).  b is only read for L1. */
+int s2e_loss_reduce(int dtype, int mode, const void* a, const void* b, long n, float scale, float* out, void* stream);
+/* da_i (=|+=) scale * upstream * d f(a_i,b_i)/d a_i ; upstream = *gscale (a DEVICE fp32 scalar, the
+ * gradient of the total loss w.r.t. this term; NULL means 1) so no host sync is needed;
+ * accumulate != 0 adds into da. */
+int s2e_loss_grad(int dtype, int mode, const void* a, const void* b, long n, float scale, const float* gscale,
+                  void* da, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * torch.optim.Adam step (pix2pix_model.py:92-110: TTUR betas (0, 0.9), eps 1e-8, no weight decay)
+ * over one flat fp32 arena: m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+ * p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), bc1 = 1-b1^t, bc2 = 1-b2^t.
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                  float eps, float bc1, float bc2, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEG2EYE_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libseg2eye_hip.so (include/seg2eye_hip.h).
+
+The library is the product path: if it is missing this module raises on import
+of any op -- there is NO CPU or stock-torch fallback for the ops it exports.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libseg2eye_hip.so')
+
+S2E_F32, S2E_BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD = 0, 1, 2
+NORM_SPADE_STYLE, NORM_PLAIN_IN = 0, 1
+LOSS_NEG_MEAN, LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_L1 = 0, 1, 2, 3
+
+
+class ConvDesc(C.Structure):
+    """s2e_conv_desc"""
+    _fields_ = [(n, C.c_int) for n in (
+        'N', 'Hi', 'Wi', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride', 'pad',
+        'transposed', 'in_act', 'out_act', 'aux_mode')]
+
+
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+# name -> argtypes; every entry returns int except the two noted below.  Must list EVERY symbol
+# declared in include/seg2eye_hip.h (tests/test_abi.py checks header <-> table <-> .so).
+SIGNATURES = {
+    's2e_version': [],
+    's2e_last_error': [],
+    's2e_conv_cout_pad': [_i],
+    's2e_conv_k_pad': [_i, _i],
+    's2e_pack_conv_weight': [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    's2e_conv2d': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp],
+    's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp],
+    's2e_in_stats': [_i, _vp, _i, _i, _i, _f, _vp, _vp, _vp],
+    's2e_modulate_fwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    's2e_modulate_bwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    's2e_colsum': [_i, _vp, _l, _i, _vp, _vp],
+    's2e_label_conv3x3': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    's2e_onehot_nhwc': [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    's2e_upsample2x_fwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
+    's2e_upsample2x_bwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
+    's2e_avgpool3x3s2_fwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
+    's2e_avgpool3x3s2_bwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
+    's2e_tanh_bwd': [_i, _vp, _vp, _vp, _l, _vp],
+    's2e_loss_reduce': [_i, _i, _vp, _vp, _l, _f, _vp, _vp],
+    's2e_loss_grad': [_i, _i, _vp, _vp, _l, _f, _vp, _vp, _i, _vp],
+    's2e_adam_flat': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _f, _vp],
+}
+
+_lib = None
+
+
+class Seg2EyeHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the CDLL.  Raises if the extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Seg2EyeHipError(
+                'libseg2eye_hip.so not found at %s -- build it with `python -m seg2eye_amd.build` '
+                '(or __graft_entry__.build()).  There is no fallback path.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_char_p if name == 's2e_last_error' else C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().s2e_last_error()
+        raise Seg2EyeHipError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))

@@ -1,0 +1,83 @@
+// Shared device/host helpers for the Seg2Eye gfx950 kernels.
+// gfx950 (CDNA4) only: 64-wide wavefronts, MFMA, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <type_traits>
+#include "../../include/seg2eye_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;   // native 16-B vector (HIP's uint4 struct copies lower to memcpy and defeat SROA)
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// ---------------------------------------------------------------- error reporting (host)
+void s2e_set_error(const char* fmt, ...);
+#define S2E_FAIL(code, ...) do { s2e_set_error(__VA_ARGS__); return (code); } while (0)
+#define S2E_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) S2E_FAIL(S2E_ERR_LAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------- 16-byte vector <-> float lanes
+template <typename T> struct Vec;
+template <> struct Vec<float>  { static constexpr int N = 4; };
+template <> struct Vec<bf16_t> { static constexpr int N = 8; };
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b16) { return __builtin_bit_cast(float, b16 << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    bf16_t h = (bf16_t)f;                                   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& r, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& r, float* f) {
+    f[0] = __builtin_bit_cast(float, r.x); f[1] = __builtin_bit_cast(float, r.y);
+    f[2] = __builtin_bit_cast(float, r.z); f[3] = __builtin_bit_cast(float, r.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& r, float* f) {
+    f[0] = bf16_bits_to_f32(r.x & 0xffffu); f[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+    f[2] = bf16_bits_to_f32(r.y & 0xffffu); f[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    f[4] = bf16_bits_to_f32(r.z & 0xffffu); f[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
+    f[6] = bf16_bits_to_f32(r.w & 0xffffu); f[7] = __builtin_bit_cast(float, r.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ u32x4_t pack16(const float* f);
+template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* f) {
+    return u32x4_t{__builtin_bit_cast(uint32_t, f[0]), __builtin_bit_cast(uint32_t, f[1]),
+                   __builtin_bit_cast(uint32_t, f[2]), __builtin_bit_cast(uint32_t, f[3])};
+}
+template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
+    return u32x4_t{f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16),
+                   f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16),
+                   f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16),
+                   f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16)};
+}
+template <typename T> __device__ __forceinline__ float load1(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void store1(T* p, float v) { *p = (T)v; }
+
+__device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * v; }
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware bijective remap of a 1-D grid: blocks that share (bid % 8) sit on one XCD
+// (observed round-robin placement; speed only, never correctness) and get a contiguous
+// range of logical tile ids, so neighbouring tiles reuse operand panels in that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N) -- indices stay constants, so small
+// per-thread arrays are always register-allocated (never scratch / LDS-promoted)
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,385 @@
+// Implicit-GEMM convolution for gfx950: forward conv and data-gradient (transposed gather) in one
+// kernel, NHWC activations, MFMA 32x32 tiles, fp32 accumulate.
+//
+//   GEMM view:  C[m][co] = sum_k A[m][k] * B[co][k]
+//     m  = output pixel (n, oy, ox)            M = N*Ho*Wo
+//     k  = (tap, ci) = (ky*KW + kx)*Cin + ci   K = KH*KW*Cin   (im2col gathered on the fly, never stored)
+//     B  = packed weights, row co, K contiguous (s2e_pack_conv_weight)
+//
+//   Workgroup = 256 threads = 4 waves (one per SIMD), tile BM=128 pixels x BN in {128,64,32} channels,
+//   K-step = one 128-byte row per tile row (64 bf16 / 32 f32).  Register-staged double buffering:
+//   global loads of K-tile t+1 are issued before the MFMAs of tile t and written to the other LDS
+//   buffer after them; one barrier per K-tile.  LDS rows are 128 B with the 16-B chunk index XORed by
+//   (row>>1)&7 so ds_read_b128 of 32 consecutive rows at one logical chunk is conflict-free.
+//   Epilogue: accumulators -> LDS (fp32 [BM][BN]) -> coalesced 16-B row stores with bias / residual /
+//   activation / mask fused.
+//
+//   HBM layout: activations NHWC so a tap's Cin run is contiguous (one 16-B load = 8 bf16 channels);
+//   the 1-D grid is remapped so tiles sharing an A panel (same pixel rows) run on one XCD's L2.
+#include "common.h"
+
+struct ConvKParams {
+    const void* x; const void* w; const float* bias; const void* res; const void* aux; void* y;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout;
+    int KH, KW, stride, pad, transposed;
+    int in_act, out_act, aux_mode;
+    int Ktot, Kpad, M, tiles_n;
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mfma<float> {
+    // lane half h holds 4 consecutive k; MFMA t pairs element t of half 0 with element t of half 1.
+    // A and B use the same (permuted) k order, so the contraction is exact.
+    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ u32x4_t apply_lrelu16(u32x4_t r) {
+    float f[Vec<T>::N];
+    unpack16<T>(r, f);
+#pragma unroll
+    for (int j = 0; j < Vec<T>::N; ++j) f[j] = lrelu02(f[j]);
+    return pack16<T>(f);
+}
+
+// VECPATH: Cin is a multiple of the 16-B vector width, so every im2col chunk is one aligned 16-B load.
+// The any-Cin element-wise gather (tiny-K layers only: Cin = 1 or 5) is a separate instantiation so
+// its index arithmetic never bloats the hot kernel.
+template <typename T, int BN, bool VECPATH>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p) {
+    constexpr int BM = 128;
+    constexpr int VEC = Vec<T>::N;
+    constexpr int BK = 8 * VEC;
+    constexpr int WN = (BN >= 64) ? 2 : 1;
+    constexpr int WM = 4 / WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NB = BN / 32;                       // B vectors per thread per K-tile
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    static_assert(2 * STAGE >= BM * BN * 4, "epilogue staging must fit");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
+
+    const T* __restrict__ xg = (const T*)p.x;
+    const T* __restrict__ wgt = (const T*)p.w;
+    const int c = tid & 7, r0 = tid >> 3;
+    const int swz_st = (c ^ ((r0 >> 1) & 7)) << 4;     // (r0+32i)>>1 & 7 == (r0>>1)&7
+
+    int by[4], bx[4], nb[4];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = tm * BM + r0 + 32 * i;
+        if (m < p.M) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            by[i] = p.transposed ? oy + p.pad : oy * p.stride - p.pad;
+            bx[i] = p.transposed ? ox + p.pad : ox * p.stride - p.pad;
+            nb[i] = n * p.Hi * p.Wi;
+        } else {
+            by[i] = -(1 << 24); bx[i] = -(1 << 24); nb[i] = 0;   // every tap out of range
+        }
+    }
+
+    // source pixel of tap (ky,kx) for row i; returns false when the tap reads padding
+    auto src_pixel = [&](int i, int ky, int kx, int& pix) __attribute__((always_inline)) -> bool {
+        int iy, ix; bool v;
+        if (!p.transposed) {
+            iy = by[i] + ky; ix = bx[i] + kx;
+            v = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        } else {
+            const int ty = by[i] - ky, tx = bx[i] - kx;
+            v = (ty | tx) >= 0;
+            if (p.stride == 2) { v = v && (((ty | tx) & 1) == 0); iy = ty >> 1; ix = tx >> 1; }
+            else { iy = ty; ix = tx; }
+            v = v && iy < p.Hi && ix < p.Wi;
+        }
+        pix = nb[i] + iy * p.Wi + ix;
+        return v;
+    };
+
+    // loader state of the vector path: (ky, kx, ci) of this thread's 16-B chunk in the NEXT K-tile,
+    // advanced incrementally (no per-tile integer division)
+    int l_ky, l_kx, l_ci;
+    {
+        const int k0 = c * VEC, tap = k0 / p.Cin;
+        l_ci = k0 - tap * p.Cin; l_ky = tap / p.KW; l_kx = tap - l_ky * p.KW;
+    }
+    u32x4_t ra[4], rb[NB];
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+        const int k0 = kt * BK + c * VEC;
+        if constexpr (VECPATH) {
+            const bool kvalid = l_ky < p.KH;             // <=> k0 < Ktot
+            static_for<0, 4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                int pix;
+                const bool v = src_pixel(i, l_ky, l_kx, pix) && kvalid;
+                ra[i] = u32x4_t{0, 0, 0, 0};
+                if (v) ra[i] = *(const u32x4_t*)(xg + (size_t)pix * p.Cin + l_ci);
+            });
+            l_ci += BK;
+            while (l_ci >= p.Cin) { l_ci -= p.Cin; if (++l_kx == p.KW) { l_kx = 0; ++l_ky; } }
+        } else {                                         // any-Cin fallback: element-wise gather
+            static_for<0, 4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                float f[VEC];
+                static_for<0, VEC>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    const int k = k0 + j;
+                    f[j] = 0.f;
+                    if (k < p.Ktot) {
+                        const int tap = k / p.Cin, ci = k - tap * p.Cin;
+                        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                        int pix;
+                        if (src_pixel(i, ky, kx, pix)) f[j] = load1<T>(xg + (size_t)pix * p.Cin + ci);
+                    }
+                });
+                ra[i] = pack16<T>(f);
+            });
+        }
+        if (p.in_act == S2E_ACT_LRELU)
+            static_for<0, 4>([&](auto I) { ra[decltype(I)::value] = apply_lrelu16<T>(ra[decltype(I)::value]); });
+        static_for<0, NB>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            rb[j] = *(const u32x4_t*)(wgt + (size_t)(tn * BN + r0 + 32 * j) * p.Kpad + kt * BK + c * VEC);
+        });
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        char* base = smem + buf * STAGE;
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            *(u32x4_t*)(base + (r0 + 32 * i) * 128 + swz_st) = ra[i];
+        });
+        static_for<0, NB>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            *(u32x4_t*)(base + A_BYTES + (r0 + 32 * j) * 128 + swz_st) = rb[j];
+        });
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int h = lane >> 5, l31 = lane & 31;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const char* As = smem + buf * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int chunk = 2 * s + h;
+            u32x4_t a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int row = wm * WTM + mi * 32 + l31;
+                a[mi] = *(const u32x4_t*)(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int row = wn * WTN + ni * 32 + l31;
+                b[ni] = *(const u32x4_t*)(Bs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) Mfma<T>::run(a[mi], b[ni], acc[mi][ni]);
+        }
+    };
+
+    const int nk = p.Kpad / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < nk; ++kt) {           // steady state: prefetch kt+1 around the MFMAs of kt
+        const int cur = kt & 1;
+        load_tile(kt + 1);
+        compute(cur);
+        store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+    __syncthreads();
+
+    // ---- epilogue: acc -> LDS fp32 [BM][BN] -> coalesced rows
+    float* Cs = (float*)smem;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = wn * WTN + ni * 32 + l31;
+                Cs[row * BN + col] = acc[mi][ni][r];
+            }
+    __syncthreads();
+
+    constexpr int TPR = BN / VEC;                      // threads per output row
+    constexpr int RPP = 256 / TPR;                     // rows per pass
+    T* __restrict__ yg = (T*)p.y;
+    const T* __restrict__ resg = (const T*)p.res;
+    const T* __restrict__ auxg = (const T*)p.aux;
+    const int cw = (tid % TPR) * VEC;
+    const int co = tn * BN + cw;
+    const bool cvec = (p.Cout % VEC) == 0;
+    for (int row = tid / TPR; row < BM; row += RPP) {
+        const int m = tm * BM + row;
+        if (m >= p.M || co >= p.Cout) continue;
+        float v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+            const f32x4_t t = *(const f32x4_t*)(Cs + row * BN + cw + j);
+            v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
+        }
+        const size_t o = (size_t)m * p.Cout + co;
+        if (cvec) {
+            if (p.bias) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] += p.bias[co + j];
+            }
+            if (resg) {
+                float rr[VEC];
+                unpack16<T>(*(const u32x4_t*)(resg + o), rr);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] += rr[j];
+            }
+            if (p.out_act == S2E_ACT_LRELU) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] = lrelu02(v[j]);
+            } else if (p.out_act == S2E_ACT_TANH) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] = tanhf(v[j]);
+            }
+            if (p.aux_mode != S2E_AUX_NONE) {
+                float aa[VEC];
+                unpack16<T>(*(const u32x4_t*)(auxg + o), aa);
+                const float neg = (p.aux_mode == S2E_AUX_RELU_MASK) ? 0.f : 0.2f;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] *= (aa[j] > 0.f ? 1.f : neg);
+            }
+            *(u32x4_t*)(yg + o) = pack16<T>(v);
+        } else {
+            for (int j = 0; j < VEC && co + j < p.Cout; ++j) {
+                float t = v[j];
+                if (p.bias) t += p.bias[co + j];
+                if (resg) t += load1<T>(resg + o + j);
+                if (p.out_act == S2E_ACT_LRELU) t = lrelu02(t);
+                else if (p.out_act == S2E_ACT_TANH) t = tanhf(t);
+                if (p.aux_mode != S2E_AUX_NONE) {
+                    const float neg = (p.aux_mode == S2E_AUX_RELU_MASK) ? 0.f : 0.2f;
+                    t *= (load1<T>(auxg + o + j) > 0.f ? 1.f : neg);
+                }
+                store1<T>(yg + o + j, t);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int kh, int kw,
+                                   int cin_pad, int transposed, int rows, int kpad) {
+    const long total = (long)rows * kpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / kpad), k = (int)(i - (long)row * kpad);
+        float v = 0.f;
+        if (!transposed) {
+            const int tap = k / cin_pad, ci = k - tap * cin_pad;
+            if (row < cout && tap < kh * kw && ci < cin) {
+                const int ky = tap / kw, kx = tap - ky * kw;
+                v = w[(((size_t)row * cin + ci) * kh + ky) * kw + kx];
+            }
+        } else {
+            const int tap = k / cout, co = k - tap * cout;
+            if (row < cin && tap < kh * kw) {
+                const int ky = tap / kw, kx = tap - ky * kw;
+                v = w[(((size_t)co * cin + row) * kh + ky) * kw + kx];
+            }
+        }
+        out[i] = (T)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+static int bn_for(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
+
+extern "C" int s2e_conv_cout_pad(int cout) { const int bn = bn_for(cout); return ceil_div(cout, bn) * bn; }
+extern "C" int s2e_conv_k_pad(int dtype, int k) { const int bk = dtype == S2E_BF16 ? 64 : 32; return ceil_div(k, bk) * bk; }
+
+extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, int cout, int cin, int kh, int kw,
+                                    int cin_pad, int transposed, void* stream) {
+    if (!w || !packed || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || cin_pad < cin)
+        S2E_FAIL(S2E_ERR_ARG, "s2e_pack_conv_weight: bad argument");
+    const int rows = s2e_conv_cout_pad(transposed ? cin_pad : cout);
+    const int kpad = s2e_conv_k_pad(dtype, kh * kw * (transposed ? cout : cin_pad));
+    const long total = (long)rows * kpad;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16)
+        pack_weight_kernel<bf16_t><<<grid, 256, 0, st>>>(w, (bf16_t*)packed, cout, cin, kh, kw, cin_pad, transposed, rows, kpad);
+    else if (dtype == S2E_F32)
+        pack_weight_kernel<float><<<grid, 256, 0, st>>>(w, (float*)packed, cout, cin, kh, kw, cin_pad, transposed, rows, kpad);
+    else S2E_FAIL(S2E_ERR_ARG, "s2e_pack_conv_weight: bad dtype %d", dtype);
+    S2E_CHECK_LAUNCH("pack_weight_kernel");
+    return S2E_OK;
+}
+
+template <typename T, int BN>
+static int launch_conv(const ConvKParams& p, hipStream_t st) {
+    const int tiles_m = ceil_div(p.M, 128);
+    if (p.Cin % Vec<T>::N == 0) conv_igemm_kernel<T, BN, true><<<tiles_m * p.tiles_n, 256, 0, st>>>(p);
+    else conv_igemm_kernel<T, BN, false><<<tiles_m * p.tiles_n, 256, 0, st>>>(p);
+    S2E_CHECK_LAUNCH("conv_igemm_kernel");
+    return S2E_OK;
+}
+
+extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* bias, const void* res,
+                          const void* aux, void* y, const s2e_conv_desc* d, void* stream) {
+    if (!x || !w || !y || !d) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: null pointer");
+    if (d->stride != 1 && d->stride != 2) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d: stride %d", d->stride);
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hi <= 0 || d->Wi <= 0)
+        S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: bad shape");
+    if (d->aux_mode != S2E_AUX_NONE && !aux) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: aux_mode without aux");
+    if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31))
+        S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d: tensor too large for 32-bit pixel indices");
+    ConvKParams p;
+    p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
+    p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.transposed = d->transposed;
+    p.in_act = d->in_act; p.out_act = d->out_act; p.aux_mode = d->aux_mode;
+    p.Ktot = d->KH * d->KW * d->Cin;
+    p.Kpad = s2e_conv_k_pad(dtype, p.Ktot);
+    p.M = d->N * d->Ho * d->Wo;
+    const int bn = bn_for(d->Cout);
+    p.tiles_n = ceil_div(d->Cout, bn);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) {
+        if (bn == 128) return launch_conv<bf16_t, 128>(p, st);
+        if (bn == 64) return launch_conv<bf16_t, 64>(p, st);
+        return launch_conv<bf16_t, 32>(p, st);
+    } else if (dtype == S2E_F32) {
+        if (bn == 128) return launch_conv<float, 128>(p, st);
+        if (bn == 64) return launch_conv<float, 64>(p, st);
+        return launch_conv<float, 32>(p, st);
+    }
+    S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: bad dtype %d", dtype);
+}

@@ -1,0 +1,252 @@
+// Convolution weight gradient for gfx950 (NHWC, MFMA 32x32, fp32 accumulate + fp32 atomics).
+//
+//   dW[co][k] += sum_m gy[m][co] * xcol[m][k]      k = (ky*KW+kx)*Cin + ci,  m = (n,oy,ox)
+//
+// The reduction index m is the SLOW dimension of both operands in HBM (NHWC), while an MFMA lane
+// needs consecutive reduction elements.  Tiles are therefore staged in LDS in their natural
+// [pixel][channel] order (coalesced 16-B loads) and
+//   bf16: fragments are fetched with ds_read_b64_tr_b16, the hardware 4x16 transpose read
+//         (rows padded to 320 B so the four rows of one block fall in disjoint bank quarters);
+//   f32 : the 32x32x2 MFMA takes ONE f32 per lane (row = lane&31, k = lane>>5), so a plain
+//         ds_read_b32 of [pixel][channel] is already the right shape, conflict-free.
+// One workgroup owns a 128(co) x 128(k) tile of dW and a contiguous slice of the pixels
+// (split-K over workgroups to fill 256 CUs); partial tiles are combined with fp32 atomics in
+// 128-B row segments (the shape global float atomics run at full rate for).
+#include "common.h"
+
+struct WgradParams {
+    const void* x; const void* gy; float* dw;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout;
+    int KH, KW, stride, pad, in_act;
+    int Ktot, M, tiles_k, tiles_co, m_per_split;
+};
+
+template <typename T> struct WgLds;
+template <> struct WgLds<bf16_t> { static constexpr int ROW = 320; };   // 128 bf16 = 256 B + 64 B pad
+template <> struct WgLds<float>  { static constexpr int ROW = 512; };   // 128 f32
+
+__device__ __forceinline__ u32x2_t lds_tr16_b64(const char* p) {
+    s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p);
+    return __builtin_bit_cast(u32x2_t, v);
+}
+
+// VECPATH: Cin and Cout are multiples of the 16-B vector width (every real layer except the 1- and
+// 5-channel heads); the element-wise gather lives in its own instantiation.
+template <typename T, bool VECPATH>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int VEC = Vec<T>::N;
+    constexpr int BR = 32;                               // pixels per chunk
+    constexpr int ROW = WgLds<T>::ROW;
+    constexpr int OP_BYTES = BR * ROW;                   // one operand tile
+    constexpr int STAGE = 2 * OP_BYTES;
+    constexpr int CPR = 128 / VEC;                       // 16-B chunks per row
+    constexpr int RPT = 256 / CPR;                       // rows per pass
+    constexpr int NI = BR / RPT;                         // vectors per thread per operand
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;             // 2x2 waves, each 64(co) x 64(k)
+    int bid = blockIdx.x;
+    const int tk = bid % p.tiles_k; bid /= p.tiles_k;
+    const int tco = bid % p.tiles_co; const int split = bid / p.tiles_co;
+    const int m_begin = split * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+    if (m_begin >= m_end) return;
+
+    const T* __restrict__ xg = (const T*)p.x;
+    const T* __restrict__ gg = (const T*)p.gy;
+    const int c = tid % CPR, rb = tid / CPR;
+    const int co0 = tco * 128 + c * VEC;                 // gy column of this thread's chunk
+    const int k0 = tk * 128 + c * VEC;                   // xcol column of this thread's chunk
+    const int HoWo = p.Ho * p.Wo;
+    // this thread's fixed tap (vector path)
+    int t_ci, t_ky, t_kx;
+    { const int tap = k0 / p.Cin; t_ci = k0 - tap * p.Cin; t_ky = tap / p.KW; t_kx = tap - t_ky * p.KW; }
+    const bool k_valid = k0 < p.Ktot;
+
+    // per-row pixel coordinates, advanced by BR each chunk
+    int rn[NI], roy[NI], rox[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int m = m_begin + rb + RPT * i;
+        rn[i] = m / HoWo; const int rem = m - rn[i] * HoWo;
+        roy[i] = rem / p.Wo; rox[i] = rem - roy[i] * p.Wo;
+    }
+
+    u32x4_t rg[NI], rx[NI];
+    auto load_chunk = [&](int ch) __attribute__((always_inline)) {
+        static_for<0, NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int m = m_begin + ch * BR + rb + RPT * i;
+            const bool mv = m < m_end;
+            // ---- gy
+            rg[i] = u32x4_t{0, 0, 0, 0};
+            if constexpr (VECPATH) {
+                if (mv && co0 < p.Cout) rg[i] = *(const u32x4_t*)(gg + (size_t)m * p.Cout + co0);
+            } else {
+                float f[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    f[j] = (mv && co0 + j < p.Cout) ? load1<T>(gg + (size_t)m * p.Cout + co0 + j) : 0.f;
+                rg[i] = pack16<T>(f);
+            }
+            // ---- xcol
+            rx[i] = u32x4_t{0, 0, 0, 0};
+            const int iy0 = roy[i] * p.stride - p.pad, ix0 = rox[i] * p.stride - p.pad;
+            if constexpr (VECPATH) {
+                const int iy = iy0 + t_ky, ix = ix0 + t_kx;
+                if (mv && k_valid && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                    rx[i] = *(const u32x4_t*)(xg + ((size_t)(rn[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + t_ci);
+            } else {
+                float f[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    f[j] = 0.f;
+                    const int k = k0 + j;
+                    if (mv && k < p.Ktot) {
+                        const int tap = k / p.Cin, ci = k - tap * p.Cin;
+                        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                        const int iy = iy0 + ky, ix = ix0 + kx;
+                        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                            f[j] = load1<T>(xg + ((size_t)(rn[i] * p.Hi + iy) * p.Wi + ix) * p.Cin + ci);
+                    }
+                }
+                rx[i] = pack16<T>(f);
+            }
+            if (p.in_act == S2E_ACT_LRELU) {
+                float f[VEC];
+                unpack16<T>(rx[i], f);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) f[j] = lrelu02(f[j]);
+                rx[i] = pack16<T>(f);
+            }
+            // advance this row by BR pixels for the next chunk
+            rox[i] += BR;
+            while (rox[i] >= p.Wo) { rox[i] -= p.Wo; ++roy[i]; }
+            while (roy[i] >= p.Ho) { roy[i] -= p.Ho; ++rn[i]; }
+        });
+    };
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+        char* base = smem + buf * STAGE;
+        static_for<0, NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int r = rb + RPT * i;
+            *(u32x4_t*)(base + r * ROW + c * 16) = rg[i];
+            *(u32x4_t*)(base + OP_BYTES + r * ROW + c * 16) = rx[i];
+        });
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int hh = lane >> 5, l31 = lane & 31;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const char* Gs = smem + buf * STAGE;
+        const char* Xs = Gs + OP_BYTES;
+        if constexpr (sizeof(T) == 2) {
+            const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, g2 = (lane >> 4) & 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int r = 16 * ks + 8 * hh + q;
+                u32x4_t a[2], b[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const char* ptr = Gs + r * ROW + (wm * 64 + mi * 32 + 16 * g2 + 4 * pp) * 2;
+                    const u32x2_t lo = lds_tr16_b64(ptr), hi = lds_tr16_b64(ptr + 4 * ROW);
+                    a[mi] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const char* ptr = Xs + r * ROW + (wn * 64 + ni * 32 + 16 * g2 + 4 * pp) * 2;
+                    const u32x2_t lo = lds_tr16_b64(ptr), hi = lds_tr16_b64(ptr + 4 * ROW);
+                    b[ni] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8_t, a[mi]), __builtin_bit_cast(bf16x8_t, b[ni]), acc[mi][ni], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < BR / 2; ++t) {
+                const int r = 2 * t + hh;
+                float a[2], b[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = *(const float*)(Gs + r * ROW + (wm * 64 + mi * 32 + l31) * 4);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) b[ni] = *(const float*)(Xs + r * ROW + (wn * 64 + ni * 32 + l31) * 4);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nch = (m_end - m_begin + BR - 1) / BR;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int ch = 0; ch + 1 < nch; ++ch) {
+        const int cur = ch & 1;
+        load_chunk(ch + 1);
+        compute(cur);
+        store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+    compute((nch - 1) & 1);
+
+    // ---- combine: lanes 0..31 of a register hold 32 consecutive k of one co row (128 B)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = tco * 128 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int k = tk * 128 + wn * 64 + ni * 32 + l31;
+                if (co < p.Cout && k < p.Ktot) atomicAdd(p.dw + (size_t)co * p.Ktot + k, acc[mi][ni][r]);
+            }
+}
+
+extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, const s2e_conv_desc* d, void* stream) {
+    if (!x || !gy || !dw || !d) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: null pointer");
+    if (d->transposed) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: describe the forward conv (transposed=0)");
+    if (d->stride != 1 && d->stride != 2) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad: stride %d", d->stride);
+    if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31))
+        S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad: tensor too large for 32-bit pixel indices");
+    WgradParams p;
+    p.x = x; p.gy = gy; p.dw = dw;
+    p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.in_act = d->in_act;
+    p.Ktot = d->KH * d->KW * d->Cin;
+    p.M = d->N * d->Ho * d->Wo;
+    p.tiles_k = ceil_div(p.Ktot, 128);
+    p.tiles_co = ceil_div(d->Cout, 128);
+    const int tiles = p.tiles_k * p.tiles_co;
+    // split the pixels so that ~1024 workgroups exist (2 per CU resident x 2 waves of work)
+    int splits = ceil_div(1024, tiles);
+    const int max_splits = ceil_div(p.M, 256);            // at least 8 chunks per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.m_per_split = ceil_div(ceil_div(p.M, splits), 32) * 32;
+    splits = ceil_div(p.M, p.m_per_split);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) {
+        if (d->Cin % 8 == 0 && d->Cout % 8 == 0) conv_wgrad_kernel<bf16_t, true><<<tiles * splits, 256, 0, st>>>(p);
+        else conv_wgrad_kernel<bf16_t, false><<<tiles * splits, 256, 0, st>>>(p);
+    } else if (dtype == S2E_F32) {
+        if (d->Cin % 4 == 0 && d->Cout % 4 == 0) conv_wgrad_kernel<float, true><<<tiles * splits, 256, 0, st>>>(p);
+        else conv_wgrad_kernel<float, false><<<tiles * splits, 256, 0, st>>>(p);
+    } else S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: bad dtype %d", dtype);
+    S2E_CHECK_LAUNCH("conv_wgrad_kernel");
+    return S2E_OK;
+}

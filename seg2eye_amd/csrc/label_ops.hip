@@ -1,0 +1,278 @@
+// Label-map and resampling kernels (all HBM-bound, NHWC, 16-byte channel groups per thread).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------ label conv3x3
+// conv3x3(one_hot(nearest_down(label))) == sum over the 9 taps of one table row selected by the
+// neighbour's class: zero MACs, 9 LDS row reads per 16-B output vector.  The [9*ncls][<=128] slice of
+// the table this block needs sits in LDS (<= 18 KiB for ncls = 4).
+template <typename T>
+__global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __restrict__ label, const float* __restrict__ table,
+        const float* __restrict__ bias, T* __restrict__ out, int N, int H, int W, int h, int w, int ncls, int Cout, int relu) {
+    constexpr int VEC = Vec<T>::N;
+    constexpr int CT = 128;                               // channels per block
+    extern __shared__ __attribute__((aligned(16))) float tab[];   // [9*ncls][CT] then bias[CT]
+    const int cbase = blockIdx.y * CT;
+    const int cw = min(CT, Cout - cbase);
+    const int rows = 9 * ncls;
+    for (int i = threadIdx.x; i < rows * CT; i += blockDim.x) {
+        const int r = i / CT, cc = i - r * CT;
+        tab[i] = cc < cw ? table[(size_t)r * Cout + cbase + cc] : 0.f;
+    }
+    for (int i = threadIdx.x; i < CT; i += blockDim.x) tab[rows * CT + i] = (bias && i < cw) ? bias[cbase + i] : 0.f;
+    __syncthreads();
+
+    const int cgb = (cw + VEC - 1) / VEC;                 // channel groups handled by this block
+    const int ppb = 256 / cgb;                            // pixels per pass
+    const int tx = threadIdx.x % cgb, ty = threadIdx.x / cgb;
+    if (ty >= ppb) return;
+    const int sy = H / h, sx = W / w;
+    const long npix = (long)N * h * w;
+    for (long pix = (long)blockIdx.x * ppb + ty; pix < npix; pix += (long)gridDim.x * ppb) {
+        const int n = (int)(pix / (h * w));
+        const int rem = (int)(pix - (long)n * h * w);
+        const int y = rem / w, x = rem - y * w;
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = tab[rows * CT + tx * VEC + j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            if ((unsigned)yy >= (unsigned)h) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = x + kx - 1;
+                if ((unsigned)xx >= (unsigned)w) continue;
+                const int cls = label[((size_t)n * H + (size_t)yy * sy) * W + (size_t)xx * sx];
+                const float* trow = tab + ((ky * 3 + kx) * ncls + cls) * CT + tx * VEC;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += trow[j];
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = fmaxf(acc[j], 0.f);
+        }
+        T* o = out + (size_t)pix * Cout + cbase + tx * VEC;
+        if ((Cout % VEC) == 0) *(u32x4_t*)o = pack16<T>(acc);
+        else for (int j = 0; j < VEC && cbase + tx * VEC + j < Cout; ++j) store1<T>(o + j, acc[j]);
+    }
+}
+
+extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* table, const float* bias, void* out,
+                                 int N, int H, int W, int h, int w, int ncls, int Cout, int relu, void* stream) {
+    if (!label || !table || !out || N <= 0 || h <= 0 || w <= 0 || Cout <= 0 || ncls <= 0 || ncls > 8)
+        S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3: bad argument");
+    if (H % h || W % w) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_label_conv3x3: %dx%d is not an integer multiple of %dx%d", H, W, h, w);
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3: bad dtype %d", dtype);
+    const long npix = (long)N * h * w;
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    const int cw = Cout < 128 ? Cout : 128;
+    const int ppb = 256 / ((cw + vec - 1) / vec);
+    long gx = (npix + ppb - 1) / ppb;
+    if (gx > 2048) gx = 2048;
+    dim3 grid((unsigned)gx, ceil_div(Cout, 128));
+    const size_t lds = (size_t)(9 * ncls + 1) * 128 * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) label_conv3x3_kernel<bf16_t><<<grid, 256, lds, st>>>(label, table, bias, (bf16_t*)out, N, H, W, h, w, ncls, Cout, relu);
+    else label_conv3x3_kernel<float><<<grid, 256, lds, st>>>(label, table, bias, (float*)out, N, H, W, h, w, ncls, Cout, relu);
+    S2E_CHECK_LAUNCH("label_conv3x3_kernel");
+    return S2E_OK;
+}
+
+// ------------------------------------------------------------------------------------ one-hot (+ image) NHWC
+template <typename T>
+__global__ void onehot_nhwc_kernel(const uint8_t* __restrict__ label, const T* __restrict__ img, T* __restrict__ out,
+                                   int N, int H, int W, int h, int w, int ncls, int cpad) {
+    const int sy = H / h, sx = W / w;
+    const long total = (long)N * h * w * cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cpad;
+        const int c = (int)(i - pix * cpad);
+        float v = 0.f;
+        if (c < ncls) {
+            const int n = (int)(pix / (h * w));
+            const int rem = (int)(pix - (long)n * h * w);
+            const int y = rem / w, x = rem - y * w;
+            v = label[((size_t)n * H + (size_t)y * sy) * W + (size_t)x * sx] == c ? 1.f : 0.f;
+        } else if (c == ncls && img) {
+            v = load1<T>(img + pix);
+        }
+        store1<T>(out + i, v);
+    }
+}
+
+extern "C" int s2e_onehot_nhwc(int dtype, const uint8_t* label, const void* img, void* out,
+                               int N, int H, int W, int h, int w, int ncls, int cpad, void* stream) {
+    if (!label || !out || N <= 0 || h <= 0 || w <= 0 || ncls <= 0 || cpad < ncls + (img ? 1 : 0))
+        S2E_FAIL(S2E_ERR_ARG, "s2e_onehot_nhwc: bad argument");
+    if (H % h || W % w) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_onehot_nhwc: non-integer downsampling ratio");
+    const long total = (long)N * h * w * cpad;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) onehot_nhwc_kernel<bf16_t><<<grid, 256, 0, st>>>(label, (const bf16_t*)img, (bf16_t*)out, N, H, W, h, w, ncls, cpad);
+    else if (dtype == S2E_F32) onehot_nhwc_kernel<float><<<grid, 256, 0, st>>>(label, (const float*)img, (float*)out, N, H, W, h, w, ncls, cpad);
+    else S2E_FAIL(S2E_ERR_ARG, "s2e_onehot_nhwc: bad dtype %d", dtype);
+    S2E_CHECK_LAUNCH("onehot_nhwc_kernel");
+    return S2E_OK;
+}
+
+// ------------------------------------------------------------------------------------ nearest x2 upsample
+template <typename T>
+__global__ void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int h, int w, int cg) {
+    constexpr int VEC = Vec<T>::N;
+    const int H2 = 2 * h, W2 = 2 * w;
+    const long nvec = (long)N * H2 * W2 * cg;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const long pix = v / cg;
+        const int g = (int)(v - pix * cg);
+        const int n = (int)(pix / ((long)H2 * W2));
+        const int rem = (int)(pix - (long)n * H2 * W2);
+        const int oy = rem / W2, ox = rem - oy * W2;
+        const size_t src = (((size_t)n * h + (oy >> 1)) * w + (ox >> 1)) * cg + g;
+        *(u32x4_t*)(y + (size_t)v * VEC) = *(const u32x4_t*)(x + src * VEC);
+    }
+}
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int N, int h, int w, int cg) {
+    constexpr int VEC = Vec<T>::N;
+    const int W2 = 2 * w;
+    const long nvec = (long)N * h * w * cg;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const long pix = v / cg;
+        const int g = (int)(v - pix * cg);
+        const int n = (int)(pix / ((long)h * w));
+        const int rem = (int)(pix - (long)n * h * w);
+        const int y = rem / w, x = rem - y * w;
+        const size_t b = (((size_t)n * 2 * h + 2 * y) * W2 + 2 * x) * cg + g;
+        float a[VEC], t[VEC];
+        unpack16<T>(*(const u32x4_t*)(gy + b * VEC), a);
+        unpack16<T>(*(const u32x4_t*)(gy + (b + cg) * VEC), t);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a[j] += t[j];
+        unpack16<T>(*(const u32x4_t*)(gy + (b + (size_t)W2 * cg) * VEC), t);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a[j] += t[j];
+        unpack16<T>(*(const u32x4_t*)(gy + (b + (size_t)W2 * cg + cg) * VEC), t);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a[j] += t[j];
+        *(u32x4_t*)(gx + (size_t)v * VEC) = pack16<T>(a);
+    }
+}
+
+static int ups_launch(int dtype, const void* a, void* b, int N, int h, int w, int C, void* stream, bool fwd, const char* name) {
+    if (!a || !b || N <= 0 || h <= 0 || w <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "%s: bad argument", name);
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "%s: bad dtype %d", name, dtype);
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "%s: C=%d not a multiple of %d", name, C, vec);
+    const int cg = C / vec;
+    const long nvec = (long)N * h * w * cg * (fwd ? 4 : 1);
+    const int grid = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (fwd) {
+        if (dtype == S2E_BF16) upsample2x_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)a, (bf16_t*)b, N, h, w, cg);
+        else upsample2x_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)a, (float*)b, N, h, w, cg);
+    } else {
+        if (dtype == S2E_BF16) upsample2x_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)a, (bf16_t*)b, N, h, w, cg);
+        else upsample2x_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)a, (float*)b, N, h, w, cg);
+    }
+    S2E_CHECK_LAUNCH(name);
+    return S2E_OK;
+}
+extern "C" int s2e_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h, int w, int C, void* stream) {
+    return ups_launch(dtype, x, y, N, h, w, C, stream, true, "s2e_upsample2x_fwd");
+}
+extern "C" int s2e_upsample2x_bwd(int dtype, const void* gy, void* gx, int N, int h, int w, int C, void* stream) {
+    return ups_launch(dtype, gy, gx, N, h, w, C, stream, false, "s2e_upsample2x_bwd");
+}
+
+// ------------------------------------------------------------------------------------ avg_pool 3x3 s2 p1
+// count_include_pad=False: divide by the number of in-bounds taps.
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)N * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C;
+        const int c = (int)(i - pix * C);
+        const int n = (int)(pix / ((long)Ho * Wo));
+        const int rem = (int)(pix - (long)n * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        float s = 0.f; int cnt = 0;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                s += load1<T>(x + (((size_t)n * H + iy) * W + ix) * C + c);
+                ++cnt;
+            }
+        }
+        store1<T>(y + i, s / (float)cnt);
+    }
+}
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int N, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)N * H * W * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C;
+        const int c = (int)(i - pix * C);
+        const int n = (int)(pix / ((long)H * W));
+        const int rem = (int)(pix - (long)n * H * W);
+        const int iy = rem / W, ix = rem - iy * W;
+        float s = 0.f;
+        // outputs oy with 2*oy-1 <= iy <= 2*oy+1
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy >= Ho) continue;
+            const int cy = min(2 * oy + 1, H - 1) - max(2 * oy - 1, 0) + 1;
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= Wo) continue;
+                const int cx = min(2 * ox + 1, W - 1) - max(2 * ox - 1, 0) + 1;
+                s += load1<T>(gy + (((size_t)n * Ho + oy) * Wo + ox) * C + c) / (float)(cy * cx);
+            }
+        }
+        store1<T>(gx + i, s);
+    }
+}
+static int pool_launch(int dtype, const void* a, void* b, int N, int H, int W, int C, void* stream, bool fwd, const char* name) {
+    if (!a || !b || N <= 0 || H <= 0 || W <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "%s: bad argument", name);
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "%s: bad dtype %d", name, dtype);
+    const long total = fwd ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) * C : (long)N * H * W * C;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (fwd) {
+        if (dtype == S2E_BF16) avgpool_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)a, (bf16_t*)b, N, H, W, C);
+        else avgpool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)a, (float*)b, N, H, W, C);
+    } else {
+        if (dtype == S2E_BF16) avgpool_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)a, (bf16_t*)b, N, H, W, C);
+        else avgpool_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)a, (float*)b, N, H, W, C);
+    }
+    S2E_CHECK_LAUNCH(name);
+    return S2E_OK;
+}
+extern "C" int s2e_avgpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    return pool_launch(dtype, x, y, N, H, W, C, stream, true, "s2e_avgpool3x3s2_fwd");
+}
+extern "C" int s2e_avgpool3x3s2_bwd(int dtype, const void* gy, void* gx, int N, int H, int W, int C, void* stream) {
+    return pool_launch(dtype, gy, gx, N, H, W, C, stream, false, "s2e_avgpool3x3s2_bwd");
+}
+
+// ------------------------------------------------------------------------------------ tanh backward
+template <typename T>
+__global__ void tanh_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gx, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float yy = load1<T>(y + i);
+        store1<T>(gx + i, load1<T>(gy + i) * (1.f - yy * yy));
+    }
+}
+extern "C" int s2e_tanh_bwd(int dtype, const void* gy, const void* y, void* gx, long n, void* stream) {
+    if (!gy || !y || !gx || n <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_tanh_bwd: bad argument");
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) tanh_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)gy, (const bf16_t*)y, (bf16_t*)gx, n);
+    else if (dtype == S2E_F32) tanh_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)gy, (const float*)y, (float*)gx, n);
+    else S2E_FAIL(S2E_ERR_ARG, "s2e_tanh_bwd: bad dtype %d", dtype);
+    S2E_CHECK_LAUNCH("tanh_bwd_kernel");
+    return S2E_OK;
+}

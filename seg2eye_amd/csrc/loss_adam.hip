@@ -1,0 +1,134 @@
+// Loss reductions (hinge GAN, feature-matching L1), their element-wise gradients, the flat-arena
+// Adam step, and the library's error/version entry points.
+#include "common.h"
+#include <stdarg.h>
+
+// ------------------------------------------------------------------------------------ error state
+static thread_local char g_err[512] = "";
+void s2e_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* s2e_last_error(void) { return g_err; }
+extern "C" int s2e_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------ loss reduce
+template <int MODE> __device__ __forceinline__ float loss_term(float a, float b) {
+    if (MODE == S2E_LOSS_NEG_MEAN) return -a;
+    if (MODE == S2E_LOSS_HINGE_REAL) return -fminf(a - 1.f, 0.f);
+    if (MODE == S2E_LOSS_HINGE_FAKE) return -fminf(-a - 1.f, 0.f);
+    return fabsf(a - b);
+}
+template <int MODE> __device__ __forceinline__ float loss_dterm(float a, float b) {
+    if (MODE == S2E_LOSS_NEG_MEAN) return -1.f;
+    if (MODE == S2E_LOSS_HINGE_REAL) return (a - 1.f < 0.f) ? -1.f : 0.f;
+    if (MODE == S2E_LOSS_HINGE_FAKE) return (-a - 1.f < 0.f) ? 1.f : 0.f;
+    const float d = a - b;
+    return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);       // torch l1_loss backward = sign(a-b)
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, long n, float scale,
+                                                          float* __restrict__ out) {
+    constexpr int VEC = Vec<T>::N;
+    __shared__ float red[4];
+    float s = 0.f;
+    // 16-B vector path only when both pointers are 16-B aligned (a fake/real half of an odd-sized map is not)
+    const bool al = ((((uintptr_t)a) | (MODE == S2E_LOSS_L1 ? (uintptr_t)b : 0)) & 15) == 0;
+    const long nv = al ? n / VEC : 0;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+        float fa[VEC], fb[VEC];
+        unpack16<T>(*(const u32x4_t*)(a + v * VEC), fa);
+        if (MODE == S2E_LOSS_L1) unpack16<T>(*(const u32x4_t*)(b + v * VEC), fb);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s += loss_term<MODE>(fa[j], MODE == S2E_LOSS_L1 ? fb[j] : 0.f);
+    }
+    for (long i = nv * VEC + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        s += loss_term<MODE>(load1<T>(a + i), MODE == S2E_LOSS_L1 ? load1<T>(b + i) : 0.f);   // tail / unaligned
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, scale * (red[0] + red[1] + red[2] + red[3]));
+}
+
+template <typename T, int MODE>
+__global__ void loss_grad_kernel(const T* __restrict__ a, const T* __restrict__ b, long n, float scale,
+                                 const float* __restrict__ gscale, T* __restrict__ da, int accumulate) {
+    if (gscale) scale *= *gscale;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float g = scale * loss_dterm<MODE>(load1<T>(a + i), MODE == S2E_LOSS_L1 ? load1<T>(b + i) : 0.f);
+        if (accumulate) g += load1<T>(da + i);
+        store1<T>(da + i, g);
+    }
+}
+
+template <typename T>
+static int loss_dispatch(bool grad, int mode, const T* a, const T* b, long n, float scale, const float* gscale, void* out,
+                         int accumulate, hipStream_t st) {
+    const long work = grad ? n : n / Vec<T>::N + 1;
+    const int grid = (int)((work + 255) / 256 < 1024 ? (work + 255) / 256 : 1024);
+#define S2E_L(MM) do { if (grad) loss_grad_kernel<T, MM><<<grid, 256, 0, st>>>(a, b, n, scale, gscale, (T*)out, accumulate); \
+                       else loss_reduce_kernel<T, MM><<<grid, 256, 0, st>>>(a, b, n, scale, (float*)out); } while (0)
+    switch (mode) {
+        case S2E_LOSS_NEG_MEAN: S2E_L(S2E_LOSS_NEG_MEAN); break;
+        case S2E_LOSS_HINGE_REAL: S2E_L(S2E_LOSS_HINGE_REAL); break;
+        case S2E_LOSS_HINGE_FAKE: S2E_L(S2E_LOSS_HINGE_FAKE); break;
+        case S2E_LOSS_L1: S2E_L(S2E_LOSS_L1); break;
+        default: S2E_FAIL(S2E_ERR_ARG, "loss: bad mode %d", mode);
+    }
+#undef S2E_L
+    S2E_CHECK_LAUNCH("loss kernel");
+    return S2E_OK;
+}
+
+extern "C" int s2e_loss_reduce(int dtype, int mode, const void* a, const void* b, long n, float scale, float* out, void* stream) {
+    if (!a || !out || n <= 0 || (mode == S2E_LOSS_L1 && !b)) S2E_FAIL(S2E_ERR_ARG, "s2e_loss_reduce: bad argument");
+    if (dtype == S2E_BF16) return loss_dispatch<bf16_t>(false, mode, (const bf16_t*)a, (const bf16_t*)b, n, scale, nullptr, out, 0, (hipStream_t)stream);
+    if (dtype == S2E_F32) return loss_dispatch<float>(false, mode, (const float*)a, (const float*)b, n, scale, nullptr, out, 0, (hipStream_t)stream);
+    S2E_FAIL(S2E_ERR_ARG, "s2e_loss_reduce: bad dtype %d", dtype);
+}
+extern "C" int s2e_loss_grad(int dtype, int mode, const void* a, const void* b, long n, float scale, const float* gscale,
+                             void* da, int accumulate, void* stream) {
+    if (!a || !da || n <= 0 || (mode == S2E_LOSS_L1 && !b)) S2E_FAIL(S2E_ERR_ARG, "s2e_loss_grad: bad argument");
+    if (dtype == S2E_BF16) return loss_dispatch<bf16_t>(true, mode, (const bf16_t*)a, (const bf16_t*)b, n, scale, gscale, da, accumulate, (hipStream_t)stream);
+    if (dtype == S2E_F32) return loss_dispatch<float>(true, mode, (const float*)a, (const float*)b, n, scale, gscale, da, accumulate, (hipStream_t)stream);
+    S2E_FAIL(S2E_ERR_ARG, "s2e_loss_grad: bad dtype %d", dtype);
+}
+
+// ------------------------------------------------------------------------------------ Adam over a flat arena
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+        float* __restrict__ v, long n, float lr_bc1, float beta1, float beta2, float eps, float rsqrt_bc2, float grad_scale) {
+    const long nv = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        f32x4_t pp = ((f32x4_t*)p)[i], gg = ((const f32x4_t*)g)[i], mm = ((f32x4_t*)m)[i], vv = ((f32x4_t*)v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = gg[j] * grad_scale;
+            mm[j] = beta1 * mm[j] + (1.f - beta1) * gr;
+            vv[j] = beta2 * vv[j] + (1.f - beta2) * gr * gr;
+            pp[j] -= lr_bc1 * mm[j] / (sqrtf(vv[j]) * rsqrt_bc2 + eps);
+        }
+        ((f32x4_t*)p)[i] = pp; ((f32x4_t*)m)[i] = mm; ((f32x4_t*)v)[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            const float gr = g[i] * grad_scale;
+            const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+            const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+            m[i] = mi; v[i] = vi;
+            p[i] -= lr_bc1 * mi / (sqrtf(vi) * rsqrt_bc2 + eps);
+        }
+}
+
+extern "C" int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                             float eps, float bc1, float bc2, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || bc1 <= 0.f || bc2 <= 0.f) S2E_FAIL(S2E_ERR_ARG, "s2e_adam_flat: bad argument");
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) S2E_FAIL(S2E_ERR_ARG, "s2e_adam_flat: arenas must be 16-byte aligned");
+    const long nv = n / 4 + 1;
+    const int grid = (int)((nv + 255) / 256 < 4096 ? (nv + 255) / 256 : 4096);
+    adam_flat_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr / bc1, beta1, beta2, eps, 1.f / sqrtf(bc2), grad_scale);
+    S2E_CHECK_LAUNCH("adam_flat_kernel");
+    return S2E_OK;
+}

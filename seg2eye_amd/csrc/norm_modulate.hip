@@ -1,0 +1,399 @@
+// HBM-bound kernels of the SPADE+Style block and the discriminator's InstanceNorm+LeakyReLU:
+// per-(n,c) statistics, the fused modulation, its backward, and column sums (bias gradients).
+//
+// Layout: x is NHWC = [N][HW][C]; one thread owns a 16-byte channel group (8 bf16 / 4 f32) so every
+// load/store is a full-width coalesced access, and walks rows (pixels).  Per-(n,c) reductions are
+// fp32 per thread over a short row slab, combined across the block's row-threads in LDS, then added to
+// an fp64 workspace with one atomic per (block, channel): no long fp32 chains, and the E[x^2]-E[x]^2
+// finalisation happens in fp64 (cancellation-safe).
+#include "common.h"
+
+static constexpr int kSlabIters = 16;     // row passes per block in the row-walking kernels
+
+struct RowGeom {       // how a 256-thread block maps onto [rows][C/VEC channel groups]
+    int cg;            // channel groups in total (C / VEC)
+    int cgb;           // channel groups per block (<= 256)
+    int rpp;           // rows per pass
+    int zblocks;       // blocks along the channel-group axis
+};
+static RowGeom row_geom(int C, int vec) {
+    RowGeom g;
+    g.cg = C / vec;
+    g.cgb = g.cg < 256 ? g.cg : 256;
+    g.rpp = 256 / g.cgb;
+    g.zblocks = ceil_div(g.cg, g.cgb);
+    return g;
+}
+
+// ------------------------------------------------------------------------------------ in_stats
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restrict__ x, double* __restrict__ ws,
+                                                               int HW, int C, int cg, int cgb, int rpp) {
+    constexpr int VEC = Vec<T>::N;
+    __shared__ float red[256 * VEC * 2];
+    const int tid = threadIdx.x;
+    const int tx = tid % cgb, ty = tid / cgb;
+    const int g = blockIdx.z * cgb + tx;
+    const int n = blockIdx.y;
+    const bool active = ty < rpp && g < cg;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (active) {
+        const int row0 = blockIdx.x * rpp * kSlabIters;
+        const T* base = x + (size_t)n * HW * C + (size_t)g * VEC;
+        for (int it = 0; it < kSlabIters; ++it) {
+            const int row = row0 + it * rpp + ty;
+            if (row < HW) {
+                float f[VEC];
+                unpack16<T>(*(const u32x4_t*)(base + (size_t)row * C), f);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[(tid * VEC + j) * 2] = s[j]; red[(tid * VEC + j) * 2 + 1] = q[j]; }
+    __syncthreads();
+    if (active && ty == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < rpp; ++r) {
+                a += red[((r * cgb + tx) * VEC + j) * 2];
+                b += red[((r * cgb + tx) * VEC + j) * 2 + 1];
+            }
+            double* w = ws + ((size_t)n * C + g * VEC + j) * 2;
+            atomicAdd(w, (double)a);
+            atomicAdd(w + 1, (double)b);
+        }
+    }
+}
+
+__global__ void in_stats_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats, int total, int HW, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double mean = ws[2 * i] / HW;
+    double var = ws[2 * i + 1] / HW - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, void* stream) {
+    if (!x || !ws || !stats || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_in_stats: bad argument");
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_in_stats: bad dtype %d", dtype);
+    if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_in_stats: C=%d not a multiple of %d", C, vec);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)N * C, st) != hipSuccess)
+        S2E_FAIL(S2E_ERR_LAUNCH, "s2e_in_stats: memset failed");
+    const RowGeom g = row_geom(C, vec);
+    dim3 grid(ceil_div(HW, g.rpp * kSlabIters), N, g.zblocks);
+    if (dtype == S2E_BF16) in_stats_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, ws, HW, C, g.cg, g.cgb, g.rpp);
+    else in_stats_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)x, ws, HW, C, g.cg, g.cgb, g.rpp);
+    S2E_CHECK_LAUNCH("in_stats_partial_kernel");
+    in_stats_finalize_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(ws, stats, N * C, HW, eps);
+    S2E_CHECK_LAUNCH("in_stats_finalize_kernel");
+    return S2E_OK;
+}
+
+// ------------------------------------------------------------------------------------ colsum
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ gsrc, float* __restrict__ out, long M, int C,
+                                                     int cg, int cgb, int rpp, int rows_per_block) {
+    constexpr int VEC = Vec<T>::N;
+    __shared__ float red[256 * VEC];
+    const int tid = threadIdx.x;
+    const int tx = tid % cgb, ty = tid / cgb;
+    const int g = blockIdx.z * cgb + tx;
+    const bool active = ty < rpp && g < cg;
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    if (active) {
+        const long row0 = (long)blockIdx.x * rows_per_block;
+        for (long row = row0 + ty; row < row0 + rows_per_block && row < M; row += rpp) {
+            float f[VEC];
+            unpack16<T>(*(const u32x4_t*)(gsrc + (size_t)row * C + (size_t)g * VEC), f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] += f[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[tid * VEC + j] = s[j];
+    __syncthreads();
+    if (active && ty == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float a = 0.f;
+            for (int r = 0; r < rpp; ++r) a += red[(r * cgb + tx) * VEC + j];
+            atomicAdd(out + g * VEC + j, a);
+        }
+    }
+}
+template <typename T>
+__global__ void colsum_scalar_kernel(const T* __restrict__ gsrc, float* __restrict__ out, long M, int C) {
+    // any-C fallback (C not a multiple of the vector width, e.g. the 1-channel heads)
+    __shared__ float red[256];
+    const int c = blockIdx.y;
+    float s = 0.f;
+    for (long row = (long)blockIdx.x * blockDim.x + threadIdx.x; row < M; row += (long)gridDim.x * blockDim.x)
+        s += load1<T>(gsrc + (size_t)row * C + c);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + c, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream) {
+    if (!g || !out || M <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_colsum: bad argument");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_colsum: bad dtype %d", dtype);
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (C % vec) {
+        dim3 grid((unsigned)(M / 1024 + 1 < 256 ? M / 1024 + 1 : 256), C);
+        if (dtype == S2E_BF16) colsum_scalar_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)g, out, M, C);
+        else colsum_scalar_kernel<float><<<grid, 256, 0, st>>>((const float*)g, out, M, C);
+        S2E_CHECK_LAUNCH("colsum_scalar_kernel");
+        return S2E_OK;
+    }
+    const RowGeom rg = row_geom(C, vec);
+    const int rows_per_block = rg.rpp * 64;
+    dim3 grid(ceil_div(M, rows_per_block), 1, rg.zblocks);
+    if (dtype == S2E_BF16) colsum_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)g, out, M, C, rg.cg, rg.cgb, rg.rpp, rows_per_block);
+    else colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)g, out, M, C, rg.cg, rg.cgb, rg.rpp, rows_per_block);
+    S2E_CHECK_LAUNCH("colsum_kernel");
+    return S2E_OK;
+}
+
+// ------------------------------------------------------------------------------------ modulation forward
+// pre = sc*(xhat*G + beta) + ssc*(x*a + b);   SPADE_STYLE: sc = ssc = 0.5, G = 1+gamma, a = 1+s0, b = s1
+//                                             PLAIN_IN   : sc = 1, ssc = 0, G = 1, beta = 0
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void modulate_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gb,
+                                                           const float* __restrict__ stats, const float* __restrict__ style,
+                                                           T* __restrict__ out, long nvec, int HW, int C, int cg, int lrelu) {
+    constexpr int VEC = Vec<T>::N;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const long row = v / cg;
+        const int g = (int)(v - row * cg);
+        const int n = (int)(row / HW);
+        const int c0 = g * VEC;
+        float f[VEC], o[VEC];
+        unpack16<T>(*(const u32x4_t*)(x + (size_t)row * C + c0), f);
+        const float* stp = stats + ((size_t)n * C + c0) * 2;
+        if (MODE == S2E_NORM_SPADE_STYLE) {
+            float ga[VEC], be[VEC];
+            unpack16<T>(*(const u32x4_t*)(gb + (size_t)row * 2 * C + c0), ga);
+            unpack16<T>(*(const u32x4_t*)(gb + (size_t)row * 2 * C + C + c0), be);
+            const float* s0 = style + (size_t)n * 2 * C + c0;
+            const float* s1 = s0 + C;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (f[j] - stp[2 * j]) * stp[2 * j + 1];
+                o[j] = 0.5f * (xh * (1.f + ga[j]) + be[j] + f[j] * (1.f + s0[j]) + s1[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = (f[j] - stp[2 * j]) * stp[2 * j + 1];
+        }
+        if (lrelu) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = lrelu02(o[j]);
+        }
+        *(u32x4_t*)(out + (size_t)row * C + c0) = pack16<T>(o);
+    }
+}
+
+extern "C" int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* gb, const float* stats, const float* style,
+                                void* out, int N, int HW, int C, int lrelu, void* stream) {
+    if (!x || !stats || !out || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_fwd: bad argument");
+    if (mode == S2E_NORM_SPADE_STYLE && (!gb || !style)) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_fwd: SPADE_STYLE needs gb and style");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_fwd: bad dtype %d", dtype);
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_fwd: C=%d not a multiple of %d", C, vec);
+    const int cg = C / vec;
+    const long nvec = (long)N * HW * cg;
+    const int grid = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+#define S2E_LAUNCH_MOD(TT, MM) modulate_fwd_kernel<TT, MM><<<grid, 256, 0, st>>>((const TT*)x, (const TT*)gb, stats, style, (TT*)out, nvec, HW, C, cg, lrelu)
+    if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_MOD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_MOD(bf16_t, S2E_NORM_PLAIN_IN); }
+    else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_MOD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_MOD(float, S2E_NORM_PLAIN_IN); }
+#undef S2E_LAUNCH_MOD
+    S2E_CHECK_LAUNCH("modulate_fwd_kernel");
+    return S2E_OK;
+}
+
+// ------------------------------------------------------------------------------------ modulation backward
+// pass 1 (row-walking): go = g*lrelu'(pre); SPADE: dgamma = 0.5*go*xhat, dbeta = 0.5*go -> dgb;
+//   per-(n,c) sums  S0 = sum gn, S1 = sum gn*xhat (gn = 0.5*go*G | go),  S2 = sum go*x, S3 = sum go
+// pass 2 (elementwise): dx = 0.5*go*a + rstd*(gn - S0/HW - xhat*S1/HW)   (PLAIN: no style term);
+//   SPADE reads go back as 2*dbeta instead of recomputing the LeakyReLU mask from gamma/beta.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __restrict__ gin, const T* __restrict__ x,
+        const T* __restrict__ gb, const float* __restrict__ stats, const float* __restrict__ style,
+        T* __restrict__ dgb, double* __restrict__ ws, int HW, int C, int cg, int cgb, int rpp, int lrelu) {
+    constexpr int VEC = Vec<T>::N;
+    constexpr int NS = (MODE == S2E_NORM_SPADE_STYLE) ? 4 : 2;
+    __shared__ float red[256 * VEC * NS];
+    const int tid = threadIdx.x;
+    const int tx = tid % cgb, ty = tid / cgb;
+    const int g = blockIdx.z * cgb + tx;
+    const int n = blockIdx.y;
+    const bool active = ty < rpp && g < cg;
+    float S[NS][VEC];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) S[k][j] = 0.f;
+    if (active) {
+        const int c0 = g * VEC;
+        float mu[VEC], rs[VEC], a[VEC], b[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            mu[j] = stats[((size_t)n * C + c0 + j) * 2];
+            rs[j] = stats[((size_t)n * C + c0 + j) * 2 + 1];
+            if (MODE == S2E_NORM_SPADE_STYLE) {
+                a[j] = 1.f + style[(size_t)n * 2 * C + c0 + j];
+                b[j] = style[(size_t)n * 2 * C + C + c0 + j];
+            }
+        }
+        const int row0 = blockIdx.x * rpp * kSlabIters;
+        for (int it = 0; it < kSlabIters; ++it) {
+            const int pr = row0 + it * rpp + ty;
+            if (pr >= HW) break;
+            const size_t row = (size_t)n * HW + pr;
+            float f[VEC], gg[VEC];
+            unpack16<T>(*(const u32x4_t*)(x + row * C + c0), f);
+            unpack16<T>(*(const u32x4_t*)(gin + row * C + c0), gg);
+            if (MODE == S2E_NORM_SPADE_STYLE) {
+                float ga[VEC], be[VEC], dga[VEC], dbe[VEC];
+                unpack16<T>(*(const u32x4_t*)(gb + row * 2 * C + c0), ga);
+                unpack16<T>(*(const u32x4_t*)(gb + row * 2 * C + C + c0), be);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float xh = (f[j] - mu[j]) * rs[j];
+                    const float G = 1.f + ga[j];
+                    float go = gg[j];
+                    if (lrelu) {
+                        const float pre = 0.5f * (xh * G + be[j] + f[j] * a[j] + b[j]);
+                        go *= (pre > 0.f ? 1.f : 0.2f);
+                    }
+                    dga[j] = 0.5f * go * xh;
+                    dbe[j] = 0.5f * go;
+                    const float gn = 0.5f * go * G;
+                    S[0][j] += gn; S[1][j] += gn * xh; S[2][j] += go * f[j]; S[3][j] += go;
+                }
+                *(u32x4_t*)(dgb + row * 2 * C + c0) = pack16<T>(dga);
+                *(u32x4_t*)(dgb + row * 2 * C + C + c0) = pack16<T>(dbe);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float xh = (f[j] - mu[j]) * rs[j];
+                    float go = gg[j];
+                    if (lrelu) go *= (xh > 0.f ? 1.f : 0.2f);
+                    S[0][j] += go; S[1][j] += go * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) red[(tid * VEC + j) * NS + k] = S[k][j];
+    __syncthreads();
+    if (active && ty == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                float acc = 0.f;
+                for (int r = 0; r < rpp; ++r) acc += red[((r * cgb + tx) * VEC + j) * NS + k];
+                atomicAdd(ws + ((size_t)n * C + g * VEC + j) * 4 + k, (double)acc);
+            }
+    }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __restrict__ gin, const T* __restrict__ x,
+        const T* __restrict__ gb, const T* __restrict__ dgb, const float* __restrict__ stats, const float* __restrict__ style,
+        const double* __restrict__ ws, T* __restrict__ dx, long nvec, int HW, int C, int cg, int lrelu) {
+    constexpr int VEC = Vec<T>::N;
+    const float inv_hw = 1.f / (float)HW;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const long row = v / cg;
+        const int g = (int)(v - row * cg);
+        const int n = (int)(row / HW);
+        const int c0 = g * VEC;
+        float f[VEC], o[VEC];
+        unpack16<T>(*(const u32x4_t*)(x + (size_t)row * C + c0), f);
+        const float* stp = stats + ((size_t)n * C + c0) * 2;
+        const double* wsp = ws + ((size_t)n * C + c0) * 4;
+        if (MODE == S2E_NORM_SPADE_STYLE) {
+            float ga[VEC], dbe[VEC];
+            unpack16<T>(*(const u32x4_t*)(gb + (size_t)row * 2 * C + c0), ga);
+            unpack16<T>(*(const u32x4_t*)(dgb + (size_t)row * 2 * C + C + c0), dbe);
+            const float* s0 = style + (size_t)n * 2 * C + c0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float rs = stp[2 * j + 1];
+                const float xh = (f[j] - stp[2 * j]) * rs;
+                const float gn = dbe[j] * (1.f + ga[j]);                 // 0.5*go*G
+                const float m0 = (float)wsp[4 * j] * inv_hw, m1 = (float)wsp[4 * j + 1] * inv_hw;
+                o[j] = dbe[j] * (1.f + s0[j]) + rs * (gn - m0 - xh * m1);
+            }
+        } else {
+            float gg[VEC];
+            unpack16<T>(*(const u32x4_t*)(gin + (size_t)row * C + c0), gg);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float rs = stp[2 * j + 1];
+                const float xh = (f[j] - stp[2 * j]) * rs;
+                float go = gg[j];
+                if (lrelu) go *= (xh > 0.f ? 1.f : 0.2f);
+                const float m0 = (float)wsp[4 * j] * inv_hw, m1 = (float)wsp[4 * j + 1] * inv_hw;
+                o[j] = rs * (go - m0 - xh * m1);
+            }
+        }
+        *(u32x4_t*)(dx + (size_t)row * C + c0) = pack16<T>(o);
+    }
+}
+
+__global__ void modulate_bwd_style_kernel(const double* __restrict__ ws, float* __restrict__ dstyle, int N, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    dstyle[(size_t)n * 2 * C + c] += 0.5f * (float)ws[(size_t)i * 4 + 2];
+    dstyle[(size_t)n * 2 * C + C + c] += 0.5f * (float)ws[(size_t)i * 4 + 3];
+}
+
+extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
+                                const float* style, void* dx, void* dgb, float* dstyle, double* ws,
+                                int N, int HW, int C, int lrelu, void* stream) {
+    if (!g || !x || !stats || !dx || !ws || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: bad argument");
+    if (mode == S2E_NORM_SPADE_STYLE && (!gb || !style || !dgb || !dstyle))
+        S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: SPADE_STYLE needs gb, style, dgb, dstyle");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: bad dtype %d", dtype);
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_bwd: C=%d not a multiple of %d", C, vec);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 4 * (size_t)N * C, st) != hipSuccess)
+        S2E_FAIL(S2E_ERR_LAUNCH, "s2e_modulate_bwd: memset failed");
+    const RowGeom rg = row_geom(C, vec);
+    dim3 grid1(ceil_div(HW, rg.rpp * kSlabIters), N, rg.zblocks);
+    const long nvec = (long)N * HW * rg.cg;
+    const int grid2 = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+#define S2E_LAUNCH_BWD(TT, MM) do { \
+    modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu); \
+    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, stats, style, ws, (TT*)dx, nvec, HW, C, rg.cg, lrelu); } while (0)
+    if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
+    else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
+#undef S2E_LAUNCH_BWD
+    S2E_CHECK_LAUNCH("modulate_bwd kernels");
+    if (mode == S2E_NORM_SPADE_STYLE) {
+        modulate_bwd_style_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(ws, dstyle, N, C);
+        S2E_CHECK_LAUNCH("modulate_bwd_style_kernel");
+    }
+    return S2E_OK;
+}

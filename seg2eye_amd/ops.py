@@ -1,0 +1,430 @@
+"""PyTorch-ROCm custom ops over the C-ABI kernels (include/seg2eye_hip.h).
+
+torch is plumbing here: it owns device memory (caching allocator), the stream and
+the autograd tape; every forward/backward body below is one or more HIP kernel
+launches through ctypes on torch's current stream.  Internal activations are
+NHWC-contiguous 4-D tensors (N, H, W, C) in the compute dtype (bf16 or fp32).
+
+There is no CPU path: calling an op with a non-CUDA tensor raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (ConvDesc, ACT_NONE, ACT_LRELU, ACT_TANH, AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD,
+                   NORM_SPADE_STYLE, NORM_PLAIN_IN, LOSS_NEG_MEAN, LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_L1)
+
+IN_EPS = 1e-5      # nn.InstanceNorm2d default (models/networks/normalization.py:41,73)
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return L.S2E_BF16
+    if t.dtype == torch.float32:
+        return L.S2E_F32
+    raise TypeError('seg2eye_amd ops take bf16 or fp32 tensors, got %s' % t.dtype)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise L.Seg2EyeHipError('seg2eye_amd ops run on the GPU only (got a %s tensor); '
+                                        'there is no CPU fallback' % t.device)
+            if not t.is_contiguous():
+                raise L.Seg2EyeHipError('seg2eye_amd ops need contiguous tensors')
+
+
+# ------------------------------------------------------------------------------ raw launchers
+
+def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False):
+    w = w_oihw.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    _need(w)
+    cout, cin, kh, kw = w.shape
+    cin_pad = cin if cin_pad is None else cin_pad
+    dt = L.S2E_BF16 if dtype == torch.bfloat16 else L.S2E_F32
+    lib = L.lib()
+    rows = lib.s2e_conv_cout_pad(cin_pad if transposed else cout)
+    kpad = lib.s2e_conv_k_pad(dt, kh * kw * (cout if transposed else cin_pad))
+    out = torch.empty(rows, kpad, dtype=dtype, device=w.device)
+    L.check(lib.s2e_pack_conv_weight(dt, _p(w), _p(out), cout, cin, kh, kw, cin_pad, int(transposed), _stream()),
+            's2e_pack_conv_weight')
+    return out
+
+
+def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transposed=False,
+               in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE):
+    _need(x, wp, bias, residual, aux)
+    n, hi, wi, cin = x.shape
+    ho, wo, cout = out_hw_c
+    y = torch.empty(n, ho, wo, cout, dtype=x.dtype, device=x.device)
+    d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, int(transposed), in_act, out_act, aux_mode)
+    L.check(L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _stream()),
+            's2e_conv2d')
+    return y
+
+
+def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE):
+    _need(x, gy)
+    n, hi, wi, cin = x.shape
+    _, ho, wo, cout = gy.shape
+    dw = torch.zeros(cout, kh * kw * cin, dtype=torch.float32, device=x.device)
+    d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
+    L.check(L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), C.byref(d), _stream()), 's2e_conv2d_wgrad')
+    return dw
+
+
+def colsum(g):
+    _need(g)
+    c = g.shape[-1]
+    out = torch.zeros(c, dtype=torch.float32, device=g.device)
+    L.check(L.lib().s2e_colsum(_dt(g), _p(g), g.numel() // c, c, _p(out), _stream()), 's2e_colsum')
+    return out
+
+
+def in_stats(x):
+    """(N,H,W,C) -> (N,C,2) fp32 {mean, rstd}; not differentiated here (the IN backward lives in
+    modulate_bwd, once per consumer of the statistics)."""
+    _need(x)
+    n, h, w, c = x.shape
+    ws = torch.empty(n * c * 2, dtype=torch.float64, device=x.device)
+    stats = torch.empty(n, c, 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().s2e_in_stats(_dt(x), _p(x), n, h * w, c, IN_EPS, _p(ws), _p(stats), _stream()), 's2e_in_stats')
+    return stats
+
+
+def label_conv3x3_raw(label, table, bias, n, H, W, h, w, cout, relu, dtype):
+    _need(label, table, bias)
+    out = torch.empty(n, h, w, cout, dtype=dtype, device=label.device)
+    ncls = table.shape[0] // 9
+    L.check(L.lib().s2e_label_conv3x3(_dt(out), _p(label), _p(table), _p(bias), _p(out), n, H, W, h, w, ncls, cout,
+                                      int(relu), _stream()), 's2e_label_conv3x3')
+    return out
+
+
+def onehot_nhwc_raw(label, img, h, w, ncls, cpad, dtype):
+    _need(label, img)
+    n, H, W = label.shape
+    out = torch.empty(n, h, w, cpad, dtype=dtype, device=label.device)
+    L.check(L.lib().s2e_onehot_nhwc(_dt(out), _p(label), _p(img), _p(out), n, H, W, h, w, ncls, cpad, _stream()),
+            's2e_onehot_nhwc')
+    return out
+
+
+def _table_of(weight):
+    """(Cout, ncls, 3, 3) conv weight -> gather table (9*ncls, Cout) fp32."""
+    return weight.detach().float().permute(2, 3, 1, 0).reshape(-1, weight.shape[0]).contiguous()
+
+
+def _unpack_dw(dw, cout, cin, kh, kw, cin_pad):
+    """(Cout, KH*KW*cin_pad) packed fp32 gradient -> (Cout, Cin, KH, KW) view."""
+    return dw.view(cout, kh, kw, cin_pad)[..., :cin].permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------ conv2d
+
+class Conv2dFn(torch.autograd.Function):
+    """y = out_act(conv(in_act(x), W) + b + residual) on NHWC tensors.  x may carry more channels
+    than W has input channels (structural zero padding)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride, pad, in_act, out_act):
+        n, hi, wi, cx = x.shape
+        cout, cin, kh, kw = weight.shape
+        if cx < cin:
+            raise ValueError('input has %d channels, weight expects %d' % (cx, cin))
+        ho = (hi + 2 * pad - kh) // stride + 1
+        wo = (wi + 2 * pad - kw) // stride + 1
+        wp = pack_weight(weight, x.dtype, cx, False)
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act)
+        ctx.cfg = (stride, pad, in_act, out_act, bias is not None, residual is not None)
+        ctx.save_for_backward(x, weight, y if out_act == ACT_TANH else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, in_act, out_act, has_bias, has_res = ctx.cfg
+        n, hi, wi, cx = x.shape
+        cout, cin, kh, kw = weight.shape
+        g = gy.contiguous()
+        if out_act == ACT_TANH:
+            g2 = torch.empty_like(g)
+            L.check(L.lib().s2e_tanh_bwd(_dt(g), _p(g), _p(y), _p(g2), g.numel(), _stream()), 's2e_tanh_bwd')
+            g = g2
+        elif out_act != ACT_NONE:
+            raise NotImplementedError('backward of out_act=%d' % out_act)
+        gx = gw = gb = gres = None
+        if ctx.needs_input_grad[0]:
+            wpt = pack_weight(weight, x.dtype, cx, True)
+            gx = conv2d_raw(g, wpt, None, None, x if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
+                            True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
+        if ctx.needs_input_grad[1]:
+            gw = _unpack_dw(conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act), cout, cin, kh, kw, cx)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = colsum(g)
+        if has_res and ctx.needs_input_grad[3]:
+            gres = g
+        return gx, gw, gb, gres, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, residual=None, stride=1, pad=0, in_act=ACT_NONE, out_act=ACT_NONE):
+    return Conv2dFn.apply(x, weight, bias, residual, stride, pad, in_act, out_act)
+
+
+# ------------------------------------------------------------------------------ label-map convs
+
+class LabelConvFn(torch.autograd.Function):
+    """conv3x3(one_hot(nearest_down(label))) (+ReLU) -- generator.py:72-73 (fc) and the
+    SPADE mlp_shared (normalization.py:85-88)."""
+
+    @staticmethod
+    def forward(ctx, label, weight, bias, h, w, relu, dtype):
+        n, H, W = label.shape
+        out = label_conv3x3_raw(label, _table_of(weight), bias.detach().float().contiguous(), n, H, W, h, w,
+                                weight.shape[0], relu, dtype)
+        ctx.cfg = (h, w, relu)
+        ctx.save_for_backward(label, weight, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        label, weight, out = ctx.saved_tensors
+        h, w, relu = ctx.cfg
+        g = g.contiguous()
+        if relu:
+            raise NotImplementedError('use SpadeParamFn for the ReLU variant (mask fused into the dgrad)')
+        cout, ncls = weight.shape[0], weight.shape[1]
+        oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
+        gw = _unpack_dw(conv2d_wgrad_raw(oh, g, 3, 3, 1, 1), cout, ncls, 3, 3, 8)
+        return None, gw, colsum(g), None, None, None, None
+
+
+def label_conv3x3(label, weight, bias, h, w, relu, dtype):
+    return LabelConvFn.apply(label, weight, bias, h, w, relu, dtype)
+
+
+class SpadeParamFn(torch.autograd.Function):
+    """gb = conv3x3(ReLU(conv3x3(one_hot(label_h)))) : the SPADE branch that produces
+    [gamma | beta] (normalization.py:97-101) as one 2C-channel tensor.  w_gb = cat(mlp_gamma.weight,
+    mlp_beta.weight).  Backward: the ReLU mask is fused into the data-gradient epilogue, and the
+    mlp_shared weight gradient is an MFMA wgrad against the (tiny) 8-channel one-hot map."""
+
+    @staticmethod
+    def forward(ctx, label, w_sh, b_sh, w_gb, b_gb, h, w, dtype):
+        n, H, W = label.shape
+        nh = w_sh.shape[0]
+        actv = label_conv3x3_raw(label, _table_of(w_sh), b_sh.detach().float().contiguous(), n, H, W, h, w, nh, True, dtype)
+        wp = pack_weight(w_gb, dtype, nh, False)
+        gb = conv2d_raw(actv, wp, b_gb.detach().float().contiguous(), None, None, (h, w, w_gb.shape[0]), 3, 3, 1, 1)
+        ctx.cfg = (h, w)
+        ctx.save_for_backward(label, w_sh, w_gb, actv)
+        return gb
+
+    @staticmethod
+    def backward(ctx, ggb):
+        label, w_sh, w_gb, actv = ctx.saved_tensors
+        h, w = ctx.cfg
+        g = ggb.contiguous()
+        c2, nh = w_gb.shape[0], w_gb.shape[1]
+        ncls = w_sh.shape[1]
+        gw_gb = _unpack_dw(conv2d_wgrad_raw(actv, g, 3, 3, 1, 1), c2, nh, 3, 3, nh)
+        gb_gb = colsum(g)
+        wpt = pack_weight(w_gb, g.dtype, nh, True)
+        dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
+        oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
+        gw_sh = _unpack_dw(conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1), nh, ncls, 3, 3, 8)
+        gb_sh = colsum(dactv)
+        return None, gw_sh, gb_sh, gw_gb, gb_gb, None, None, None
+
+
+def spade_params(label, w_sh, b_sh, w_gb, b_gb, h, w, dtype):
+    return SpadeParamFn.apply(label, w_sh, b_sh, w_gb, b_gb, h, w, dtype)
+
+
+# ------------------------------------------------------------------------------ modulation / IN
+
+class ModulateFn(torch.autograd.Function):
+    """SPADE+Style modulation (optionally + LeakyReLU).  stats come from in_stats(x) and may be
+    shared between consumers (norm_0 and norm_s normalise the same x, architecture.py:44-59)."""
+
+    @staticmethod
+    def forward(ctx, x, gb, style, stats, lrelu):
+        _need(x, gb, style, stats)
+        n, h, w, c = x.shape
+        out = torch.empty_like(x)
+        L.check(L.lib().s2e_modulate_fwd(_dt(x), NORM_SPADE_STYLE, _p(x), _p(gb), _p(stats), _p(style), _p(out),
+                                         n, h * w, c, int(lrelu), _stream()), 's2e_modulate_fwd')
+        ctx.lrelu = lrelu
+        ctx.save_for_backward(x, gb, style, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gb, style, stats = ctx.saved_tensors
+        n, h, w, c = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        dgb = torch.empty_like(gb)
+        dstyle = torch.zeros_like(style)
+        ws = torch.empty(n * c * 4, dtype=torch.float64, device=x.device)
+        L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_SPADE_STYLE, _p(g), _p(x), _p(gb), _p(stats), _p(style), _p(dx),
+                                         _p(dgb), _p(dstyle), _p(ws), n, h * w, c, int(ctx.lrelu), _stream()),
+                's2e_modulate_bwd')
+        return dx, dgb, dstyle, None, None
+
+
+def spade_style_modulate(x, gb, style, stats, lrelu):
+    return ModulateFn.apply(x, gb, style.float().contiguous(), stats, lrelu)
+
+
+class InstanceNormFn(torch.autograd.Function):
+    """InstanceNorm2d(affine=False) (+ LeakyReLU 0.2): discriminator.py:91-94, encoder.py layers."""
+
+    @staticmethod
+    def forward(ctx, x, lrelu):
+        _need(x)
+        n, h, w, c = x.shape
+        stats = in_stats(x)
+        out = torch.empty_like(x)
+        L.check(L.lib().s2e_modulate_fwd(_dt(x), NORM_PLAIN_IN, _p(x), None, _p(stats), None, _p(out),
+                                         n, h * w, c, int(lrelu), _stream()), 's2e_modulate_fwd')
+        ctx.lrelu = lrelu
+        ctx.save_for_backward(x, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats = ctx.saved_tensors
+        n, h, w, c = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        ws = torch.empty(n * c * 4, dtype=torch.float64, device=x.device)
+        L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_PLAIN_IN, _p(g), _p(x), None, _p(stats), None, _p(dx), None, None,
+                                         _p(ws), n, h * w, c, int(ctx.lrelu), _stream()), 's2e_modulate_bwd')
+        return dx, None
+
+
+def instance_norm(x, lrelu=False):
+    return InstanceNormFn.apply(x, lrelu)
+
+
+# ------------------------------------------------------------------------------ resampling
+
+class Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need(x)
+        n, h, w, c = x.shape
+        y = torch.empty(n, 2 * h, 2 * w, c, dtype=x.dtype, device=x.device)
+        L.check(L.lib().s2e_upsample2x_fwd(_dt(x), _p(x), _p(y), n, h, w, c, _stream()), 's2e_upsample2x_fwd')
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        n, h2, w2, c = gy.shape
+        gx = torch.empty(n, h2 // 2, w2 // 2, c, dtype=gy.dtype, device=gy.device)
+        L.check(L.lib().s2e_upsample2x_bwd(_dt(gy), _p(gy), _p(gx), n, h2 // 2, w2 // 2, c, _stream()), 's2e_upsample2x_bwd')
+        return gx
+
+
+def upsample2x(x):
+    return Upsample2xFn.apply(x)
+
+
+class AvgPool3x3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need(x)
+        n, h, w, c = x.shape
+        y = torch.empty(n, (h + 1) // 2, (w + 1) // 2, c, dtype=x.dtype, device=x.device)
+        L.check(L.lib().s2e_avgpool3x3s2_fwd(_dt(x), _p(x), _p(y), n, h, w, c, _stream()), 's2e_avgpool3x3s2_fwd')
+        ctx.hw = (h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        h, w = ctx.hw
+        n, _, _, c = gy.shape
+        gx = torch.empty(n, h, w, c, dtype=gy.dtype, device=gy.device)
+        L.check(L.lib().s2e_avgpool3x3s2_bwd(_dt(gy), _p(gy), _p(gx), n, h, w, c, _stream()), 's2e_avgpool3x3s2_bwd')
+        return gx
+
+
+def avgpool3x3s2(x):
+    return AvgPool3x3s2Fn.apply(x)
+
+
+class SegImageConcatFn(torch.autograd.Function):
+    """cat([one_hot(label), image], channel) as an NHWC tensor zero-padded to `cpad` channels
+    (pix2pix_model.py:328-336).  Differentiable w.r.t. the image only."""
+
+    @staticmethod
+    def forward(ctx, label, img, ncls, cpad):
+        n, H, W = label.shape
+        ctx.ncls = ncls
+        return onehot_nhwc_raw(label, img.contiguous(), H, W, ncls, cpad, img.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g[..., ctx.ncls].contiguous(), None, None
+
+
+def seg_image_concat(label, img, ncls=4, cpad=8):
+    """label (N,H,W) uint8, img (N,H,W) -> (N,H,W,cpad)."""
+    return SegImageConcatFn.apply(label, img, ncls, cpad)
+
+
+# ------------------------------------------------------------------------------ losses
+
+class LossSumFn(torch.autograd.Function):
+    """scale * sum_i f(a_i, b_i) as a 0-dim fp32 tensor (see s2e_loss_reduce for f)."""
+
+    @staticmethod
+    def forward(ctx, a, b, mode, scale):
+        _need(a, b)
+        out = torch.zeros((), dtype=torch.float32, device=a.device)
+        L.check(L.lib().s2e_loss_reduce(_dt(a), mode, _p(a), _p(b), a.numel(), float(scale), _p(out), _stream()),
+                's2e_loss_reduce')
+        ctx.cfg = (mode, float(scale))
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        mode, scale = ctx.cfg
+        gs = gout.detach().float().contiguous()
+        da = torch.empty_like(a)
+        L.check(L.lib().s2e_loss_grad(_dt(a), mode, _p(a), _p(b), a.numel(), scale, _p(gs), _p(da), 0, _stream()),
+                's2e_loss_grad')
+        return da, None, None, None
+
+
+def loss_sum(a, b, mode, scale):
+    return LossSumFn.apply(a, b, mode, scale)
+
+
+# ------------------------------------------------------------------------------ optimizer
+
+def adam_flat_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """One torch.optim.Adam step over flat fp32 arenas (pix2pix_model.py:92-110 semantics)."""
+    _need(p, g, m, v)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    L.check(L.lib().s2e_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2,
+                                  float(grad_scale), _stream()), 's2e_adam_flat')

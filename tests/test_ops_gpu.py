@@ -1,0 +1,292 @@
+"""Op-level parity of every HIP kernel (through the C-ABI / ctypes path) against plain
+PyTorch fp64 CPU references of the same op.  fp32 kernels: tight tolerance; bf16 kernels:
+both sides start from the same bf16-rounded inputs, tolerance = bf16 output rounding."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+def _rnd(shape, seed, dtype, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = (torch.randn(shape, generator=g) * scale).to(dtype)
+    return t
+
+
+def _tol(dtype):
+    return dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=2e-4, atol=2e-4)
+
+
+def _close(got, ref, dtype, scale=None, what=''):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    s = float(ref.abs().max()) if scale is None else scale
+    s = max(s, 1e-6)
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 1e-4
+    err = float((got - ref).abs().max())
+    assert err <= tol * s, '%s: max err %.3e vs scale %.3e (tol %.1e)' % (what, err, s, tol)
+
+
+def nhwc(t):      # NCHW -> NHWC contiguous
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # (N, H, W, Cin, Cout, k, stride, pad, bias, residual, in_act, out_act, cin_pad)
+    (2, 16, 16, 16, 32, 3, 1, 1, True, False, 0, 0, None),
+    (2, 16, 12, 64, 128, 3, 1, 1, True, True, 0, 0, None),
+    (1, 9, 11, 128, 200, 3, 1, 1, False, False, 0, 0, None),     # ragged M and Cout (masked tiles)
+    (2, 16, 16, 32, 16, 1, 1, 0, False, False, 0, 0, None),      # 1x1 shortcut
+    (2, 33, 33, 8, 64, 4, 2, 2, True, False, 0, 0, None),        # D model0-like (padded 5->8 elsewhere)
+    (2, 17, 17, 64, 128, 4, 2, 2, False, False, 0, 0, None),     # D stride-2
+    (2, 9, 9, 32, 64, 4, 1, 2, False, False, 0, 0, None),        # D stride-1 pad 2
+    (2, 10, 10, 64, 1, 4, 1, 2, True, False, 0, 0, None),        # D head, Cout=1
+    (2, 32, 32, 64, 1, 3, 1, 1, True, False, 1, 2, None),        # conv_img: lrelu -> conv -> tanh
+    (3, 32, 32, 1, 16, 3, 2, 1, False, False, 0, 0, None),       # encoder layer0, Cin=1 (gather fallback)
+    (2, 32, 32, 16, 32, 3, 2, 1, False, False, 0, 0, None),      # encoder stride-2
+    (2, 16, 16, 5, 16, 4, 2, 2, True, False, 0, 0, 8),           # 5 real channels stored as 8
+    (2, 8, 8, 256, 256, 3, 1, 1, True, True, 0, 0, None),        # deep K (36 K-tiles)
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_forward_backward(case, dtype):
+    from seg2eye_amd import ops
+    N, H, W, Cin, Cout, k, s, p, has_b, has_r, in_act, out_act, cin_pad = case
+    dev = _dev()
+    x = _rnd((N, Cin, H, W), 1, dtype)
+    w = _rnd((Cout, Cin, k, k), 2, torch.float32, (1.0 / (Cin * k * k)) ** 0.5)
+    b = _rnd((Cout,), 3, torch.float32, 0.1) if has_b else None
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    r = _rnd((N, Cout, Ho, Wo), 4, dtype) if has_r else None
+    gy = _rnd((N, Cout, Ho, Wo), 5, dtype)
+
+    # reference (fp64 CPU), weights rounded to the compute dtype like the packed ones
+    xr = x.double().requires_grad_(True)
+    wr = w.to(dtype).double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if has_b else None
+    rr = r.double().requires_grad_(True) if has_r else None
+    xi = F.leaky_relu(xr, 0.2) if in_act == 1 else xr
+    yr = F.conv2d(xi, wr, br, stride=s, padding=p)
+    if has_r:
+        yr = yr + rr
+    if out_act == 2:
+        yr = torch.tanh(yr)
+    yr.backward(gy.double())
+
+    xg = nhwc(x)
+    if cin_pad:
+        xg = torch.cat([xg, torch.zeros(N, H, W, cin_pad - Cin, dtype=dtype)], dim=-1)
+    xg = xg.to(dev).requires_grad_(True)
+    wg = w.to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True) if has_b else None
+    rg = nhwc(r).to(dev).requires_grad_(True) if has_r else None
+    y = ops.conv2d(xg, wg, bg, rg, s, p, in_act, out_act)
+    assert y.shape == (N, Ho, Wo, Cout)
+    _close(nchw(y), yr, dtype, what='y')
+    y.backward(nhwc(gy).to(dev))
+    gx = xg.grad[..., :Cin] if cin_pad else xg.grad
+    _close(nchw(gx), xr.grad, dtype, what='dx')
+    if cin_pad:
+        assert float(xg.grad[..., Cin:].abs().max()) == 0.0
+    _close(wg.grad, wr.grad, dtype, what='dw')
+    if has_b:
+        _close(bg.grad, br.grad, dtype, what='db')
+    if has_r:
+        _close(nchw(rg.grad), rr.grad, dtype, what='dres')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (3, 7, 5, 8), (1, 64, 64, 64), (2, 4, 4, 1024), (2, 8, 8, 48)])
+def test_in_stats_and_instance_norm(shape, dtype):
+    from seg2eye_amd import ops
+    N, H, W, C = shape
+    x = _rnd((N, C, H, W), 7, dtype) * 1.5 + 0.7
+    gy = _rnd((N, C, H, W), 8, dtype)
+    xr = x.double().requires_grad_(True)
+    for lrelu in (False, True):
+        xr.grad = None
+        yr = F.instance_norm(xr, eps=1e-5)
+        if lrelu:
+            yr = F.leaky_relu(yr, 0.2)
+        yr.backward(gy.double())
+        xg = nhwc(x).to(_dev()).requires_grad_(True)
+        st = ops.in_stats(xg.detach())
+        mean = x.double().mean(dim=(2, 3))
+        rstd = 1.0 / torch.sqrt(x.double().var(dim=(2, 3), unbiased=False) + 1e-5)
+        _close(st[..., 0], mean, torch.float32, what='mean')
+        _close(st[..., 1], rstd, torch.float32, what='rstd')
+        y = ops.instance_norm(xg, lrelu)
+        _close(nchw(y), yr, dtype, what='in out')
+        y.backward(nhwc(gy).to(_dev()))
+        _close(nchw(xg.grad), xr.grad, dtype, what='in dx')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (2, 9, 7, 8), (1, 32, 32, 128)])
+@pytest.mark.parametrize('lrelu', [False, True])
+def test_spade_style_modulate(shape, dtype, lrelu):
+    from seg2eye_amd import ops
+    N, H, W, C = shape
+    x = _rnd((N, C, H, W), 11, dtype) * 1.3 + 0.2
+    gb = _rnd((N, 2 * C, H, W), 12, dtype, 0.5)
+    style = _rnd((N, 2 * C), 13, torch.float32, 0.5)
+    gy = _rnd((N, C, H, W), 14, dtype)
+    xr, gbr, sr = x.double().requires_grad_(True), gb.double().requires_grad_(True), style.double().requires_grad_(True)
+    gamma, beta = gbr[:, :C], gbr[:, C:]
+    s0, s1 = sr[:, :C, None, None], sr[:, C:, None, None]
+    yr = 0.5 * (F.instance_norm(xr, eps=1e-5) * (1 + gamma) + beta + xr * (1 + s0) + s1)
+    if lrelu:
+        yr = F.leaky_relu(yr, 0.2)
+    yr.backward(gy.double())
+    dev = _dev()
+    xg = nhwc(x).to(dev).requires_grad_(True)
+    gbg = nhwc(gb).to(dev).requires_grad_(True)
+    sg = style.to(dev).requires_grad_(True)
+    y = ops.spade_style_modulate(xg, gbg, sg, ops.in_stats(xg.detach()), lrelu)
+    _close(nchw(y), yr, dtype, what='mod out')
+    y.backward(nhwc(gy).to(dev))
+    _close(nchw(xg.grad), xr.grad, dtype, what='mod dx')
+    _close(nchw(gbg.grad), gbr.grad, dtype, what='mod dgb')
+    _close(sg.grad, sr.grad, dtype, scale=float(sr.grad.abs().max()), what='mod dstyle')
+
+
+def _labels(n, H, W, seed):
+    from seg2eye_amd.synthetic import ellipse_labels
+    lab = ellipse_labels(n, H, W, seed)[:, 0]
+    g = np.random.RandomState(seed)
+    noise = g.randint(0, 4, size=lab.shape).astype(np.uint8)
+    m = g.rand(*lab.shape) < 0.15                       # salt some random classes in
+    lab = np.where(m, noise, lab).astype(np.uint8)
+    return torch.from_numpy(lab)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(2, 32, 32, 32, 32, 128), (2, 64, 32, 8, 4, 128), (2, 64, 64, 2, 2, 256), (1, 32, 32, 16, 16, 24)])
+def test_spade_params_and_label_conv(cfg, dtype):
+    from seg2eye_amd import ops
+    N, H, W, h, w, C2 = cfg
+    dev = _dev()
+    lab = _labels(N, H, W, 3)
+    onehot = torch.zeros(N, 4, H, W).scatter_(1, lab.long().unsqueeze(1), 1.0)
+    seg_h = F.interpolate(onehot, size=(h, w), mode='nearest').double()
+    w_sh = _rnd((128, 4, 3, 3), 21, torch.float32, 0.3)
+    b_sh = _rnd((128,), 22, torch.float32, 0.1)
+    w_gb = _rnd((C2, 128, 3, 3), 23, torch.float32, 0.03)
+    b_gb = _rnd((C2,), 24, torch.float32, 0.1)
+    ggb = _rnd((N, C2, h, w), 25, dtype)
+    refs = [t.double().requires_grad_(True) for t in (w_sh, b_sh, w_gb.to(dtype), b_gb)]
+    actv = F.relu(F.conv2d(seg_h, refs[0], refs[1], padding=1))
+    if dtype == torch.bfloat16:
+        actv = actv + (actv.detach().to(dtype).double() - actv.detach())      # the kernel stores actv in bf16
+    gbr = F.conv2d(actv, refs[2], refs[3], padding=1)
+    gbr.backward(ggb.double())
+    prm = [t.to(dev).requires_grad_(True) for t in (w_sh, b_sh, w_gb, b_gb)]
+    gb = ops.spade_params(lab.to(dev), prm[0], prm[1], prm[2], prm[3], h, w, dtype)
+    _close(nchw(gb), gbr, dtype, what='gb')
+    gb.backward(nhwc(ggb).to(dev))
+    for name, a, b in zip(('dw_sh', 'db_sh', 'dw_gb', 'db_gb'), prm, refs):
+        _close(a.grad, b.grad, dtype, what=name)
+    # plain label conv (generator fc), no ReLU, wide Cout
+    w_fc = _rnd((C2 * 2, 4, 3, 3), 26, torch.float32, 0.3)
+    b_fc = _rnd((C2 * 2,), 27, torch.float32, 0.1)
+    gfc = _rnd((N, C2 * 2, h, w), 28, dtype)
+    wr, br = w_fc.double().requires_grad_(True), b_fc.double().requires_grad_(True)
+    yr = F.conv2d(seg_h, wr, br, padding=1)
+    yr.backward(gfc.double())
+    wg, bg = w_fc.to(dev).requires_grad_(True), b_fc.to(dev).requires_grad_(True)
+    y = ops.label_conv3x3(lab.to(dev), wg, bg, h, w, False, dtype)
+    _close(nchw(y), yr, dtype, what='fc')
+    y.backward(nhwc(gfc).to(dev))
+    _close(wg.grad, wr.grad, dtype, what='fc dw')
+    _close(bg.grad, br.grad, dtype, what='fc db')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_resampling_and_concat(dtype):
+    from seg2eye_amd import ops
+    dev = _dev()
+    x = _rnd((2, 16, 5, 7), 31, dtype)
+    xr = x.double().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode='nearest')
+    gy = _rnd(tuple(yr.shape), 32, dtype)
+    yr.backward(gy.double())
+    xg = nhwc(x).to(dev).requires_grad_(True)
+    y = ops.upsample2x(xg)
+    assert torch.equal(nchw(y).cpu().double(), yr.detach())
+    y.backward(nhwc(gy).to(dev))
+    _close(nchw(xg.grad), xr.grad, dtype, what='ups bwd')
+    for H, W in ((32, 32), (17, 13)):
+        x = _rnd((3, 8, H, W), 33, dtype)
+        xr = x.double().requires_grad_(True)
+        yr = F.avg_pool2d(xr, 3, stride=2, padding=[1, 1], count_include_pad=False)
+        gy = _rnd(tuple(yr.shape), 34, dtype)
+        yr.backward(gy.double())
+        xg = nhwc(x).to(dev).requires_grad_(True)
+        y = ops.avgpool3x3s2(xg)
+        _close(nchw(y), yr, dtype, what='pool')
+        y.backward(nhwc(gy).to(dev))
+        _close(nchw(xg.grad), xr.grad, dtype, what='pool bwd')
+    lab = _labels(2, 16, 16, 5)
+    img = _rnd((2, 16, 16), 35, dtype)
+    ig = img.to(dev).requires_grad_(True)
+    cat = ops.seg_image_concat(lab.to(dev), ig)
+    ref = torch.cat([torch.zeros(2, 4, 16, 16).scatter_(1, lab.long().unsqueeze(1), 1.0), img.float().unsqueeze(1),
+                     torch.zeros(2, 3, 16, 16)], 1)
+    assert torch.equal(nchw(cat).float().cpu(), ref)
+    g = _rnd((2, 16, 16, 8), 36, dtype).to(dev)
+    cat.backward(g)
+    assert torch.equal(ig.grad, g[..., 4])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('n', [121, 4096, 50003])
+def test_losses(dtype, n):
+    from seg2eye_amd import ops, _lib as L
+    dev = _dev()
+    a = _rnd((n,), 41, dtype, 1.5)
+    b = _rnd((n,), 42, dtype, 1.5)
+    for mode, fn in ((L.LOSS_NEG_MEAN, lambda a, b: -a.sum()),
+                     (L.LOSS_HINGE_REAL, lambda a, b: -torch.min(a - 1, torch.zeros_like(a)).sum()),
+                     (L.LOSS_HINGE_FAKE, lambda a, b: -torch.min(-a - 1, torch.zeros_like(a)).sum()),
+                     (L.LOSS_L1, lambda a, b: (a - b).abs().sum())):
+        ar = a.double().requires_grad_(True)
+        lr = fn(ar, b.double()) * (0.37 / n)
+        (lr * 1.7).backward()
+        ag = a.to(dev).requires_grad_(True)
+        bg = b.to(dev) if mode == L.LOSS_L1 else None
+        l = ops.loss_sum(ag, bg, mode, 0.37 / n)
+        assert abs(float(l) - float(lr)) <= 2e-4 * max(1.0, abs(float(lr)))
+        (l * 1.7).backward()
+        _close(ag.grad, ar.grad, dtype, what='loss grad %d' % mode)
+
+
+def test_adam_flat_matches_torch():
+    from seg2eye_amd import ops
+    dev = _dev()
+    n = 10007
+    p0 = _rnd((n,), 51, torch.float32)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.0, 0.9), eps=1e-8)
+    p = p0.to(dev).clone()
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        g = _rnd((n,), 60 + step, torch.float32)
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_flat_step(p, g.to(dev), m, v, 1e-3, 0.0, 0.9, 1e-8, step)
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
