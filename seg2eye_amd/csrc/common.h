@@ -11,8 +11,10 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;   // native 16-B vector (HIP's uint4 struct copies lower to memcpy and defeat SROA)
-typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+// native 16-B vector used for ALL type-punned 16-B global/LDS accesses: HIP's uint4 struct copies lower to
+// memcpy (defeats SROA), and without may_alias clang's TBAA miscompiles float memory read through it
+typedef __attribute__((ext_vector_type(4), may_alias)) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2), may_alias)) uint32_t u32x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // ---------------------------------------------------------------- error reporting (host)
@@ -32,16 +34,20 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     return (uint32_t)__builtin_bit_cast(unsigned short, h);
 }
 
-template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& r, float* f);
-template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& r, float* f) {
-    f[0] = __builtin_bit_cast(float, r.x); f[1] = __builtin_bit_cast(float, r.y);
-    f[2] = __builtin_bit_cast(float, r.z); f[3] = __builtin_bit_cast(float, r.w);
+// NOTE: take the vector BY VALUE and index with []: hipcc (ROCm 7.2) miscompiles
+// __builtin_bit_cast(float, r.x) on a const-reference ext-vector (loads element 0 only).
+template <typename T> __device__ __forceinline__ void unpack16(u32x4_t r, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(u32x4_t r, float* f) {
+    const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    f[0] = __builtin_bit_cast(float, r0); f[1] = __builtin_bit_cast(float, r1);
+    f[2] = __builtin_bit_cast(float, r2); f[3] = __builtin_bit_cast(float, r3);
 }
-template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& r, float* f) {
-    f[0] = bf16_bits_to_f32(r.x & 0xffffu); f[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
-    f[2] = bf16_bits_to_f32(r.y & 0xffffu); f[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
-    f[4] = bf16_bits_to_f32(r.z & 0xffffu); f[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
-    f[6] = bf16_bits_to_f32(r.w & 0xffffu); f[7] = __builtin_bit_cast(float, r.w & 0xffff0000u);
+template <> __device__ __forceinline__ void unpack16<bf16_t>(u32x4_t r, float* f) {
+    const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    f[0] = bf16_bits_to_f32(r0 & 0xffffu); f[1] = __builtin_bit_cast(float, r0 & 0xffff0000u);
+    f[2] = bf16_bits_to_f32(r1 & 0xffffu); f[3] = __builtin_bit_cast(float, r1 & 0xffff0000u);
+    f[4] = bf16_bits_to_f32(r2 & 0xffffu); f[5] = __builtin_bit_cast(float, r2 & 0xffff0000u);
+    f[6] = bf16_bits_to_f32(r3 & 0xffffu); f[7] = __builtin_bit_cast(float, r3 & 0xffff0000u);
 }
 template <typename T> __device__ __forceinline__ u32x4_t pack16(const float* f);
 template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* f) {

@@ -28,7 +28,7 @@ struct ConvKParams {
 
 template <typename T> struct Mfma;
 template <> struct Mfma<bf16_t> {
-    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& acc) {
+    static __device__ __forceinline__ void run(u32x4_t a, u32x4_t b, f32x16_t& acc) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                       __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     }
@@ -36,11 +36,13 @@ template <> struct Mfma<bf16_t> {
 template <> struct Mfma<float> {
     // lane half h holds 4 consecutive k; MFMA t pairs element t of half 0 with element t of half 1.
     // A and B use the same (permuted) k order, so the contraction is exact.
-    static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+    // (vectors by value + whole-vector bit_cast: see the note at unpack16 in common.h)
+    static __device__ __forceinline__ void run(u32x4_t a, u32x4_t b, f32x16_t& acc) {
+        const f32x4_t fa = __builtin_bit_cast(f32x4_t, a), fb = __builtin_bit_cast(f32x4_t, b);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], acc, 0, 0, 0);
     }
 };
 

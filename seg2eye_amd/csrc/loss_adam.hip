@@ -23,8 +23,9 @@ template <int MODE> __device__ __forceinline__ float loss_term(float a, float b)
 }
 template <int MODE> __device__ __forceinline__ float loss_dterm(float a, float b) {
     if (MODE == S2E_LOSS_NEG_MEAN) return -1.f;
-    if (MODE == S2E_LOSS_HINGE_REAL) return (a - 1.f < 0.f) ? -1.f : 0.f;
-    if (MODE == S2E_LOSS_HINGE_FAKE) return (-a - 1.f < 0.f) ? 1.f : 0.f;
+    // torch.min(x, 0) (loss.py:68,71) splits the gradient 0.5/0.5 at an exact tie x == 0
+    if (MODE == S2E_LOSS_HINGE_REAL) { const float x = a - 1.f; return x < 0.f ? -1.f : (x == 0.f ? -0.5f : 0.f); }
+    if (MODE == S2E_LOSS_HINGE_FAKE) { const float x = -a - 1.f; return x < 0.f ? 1.f : (x == 0.f ? 0.5f : 0.f); }
     const float d = a - b;
     return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);       // torch l1_loss backward = sign(a-b)
 }
