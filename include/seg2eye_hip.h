@@ -129,6 +129,9 @@ int s2e_avgpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W,
 int s2e_avgpool3x3s2_bwd(int dtype, const void* gy, void* gx, int N, int H, int W, int C, void* stream);
 /* gx = gy * (1 - y*y)   (backward of torch.tanh, generator.py:100). */
 int s2e_tanh_bwd(int dtype, const void* gy, const void* y, void* gx, long n, void* stream);
+/* gx = gy * (y > 0 ? 1 : 0.2): backward of LeakyReLU(0.2) (discriminator.py:85, nn.LeakyReLU) given its
+ * OUTPUT y (LeakyReLU preserves sign, so the mask of the output equals the mask of the input). */
+int s2e_lrelu_bwd(int dtype, const void* gy, const void* y, void* gx, long n, void* stream);
 
 /* ------------------------------------------------------------------ losses
  * Scalar reductions of GANLoss hinge (loss.py:66-77) and the GAN feature-matching L1

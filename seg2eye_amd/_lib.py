@@ -45,6 +45,7 @@ SIGNATURES = {
     's2e_avgpool3x3s2_fwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
     's2e_avgpool3x3s2_bwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
     's2e_tanh_bwd': [_i, _vp, _vp, _vp, _l, _vp],
+    's2e_lrelu_bwd': [_i, _vp, _vp, _vp, _l, _vp],
     's2e_loss_reduce': [_i, _i, _vp, _vp, _l, _f, _vp, _vp],
     's2e_loss_grad': [_i, _i, _vp, _vp, _l, _f, _vp, _vp, _i, _vp],
     's2e_adam_flat': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _f, _vp],

@@ -276,3 +276,32 @@ extern "C" int s2e_tanh_bwd(int dtype, const void* gy, const void* y, void* gx, 
     S2E_CHECK_LAUNCH("tanh_bwd_kernel");
     return S2E_OK;
 }
+
+// ------------------------------------------------------------------------------------ LeakyReLU backward
+template <typename T>
+__global__ void lrelu_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gx, long n) {
+    constexpr int VEC = Vec<T>::N;
+    const long nv = n / VEC;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+        float g[VEC], yy[VEC];
+        unpack16<T>(*(const u32x4_t*)(gy + v * VEC), g);
+        unpack16<T>(*(const u32x4_t*)(y + v * VEC), yy);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) g[j] *= (yy[j] > 0.f ? 1.f : 0.2f);
+        *(u32x4_t*)(gx + v * VEC) = pack16<T>(g);
+    }
+    for (long i = nv * VEC + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        store1<T>(gx + i, load1<T>(gy + i) * (load1<T>(y + i) > 0.f ? 1.f : 0.2f));
+}
+extern "C" int s2e_lrelu_bwd(int dtype, const void* gy, const void* y, void* gx, long n, void* stream) {
+    if (!gy || !y || !gx || n <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_lrelu_bwd: bad argument");
+    if (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)gx) & 15) S2E_FAIL(S2E_ERR_ARG, "s2e_lrelu_bwd: pointers must be 16-byte aligned");
+    const long nv = n / 4 + 1;
+    const int grid = (int)((nv + 255) / 256 < 8192 ? (nv + 255) / 256 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) lrelu_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)gy, (const bf16_t*)y, (bf16_t*)gx, n);
+    else if (dtype == S2E_F32) lrelu_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)gy, (const float*)y, (float*)gx, n);
+    else S2E_FAIL(S2E_ERR_ARG, "s2e_lrelu_bwd: bad dtype %d", dtype);
+    S2E_CHECK_LAUNCH("lrelu_bwd_kernel");
+    return S2E_OK;
+}

@@ -1,0 +1,46 @@
+"""SPADE+Style residual block (reference models/networks/architecture.py:13-62)."""
+import torch.nn as nn
+from torch.nn.utils import spectral_norm
+
+from .. import ops
+from .base_network import sn_weight
+from .normalization import SPADE_STYLE_Block, SegMap
+
+
+class SPADE_STYLE_ResnetBlock(nn.Module):
+    """x_s = conv_s(SSB_s(x)) if fin != fout else x;  dx = conv_0(lrelu(SSB_0(x)));
+    dx = conv_1(lrelu(SSB_1(dx)));  out = x_s + dx.
+    HIP schedule: IN statistics of x are computed once and shared by norm_0 and norm_s; the
+    LeakyReLU is fused into the modulation kernel; bias and the residual add are fused into the
+    conv epilogue.  x, out: (N,h,w,C) NHWC."""
+
+    def __init__(self, fin, fout, opt):
+        super().__init__()
+        self.learned_shortcut = (fin != fout)
+        fmiddle = min(fin, fout)
+        self.conv_0 = nn.Conv2d(fin, fmiddle, kernel_size=3, padding=1)
+        self.conv_1 = nn.Conv2d(fmiddle, fout, kernel_size=3, padding=1)
+        if self.learned_shortcut:
+            self.conv_s = nn.Conv2d(fin, fout, kernel_size=1, bias=False)
+        if 'spectral' in opt.norm_G:
+            self.conv_0 = spectral_norm(self.conv_0)
+            self.conv_1 = spectral_norm(self.conv_1)
+            if self.learned_shortcut:
+                self.conv_s = spectral_norm(self.conv_s)
+        self.norm_0 = SPADE_STYLE_Block(fin, opt)
+        self.norm_1 = SPADE_STYLE_Block(fmiddle, opt)
+        if self.learned_shortcut:
+            self.norm_s = SPADE_STYLE_Block(fin, opt)
+
+    def forward(self, x, seg, latent_style):
+        seg = SegMap.of(seg)
+        stats = ops.in_stats(x.detach())
+        if self.learned_shortcut:
+            x_s = ops.conv2d(self.norm_s(x, seg, latent_style, stats, lrelu=False), sn_weight(self.conv_s))
+        else:
+            x_s = x
+        dx = ops.conv2d(self.norm_0(x, seg, latent_style, stats, lrelu=True), sn_weight(self.conv_0),
+                        self.conv_0.bias, None, 1, 1)
+        dx = ops.conv2d(self.norm_1(dx, seg, latent_style, None, lrelu=True), sn_weight(self.conv_1),
+                        self.conv_1.bias, x_s, 1, 1)
+        return dx

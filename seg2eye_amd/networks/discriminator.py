@@ -1,0 +1,107 @@
+"""Multi-scale PatchGAN discriminator (reference models/networks/discriminator.py:14-116)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import ACT_NONE, ACT_LRELU
+from .base_network import BaseNetwork, compute_dtype_of, sn_weight
+from .normalization import get_nonspade_norm_layer
+
+D_CPAD = 8          # the 5-channel input cat([one-hot seg, image]) is stored as 8 NHWC channels (16-B vectors)
+
+
+def to_d_input(x, dtype):
+    """(2N, label_nc+output_nc, H, W) float tensor of the reference API -> (2N,H,W,8) NHWC.
+    Slow path (torch copies); Pix2PixModel builds the same tensor with ops.seg_image_concat."""
+    n, c, h, w = x.shape
+    out = torch.zeros(n, h, w, D_CPAD, dtype=dtype, device=x.device)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(dtype)
+    return out
+
+
+class NLayerDiscriminator(BaseNetwork):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.add_argument('--n_layers_D', type=int, default=4, help='# layers in each discriminator')
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        kw = 4
+        self.padw = int(np.ceil((kw - 1.0) / 2))
+        nf = opt.ndf
+        input_nc = opt.label_nc + opt.output_nc
+        norm_layer = get_nonspade_norm_layer(opt, opt.norm_D)
+        sequence = [[nn.Conv2d(input_nc, nf, kernel_size=kw, stride=2, padding=self.padw), nn.LeakyReLU(0.2, False)]]
+        self.strides = [2]
+        for n in range(1, opt.n_layers_D):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            stride = 1 if n == opt.n_layers_D - 1 else 2
+            self.strides.append(stride)
+            sequence += [[norm_layer(nn.Conv2d(nf_prev, nf, kernel_size=kw, stride=stride, padding=self.padw)),
+                          nn.LeakyReLU(0.2, False)]]
+        sequence += [[nn.Conv2d(nf, 1, kernel_size=kw, stride=1, padding=self.padw)]]
+        self.strides.append(1)
+        for n in range(len(sequence)):
+            self.add_module('model' + str(n), nn.Sequential(*sequence[n]))
+        self.n_groups = len(sequence)
+
+    def forward_nhwc(self, x):
+        """x: (M,H,W,8).  Returns the NHWC outputs of model0..model{n} (after their activations)."""
+        feats = []
+        first = self.model0[0]
+        h = ops.conv2d(x, first.weight, first.bias, None, 2, self.padw, ACT_NONE, ACT_LRELU)   # conv + LeakyReLU, one launch
+        feats.append(h)
+        for n in range(1, self.n_groups - 1):
+            blk = getattr(self, 'model%d' % n)[0]
+            if isinstance(blk, nn.Sequential):                     # SN conv (bias removed) -> InstanceNorm -> LeakyReLU
+                conv = blk[0]
+                h = ops.conv2d(h, sn_weight(conv), None, None, self.strides[n], self.padw)
+                h = ops.instance_norm(h, lrelu=True)
+            else:                                                  # norm_D without a norm layer: conv -> LeakyReLU
+                h = ops.conv2d(h, sn_weight(blk), blk.bias, None, self.strides[n], self.padw, ACT_NONE, ACT_LRELU)
+            feats.append(h)
+        last = getattr(self, 'model%d' % (self.n_groups - 1))[0]
+        h = ops.conv2d(h, last.weight, last.bias, None, 1, self.padw)
+        feats.append(h)
+        return feats
+
+    def forward(self, input):
+        feats = self.forward_nhwc(input)
+        outs = [f.permute(0, 3, 1, 2) for f in feats]
+        return outs if not self.opt.no_ganFeat_loss else outs[-1]
+
+
+class MultiscaleDiscriminator(BaseNetwork):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.add_argument('--netD_subarch', type=str, default='n_layer', help='architecture of each discriminator')
+        parser.add_argument('--num_D', type=int, default=2, help='number of discriminators to be used in multiscale')
+        NLayerDiscriminator.modify_commandline_options(parser, is_train)
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.cdtype = compute_dtype_of(opt)
+        if opt.netD_subarch != 'n_layer':
+            raise ValueError('unrecognized discriminator subarchitecture %s' % opt.netD_subarch)
+        for i in range(opt.num_D):
+            self.add_module('discriminator_%d' % i, NLayerDiscriminator(opt))
+
+    def forward(self, input):
+        """input: (2N, label_nc+output_nc, H, W) as in the reference call (pix2pix_model.py:338), or
+        the already-built (2N,H,W,8) NHWC tensor.  Returns list[num_D] of list[n_layers_D+1] tensors,
+        logical NCHW (NHWC storage); list[num_D][1] with --no_ganFeat_loss (discriminator.py:53-63)."""
+        self.require_gpu(input)
+        x = input if (input.dim() == 4 and input.shape[-1] == D_CPAD and input.shape[1] != self.opt.label_nc + self.opt.output_nc) \
+            else to_d_input(input, self.cdtype)
+        result = []
+        keep_all = not self.opt.no_ganFeat_loss
+        for name, D in self.named_children():
+            feats = [f.permute(0, 3, 1, 2) for f in D.forward_nhwc(x)]
+            result.append(feats if keep_all else [feats[-1]])
+            x = ops.avgpool3x3s2(x)                    # F.avg_pool2d(3, 2, 1, count_include_pad=False)
+        return result

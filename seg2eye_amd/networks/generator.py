@@ -1,0 +1,62 @@
+"""SPADE+Style generator (reference models/networks/generator.py:13-101)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import ACT_LRELU, ACT_TANH
+from ..options import latent_size
+from .architecture import SPADE_STYLE_ResnetBlock
+from .base_network import BaseNetwork, compute_dtype_of
+from .normalization import SegMap
+
+
+class SPADESTYLEGenerator(BaseNetwork):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.add_argument('--num_upsampling_layers', choices=('normal', 'more'), default='normal',
+                            help="If 'more', adds upsampling layer between the two middle resnet blocks "
+                                 "('most' is broken in the reference and not offered)")
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.cdtype = compute_dtype_of(opt)
+        nf = opt.ngf
+        self.sw, self.sh = latent_size(opt)
+        self.fc = nn.Conv2d(opt.semantic_nc, 16 * nf, 3, padding=1)
+        self.head_0 = SPADE_STYLE_ResnetBlock(16 * nf, 16 * nf, opt)
+        self.G_middle_0 = SPADE_STYLE_ResnetBlock(16 * nf, 16 * nf, opt)
+        self.G_middle_1 = SPADE_STYLE_ResnetBlock(16 * nf, 16 * nf, opt)
+        self.up_0 = SPADE_STYLE_ResnetBlock(16 * nf, 8 * nf, opt)
+        self.up_1 = SPADE_STYLE_ResnetBlock(8 * nf, 4 * nf, opt)
+        self.up_2 = SPADE_STYLE_ResnetBlock(4 * nf, 2 * nf, opt)
+        self.up_3 = SPADE_STYLE_ResnetBlock(2 * nf, 1 * nf, opt)
+        self.conv_img = nn.Conv2d(nf, opt.output_nc, 3, padding=1)
+        self.up = nn.Upsample(scale_factor=2)          # kept for attribute parity; forward uses ops.upsample2x
+
+    def forward(self, input, w=None):
+        """input: one-hot segmap (N,label_nc,H,W) as in the reference call site
+        (pix2pix_model.py:316-318), or a label map / SegMap.  w: (N,w_dim) style code.
+        Returns (N,output_nc,H,W) in [-1,1] (compute dtype; NHWC storage)."""
+        seg = SegMap.of(input)
+        self.require_gpu(seg.label, w)
+        n, H, W = seg.shape
+        f = 32 if self.opt.num_upsampling_layers == 'normal' else 64
+        if (H, W) != (self.sh * f, self.sw * f):
+            raise ValueError('label map is %dx%d but this generator emits %dx%d (SURVEY F5)' % (H, W, self.sh * f, self.sw * f))
+        w = w.float()
+        # F.interpolate(seg, (sh, sw)) + fc conv, generator.py:72-73
+        x = ops.label_conv3x3(seg.label, self.fc.weight, self.fc.bias, self.sh, self.sw, False, self.cdtype)
+        x = self.head_0(x, seg, w)
+        x = ops.upsample2x(x)
+        x = self.G_middle_0(x, seg, w)
+        if self.opt.num_upsampling_layers == 'more':
+            x = ops.upsample2x(x)
+        x = self.G_middle_1(x, seg, w)
+        for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
+            x = ops.upsample2x(x)
+            x = blk(x, seg, w)
+        # conv_img(leaky_relu(x)) + tanh, generator.py:99-100: one launch
+        y = ops.conv2d(x, self.conv_img.weight, self.conv_img.bias, None, 1, 1, ACT_LRELU, ACT_TANH)
+        return y.permute(0, 3, 1, 2)

@@ -1,0 +1,61 @@
+"""GAN losses (reference models/networks/loss.py:17-99 and the feature-matching term of
+pix2pix_model.py:231-241) as HIP reductions."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import LOSS_NEG_MEAN, LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_L1
+
+
+def _flat(t):
+    """Any tensor whose storage order is irrelevant for an element-wise reduction -> contiguous."""
+    if t.is_contiguous():
+        return t
+    p = t.permute(0, 2, 3, 1) if t.dim() == 4 else t
+    return p if p.is_contiguous() else t.contiguous()
+
+
+class GANLoss(nn.Module):
+    """hinge GAN loss with the reference's list-of-lists handling (loss.py:85-99): the last output of
+    every scale, averaged over scales; returns a tensor of shape [1]."""
+
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0, tensor=None, opt=None):
+        super().__init__()
+        if gan_mode != 'hinge':
+            if gan_mode in ('ls', 'original', 'w'):
+                raise NotImplementedError("gan_mode '%s' is outside the hot path this build covers (hinge)" % gan_mode)
+            raise ValueError('Unexpected gan_mode {}'.format(gan_mode))
+        self.gan_mode = gan_mode
+        self.opt = opt
+
+    def loss(self, input, target_is_real, for_discriminator=True):
+        x = _flat(input)
+        n = x.numel()
+        if for_discriminator:
+            mode = LOSS_HINGE_REAL if target_is_real else LOSS_HINGE_FAKE
+        else:
+            assert target_is_real, "The generator's hinge loss must be aiming for real"
+            mode = LOSS_NEG_MEAN
+        return ops.loss_sum(x, None, mode, 1.0 / n)
+
+    def __call__(self, input, target_is_real, for_discriminator=True):
+        if isinstance(input, list):
+            total = 0
+            for pred_i in input:
+                if isinstance(pred_i, list):
+                    pred_i = pred_i[-1]
+                total = total + self.loss(pred_i, target_is_real, for_discriminator).view(1)
+            return total / len(input)
+        return self.loss(input, target_is_real, for_discriminator)
+
+
+def feature_matching_loss(pred_fake, pred_real, lambda_feat):
+    """sum_i sum_{j<last} L1mean(fake_ij, real_ij.detach()) * lambda_feat / num_D, shape [1]."""
+    num_D = len(pred_fake)
+    total = None
+    for i in range(num_D):
+        for j in range(len(pred_fake[i]) - 1):
+            a, b = _flat(pred_fake[i][j]), _flat(pred_real[i][j].detach())
+            term = ops.loss_sum(a, b, LOSS_L1, lambda_feat / num_D / a.numel())
+            total = term if total is None else total + term
+    return total.view(1)

@@ -1,0 +1,138 @@
+"""SPADE+Style block and the style FC (reference models/networks/normalization.py).
+
+Parameter containers keep the reference's attribute names so state_dict keys match
+(`spade.mlp_shared.0.weight`, `spade.mlp_gamma.weight`, `adain.linear.weight`, ...); the forward is
+three HIP launches: label-gather conv (mlp_shared on the nearest-downsampled label map), one
+implicit-GEMM conv producing [gamma | beta], and the fused modulation kernel."""
+import re
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class SegMap:
+    """The segmentation input of the generator as the kernels want it: a uint8 label map
+    (N,H,W) on the GPU.  Built once per forward from whatever the caller passed: the one-hot
+    float tensor of the reference API (pix2pix_model.py:146-154), a (N,1,H,W)/(N,H,W) label map,
+    or another SegMap."""
+
+    def __init__(self, label):
+        assert label.dtype == torch.uint8 and label.dim() == 3
+        self.label = label.contiguous()
+
+    @property
+    def shape(self):
+        return tuple(self.label.shape)
+
+    @staticmethod
+    def of(seg):
+        if isinstance(seg, SegMap):
+            return seg
+        if seg.dim() == 4 and seg.shape[1] > 1 and seg.is_floating_point():      # one-hot (N,nc,H,W)
+            return SegMap(seg.argmax(dim=1).to(torch.uint8))
+        if seg.dim() == 4 and seg.shape[1] == 1:
+            seg = seg[:, 0]
+        return SegMap(seg.to(torch.uint8))
+
+
+class SPADE(nn.Module):
+    """Parameter holder for SPADE (normalization.py:63-105).  Only `instance` is built: it is the
+    variant the hot path is defined on; `batch` needs cross-sample statistics and is a
+    follow-up row."""
+
+    def __init__(self, config_text, norm_nc, label_nc):
+        super().__init__()
+        assert config_text.startswith('spade')
+        parsed = re.search(r'spade(\D+)(\d)x\d', config_text)
+        kind, ks = str(parsed.group(1)), int(parsed.group(2))
+        if kind != 'instance':
+            raise ValueError('%s is not a param-free norm type this build supports in SPADE '
+                             '(only instance)' % kind)
+        if ks != 3:
+            raise ValueError('SPADE kernel size %d not supported (3 only)' % ks)
+        nhidden = 128
+        self.mlp_shared = nn.Sequential(nn.Conv2d(label_nc, nhidden, kernel_size=3, padding=1), nn.ReLU())
+        self.mlp_gamma = nn.Conv2d(nhidden, norm_nc, kernel_size=3, padding=1)
+        self.mlp_beta = nn.Conv2d(nhidden, norm_nc, kernel_size=3, padding=1)
+
+    def gamma_beta(self, seg, h, w, dtype):
+        """[gamma | beta] as one (N,h,w,2C) tensor."""
+        w_gb = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], 0)
+        b_gb = torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], 0)
+        return ops.spade_params(seg.label, self.mlp_shared[0].weight, self.mlp_shared[0].bias, w_gb, b_gb, h, w, dtype)
+
+
+class FC(nn.Module):
+    """Dense layer of the style path (normalization.py:108-141): fp32 torch ops on (N, w_dim)."""
+
+    def __init__(self, in_channels, out_channels, gain=2 ** 0.5, use_wscale=False, lrmul=1.0, bias=True):
+        super().__init__()
+        he_std = gain * in_channels ** (-0.5)
+        if use_wscale:
+            init_std = 1.0 / lrmul
+            self.w_lrmul = he_std * lrmul
+        else:
+            init_std = he_std / lrmul
+            self.w_lrmul = lrmul
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels) * init_std)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+            self.b_lrmul = lrmul
+        else:
+            self.bias = None
+
+    def forward(self, x):
+        b = None if self.bias is None else self.bias * self.b_lrmul
+        return F.leaky_relu(F.linear(x.float(), self.weight * self.w_lrmul, b), 0.2)
+
+
+class ApplyStyle(nn.Module):
+    """Holds the style FC (normalization.py:144-169); its affine x*(s0+1)+s1 is applied inside the
+    fused modulation kernel."""
+
+    def __init__(self, latent_size, channels, use_wscale):
+        super().__init__()
+        self.linear = FC(latent_size, channels * 2, gain=1.0, use_wscale=use_wscale)
+
+
+class SPADE_STYLE_Block(nn.Module):
+    """out = (SPADE(x, seg) + ApplyStyle(x, w)) / 2  (normalization.py:172-192), optionally with the
+    LeakyReLU(0.2) that follows it in the ResBlk (architecture.py:61) fused in.
+    x: (N,h,w,C) NHWC compute-dtype tensor.  stats: in_stats(x) if the caller already has them."""
+
+    def __init__(self, fin, opt):
+        super().__init__()
+        self.spade = SPADE(opt.norm_G.replace('spectral', ''), fin, opt.semantic_nc)
+        self.adain = ApplyStyle(opt.w_dim, channels=fin, use_wscale=False)
+
+    def forward(self, x, segmap, latent_style, stats=None, lrelu=False):
+        seg = SegMap.of(segmap)
+        n, h, w, c = x.shape
+        gb = self.spade.gamma_beta(seg, h, w, x.dtype)
+        style = self.adain.linear(latent_style)                     # (N, 2C) fp32
+        if stats is None:
+            stats = ops.in_stats(x.detach())
+        return ops.spade_style_modulate(x, gb, style, stats, lrelu)
+
+
+def get_nonspade_norm_layer(opt, norm_type='instance'):
+    """normalization.py:15-47 for the variants the hot path uses: 'spectralinstance' (and
+    'spectralnone' / 'instance' / 'none').  Returns add_norm_layer(conv) -> nn.Sequential(conv[, IN])
+    with the conv's bias removed when a norm follows, so state_dict keys match (`model1.0.0.weight_orig`)."""
+    def add_norm_layer(layer):
+        sub = norm_type
+        if norm_type.startswith('spectral'):
+            layer = nn.utils.spectral_norm(layer)
+            sub = norm_type[len('spectral'):]
+        if sub == 'none' or len(sub) == 0:
+            return layer
+        if getattr(layer, 'bias', None) is not None:
+            delattr(layer, 'bias')
+            layer.register_parameter('bias', None)
+        if sub == 'instance':
+            return nn.Sequential(layer, nn.InstanceNorm2d(layer.out_channels, affine=False))
+        raise ValueError('normalization layer %s is not supported by this build (instance only)' % sub)
+    return add_norm_layer

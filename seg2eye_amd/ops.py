@@ -150,7 +150,7 @@ class Conv2dFn(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act)
         ctx.cfg = (stride, pad, in_act, out_act, bias is not None, residual is not None)
-        ctx.save_for_backward(x, weight, y if out_act == ACT_TANH else None)
+        ctx.save_for_backward(x, weight, y if out_act != ACT_NONE else None)
         return y
 
     @staticmethod
@@ -164,8 +164,10 @@ class Conv2dFn(torch.autograd.Function):
             g2 = torch.empty_like(g)
             L.check(L.lib().s2e_tanh_bwd(_dt(g), _p(g), _p(y), _p(g2), g.numel(), _stream()), 's2e_tanh_bwd')
             g = g2
-        elif out_act != ACT_NONE:
-            raise NotImplementedError('backward of out_act=%d' % out_act)
+        elif out_act == ACT_LRELU:
+            g2 = torch.empty_like(g)
+            L.check(L.lib().s2e_lrelu_bwd(_dt(g), _p(g), _p(y), _p(g2), g.numel(), _stream()), 's2e_lrelu_bwd')
+            g = g2
         gx = gw = gb = gres = None
         if ctx.needs_input_grad[0]:
             wpt = pack_weight(weight, x.dtype, cx, True)

@@ -1,0 +1,73 @@
+"""Flat-arena Adam: every parameter of a group lives in ONE fp32 buffer (and its gradient in another),
+so the optimizer step is a single HIP launch (s2e_adam_flat) and the data-parallel gradient exchange is
+an all-reduce over contiguous slices with no packing.  Mirrors torch.optim.Adam as the reference
+configures it (models/pix2pix_model.py:92-110): TTUR betas (0, 0.9), eps 1e-8, weight_decay 0."""
+import torch
+
+from . import ops
+
+_ALIGN = 4          # elements; keeps every parameter 16-byte aligned inside the arena
+
+
+class FlatAdam:
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if weight_decay:
+            raise NotImplementedError('weight_decay != 0 is outside the reference defaults this build covers')
+        seen, plist = set(), []
+        for p in params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                plist.append(p)
+        if not plist:
+            raise ValueError('FlatAdam got an empty parameter list')
+        dev = plist[0].device
+        self.offsets, n = [], 0
+        for p in plist:
+            if p.dtype != torch.float32:
+                raise TypeError('FlatAdam keeps fp32 master parameters')
+            self.offsets.append(n)
+            n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(plist, self.offsets):
+                view = self.flat_p[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view                                           # parameter now aliases the arena
+                p.grad = self.flat_g[off:off + p.numel()].view(p.shape)  # autograd accumulates in place
+        self.params = plist
+        self.betas = (float(betas[0]), float(betas[1]))                   # (0, 0.9) must be floats
+        self.eps = float(eps)
+        self.step_count = 0
+        self.param_groups = [{'params': plist, 'lr': float(lr)}]         # update_learning_rate writes ['lr']
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+
+    def rebind_grads(self):
+        """Re-attach .grad views if something replaced them (e.g. a zero_grad(set_to_none=True))."""
+        for p, off in zip(self.params, self.offsets):
+            g = p.grad
+            want = self.flat_g[off:off + p.numel()].view(p.shape)
+            if g is None or g.data_ptr() != want.data_ptr():
+                if g is not None:
+                    want.copy_(g)
+                p.grad = want
+
+    def step(self, grad_scale=1.0):
+        self.rebind_grads()
+        self.step_count += 1
+        ops.adam_flat_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.param_groups[0]['lr'],
+                           self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale)
+
+    def state_dict(self):
+        return {'step': self.step_count, 'm': self.flat_m, 'v': self.flat_v, 'lr': self.param_groups[0]['lr']}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        self.flat_m.copy_(sd['m'])
+        self.flat_v.copy_(sd['v'])
+        self.param_groups[0]['lr'] = float(sd['lr'])

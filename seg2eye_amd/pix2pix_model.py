@@ -1,0 +1,193 @@
+"""Pix2PixModel: mode-dispatched model of the reference (models/pix2pix_model.py:13-374) for the
+G+D train step and inference, over the HIP networks.
+
+Same constructor, forward(data, mode) modes and return types, create_optimizers, save,
+loss-log helpers and netG/netD/netE attributes.  Deliberate, documented differences:
+  * labels stay uint8 on the GPU (no one-hot tensor is materialised for G; D's 5-channel input is built
+    by one kernel), and 3-D (N,H,W) labels are handled correctly for N > 1;
+  * the per-sample python loop over netE (pix2pix_model.py:280-290) is one batched call, with the
+    skipped spectral-norm power iterations made up first (encoder.extra_power_iterations);
+  * netE is loaded whenever netG is;
+  * D's weight gradients are not computed during the G step (the reference computes and then zeroes
+    them, trainers/pix2pix_trainer.py:38) -- the parameters after the step are identical.
+"""
+import torch
+import torch.nn as nn
+
+from . import checkpoint, networks, ops
+from ._lib import LOSS_L1
+from .networks.base_network import compute_dtype_of
+from .networks.normalization import SegMap
+from .optim import FlatAdam
+
+
+class Pix2PixModel(nn.Module):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        networks.modify_commandline_options(parser, is_train)
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.cdtype = compute_dtype_of(opt)
+        if 'batch' in opt.norm_G:
+            raise NotImplementedError('norm_G=%s: only the InstanceNorm SPADE variant is built (SURVEY F2)' % opt.norm_G)
+        self.netG, self.netD, self.netE = self.initialize_networks(opt)
+        if opt.isTrain:
+            self.criterionGAN = networks.GANLoss(opt.gan_mode, opt=opt)
+            if not opt.no_vgg_loss:
+                raise NotImplementedError('VGGLoss does not exist in the reference either (SURVEY F1); '
+                                          'keep --no_vgg_loss')
+            for name in ('lambda_l2', 'lambda_openeds', 'lambda_style_w', 'lambda_style_feat', 'lambda_gram'):
+                if getattr(opt, name, 0):
+                    raise NotImplementedError('%s != 0 is outside the hot path built so far' % name)
+            self.reset_loss_log()
+
+    # ------------------------------------------------------------------ loss log (pix2pix_model.py:49-59)
+    def get_loss_log(self):
+        return {k: torch.mean(torch.stack(v)) for k, v in self.loss_log.items() if len(v)}
+
+    def add_to_loss_log(self, key, value):
+        self.loss_log.setdefault(key, []).append(value)
+
+    def reset_loss_log(self):
+        self.loss_log = {}
+
+    # ------------------------------------------------------------------ entry point
+    def forward(self, data, mode):
+        seg, style_image, target_image = self.preprocess_input(data)
+        if mode == 'generator':
+            return self.compute_generator_loss(seg, style_image, target_image)
+        elif mode == 'discriminator':
+            return self.compute_discriminator_loss(seg, style_image, target_image)
+        elif mode == 'encode_only':
+            w, _ = self.encode_w(style_image)
+            return w
+        elif mode == 'inference':
+            with torch.no_grad():
+                if 'latent_style' in data:
+                    fake_image = self.generate_fake_from_stylecode(seg, data['latent_style'].to(self.device()))
+                else:
+                    fake_image, _, _ = self.generate_fake(seg, style_image)
+                self.reset_loss_log()
+            return fake_image
+        raise ValueError("|mode| is invalid")
+
+    def create_optimizers(self, opt):
+        """TTUR: betas (0, 0.9), lr_G = lr/2 over netG+netE, lr_D = 2*lr (pix2pix_model.py:92-110)."""
+        G_params = list(self.netG.parameters()) + list(self.netE.parameters())
+        if opt.no_TTUR:
+            beta1, beta2, G_lr, D_lr = opt.beta1, opt.beta2, opt.lr, opt.lr
+        else:
+            beta1, beta2, G_lr, D_lr = 0.0, 0.9, opt.lr / 2, opt.lr * 2
+        optimizer_G = FlatAdam(G_params, lr=G_lr, betas=(beta1, beta2), weight_decay=opt.weight_decay)
+        optimizer_D = FlatAdam(list(self.netD.parameters()), lr=D_lr, betas=(beta1, beta2),
+                               weight_decay=opt.weight_decay) if opt.isTrain else None
+        return optimizer_G, optimizer_D
+
+    def save(self, epoch):
+        checkpoint.save_network(self.netG, 'G', epoch, self.opt)
+        checkpoint.save_network(self.netD, 'D', epoch, self.opt)
+        checkpoint.save_network(self.netE, 'E', epoch, self.opt)
+
+    # ------------------------------------------------------------------ helpers
+    def device(self):
+        return next(self.netG.parameters()).device
+
+    def initialize_networks(self, opt):
+        netG = networks.define_G(opt)
+        netD = networks.define_D(opt) if opt.isTrain else None
+        netE = networks.define_E(opt)
+        if not opt.isTrain or opt.continue_train:
+            checkpoint.load_network(netG, 'G', opt.which_epoch, opt)
+            checkpoint.load_network(netE, 'E', opt.which_epoch, opt)
+            if opt.isTrain:
+                checkpoint.load_network(netD, 'D', opt.which_epoch, opt)
+        return netG, netD, netE
+
+    def preprocess_input(self, data):
+        """Move to the GPU; the label map becomes a uint8 SegMap instead of a one-hot float tensor
+        (pix2pix_model.py:138-160)."""
+        dev = self.device()
+        label = data['label']
+        if label.dim() == 4:
+            label = label[:, 0]
+        elif label.dim() == 2:
+            label = label.unsqueeze(0)
+        seg = SegMap(label.to(dev).to(torch.uint8))
+        style = data['style_image'].to(dev)
+        target = data['target'].to(dev) if 'target' in data else None
+        return seg, style, target
+
+    def compute_generator_loss(self, seg, style_image, target_image):
+        G_losses = {}
+        fake_image, _, _ = self.generate_fake(seg, style_image)
+        d_params = list(self.netD.parameters())
+        flags = [p.requires_grad for p in d_params]
+        for p in d_params:                      # D's weight grads are dead in the G step
+            p.requires_grad_(False)
+        try:
+            pred_fake, pred_real = self.discriminate(seg, fake_image, target_image)
+        finally:
+            for p, f in zip(d_params, flags):
+                p.requires_grad_(f)
+        G_losses['GAN'] = self.criterionGAN(pred_fake, True, for_discriminator=False)
+        if self.opt.lambda_l1:
+            a = fake_image.permute(0, 2, 3, 1)
+            b = target_image.to(a.dtype).permute(0, 2, 3, 1).contiguous()
+            l1 = ops.loss_sum(a, b, LOSS_L1, 1.0 / a.numel()).view(1)
+            G_losses['L1/weighted'] = l1 * self.opt.lambda_l1
+            self.add_to_loss_log('L1/raw', l1.detach())
+        if not self.opt.no_ganFeat_loss:
+            G_losses['GAN_Feat'] = networks.feature_matching_loss(pred_fake, pred_real, self.opt.lambda_feat)
+        return G_losses, fake_image
+
+    def compute_discriminator_loss(self, seg, real_image, target_image):
+        with torch.no_grad():
+            fake_image, _, _ = self.generate_fake(seg, real_image)
+        fake_image = fake_image.detach()
+        pred_fake, pred_real = self.discriminate(seg, fake_image, target_image)
+        return {'D/Fake': self.criterionGAN(pred_fake, False, for_discriminator=True),
+                'D/real': self.criterionGAN(pred_real, True, for_discriminator=True)}
+
+    def _aggregate(self, t, dim=1):
+        if self.opt.style_aggr_method == 'mean':
+            return torch.mean(t, dim=dim)
+        if self.opt.style_aggr_method == 'max':
+            return torch.max(t, dim=dim).values
+        raise ValueError('Aggregation method not found: %s' % self.opt.style_aggr_method)
+
+    def encode_w(self, real_image):
+        """(N, input_ns, 1, h, w) style images -> w (N, w_dim) = aggregate over the style dimension of
+        netE's mu (pix2pix_model.py:271-314), as ONE batched netE call."""
+        if real_image.dim() != 5:
+            raise ValueError('real_image should have 5 dimensions')
+        n, ns = real_image.shape[:2]
+        self.netE.extra_power_iterations(n - 1)
+        mu, _, feats = self.netE(real_image.reshape(n * ns, *real_image.shape[2:]))
+        return self._aggregate(mu.view(n, ns, -1)), feats
+
+    def generate_fake_from_stylecode(self, seg, latent_style):
+        return self.netG(seg, latent_style)
+
+    def generate_fake(self, seg, style_image):
+        latent_style, feats = self.encode_w(style_image)
+        return self.generate_fake_from_stylecode(seg, latent_style), latent_style, feats
+
+    def discriminate(self, seg, fake_image, real_image):
+        """D on cat over the batch of [cat(seg, fake); cat(seg, real)] (pix2pix_model.py:328-342); the
+        (2N,H,W,8) input is built by one kernel from the label map and the two image batches."""
+        imgs = torch.cat([fake_image[:, 0].to(self.cdtype), real_image[:, 0].to(self.cdtype)], 0).contiguous()
+        labels = torch.cat([seg.label, seg.label], 0)
+        out = self.netD(ops.seg_image_concat(labels, imgs, self.opt.label_nc, networks.discriminator.D_CPAD))
+        return self.divide_pred(out)
+
+    @staticmethod
+    def divide_pred(pred):
+        fake = [[t[:t.size(0) // 2] for t in p] for p in pred]
+        real = [[t[t.size(0) // 2:] for t in p] for p in pred]
+        return fake, real
+
+    def use_gpu(self):
+        return len(self.opt.gpu_ids) > 0

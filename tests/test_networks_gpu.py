@@ -1,0 +1,306 @@
+"""Network-level parity of the HIP path (through define_G/define_D/define_E, Pix2PixModel and
+Pix2PixTrainer) against (a) the golden vectors produced by the REAL reference and (b) the CPU oracle
+on the same seeded inputs.
+
+Tolerances: the north-star bar for the fp32 generator is max-abs-diff < 1e-3 on trained-scale weights
+(output std ~0.5); gradients and parameters are compared through the fixtures' checksums with a
+relative bound; bf16 runs are compared against the fp32 result with a bound that reflects bf16's
+8 significant bits through ~40 layers."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, filled_state, manifest_of, assert_checksum_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+G_TOL = 1e-3        # north_star: generator output max-abs-diff vs the CPU reference path, fp32
+KINK_TOL = 2e-2     # whole-network gradients (see test_generator_fp32_matches_reference)
+
+
+def _opt(**kw):
+    from seg2eye_amd.options import default_opt
+    kw.setdefault('gpu_ids', [0])
+    return default_opt(**kw)
+
+
+def _load(net, z, prefix):
+    sd = filled_state(z, prefix)
+    net.load_state_dict(sd)
+    return net
+
+
+def _label(z):
+    return torch.from_numpy(z['label']).to(DEV)       # (N,1,H,W) uint8
+
+
+@pytest.mark.parametrize('tag,ngf,crop,ar', [('g_ngf8_64', 8, 64, 1.0), ('g_ngf16_128x64', 16, 64, 0.5)])
+def test_generator_fp32_matches_reference(tag, ngf, crop, ar):
+    from seg2eye_amd import networks
+    z = load_golden(tag)
+    opt = _opt(ngf=ngf, crop_size=crop, aspect_ratio=ar, compute_dtype='fp32')
+    G = _load(networks.define_G(opt), z, 'G')
+    w = torch.from_numpy(z['w']).to(DEV)
+    G.eval()
+    with torch.no_grad():
+        y = G(_label(z), w)
+    assert y.shape == z['y_eval'].shape
+    err = float((y.float().cpu() - torch.from_numpy(z['y_eval'])).abs().max())
+    assert err < G_TOL, 'eval-mode G output differs from the reference by %.3e' % err
+    # also accepts the one-hot float tensor of the reference call site
+    onehot = torch.zeros(z['label'].shape[0], 4, *z['label'].shape[2:], device=DEV).scatter_(1, _label(z).long(), 1.0)
+    with torch.no_grad():
+        y2 = G(onehot, w)
+    assert torch.equal(y, y2)
+    # backward (eval mode): every parameter gradient vs the reference's checksums
+    G.zero_grad()
+    wt = w.clone().requires_grad_(True)
+    yg = G(_label(z), wt)
+    from seg2eye_amd import synthetic as syn
+    proj = torch.from_numpy(syn.hash_uniform('g_proj', tuple(yg.shape), seed=7)).to(DEV)
+    (yg.float() * proj).sum().backward()
+    # Whole-network gradients are compared with a kink-tolerant bound: a LeakyReLU pre-activation that
+    # sits within fp32 rounding of 0 may fall on either side in two fp32 implementations, and one
+    # flipped mask element moves every upstream gradient by a few 1e-3 (measured: exactly one such
+    # element in this fixture; all other intermediate gradients agree to 1e-6).  The tight gradient
+    # checks live in test_resblk_matches_oracle_tight / test_modules_fp32_match_reference.
+    gw = z['grad_w']
+    assert float((wt.grad.cpu() - torch.from_numpy(gw)).abs().max()) < KINK_TOL * np.abs(gw).max()
+    for k, p in G.named_parameters():
+        assert_checksum_close(p.grad, z['grad_' + k], KINK_TOL, k)
+    # one train-mode forward from the pinned u, v: output and post-forward buffers
+    G.train()
+    with torch.no_grad():
+        yt = G(_label(z), w)
+    err = float((yt.float().cpu() - torch.from_numpy(z['y_train'])).abs().max())
+    assert err < G_TOL, 'train-mode G output differs by %.3e' % err
+    sd = G.state_dict()
+    for k in [k[3:] for k in z.files if k.startswith('uv_')]:
+        np.testing.assert_allclose(sd[k].cpu().numpy(), z['uv_' + k], atol=2e-5, rtol=0)
+
+
+def test_generator_bf16_close_to_fp32():
+    from seg2eye_amd import networks
+    z = load_golden('g_ngf16_128x64')
+    outs = {}
+    for dt in ('fp32', 'bf16'):
+        opt = _opt(ngf=16, crop_size=64, aspect_ratio=0.5, compute_dtype=dt)
+        G = _load(networks.define_G(opt), z, 'G').eval()
+        with torch.no_grad():
+            outs[dt] = G(_label(z), torch.from_numpy(z['w']).to(DEV)).float().cpu()
+    assert outs['bf16'].dtype == torch.float32
+    d = (outs['bf16'] - outs['fp32']).abs()
+    assert float(d.mean()) < 2e-2 and float(d.max()) < 0.25, (float(d.mean()), float(d.max()))
+
+
+def test_discriminator_and_losses_fp32():
+    from seg2eye_amd import networks, ops
+    z = load_golden('d_ndf8_32')
+    opt = _opt(ndf=8, crop_size=32, compute_dtype='fp32')
+    D = _load(networks.define_D(opt), z, 'D').eval()
+    lab = _label(z)[:, 0]
+    fake = torch.from_numpy(z['fake']).to(DEV).requires_grad_(True)
+    real = torch.from_numpy(z['real']).to(DEV)
+    imgs = torch.cat([fake[:, 0], real[:, 0]], 0)
+    x = ops.seg_image_concat(torch.cat([lab, lab], 0), imgs)
+    pred = D(x)
+    for i in range(2):
+        for j in range(5):
+            ref = z['pred_%d_%d' % (i, j)]
+            if ref.ndim == 1 and ref.shape[0] == 18:
+                assert_checksum_close(pred[i][j].contiguous(), ref, 1e-4, 'pred%d%d' % (i, j))
+            else:
+                np.testing.assert_allclose(pred[i][j].detach().cpu().numpy(), ref, atol=2e-4, rtol=0)
+    # reference API: the NCHW 5-channel tensor gives the same result
+    onehot = torch.zeros(2, 4, 32, 32, device=DEV).scatter_(1, lab.long().unsqueeze(1), 1.0)
+    xin = torch.cat([torch.cat([onehot, fake.detach()], 1), torch.cat([onehot, real], 1)], 0)
+    pred2 = D(xin)
+    assert torch.equal(pred2[1][4], pred[1][4].detach())
+    crit = networks.GANLoss('hinge', opt=opt)
+    pf = [[t[:2] for t in p] for p in pred]
+    pr = [[t[2:] for t in p] for p in pred]
+    l_g = crit(pf, True, for_discriminator=False)
+    l_df = crit(pf, False, for_discriminator=True)
+    l_dr = crit(pr, True, for_discriminator=True)
+    feat = networks.feature_matching_loss(pf, pr, 10.0)
+    for got, key in ((l_g, 'l_g'), (l_df, 'l_df'), (l_dr, 'l_dr'), (feat, 'l_feat')):
+        assert tuple(got.shape) == (1,)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), z[key], atol=2e-5, rtol=2e-5)
+    params = dict(D.named_parameters())
+    grads = torch.autograd.grad((l_g + feat).sum(), [fake] + list(params.values()), retain_graph=True)
+    gf = z['grad_fake']
+    assert float((grads[0].cpu() - torch.from_numpy(gf)).abs().max()) < KINK_TOL * np.abs(gf).max()
+    for k, g in zip(params, grads[1:]):
+        assert_checksum_close(g, z['gradG_' + k], KINK_TOL, k)
+    grads = torch.autograd.grad((l_df + l_dr).sum(), list(params.values()))
+    for k, g in zip(params, grads):
+        assert_checksum_close(g, z['gradD_' + k], KINK_TOL, k)
+
+
+def test_encoder_fp32():
+    from seg2eye_amd import networks
+    z = load_golden('e_ngf8')
+    opt = _opt(ngf=8, crop_size=256, compute_dtype='fp32')
+    E = _load(networks.define_E(opt), z, 'E').eval()
+    with torch.no_grad():
+        mu, logvar, feats = E(torch.from_numpy(z['x']).to(DEV))
+    np.testing.assert_allclose(mu.cpu().numpy(), z['mu'], atol=3e-4, rtol=0)
+    np.testing.assert_allclose(logvar.cpu().numpy(), z['logvar'], atol=3e-4, rtol=0)
+    np.testing.assert_allclose(feats[-1].float().cpu().numpy(), z['feat_last'], atol=3e-4, rtol=0)
+
+
+def _batch(n, h, w, seed):
+    from seg2eye_amd import synthetic as syn
+    b = syn.make_batch(n, h, w, seed=seed)
+    return {'label': torch.from_numpy(b['label']), 'style_image': torch.from_numpy(b['style_image']),
+            'target': torch.from_numpy(b['target']), 'filename': b['filename']}
+
+
+def test_trainer_two_iterations_fp32_match_reference():
+    """T1: G-step, D-step, G-step, D-step through Pix2PixTrainer on the HIP path vs the REAL
+    reference's losses and parameter/buffer checksums (TTUR Adam, double power iteration, G
+    regeneration in the D step)."""
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    z = load_golden('trainer_ngf8_256')
+    opt = _opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='fp32')
+    tr = Pix2PixTrainer(opt)
+    m = tr.pix2pix_model
+    for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+        sd = filled_state(z, tag)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(sd[k])                           # in place: parameters alias the Adam arenas
+    data = _batch(2, 256, 256, 21)
+    for it in range(2):
+        tr.run_generator_one_step(dict(data))
+        tr.run_discriminator_one_step(dict(data))
+        for k, v in tr.get_latest_losses().items():
+            ref = z['it%d_%s' % (it, k.replace('/', '_'))]
+            np.testing.assert_allclose(v.detach().cpu().numpy().reshape(ref.shape), ref, rtol=2e-3, atol=2e-4,
+                                       err_msg='it%d %s' % (it, k))
+        if it == 0:
+            sub = tr.get_latest_generated().detach()[:, :, ::8, ::8].float().cpu().numpy()
+            assert np.abs(sub - z['it0_fake_sub']).max() < G_TOL
+        for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+            for k, v in net.state_dict().items():
+                assert_checksum_close(v, z['it%d_ck_%s.%s' % (it, tag, k)], 2e-3, 'it%d %s.%s' % (it, tag, k))
+
+
+def test_model_modes_and_bf16_step():
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    z = load_golden('trainer_ngf8_256')
+    opt = _opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='bf16')
+    tr = Pix2PixTrainer(opt)
+    m = tr.pix2pix_model
+    for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+        sd = filled_state(z, tag)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(sd[k])
+    data = _batch(2, 256, 256, 21)
+    w = m(dict(data), 'encode_only')
+    assert tuple(w.shape) == (2, 16)
+    fake = m(dict(data), 'inference')
+    assert tuple(fake.shape) == (2, 1, 256, 256) and float(fake.abs().max()) <= 1.0
+    fake2 = m({**data, 'latent_style': w.detach().cpu()}, 'inference')
+    assert tuple(fake2.shape) == (2, 1, 256, 256)
+    with pytest.raises(ValueError):
+        m(dict(data), 'nonsense')
+    tr.run_generator_one_step(dict(data))
+    tr.run_discriminator_one_step(dict(data))
+    losses = {k: float(v) for k, v in tr.get_latest_losses().items()}
+    assert set(losses) == {'GAN', 'GAN_Feat', 'D/Fake', 'D/real'}
+    ref = {k: float(z['it0_%s' % k.replace('/', '_')]) for k in losses}
+    for k in losses:                                     # bf16 step stays close to the fp32 reference
+        assert abs(losses[k] - ref[k]) < 0.05 * max(1.0, abs(ref[k])), (k, losses[k], ref[k])
+
+
+def test_full_size_generator_fp32_pin():
+    """Config 2 (BASELINE.json): ngf=64, 256x256, N=8, fp32 eval-mode G vs the reference's output
+    (every 8th pixel + moments stored in the fixture)."""
+    from seg2eye_amd import networks, synthetic as syn
+    z = load_golden('g_ngf64_256_pin')
+    opt = _opt(ngf=64, crop_size=256, aspect_ratio=1.0, compute_dtype='fp32')
+    G = networks.define_G(opt)
+    sd = syn.fill_state_dict(manifest_of(z, 'G'))
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    G.eval()
+    label = torch.from_numpy(syn.ellipse_labels(8, 256, 256, seed=1234)).to(DEV)
+    w = torch.from_numpy(syn.hash_normal('latent_w', (8, 16), seed=1234)).to(DEV)
+    with torch.no_grad():
+        y = G(label, w).float().cpu()
+    err = float((y[:, :, ::8, ::8] - torch.from_numpy(z['y_sub'])).abs().max())
+    assert err < G_TOL, 'full-size G differs from the reference by %.3e' % err
+    np.testing.assert_allclose([float(y.mean()), float(y.std())], z['stats'][:2], atol=1e-4)
+
+
+def test_modules_fp32_match_reference():
+    """G3: SPADE_STYLE_Block and both ResBlk flavours (fin == fout, fin != fout) vs the reference's
+    outputs, input gradients and parameter-gradient checksums."""
+    from seg2eye_amd import synthetic as syn
+    from seg2eye_amd.networks.architecture import SPADE_STYLE_ResnetBlock
+    from seg2eye_amd.networks.normalization import SPADE_STYLE_Block, SegMap
+    z = load_golden('modules')
+    opt = _opt(ngf=8, crop_size=64, compute_dtype='fp32')
+    seg = SegMap.of(_label(z))
+    C = 16
+    errs = []
+    for name, ctor in (('ssb', lambda: SPADE_STYLE_Block(C, opt)),
+                       ('res_same', lambda: SPADE_STYLE_ResnetBlock(C, C, opt)),
+                       ('res_diff', lambda: SPADE_STYLE_ResnetBlock(C, C // 2, opt))):
+        m = ctor().to(DEV)
+        m.load_state_dict(filled_state(z, name))
+        m.eval()
+        x = torch.from_numpy(z['x']).to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+        w = torch.from_numpy(z['w']).to(DEV).requires_grad_(True)
+        y = m(x, seg, w)
+        yr = z[name + '_y']
+        e = float((y.permute(0, 3, 1, 2).cpu() - torch.from_numpy(yr)).abs().max())
+        errs.append((name + ' y', e, 2e-4 * np.abs(yr).max()))
+        proj = torch.from_numpy(syn.hash_uniform('proj_' + name, yr.shape, seed=11)).to(DEV).permute(0, 2, 3, 1)
+        (y * proj).sum().backward()
+        for key, got in (('_dx', x.grad.permute(0, 3, 1, 2)), ('_dw', w.grad)):
+            ref = z[name + key]
+            errs.append((name + key, float((got.cpu() - torch.from_numpy(ref)).abs().max()), 1e-3 * np.abs(ref).max()))
+        for k, p in m.named_parameters():
+            ref = z['%s_grad_%s' % (name, k)]
+            from conftest import checksum
+            got = checksum(p.grad)
+            errs.append(('%s:%s' % (name, k), abs(got[1] - ref[1]) + abs(got[0] - ref[0]), 2e-3 * ref[1]))
+    bad = [e for e in errs if not e[1] <= e[2]]
+    assert not bad, '\n'.join('%s err %.3e > %.3e' % e for e in bad)
+
+
+@pytest.mark.parametrize('fin,fout,name', [(16, 8, 'res_diff'), (16, 16, 'res_same')])
+@pytest.mark.parametrize('hw', [16, 64])
+def test_resblk_matches_oracle_tight(fin, fout, name, hw):
+    """One SPADE+Style ResBlk, forward and every gradient, against the CPU oracle at 1e-5 relative."""
+    from oracle import seg2eye_oracle as O
+    from seg2eye_amd import synthetic as syn
+    from seg2eye_amd.networks.architecture import SPADE_STYLE_ResnetBlock
+    from seg2eye_amd.networks.normalization import SegMap
+    z = load_golden('modules')
+    sd = filled_state(z, name)
+    opt = _opt(ngf=8, crop_size=64, compute_dtype='fp32')
+    lab = torch.from_numpy(syn.ellipse_labels(2, 64, 64, seed=11))
+    seg = O.one_hot_labels(lab.long(), 4)
+    x = torch.from_numpy(syn.hash_normal('dbg_x', (2, fin, hw, hw), seed=hw))
+    w = torch.from_numpy(syn.hash_normal('dbg_w', (2, 16), seed=3))
+    leaf = {('p.' + k): (v.clone().requires_grad_(True) if O.OracleModel.is_param(k) else v) for k, v in sd.items()}
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yo = O.spade_style_resblk(leaf, 'p', xo, seg, wo, False, None)
+    proj = torch.from_numpy(syn.hash_uniform('dbg_p', tuple(yo.shape), seed=5))
+    (yo * proj).sum().backward()
+    m = SPADE_STYLE_ResnetBlock(fin, fout, opt).to(DEV)
+    m.load_state_dict(sd)
+    m.eval()
+    xg = x.to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    y = m(xg, SegMap.of(lab.to(DEV)), wg)
+    (y * proj.to(DEV).permute(0, 2, 3, 1)).sum().backward()
+    rel = lambda a, b: float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(y.permute(0, 3, 1, 2).detach(), yo.detach()) < 1e-5
+    assert rel(xg.grad.permute(0, 3, 1, 2), xo.grad) < 1e-5
+    assert rel(wg.grad, wo.grad) < 1e-5
+    for k, p in m.named_parameters():
+        assert rel(p.grad, leaf['p.' + k].grad) < 2e-5, k

@@ -58,6 +58,9 @@ CONV_CASES = [
     (2, 32, 32, 16, 32, 3, 2, 1, False, False, 0, 0, None),      # encoder stride-2
     (2, 16, 16, 5, 16, 4, 2, 2, True, False, 0, 0, 8),           # 5 real channels stored as 8
     (2, 8, 8, 256, 256, 3, 1, 1, True, True, 0, 0, None),        # deep K (36 K-tiles)
+    (2, 64, 64, 8, 8, 3, 1, 1, True, True, 0, 0, None),          # tiny channels: several taps per K-tile
+    (2, 16, 16, 8, 16, 3, 1, 1, True, False, 0, 0, None),
+    (2, 16, 16, 16, 8, 1, 1, 0, False, False, 0, 0, None),
 ]
 
 
@@ -136,7 +139,7 @@ def test_in_stats_and_instance_norm(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (2, 9, 7, 8), (1, 32, 32, 128)])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (2, 9, 7, 8), (1, 32, 32, 128), (2, 64, 64, 8), (2, 64, 64, 16)])
 @pytest.mark.parametrize('lrelu', [False, True])
 def test_spade_style_modulate(shape, dtype, lrelu):
     from seg2eye_amd import ops
