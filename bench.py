@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s for one G+D train step (run_generator_one_step +
+run_discriminator_one_step, optimizer steps included) at 256x256, batch 8 per GPU, bf16 MFMA /
+fp32 accumulate, synthetic 4-class label maps + styles (BASELINE.json metric; configs[2]).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the driver contract it carries
+  roofline     : the dominant kernel family (implicit-GEMM conv, MFMA-bound): algorithmic FLOPs of its
+                 launches / their HIP-event durations, measured live in the timed steps;
+  cpu_baseline : the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded
+                 sample (one G+D step at batch 1 of the same 256x256 ngf=64 workload), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_BF16 = 2500.0     # TFLOP/s dense (MI355X_MICROARCH.md)
+MFMA_PEAK_F32 = 157.3
+
+
+def make_data(n, hw, seed, dev):
+    from seg2eye_amd import synthetic as syn
+    b = syn.make_batch(n, hw, hw, seed=seed)
+    return {'label': torch.from_numpy(b['label']).to(dev), 'style_image': torch.from_numpy(b['style_image']).to(dev),
+            'target': torch.from_numpy(b['target']).to(dev), 'filename': b['filename']}
+
+
+def fill_weights(model):
+    from seg2eye_amd import synthetic as syn
+    for net in (model.netG, model.netD, model.netE):
+        sd = net.state_dict()
+        filled = syn.fill_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], seed=0, settle=False)
+        with torch.no_grad():
+            for k, v in sd.items():
+                v.copy_(torch.from_numpy(filled[k]))
+
+
+def cpu_baseline(opt_kwargs, hw, seconds_hint=25.0):
+    """One G+D step of the CPU oracle at batch 1 (same shapes otherwise)."""
+    from oracle import seg2eye_oracle as O
+    from seg2eye_amd import networks, synthetic as syn
+    from seg2eye_amd.options import default_opt, latent_size
+    opt = default_opt(**{**opt_kwargs, 'gpu_ids': [], 'batchSize': 1})
+    sds = []
+    for cls in (networks.SPADESTYLEGenerator, networks.MultiscaleDiscriminator, networks.ConvEncoder):
+        net = cls(opt)
+        man = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        sds.append({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(man, seed=0, settle=False).items()})
+    sw, sh = latent_size(opt)
+    m = O.OracleModel(sds[0], sds[1], sds[2], opt, sh, sw)
+    b = syn.make_batch(1, hw, hw, seed=1234)
+    data = {'label': torch.from_numpy(b['label'].astype(np.int64)), 'style_image': torch.from_numpy(b['style_image']),
+            'target': torch.from_numpy(b['target'])}
+    cores = min(16, os.cpu_count() or 1)       # more threads oversubscribe oneDNN on this workload (441 s at 256)
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    m.run_generator_one_step(data)
+    m.run_discriminator_one_step(data)
+    dt = time.time() - t0
+    return {'value': 1.0 / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'one G+D train step of oracle/seg2eye_oracle.py (torch %s CPU fp32) at batch 1, 256x256, '
+                      'ngf=ndf=64, %.1f s' % (torch.__version__, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (BASELINE: 8)')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--ngf', type=int, default=64)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    args = ap.parse_args()
+
+    from seg2eye_amd import distributed as sdist, ops
+    from seg2eye_amd.options import default_opt
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    rank, world, local_rank = sdist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    opt_kwargs = dict(ngf=args.ngf, ndf=args.ngf, crop_size=args.size, aspect_ratio=1.0, batchSize=args.batch,
+                      compute_dtype=args.dtype, gpu_ids=[local_rank])
+    opt = default_opt(**opt_kwargs)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        trainer = Pix2PixTrainer(opt)
+    fill_weights(trainer.pix2pix_model)
+    data = make_data(args.batch, args.size, 1234 + rank, dev)          # resident in HBM before timing
+
+    def step():
+        trainer.run_generator_one_step(dict(data))
+        trainer.run_discriminator_one_step(dict(data))
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    ops.LaunchProfiler.reset()
+    ops.LaunchProfiler.enabled = not args.no_kernel_events
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.LaunchProfiler.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = {k: float(v.detach().float().mean()) for k, v in trainer.get_latest_losses().items()}
+    if not all(np.isfinite(list(losses.values()))):
+        raise SystemExit('non-finite losses: %s' % losses)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        global_batch = args.batch * world
+        out = {
+            'metric': 'images/sec per G+D train step, 256x256 bs=8', 'value': global_batch / (ms / 1e3),
+            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'Seg2Eye G+D hinge-GAN train step (G step + D step, TTUR Adam, GAN + GAN_Feat), '
+                                   '%dx%d, batch %d per GPU, ngf=ndf=%d, 4 style images, synthetic ellipse labels'
+                                   % (args.size, args.size, args.batch, args.ngf),
+                       'global_batch': global_batch, 'parallelism': 'dp%d' % world},
+            'losses': losses,
+        }
+        prof = ops.LaunchProfiler.summary()
+        if prof:
+            peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
+            fam = max(prof, key=lambda k: prof[k]['ms'])
+            d = prof[fam]
+            ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'kernel': fam, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                               'frac': ach / peak, 'traffic': None,
+                               'launches_per_step': d['launches'] / args.steps, 'ms_per_step': d['ms'] / args.steps,
+                               'gflop_per_step': d['flops'] / args.steps / 1e9}
+            out['kernels'] = {k: {'launches_per_step': v['launches'] / args.steps, 'ms_per_step': v['ms'] / args.steps,
+                                  'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} for k, v in prof.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(opt_kwargs, args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -6,6 +6,9 @@ of any op -- there is NO CPU or stock-torch fallback for the ops it exports.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST load before the library: both link libamdhip64 and the process must
+#                       end up with torch's HIP runtime, or launches from the .so see "no ROCm-capable device"
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libseg2eye_hip.so')
 

@@ -44,6 +44,41 @@ def _need(*ts):
                 raise L.Seg2EyeHipError('seg2eye_amd ops need contiguous tensors')
 
 
+# ------------------------------------------------------------------------------ per-launch timing
+class LaunchProfiler:
+    """Optional HIP-event timing of the MFMA kernels, per launch, on the stream they are launched on
+    (torch's current stream).  bench.py turns it on to measure the dominant kernel's achieved rate
+    live; off by default (zero overhead)."""
+    enabled = False
+    records = []          # (family, algorithmic_flops, start_event, end_event)
+
+    @classmethod
+    def run(cls, family, flops, fn):
+        if not cls.enabled:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        cls.records.append((family, flops, s, e))
+        return r
+
+    @classmethod
+    def summary(cls):
+        """family -> dict(launches, flops, ms); call after a device synchronize."""
+        out = {}
+        for fam, fl, s, e in cls.records:
+            d = out.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0))
+            d['launches'] += 1
+            d['flops'] += fl
+            d['ms'] += s.elapsed_time(e)
+        return out
+
+    @classmethod
+    def reset(cls):
+        cls.records = []
+
+
 # ------------------------------------------------------------------------------ raw launchers
 
 def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False):
@@ -70,8 +105,13 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     ho, wo, cout = out_hw_c
     y = torch.empty(n, ho, wo, cout, dtype=x.dtype, device=x.device)
     d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, int(transposed), in_act, out_act, aux_mode)
-    L.check(L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _stream()),
-            's2e_conv2d')
+    # algorithmic FLOPs = those of the forward conv this launch computes or differentiates (a stride-2
+    # data-gradient executes 4x that on structural zeros; not counted)
+    pix = hi * wi if transposed else ho * wo
+    flops = 2.0 * n * pix * cin * cout * kh * kw
+    LaunchProfiler.run('conv_igemm', flops, lambda: L.check(
+        L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _stream()),
+        's2e_conv2d'))
     return y
 
 
@@ -81,7 +121,8 @@ def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE):
     _, ho, wo, cout = gy.shape
     dw = torch.zeros(cout, kh * kw * cin, dtype=torch.float32, device=x.device)
     d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
-    L.check(L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), C.byref(d), _stream()), 's2e_conv2d_wgrad')
+    LaunchProfiler.run('conv_wgrad', 2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
+        L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), C.byref(d), _stream()), 's2e_conv2d_wgrad'))
     return dw
 
 

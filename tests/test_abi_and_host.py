@@ -1,0 +1,134 @@
+"""CPU-side checks: the C-ABI library loads and exports exactly what include/seg2eye_hip.h declares;
+host logic (options, synthetic data, state-dict compatibility, flat Adam arenas, fail-loud on CPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, manifest_of
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'seg2eye_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(s2e_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from seg2eye_amd import _lib
+    import __graft_entry__
+    __graft_entry__.build()                       # hipcc cross-compiles gfx950 without a GPU
+    assert os.path.exists(_lib.LIB_PATH)
+    declared = _header_symbols()
+    assert len(declared) >= 20
+    assert sorted(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ set(declared)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    L = _lib.lib()
+    assert L.s2e_version() >= 1
+    assert L.s2e_conv_cout_pad(1) == 32 and L.s2e_conv_cout_pad(64) == 64 and L.s2e_conv_cout_pad(200) == 256
+    assert L.s2e_conv_k_pad(_lib.S2E_BF16, 9 * 128) == 1152 and L.s2e_conv_k_pad(_lib.S2E_F32, 80) == 96
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from seg2eye_amd import _lib
+    L = _lib.lib()
+    assert L.s2e_colsum(_lib.S2E_BF16, None, 10, 8, None, None) == -1          # S2E_ERR_ARG before any launch
+    assert b's2e_colsum' in L.s2e_last_error()
+    d = _lib.ConvDesc(1, 8, 8, 8, 8, 8, 8, 3, 3, 3, 1, 0, 0, 0, 0)             # stride 3 unsupported
+    assert L.s2e_conv2d(_lib.S2E_BF16, 1, 1, None, None, None, 1, ctypes.byref(d), None) == -3
+    with pytest.raises(_lib.Seg2EyeHipError):
+        _lib.check(-1, 'x')
+
+
+def test_ops_refuse_cpu_tensors():
+    from seg2eye_amd import ops, _lib, networks
+    from seg2eye_amd.options import default_opt
+    with pytest.raises(_lib.Seg2EyeHipError):
+        ops.in_stats(torch.zeros(1, 4, 4, 8))
+    G = networks.SPADESTYLEGenerator(default_opt(ngf=8, crop_size=64, gpu_ids=[]))
+    with pytest.raises(_lib.Seg2EyeHipError):
+        G(torch.zeros(1, 4, 64, 64), torch.zeros(1, 16))
+
+
+def test_state_dict_layout_matches_reference():
+    from seg2eye_amd import networks
+    from seg2eye_amd.options import default_opt
+    z = load_golden('trainer_ngf8_256')
+    opt = default_opt(ngf=8, ndf=8, crop_size=256, gpu_ids=[])
+    for tag, cls in (('G', networks.SPADESTYLEGenerator), ('D', networks.MultiscaleDiscriminator), ('E', networks.ConvEncoder)):
+        sd = cls(opt).state_dict()
+        assert [(k, tuple(v.shape)) for k, v in sd.items()] == manifest_of(z, tag)
+    big = default_opt(ngf=64, ndf=64, crop_size=256, gpu_ids=[])
+    n = lambda net: sum(p.numel() for p in net.parameters())
+    assert abs(n(networks.SPADESTYLEGenerator(big)) / 1e6 - 92.46) < 0.01
+    assert abs(n(networks.MultiscaleDiscriminator(big)) / 1e6 - 5.53) < 0.01
+    assert abs(n(networks.ConvEncoder(big)) / 1e6 - 6.53) < 0.01
+
+
+def test_options_and_shapes():
+    from seg2eye_amd.options import default_opt, latent_size, image_hw
+    assert latent_size(default_opt(crop_size=256, aspect_ratio=1.0)) == (8, 8)
+    assert image_hw(default_opt(crop_size=256, aspect_ratio=0.8)) == (320, 256)
+    assert image_hw(default_opt(crop_size=384, aspect_ratio=0.6)) == (640, 384)
+    with pytest.raises(ValueError):
+        latent_size(default_opt(num_upsampling_layers='most'))
+    with pytest.raises(KeyError):
+        default_opt(not_an_option=1)
+    from seg2eye_amd.pix2pix_model import Pix2PixModel
+    with pytest.raises(NotImplementedError):
+        Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], norm_G='spectralspadebatch3x3'))
+    with pytest.raises(NotImplementedError):
+        Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], no_vgg_loss=False))
+
+
+def test_synthetic_is_deterministic_and_wellformed():
+    from seg2eye_amd import synthetic as syn
+    a, b = syn.make_batch(2, 64, 64, seed=5), syn.make_batch(2, 64, 64, seed=5)
+    assert all(np.array_equal(a[k], b[k]) for k in ('label', 'style_image', 'target'))
+    assert a['label'].dtype == np.uint8 and a['label'].shape == (2, 1, 64, 64) and set(np.unique(a['label'])) <= {0, 1, 2, 3}
+    assert len(np.unique(a['label'])) == 4
+    assert a['style_image'].shape == (2, 4, 1, 64, 64) and np.abs(a['style_image']).max() <= 1.0
+    assert not np.array_equal(a['label'], syn.make_batch(2, 64, 64, seed=6)['label'])
+    sd = syn.fill_state_dict([('c.weight_orig', (8, 4, 3, 3)), ('c.weight_u', (8,)), ('c.weight_v', (36,)), ('c.bias', (8,))])
+    wm = sd['c.weight_orig'].reshape(8, -1).astype(np.float64)
+    sigma = sd['c.weight_u'] @ wm @ sd['c.weight_v']
+    assert abs(sigma - np.linalg.svd(wm, compute_uv=False)[0]) < 1e-3 * sigma       # settled to the top singular pair
+
+
+def test_flat_adam_arena_aliases_parameters():
+    from seg2eye_amd.optim import FlatAdam
+    lin = torch.nn.Linear(5, 3)
+    w0 = lin.weight.detach().clone()
+    opt = FlatAdam(list(lin.parameters()), lr=1e-3, betas=(0, 0.9))
+    assert opt.betas == (0.0, 0.9) and isinstance(opt.betas[0], float)
+    assert torch.equal(lin.weight.detach(), w0)
+    assert lin.weight.data_ptr() == opt.flat_p.data_ptr() and lin.weight.grad.data_ptr() == opt.flat_g.data_ptr()
+    assert all(o % 4 == 0 for o in opt.offsets) and opt.numel == 16 + 4
+    lin(torch.ones(2, 5)).sum().backward()
+    assert float(opt.flat_g.abs().sum()) > 0 and lin.weight.grad.data_ptr() == opt.flat_g.data_ptr()
+    opt.zero_grad()
+    assert float(opt.flat_g.abs().sum()) == 0
+    with pytest.raises(Exception):
+        opt.step()                                                                        # GPU-only kernel
+    with pytest.raises(NotImplementedError):
+        FlatAdam(list(torch.nn.Linear(2, 2).parameters()), lr=1e-3, weight_decay=0.1)
+
+
+def test_checkpoint_roundtrip_and_module_prefix(tmp_path):
+    from seg2eye_amd import checkpoint, networks
+    from seg2eye_amd.options import default_opt
+    opt = default_opt(ngf=8, ndf=8, crop_size=64, gpu_ids=[], checkpoints_dir=str(tmp_path), name='t')
+    D = networks.MultiscaleDiscriminator(opt)
+    path = checkpoint.save_network(D, 'D', 'latest', opt)
+    assert path.endswith('latest_net_D.pth')                                              # util/util.py:195-200
+    sd = torch.load(path)
+    torch.save({'module.' + k: v for k, v in sd.items()}, path)                           # DataParallel-style keys
+    D2 = networks.MultiscaleDiscriminator(opt)
+    checkpoint.load_network(D2, 'D', 'latest', opt)
+    for (k, a), (_, b) in zip(D.state_dict().items(), D2.state_dict().items()):
+        assert torch.equal(a, b), k

@@ -1,0 +1,57 @@
+"""The N>1 path on CPU: world_size-2 gloo processes run the flat-arena gradient exchange and must end
+with identical, correctly averaged updates (the same code path RCCL takes on the GPUs)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from seg2eye_amd import distributed as sdist
+    from seg2eye_amd.optim import FlatAdam
+    r, w, _ = sdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world) and sdist.world_size() == world and sdist.get_rank() == rank
+    assert sdist.shard_seed(1234) == 1234 + rank
+    torch.manual_seed(100 + rank)                       # replicas start DIFFERENT on purpose
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    opt = FlatAdam(list(net.parameters()), lr=1e-2, betas=(0.0, 0.9))
+    sdist.broadcast_flat(opt.flat_p)                     # ...and are made identical here
+    p0 = opt.flat_p.clone()
+    sync = sdist.FlatGradSync(opt.flat_g, bucket_bytes=64)         # tiny buckets -> several all-reduces
+    assert len(sync.buckets) > 1
+    x = torch.full((4, 6), float(rank + 1))
+    opt.zero_grad()
+    net(x).sum().backward()
+    local = opt.flat_g.clone()
+    scale = sync.all_reduce()
+    assert abs(scale - 1.0 / world) < 1e-12
+    out[rank] = (p0, local, opt.flat_g.clone())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_grad_allreduce_world2():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    (p_a, l_a, s_a), (p_b, l_b, s_b) = out[0], out[1]
+    assert torch.equal(p_a, p_b)                                   # broadcast made replicas identical
+    assert torch.allclose(s_a, l_a + l_b) and torch.equal(s_a, s_b)  # sum all-reduce, same on both ranks
+    assert not torch.equal(l_a, l_b)
+
+
+def test_single_process_is_a_noop():
+    from seg2eye_amd import distributed as sdist
+    g = torch.ones(10)
+    assert sdist.FlatGradSync(g).all_reduce() == 1.0 and sdist.world_size() == 1 and sdist.get_rank() == 0
