@@ -74,8 +74,14 @@ int s2e_conv_k_pad(int dtype, int k);            /* columns of a packed weight m
  * transposed = 1: packed[ci][(ky*kw+kx)*cout + co]              (cout_pad(cin_pad) x k_pad(kh*kw*cout)) */
 int s2e_pack_conv_weight(int dtype, const float* w_oihw, void* packed, int cout, int cin, int kh, int kw,
                          int cin_pad, int transposed, void* stream);
+/* Layers that cannot fill the chip from their output tiling alone (small N*Ho*Wo, large K) are
+ * split over K: each split writes an fp32 partial slab into `workspace` and a finishing kernel sums
+ * the slabs and applies the epilogue (deterministic; no atomics).  workspace_bytes(d) is 0 for
+ * shapes that do not split; the caller allocates (no initialisation needed). */
+size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d);
 int s2e_conv2d(int dtype, const void* x, const void* w_packed, const float* bias, const void* residual,
-               const void* aux, void* y, const s2e_conv_desc* d, void* stream);
+               const void* aux, void* y, const s2e_conv_desc* d, void* workspace, size_t workspace_bytes,
+               void* stream);
 /* Weight gradient of the forward conv described by d (d->transposed must be 0):
  * dw[co][(ky*KW+kx)*Cin + ci] += sum_{n,oy,ox} gy[n,oy,ox,co] * in_act(x)[n, oy*s-p+ky, ox*s-p+kx, ci]
  * dw: fp32 (Cout x KH*KW*Cin), row-major, ACCUMULATED into (caller zeroes it); split over pixels
@@ -148,10 +154,11 @@ int s2e_loss_grad(int dtype, int mode, const void* a, const void* b, long n, flo
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam step (pix2pix_model.py:92-110: TTUR betas (0, 0.9), eps 1e-8, no weight decay)
  * over one flat fp32 arena: m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
- * p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), bc1 = 1-b1^t, bc2 = 1-b2^t.
+ * p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), bc1 = 1-b1^t, bc2 = 1-b2^t, t = steps+1.
+ * hyper: 6 fp32 in DEVICE memory {lr, beta1, beta2, eps, completed steps, grad_scale}; the call
+ * increments hyper[4].  Device-resident so a captured hipGraph replays with current values;
  * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
-int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                  float eps, float bc1, float bc2, float grad_scale, void* stream);
+int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float* hyper, void* stream);
 
 #ifdef __cplusplus
 }

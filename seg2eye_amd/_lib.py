@@ -35,7 +35,8 @@ SIGNATURES = {
     's2e_conv_cout_pad': [_i],
     's2e_conv_k_pad': [_i, _i],
     's2e_pack_conv_weight': [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    's2e_conv2d': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp],
+    's2e_conv2d_workspace_bytes': [_i, C.POINTER(ConvDesc)],
+    's2e_conv2d': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp],
     's2e_in_stats': [_i, _vp, _i, _i, _i, _f, _vp, _vp, _vp],
     's2e_modulate_fwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -51,7 +52,7 @@ SIGNATURES = {
     's2e_lrelu_bwd': [_i, _vp, _vp, _vp, _l, _vp],
     's2e_loss_reduce': [_i, _i, _vp, _vp, _l, _f, _vp, _vp],
     's2e_loss_grad': [_i, _i, _vp, _vp, _l, _f, _vp, _vp, _i, _vp],
-    's2e_adam_flat': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _f, _vp],
+    's2e_adam_flat': [_vp, _vp, _vp, _vp, _l, _vp, _vp],
 }
 
 _lib = None
@@ -73,7 +74,8 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = argtypes
-            fn.restype = C.c_char_p if name == 's2e_last_error' else C.c_int
+            fn.restype = (C.c_char_p if name == 's2e_last_error' else
+                          C.c_size_t if name == 's2e_conv2d_workspace_bytes' else C.c_int)
         _lib = L
     return _lib
 

@@ -24,6 +24,8 @@ struct ConvKParams {
     int KH, KW, stride, pad, transposed;
     int in_act, out_act, aux_mode;
     int Ktot, Kpad, M, tiles_n;
+    int tiles, splits, kt_per_split;      // split-K: grid = tiles * splits, split s owns K-tiles [s*per, (s+1)*per)
+    float* partial;                       // splits > 1: fp32 slabs [splits][M][Cout], combined by conv_finish_kernel
 };
 
 template <typename T> struct Mfma;
@@ -76,7 +78,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
+    const int split = wg / p.tiles, tile = wg - split * p.tiles;
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int nk_all = p.Kpad / BK;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(nk_all, kt0 + p.kt_per_split);
 
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ wgt = (const T*)p.w;
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
     // advanced incrementally (no per-tile integer division)
     int l_ky, l_kx, l_ci;
     {
-        const int k0 = c * VEC, tap = k0 / p.Cin;
+        const int k0 = kt0 * BK + c * VEC, tap = k0 / p.Cin;
         l_ci = k0 - tap * p.Cin; l_ky = tap / p.KW; l_kx = tap - l_ky * p.KW;
     }
     u32x4_t ra[4], rb[NB];
@@ -207,13 +213,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
         }
     };
 
-    const int nk = p.Kpad / BK;
-    load_tile(0);
+    const int nk = kt1 - kt0;                       // >= 1 by construction of kt_per_split
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt + 1 < nk; ++kt) {           // steady state: prefetch kt+1 around the MFMAs of kt
         const int cur = kt & 1;
-        load_tile(kt + 1);
+        load_tile(kt0 + kt + 1);
         compute(cur);
         store_tile(cur ^ 1);
         __syncthreads();
@@ -243,6 +249,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
     const int cw = (tid % TPR) * VEC;
     const int co = tn * BN + cw;
     const bool cvec = (p.Cout % VEC) == 0;
+    if (p.splits > 1) {                              // split-K: raw fp32 partial tile -> this split's slab
+        float* slab = p.partial + (size_t)split * p.M * p.Cout;
+        constexpr int TPR4 = BN / 4, RPP4 = 256 / TPR4;
+        const int cw4 = (tid % TPR4) * 4, co4 = tn * BN + cw4;
+        for (int row = tid / TPR4; row < BM; row += RPP4) {
+            const int m = tm * BM + row;
+            if (m >= p.M || co4 >= p.Cout) continue;
+            const f32x4_t t = *(const f32x4_t*)(Cs + row * BN + cw4);
+            float* dst = slab + (size_t)m * p.Cout + co4;
+            if ((p.Cout & 3) == 0) *(f32x4_t*)dst = t;
+            else for (int j = 0; j < 4 && co4 + j < p.Cout; ++j) dst[j] = t[j];
+        }
+        return;
+    }
     for (int row = tid / TPR; row < BM; row += RPP) {
         const int m = tm * BM + row;
         if (m >= p.M || co >= p.Cout) continue;
@@ -292,6 +312,66 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
                 }
                 store1<T>(yg + o + j, t);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ split-K finish
+// y = out_act(sum_s slab[s] + bias + residual) * aux-mask, one thread per 16-byte output vector.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_finish_kernel(const ConvKParams p) {
+    constexpr int VEC = Vec<T>::N;
+    const long total = (long)p.M * p.Cout;
+    const bool cvec = (p.Cout % VEC) == 0;
+    const long nvec = cvec ? total / VEC : total;
+    const size_t slab = (size_t)p.M * p.Cout;
+    T* __restrict__ yg = (T*)p.y;
+    const T* __restrict__ resg = (const T*)p.res;
+    const T* __restrict__ auxg = (const T*)p.aux;
+    const float neg = (p.aux_mode == S2E_AUX_RELU_MASK) ? 0.f : 0.2f;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        if (cvec) {
+            const size_t o = (size_t)v * VEC;
+            const int co = (int)(o % p.Cout);
+            float acc[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = p.bias ? p.bias[co + j] : 0.f;
+            for (int s = 0; s < p.splits; ++s) {
+#pragma unroll
+                for (int j = 0; j < VEC; j += 4) {
+                    const f32x4_t t = *(const f32x4_t*)(p.partial + s * slab + o + j);
+                    acc[j] += t[0]; acc[j + 1] += t[1]; acc[j + 2] += t[2]; acc[j + 3] += t[3];
+                }
+            }
+            if (resg) {
+                float rr[VEC];
+                unpack16<T>(*(const u32x4_t*)(resg + o), rr);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += rr[j];
+            }
+            if (p.out_act == S2E_ACT_LRELU) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = lrelu02(acc[j]);
+            } else if (p.out_act == S2E_ACT_TANH) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = tanhf(acc[j]);
+            }
+            if (p.aux_mode != S2E_AUX_NONE) {
+                float aa[VEC];
+                unpack16<T>(*(const u32x4_t*)(auxg + o), aa);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] *= (aa[j] > 0.f ? 1.f : neg);
+            }
+            *(u32x4_t*)(yg + o) = pack16<T>(acc);
+        } else {
+            const int co = (int)(v % p.Cout);
+            float t = p.bias ? p.bias[co] : 0.f;
+            for (int s = 0; s < p.splits; ++s) t += p.partial[s * slab + v];
+            if (resg) t += load1<T>(resg + v);
+            if (p.out_act == S2E_ACT_LRELU) t = lrelu02(t);
+            else if (p.out_act == S2E_ACT_TANH) t = tanhf(t);
+            if (p.aux_mode != S2E_AUX_NONE) t *= (load1<T>(auxg + v) > 0.f ? 1.f : neg);
+            store1<T>(yg + v, t);
         }
     }
 }
@@ -347,15 +427,47 @@ extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, int
 
 template <typename T, int BN>
 static int launch_conv(const ConvKParams& p, hipStream_t st) {
-    const int tiles_m = ceil_div(p.M, 128);
-    if (p.Cin % Vec<T>::N == 0) conv_igemm_kernel<T, BN, true><<<tiles_m * p.tiles_n, 256, 0, st>>>(p);
-    else conv_igemm_kernel<T, BN, false><<<tiles_m * p.tiles_n, 256, 0, st>>>(p);
+    const int grid = p.tiles * p.splits;
+    if (p.Cin % Vec<T>::N == 0) conv_igemm_kernel<T, BN, true><<<grid, 256, 0, st>>>(p);
+    else conv_igemm_kernel<T, BN, false><<<grid, 256, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_igemm_kernel");
+    if (p.splits > 1) {
+        const long nvec = (long)p.M * p.Cout / Vec<T>::N + 1;
+        const int fgrid = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
+        conv_finish_kernel<T><<<fgrid, 256, 0, st>>>(p);
+        S2E_CHECK_LAUNCH("conv_finish_kernel");
+    }
     return S2E_OK;
 }
 
+// Split-K plan: layers whose output tiling cannot fill 256 CUs (small M, huge K: the 1024-channel
+// blocks at 8x8 / 16x16, the encoder tail) are split over K-tiles so ~512 workgroups exist.
+static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tiles_n, int* splits, int* per) {
+    const int bn = bn_for(d->Cout);
+    const int M = d->N * d->Ho * d->Wo;
+    *tiles_n = ceil_div(d->Cout, bn);
+    *tiles = ceil_div(M, 128) * (*tiles_n);
+    const int nk = s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin) / (dtype == S2E_BF16 ? 64 : 32);
+    int s = 1;
+    if (*tiles < 256 && nk >= 8) {
+        s = ceil_div(512, *tiles);
+        if (s > nk / 4) s = nk / 4;                  // at least 4 K-tiles per split
+        if (s < 1) s = 1;
+    }
+    *per = ceil_div(nk, s);
+    *splits = ceil_div(nk, *per);                    // no empty split
+}
+
+extern "C" size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d) {
+    if (!d) return 0;
+    int tiles, tiles_n, splits, per;
+    plan_splits(dtype, d, &tiles, &tiles_n, &splits, &per);
+    return splits > 1 ? (size_t)splits * d->N * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
+}
+
 extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* bias, const void* res,
-                          const void* aux, void* y, const s2e_conv_desc* d, void* stream) {
+                          const void* aux, void* y, const s2e_conv_desc* d, void* workspace, size_t workspace_bytes,
+                          void* stream) {
     if (!x || !w || !y || !d) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: null pointer");
     if (d->stride != 1 && d->stride != 2) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d: stride %d", d->stride);
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hi <= 0 || d->Wi <= 0)
@@ -372,7 +484,11 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
     p.Kpad = s2e_conv_k_pad(dtype, p.Ktot);
     p.M = d->N * d->Ho * d->Wo;
     const int bn = bn_for(d->Cout);
-    p.tiles_n = ceil_div(d->Cout, bn);
+    plan_splits(dtype, d, &p.tiles, &p.tiles_n, &p.splits, &p.kt_per_split);
+    p.partial = (float*)workspace;
+    if (p.splits > 1 && (!workspace || workspace_bytes < s2e_conv2d_workspace_bytes(dtype, d)))
+        S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: this shape needs %zu bytes of workspace (s2e_conv2d_workspace_bytes)",
+                 s2e_conv2d_workspace_bytes(dtype, d));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16) {
         if (bn == 128) return launch_conv<bf16_t, 128>(p, st);

@@ -99,8 +99,13 @@ extern "C" int s2e_loss_grad(int dtype, int mode, const void* a, const void* b, 
 }
 
 // ------------------------------------------------------------------------------------ Adam over a flat arena
+// Hyper-parameters live in DEVICE memory (hyper[0..5] = lr, beta1, beta2, eps, completed steps, grad_scale)
+// so that a captured hipGraph replays with the current learning rate and bias corrections.
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-        float* __restrict__ v, long n, float lr_bc1, float beta1, float beta2, float eps, float rsqrt_bc2, float grad_scale) {
+        float* __restrict__ v, long n, const float* __restrict__ hyper) {
+    const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], t = hyper[4] + 1.f, grad_scale = hyper[5];
+    const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
+    const float lr_bc1 = lr / bc1, rsqrt_bc2 = 1.f / sqrtf(bc2);
     const long nv = n / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
         f32x4_t pp = ((f32x4_t*)p)[i], gg = ((const f32x4_t*)g)[i], mm = ((f32x4_t*)m)[i], vv = ((f32x4_t*)v)[i];
@@ -122,14 +127,16 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
             p[i] -= lr_bc1 * mi / (sqrtf(vi) * rsqrt_bc2 + eps);
         }
 }
+__global__ void adam_tick_kernel(float* hyper) { hyper[4] += 1.f; }
 
-extern "C" int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                             float eps, float bc1, float bc2, float grad_scale, void* stream) {
-    if (!p || !g || !m || !v || n <= 0 || bc1 <= 0.f || bc2 <= 0.f) S2E_FAIL(S2E_ERR_ARG, "s2e_adam_flat: bad argument");
+extern "C" int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float* hyper, void* stream) {
+    if (!p || !g || !m || !v || !hyper || n <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_adam_flat: bad argument");
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) S2E_FAIL(S2E_ERR_ARG, "s2e_adam_flat: arenas must be 16-byte aligned");
     const long nv = n / 4 + 1;
     const int grid = (int)((nv + 255) / 256 < 4096 ? (nv + 255) / 256 : 4096);
-    adam_flat_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr / bc1, beta1, beta2, eps, 1.f / sqrtf(bc2), grad_scale);
+    adam_flat_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper);
     S2E_CHECK_LAUNCH("adam_flat_kernel");
+    adam_tick_kernel<<<1, 1, 0, (hipStream_t)stream>>>(hyper);      // after every block has read hyper[4]
+    S2E_CHECK_LAUNCH("adam_tick_kernel");
     return S2E_OK;
 }

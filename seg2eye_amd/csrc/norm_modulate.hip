@@ -113,9 +113,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ gsrc,
     for (int j = 0; j < VEC; ++j) s[j] = 0.f;
     if (active) {
         const long row0 = (long)blockIdx.x * rows_per_block;
-        for (long row = row0 + ty; row < row0 + rows_per_block && row < M; row += rpp) {
+        const long rend = (row0 + rows_per_block < M) ? row0 + rows_per_block : M;
+        const T* base = gsrc + (size_t)g * VEC;
+        long row = row0 + ty;
+        for (; row + 3L * rpp < rend; row += 4L * rpp) {          // 4 independent 16-B loads in flight
+            u32x4_t r0 = *(const u32x4_t*)(base + (size_t)row * C);
+            u32x4_t r1 = *(const u32x4_t*)(base + (size_t)(row + rpp) * C);
+            u32x4_t r2 = *(const u32x4_t*)(base + (size_t)(row + 2L * rpp) * C);
+            u32x4_t r3 = *(const u32x4_t*)(base + (size_t)(row + 3L * rpp) * C);
+            float f0[VEC], f1[VEC], f2[VEC], f3[VEC];
+            unpack16<T>(r0, f0); unpack16<T>(r1, f1); unpack16<T>(r2, f2); unpack16<T>(r3, f3);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
+        }
+        for (; row < rend; row += rpp) {
             float f[VEC];
-            unpack16<T>(*(const u32x4_t*)(gsrc + (size_t)row * C + (size_t)g * VEC), f);
+            unpack16<T>(*(const u32x4_t*)(base + (size_t)row * C), f);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) s[j] += f[j];
         }
@@ -159,7 +172,7 @@ extern "C" int s2e_colsum(int dtype, const void* g, long M, int C, float* out, v
         return S2E_OK;
     }
     const RowGeom rg = row_geom(C, vec);
-    const int rows_per_block = rg.rpp * 64;
+    const int rows_per_block = rg.rpp * 16;      // short slabs: >= 2k workgroups on the big maps
     dim3 grid(ceil_div(M, rows_per_block), 1, rg.zblocks);
     if (dtype == S2E_BF16) colsum_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)g, out, M, C, rg.cg, rg.cgb, rg.rpp, rows_per_block);
     else colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)g, out, M, C, rg.cg, rg.cgb, rg.rpp, rows_per_block);

@@ -109,9 +109,11 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     # data-gradient executes 4x that on structural zeros; not counted)
     pix = hi * wi if transposed else ho * wo
     flops = 2.0 * n * pix * cin * cout * kh * kw
+    wsb = L.lib().s2e_conv2d_workspace_bytes(_dt(x), C.byref(d))          # > 0 only for split-K shapes
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     LaunchProfiler.run('conv_igemm', flops, lambda: L.check(
-        L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _stream()),
-        's2e_conv2d'))
+        L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _p(ws), wsb,
+                           _stream()), 's2e_conv2d'))
     return y
 
 
@@ -464,10 +466,8 @@ def loss_sum(a, b, mode, scale):
 
 # ------------------------------------------------------------------------------ optimizer
 
-def adam_flat_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
-    """One torch.optim.Adam step over flat fp32 arenas (pix2pix_model.py:92-110 semantics)."""
-    _need(p, g, m, v)
-    bc1 = 1.0 - beta1 ** step
-    bc2 = 1.0 - beta2 ** step
-    L.check(L.lib().s2e_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2,
-                                  float(grad_scale), _stream()), 's2e_adam_flat')
+def adam_flat_step(p, g, m, v, hyper):
+    """One torch.optim.Adam step over flat fp32 arenas (pix2pix_model.py:92-110 semantics).
+    hyper: 6-float DEVICE tensor {lr, beta1, beta2, eps, completed steps, grad_scale}."""
+    _need(p, g, m, v, hyper)
+    L.check(L.lib().s2e_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _stream()), 's2e_adam_flat')

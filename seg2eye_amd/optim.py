@@ -43,6 +43,10 @@ class FlatAdam:
         self.eps = float(eps)
         self.step_count = 0
         self.param_groups = [{'params': plist, 'lr': float(lr)}]         # update_learning_rate writes ['lr']
+        # device-resident hyper-parameters {lr, beta1, beta2, eps, completed steps, grad_scale}
+        self.hyper = torch.tensor([float(lr), self.betas[0], self.betas[1], self.eps, 0.0, 1.0],
+                                  dtype=torch.float32, device=dev)
+        self._hyper_host = (float(lr), 1.0)
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
@@ -57,11 +61,19 @@ class FlatAdam:
                     want.copy_(g)
                 p.grad = want
 
+    def sync_hyper(self, grad_scale=1.0):
+        """Push lr / grad_scale to the device only when they changed (never inside a graph)."""
+        cur = (float(self.param_groups[0]['lr']), float(grad_scale))
+        if cur != self._hyper_host:
+            self.hyper[0:1].fill_(cur[0])
+            self.hyper[5:6].fill_(cur[1])
+            self._hyper_host = cur
+
     def step(self, grad_scale=1.0):
         self.rebind_grads()
+        self.sync_hyper(grad_scale)
         self.step_count += 1
-        ops.adam_flat_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.param_groups[0]['lr'],
-                           self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale)
+        ops.adam_flat_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hyper)
 
     def state_dict(self):
         return {'step': self.step_count, 'm': self.flat_m, 'v': self.flat_v, 'lr': self.param_groups[0]['lr']}
@@ -71,3 +83,5 @@ class FlatAdam:
         self.flat_m.copy_(sd['m'])
         self.flat_v.copy_(sd['v'])
         self.param_groups[0]['lr'] = float(sd['lr'])
+        self.hyper[4:5].fill_(float(self.step_count))
+        self.sync_hyper(self._hyper_host[1])

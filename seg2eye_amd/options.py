@@ -28,6 +28,7 @@ _DEFAULTS = dict(
     num_upsampling_layers='normal', netD_subarch='n_layer', num_D=2, n_layers_D=4,
     # build-only knobs (no reference counterpart)
     compute_dtype='bf16',      # 'bf16' | 'fp32': storage + MFMA input type of the HIP path
+    hip_graphs=False,          # capture zero_grad+forward+backward of each step into a hipGraph (fixed shapes)
 )
 
 

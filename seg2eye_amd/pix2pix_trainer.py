@@ -12,6 +12,7 @@ class Pix2PixTrainer:
         self.pix2pix_model_on_one_gpu = self.pix2pix_model
         self.generated = None
         self.g_losses, self.d_losses = {}, {}
+        self._static, self.graph_G, self.graph_D = None, None, None
         if opt.isTrain:
             self.optimizer_G, self.optimizer_D = self.pix2pix_model_on_one_gpu.create_optimizers(opt)
             self.old_lr = opt.lr
@@ -20,24 +21,83 @@ class Pix2PixTrainer:
             broadcast_flat(self.optimizer_G.flat_p)          # identical replicas at step 0
             broadcast_flat(self.optimizer_D.flat_p)
 
-    def run_generator_one_step(self, data):
-        self.pix2pix_model.train()
+    # ---- step bodies: zero_grad + forward + backward (what a hipGraph captures) -------------------
+    def _g_body(self, data):
         self.optimizer_G.zero_grad()
         g_losses, generated = self.pix2pix_model(data, mode='generator')
-        g_loss = sum(g_losses.values()).mean()
-        g_loss.backward()
-        self.optimizer_G.step(grad_scale=self.sync_G.all_reduce())
-        self.g_losses = g_losses
-        self.generated = generated
+        sum(g_losses.values()).mean().backward()
+        self.g_losses, self.generated = g_losses, generated
 
-    def run_discriminator_one_step(self, data):
-        self.pix2pix_model.train()
+    def _d_body(self, data):
         self.optimizer_D.zero_grad()
         d_losses = self.pix2pix_model(data, mode='discriminator')
-        d_loss = sum(d_losses.values()).mean()
-        d_loss.backward()
-        self.optimizer_D.step(grad_scale=self.sync_D.all_reduce())
+        sum(d_losses.values()).mean().backward()
         self.d_losses = d_losses
+
+    def run_generator_one_step(self, data):
+        """trainers/pix2pix_trainer.py:26-35.  With opt.hip_graphs the body is one graph replay."""
+        self.pix2pix_model.train()
+        if self.use_graphs:
+            self._stage_inputs(data)
+            self.graph_G.replay()
+        else:
+            self._g_body(data)
+        self.optimizer_G.step(grad_scale=self.sync_G.all_reduce())
+
+    def run_discriminator_one_step(self, data):
+        """trainers/pix2pix_trainer.py:37-45."""
+        self.pix2pix_model.train()
+        if self.use_graphs:
+            self._stage_inputs(data)
+            self.graph_D.replay()
+        else:
+            self._d_body(data)
+        self.optimizer_D.step(grad_scale=self.sync_D.all_reduce())
+
+    # ---- hipGraph capture ---------------------------------------------------------------------------
+    @property
+    def use_graphs(self):
+        return bool(getattr(self.opt, 'hip_graphs', False))
+
+    def _stage_inputs(self, data):
+        """Copy the batch into the static input buffers the graphs read (capturing on first use).
+        Shapes are fixed for the lifetime of the graphs."""
+        if self._static is None:
+            self._capture(data)
+        for k, buf in self._static.items():
+            src = data[k]
+            if src.data_ptr() != buf.data_ptr():
+                if tuple(src.shape) != tuple(buf.shape):
+                    raise ValueError('hip_graphs: %s changed shape %s -> %s' % (k, tuple(buf.shape), tuple(src.shape)))
+                buf.copy_(src, non_blocking=True)
+
+    def _capture(self, data):
+        import torch
+        m = self.pix2pix_model
+        dev = m.device()
+        self._static = {k: data[k].to(dev).clone() for k in ('label', 'style_image', 'target')}
+        # the warm-up passes run the spectral-norm power iterations for real: snapshot u, v and put them
+        # back afterwards so capturing does not change the training trajectory (weights are untouched:
+        # the bodies contain no optimizer step)
+        bufs = [b for net in (m.netG, m.netD, m.netE) for b in net.buffers()]
+        snap = [b.detach().clone() for b in bufs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._g_body(self._static)
+                self._d_body(self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_G = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_G):
+            self._g_body(self._static)
+        self.graph_D = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_D, pool=self.graph_G.pool()):
+            self._d_body(self._static)
+        with torch.no_grad():
+            for b, s in zip(bufs, snap):
+                b.copy_(s)
 
     def get_latest_losses(self, include_log_losses=False):
         losses = {**self.g_losses, **self.d_losses}

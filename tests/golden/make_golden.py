@@ -56,6 +56,7 @@ def ref_opt(**kw):
     kw.setdefault('gpu_ids', [])
     opt = default_opt(**kw)
     delattr(opt, 'compute_dtype')
+    delattr(opt, 'hip_graphs')
     return opt
 
 

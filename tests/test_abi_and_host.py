@@ -40,7 +40,12 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.s2e_colsum(_lib.S2E_BF16, None, 10, 8, None, None) == -1          # S2E_ERR_ARG before any launch
     assert b's2e_colsum' in L.s2e_last_error()
     d = _lib.ConvDesc(1, 8, 8, 8, 8, 8, 8, 3, 3, 3, 1, 0, 0, 0, 0)             # stride 3 unsupported
-    assert L.s2e_conv2d(_lib.S2E_BF16, 1, 1, None, None, None, 1, ctypes.byref(d), None) == -3
+    assert L.s2e_conv2d(_lib.S2E_BF16, 1, 1, None, None, None, 1, ctypes.byref(d), None, 0, None) == -3
+    d2 = _lib.ConvDesc(8, 8, 8, 1024, 8, 8, 1024, 3, 3, 1, 1, 0, 0, 0, 0)         # small M, K = 9216: split-K
+    assert L.s2e_conv2d_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d2)) == 16 * 512 * 1024 * 4
+    assert L.s2e_conv2d(_lib.S2E_BF16, 1, 1, None, None, None, 1, ctypes.byref(d2), None, 0, None) == -1   # workspace missing
+    d3 = _lib.ConvDesc(8, 256, 256, 128, 256, 256, 256, 3, 3, 1, 1, 0, 0, 0, 0)
+    assert L.s2e_conv2d_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d3)) == 0
     with pytest.raises(_lib.Seg2EyeHipError):
         _lib.check(-1, 'x')
 

@@ -61,6 +61,10 @@ CONV_CASES = [
     (2, 64, 64, 8, 8, 3, 1, 1, True, True, 0, 0, None),          # tiny channels: several taps per K-tile
     (2, 16, 16, 8, 16, 3, 1, 1, True, False, 0, 0, None),
     (2, 16, 16, 16, 8, 1, 1, 0, False, False, 0, 0, None),
+    (1, 4, 4, 512, 512, 3, 1, 1, True, True, 0, 0, None),         # split-K: 4 tiles, 72 K-tiles
+    (4, 16, 16, 256, 192, 3, 2, 1, False, False, 0, 0, None),    # split-K, stride 2, ragged Cout
+    (2, 8, 8, 512, 1, 4, 1, 2, True, False, 0, 0, None),         # split-K with Cout = 1 (scalar finish)
+    (2, 8, 8, 128, 256, 3, 1, 1, True, False, 1, 2, None),       # split-K + lrelu prologue + tanh epilogue
 ]
 
 
@@ -278,18 +282,22 @@ def test_losses(dtype, n):
 
 
 def test_adam_flat_matches_torch():
-    from seg2eye_amd import ops
+    from seg2eye_amd.optim import FlatAdam
     dev = _dev()
     n = 10007
     p0 = _rnd((n,), 51, torch.float32)
     ref = torch.nn.Parameter(p0.clone())
     opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.0, 0.9), eps=1e-8)
-    p = p0.to(dev).clone()
-    m = torch.zeros(n, device=dev)
-    v = torch.zeros(n, device=dev)
-    for step in range(1, 4):
+    mine = torch.nn.Parameter(p0.to(dev).clone())
+    fa = FlatAdam([mine], lr=1e-3, betas=(0, 0.9))
+    for step in range(1, 5):
         g = _rnd((n,), 60 + step, torch.float32)
+        if step == 3:
+            fa.param_groups[0]['lr'] = 5e-4              # LR decay reaches the device-side hyper block
+            opt.param_groups[0]['lr'] = 5e-4
         ref.grad = g.clone()
         opt.step()
-        ops.adam_flat_step(p, g.to(dev), m, v, 1e-3, 0.0, 0.9, 1e-8, step)
-    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+        mine.grad.copy_(g.to(dev) * 2.0)                 # a 2-rank sum all-reduce ...
+        fa.step(grad_scale=0.5)                          # ... averaged inside the kernel
+    assert float(fa.hyper[4]) == 4.0
+    np.testing.assert_allclose(mine.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
