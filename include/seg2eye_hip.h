@@ -70,10 +70,12 @@ int s2e_conv_cout_pad(int cout);                 /* rows of a packed weight matr
 int s2e_conv_k_pad(int dtype, int k);            /* columns of a packed weight matrix */
 /* w_oihw: fp32 (cout, cin, kh, kw) contiguous (torch layout).  cin_pad >= cin: channels
  * cin..cin_pad-1 of the activation are structural zeros (e.g. the 5->8 padded D input).
+ * sigma: NULL, or a DEVICE fp32 scalar: the packed weight is w / *sigma (spectral norm applied on
+ * the fly; W/sigma is never materialised in fp32).
  * transposed = 0: packed[co][(ky*kw+kx)*cin_pad + ci]           (cout_pad(cout) x k_pad(kh*kw*cin_pad))
  * transposed = 1: packed[ci][(ky*kw+kx)*cout + co]              (cout_pad(cin_pad) x k_pad(kh*kw*cout)) */
-int s2e_pack_conv_weight(int dtype, const float* w_oihw, void* packed, int cout, int cin, int kh, int kw,
-                         int cin_pad, int transposed, void* stream);
+int s2e_pack_conv_weight(int dtype, const float* w_oihw, void* packed, const float* sigma, int cout, int cin,
+                         int kh, int kw, int cin_pad, int transposed, void* stream);
 /* Layers that cannot fill the chip from their output tiling alone (small N*Ho*Wo, large K) are
  * split over K: each split writes an fp32 partial slab into `workspace` and a finishing kernel sums
  * the slabs and applies the epilogue (deterministic; no atomics).  workspace_bytes(d) is 0 for
@@ -87,6 +89,28 @@ int s2e_conv2d(int dtype, const void* x, const void* w_packed, const float* bias
  * dw: fp32 (Cout x KH*KW*Cin), row-major, ACCUMULATED into (caller zeroes it); split over pixels
  * with fp32 atomics. */
 int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, const s2e_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ spectral normalisation
+ * torch.nn.utils.spectral_norm as applied at architecture.py:30-34 and normalization.py:25-26
+ * (n_power_iterations=1, eps 1e-12, dim 0), for ALL spectral-normed convs of a
+ * network at once.  Per layer, W = weight_orig viewed (rows=Cout) x (cols=Cin*kh*kw), row-major:
+ *   train != 0 (per iteration): v = normalize(W^T u); u = normalize(W v); sigma = u . (W v)   (u, v updated in place)
+ *   train == 0:                 sigma = u . (W v)                                              (u, v untouched)
+ * layers: DEVICE array of n_layers descriptors.  block_map: DEVICE int32 [n_blocks][3] = {layer, row0, col0}
+ * covering every layer with 64-row x 256-column blocks.  t (cols floats) and s (rows floats) of all layers
+ * live in `scratch` (zeroed here each iteration).  sigma: fp32 [n_layers] out. */
+typedef struct {
+    const float* w; float* u; float* v; float* t; float* s;
+    int rows, cols;
+} s2e_sn_layer;
+int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map, int n_blocks,
+                           void* scratch, size_t scratch_bytes, float* sigma, int train, int iterations,
+                           float eps, void* stream);
+/* Gradient through W = W_orig / sigma (sigma = u^T W_orig v; u, v constants):
+ *   gw_orig = gW / sigma - (<gW, W_orig> / sigma^2) * u v^T     in OIHW order,
+ * with gW given in the packed order of s2e_conv2d_wgrad ([co][(tap)*cin_pad + ci]).  dot_ws: 1 float scratch. */
+int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, const float* u, const float* v, const float* sigma,
+                       float* dot_ws, float* gw_orig, int cout, int cin, int kh, int kw, int cin_pad, void* stream);
 
 /* ------------------------------------------------------------------ InstanceNorm statistics
  * nn.InstanceNorm2d(affine=False) statistics, normalization.py:73 / :41 (biased variance, eps 1e-5).

@@ -26,6 +26,12 @@ class ConvDesc(C.Structure):
         'transposed', 'in_act', 'out_act', 'aux_mode')]
 
 
+class SnLayer(C.Structure):
+    """s2e_sn_layer"""
+    _fields_ = [('w', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p), ('t', C.c_void_p), ('s', C.c_void_p),
+                ('rows', C.c_int), ('cols', C.c_int)]
+
+
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 # name -> argtypes; every entry returns int except the two noted below.  Must list EVERY symbol
 # declared in include/seg2eye_hip.h (tests/test_abi.py checks header <-> table <-> .so).
@@ -34,7 +40,9 @@ SIGNATURES = {
     's2e_last_error': [],
     's2e_conv_cout_pad': [_i],
     's2e_conv_k_pad': [_i, _i],
-    's2e_pack_conv_weight': [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    's2e_pack_conv_weight': [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    's2e_sn_power_iteration': [_vp, _i, _vp, _i, _vp, C.c_size_t, _vp, _i, _i, _f, _vp],
+    's2e_sn_weight_grad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     's2e_conv2d_workspace_bytes': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp],

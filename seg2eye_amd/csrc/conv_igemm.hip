@@ -376,54 +376,11 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvKParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------ weight packing
-template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int kh, int kw,
-                                   int cin_pad, int transposed, int rows, int kpad) {
-    const long total = (long)rows * kpad;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(i / kpad), k = (int)(i - (long)row * kpad);
-        float v = 0.f;
-        if (!transposed) {
-            const int tap = k / cin_pad, ci = k - tap * cin_pad;
-            if (row < cout && tap < kh * kw && ci < cin) {
-                const int ky = tap / kw, kx = tap - ky * kw;
-                v = w[(((size_t)row * cin + ci) * kh + ky) * kw + kx];
-            }
-        } else {
-            const int tap = k / cout, co = k - tap * cout;
-            if (row < cin && tap < kh * kw) {
-                const int ky = tap / kw, kx = tap - ky * kw;
-                v = w[(((size_t)co * cin + row) * kh + ky) * kw + kx];
-            }
-        }
-        out[i] = (T)v;
-    }
-}
-
 // ------------------------------------------------------------------------------------ host side
 static int bn_for(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
 extern "C" int s2e_conv_cout_pad(int cout) { const int bn = bn_for(cout); return ceil_div(cout, bn) * bn; }
 extern "C" int s2e_conv_k_pad(int dtype, int k) { const int bk = dtype == S2E_BF16 ? 64 : 32; return ceil_div(k, bk) * bk; }
-
-extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, int cout, int cin, int kh, int kw,
-                                    int cin_pad, int transposed, void* stream) {
-    if (!w || !packed || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || cin_pad < cin)
-        S2E_FAIL(S2E_ERR_ARG, "s2e_pack_conv_weight: bad argument");
-    const int rows = s2e_conv_cout_pad(transposed ? cin_pad : cout);
-    const int kpad = s2e_conv_k_pad(dtype, kh * kw * (transposed ? cout : cin_pad));
-    const long total = (long)rows * kpad;
-    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2E_BF16)
-        pack_weight_kernel<bf16_t><<<grid, 256, 0, st>>>(w, (bf16_t*)packed, cout, cin, kh, kw, cin_pad, transposed, rows, kpad);
-    else if (dtype == S2E_F32)
-        pack_weight_kernel<float><<<grid, 256, 0, st>>>(w, (float*)packed, cout, cin, kh, kw, cin_pad, transposed, rows, kpad);
-    else S2E_FAIL(S2E_ERR_ARG, "s2e_pack_conv_weight: bad dtype %d", dtype);
-    S2E_CHECK_LAUNCH("pack_weight_kernel");
-    return S2E_OK;
-}
 
 template <typename T, int BN>
 static int launch_conv(const ConvKParams& p, hipStream_t st) {

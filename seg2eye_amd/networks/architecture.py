@@ -3,7 +3,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from .. import ops
-from .base_network import sn_weight
+from ..spectral import sn_begin
 from .normalization import SPADE_STYLE_Block, SegMap
 
 
@@ -34,13 +34,12 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
 
     def forward(self, x, seg, latent_style):
         seg = SegMap.of(seg)
+        sn_begin(self)                  # no-op inside a generator (its forward already stepped the bank)
         stats = ops.in_stats(x.detach())
         if self.learned_shortcut:
-            x_s = ops.conv2d(self.norm_s(x, seg, latent_style, stats, lrelu=False), sn_weight(self.conv_s))
+            x_s = ops.conv2d_m(self.norm_s(x, seg, latent_style, stats, lrelu=False), self.conv_s)
         else:
             x_s = x
-        dx = ops.conv2d(self.norm_0(x, seg, latent_style, stats, lrelu=True), sn_weight(self.conv_0),
-                        self.conv_0.bias, None, 1, 1)
-        dx = ops.conv2d(self.norm_1(dx, seg, latent_style, None, lrelu=True), sn_weight(self.conv_1),
-                        self.conv_1.bias, x_s, 1, 1)
+        dx = ops.conv2d_m(self.norm_0(x, seg, latent_style, stats, lrelu=True), self.conv_0, None, 1, 1)
+        dx = ops.conv2d_m(self.norm_1(dx, seg, latent_style, None, lrelu=True), self.conv_1, x_s, 1, 1)
         return dx

@@ -17,15 +17,6 @@ def compute_dtype_of(opt):
     raise ValueError('compute_dtype must be bf16 or fp32, got %r' % (name,))
 
 
-def sn_weight(conv):
-    """Weight of a (possibly spectral-normed) conv exactly as a module call would see it: runs the
-    torch.nn.utils.spectral_norm pre-forward hook (one power iteration in train mode, W = W_orig/sigma;
-    reference architecture.py:30-34, normalization.py:25-26) without running the conv itself."""
-    for hook in conv._forward_pre_hooks.values():
-        hook(conv, None)
-    return conv.weight
-
-
 def _fill(w, init_type, gain):
     if init_type == 'normal':
         init.normal_(w, 0.0, gain)

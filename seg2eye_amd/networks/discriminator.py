@@ -5,7 +5,8 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_NONE, ACT_LRELU
-from .base_network import BaseNetwork, compute_dtype_of, sn_weight
+from ..spectral import sn_begin
+from .base_network import BaseNetwork, compute_dtype_of
 from .normalization import get_nonspade_norm_layer
 
 D_CPAD = 8          # the 5-channel input cat([one-hot seg, image]) is stored as 8 NHWC channels (16-B vectors)
@@ -50,6 +51,7 @@ class NLayerDiscriminator(BaseNetwork):
 
     def forward_nhwc(self, x):
         """x: (M,H,W,8).  Returns the NHWC outputs of model0..model{n} (after their activations)."""
+        sn_begin(self)                  # no-op when MultiscaleDiscriminator.forward already stepped
         feats = []
         first = self.model0[0]
         h = ops.conv2d(x, first.weight, first.bias, None, 2, self.padw, ACT_NONE, ACT_LRELU)   # conv + LeakyReLU, one launch
@@ -58,10 +60,10 @@ class NLayerDiscriminator(BaseNetwork):
             blk = getattr(self, 'model%d' % n)[0]
             if isinstance(blk, nn.Sequential):                     # SN conv (bias removed) -> InstanceNorm -> LeakyReLU
                 conv = blk[0]
-                h = ops.conv2d(h, sn_weight(conv), None, None, self.strides[n], self.padw)
+                h = ops.conv2d_m(h, conv, None, self.strides[n], self.padw)
                 h = ops.instance_norm(h, lrelu=True)
             else:                                                  # norm_D without a norm layer: conv -> LeakyReLU
-                h = ops.conv2d(h, sn_weight(blk), blk.bias, None, self.strides[n], self.padw, ACT_NONE, ACT_LRELU)
+                h = ops.conv2d_m(h, blk, None, self.strides[n], self.padw, ACT_NONE, ACT_LRELU)
             feats.append(h)
         last = getattr(self, 'model%d' % (self.n_groups - 1))[0]
         h = ops.conv2d(h, last.weight, last.bias, None, 1, self.padw)
@@ -98,6 +100,7 @@ class MultiscaleDiscriminator(BaseNetwork):
         self.require_gpu(input)
         x = input if (input.dim() == 4 and input.shape[-1] == D_CPAD and input.shape[1] != self.opt.label_nc + self.opt.output_nc) \
             else to_d_input(input, self.cdtype)
+        sn_begin(self)                  # one batched power iteration for both scales' SN convs
         result = []
         keep_all = not self.opt.no_ganFeat_loss
         for name, D in self.named_children():

@@ -6,7 +6,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .base_network import BaseNetwork, compute_dtype_of, sn_weight
+from ..spectral import sn_begin
+from .base_network import BaseNetwork, compute_dtype_of
 from .normalization import get_nonspade_norm_layer
 
 
@@ -30,27 +31,15 @@ class ConvEncoder(BaseNetwork):
         self.fc_var = nn.Linear(ndf * 8 * s0 * s0, opt.w_dim)
         self.actvn = nn.LeakyReLU(0.2, False)
 
-    def extra_power_iterations(self, n):
-        """Advance every layer's spectral-norm u, v by n power iterations without a forward.  The
-        reference calls netE once per SAMPLE (pix2pix_model.py:280-290), i.e. N power iterations per
-        encode; the batched forward below does one, so Pix2PixModel calls this with N-1 first.
-        Layer outputs are unaffected beyond eps effects: InstanceNorm follows each conv and removes the
-        1/sigma scale."""
-        if n <= 0 or not self.training:
-            return
-        with torch.no_grad():
-            for i in range(self.len_sequence):
-                conv = getattr(self, 'layer%d' % i)[0]
-                wm = conv.weight_orig.reshape(conv.weight_orig.shape[0], -1)
-                u, v = conv.weight_u, conv.weight_v
-                for _ in range(n):
-                    v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12))
-                    u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=1e-12))
-
-    def forward(self, x, get_intermediate_features=False):
+    def forward(self, x, get_intermediate_features=False, power_iterations=1):
         """x: (M,1,h,w) style images.  Returns (mu, logvar, features) like encoder.py:53-73; features are
-        logical-NCHW views of the NHWC layer outputs."""
+        logical-NCHW views of the NHWC layer outputs.
+        power_iterations: spectral-norm iterations for this call.  The reference calls netE once per
+        SAMPLE (pix2pix_model.py:280-290), i.e. N power iterations per encode; the batched call made by
+        Pix2PixModel passes N so u, v follow the same trajectory.  Layer outputs are unaffected beyond
+        eps effects: InstanceNorm follows each conv and removes the 1/sigma scale."""
         self.require_gpu(x)
+        sn_begin(self, power_iterations)
         if x.size(2) != 256 or x.size(3) != 256:
             x = F.interpolate(x.float(), size=(256, 256), mode='bilinear')
         h = x.permute(0, 2, 3, 1).contiguous().to(self.cdtype)          # (M,256,256,1): same memory order as NCHW
@@ -58,7 +47,7 @@ class ConvEncoder(BaseNetwork):
         for i in range(self.len_sequence):
             blk = getattr(self, 'layer%d' % i)
             conv = blk[0] if isinstance(blk, nn.Sequential) else blk
-            h = ops.conv2d(h, sn_weight(conv), getattr(conv, 'bias', None), None, 2, 1)
+            h = ops.conv2d_m(h, conv, None, 2, 1)
             if isinstance(blk, nn.Sequential):
                 h = ops.instance_norm(h, lrelu=False)
             feats.append(h.permute(0, 3, 1, 2))

@@ -5,6 +5,7 @@ import torch.nn as nn
 from .. import ops
 from .._lib import ACT_LRELU, ACT_TANH
 from ..options import latent_size
+from ..spectral import sn_begin
 from .architecture import SPADE_STYLE_ResnetBlock
 from .base_network import BaseNetwork, compute_dtype_of
 from .normalization import SegMap
@@ -46,6 +47,7 @@ class SPADESTYLEGenerator(BaseNetwork):
         if (H, W) != (self.sh * f, self.sw * f):
             raise ValueError('label map is %dx%d but this generator emits %dx%d (SURVEY F5)' % (H, W, self.sh * f, self.sw * f))
         w = w.float()
+        sn_begin(self)          # one batched power iteration for all 18 spectral-normed convs
         # F.interpolate(seg, (sh, sw)) + fc conv, generator.py:72-73
         x = ops.label_conv3x3(seg.label, self.fc.weight, self.fc.bias, self.sh, self.sw, False, self.cdtype)
         x = self.head_0(x, seg, w)

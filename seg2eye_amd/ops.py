@@ -81,11 +81,13 @@ class LaunchProfiler:
 
 # ------------------------------------------------------------------------------ raw launchers
 
-def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False):
+def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False, sigma=None):
+    """OIHW fp32 -> MFMA B-operand matrix in the compute dtype; divided by the device scalar `sigma`
+    (spectral norm) on the fly when given."""
     w = w_oihw.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
-    _need(w)
+    _need(w, sigma)
     cout, cin, kh, kw = w.shape
     cin_pad = cin if cin_pad is None else cin_pad
     dt = L.S2E_BF16 if dtype == torch.bfloat16 else L.S2E_F32
@@ -93,7 +95,7 @@ def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False):
     rows = lib.s2e_conv_cout_pad(cin_pad if transposed else cout)
     kpad = lib.s2e_conv_k_pad(dt, kh * kw * (cout if transposed else cin_pad))
     out = torch.empty(rows, kpad, dtype=dtype, device=w.device)
-    L.check(lib.s2e_pack_conv_weight(dt, _p(w), _p(out), cout, cin, kh, kw, cin_pad, int(transposed), _stream()),
+    L.check(lib.s2e_pack_conv_weight(dt, _p(w), _p(out), _p(sigma), cout, cin, kh, kw, cin_pad, int(transposed), _stream()),
             's2e_pack_conv_weight')
     return out
 
@@ -179,26 +181,28 @@ def _unpack_dw(dw, cout, cin, kh, kw, cin_pad):
 
 class Conv2dFn(torch.autograd.Function):
     """y = out_act(conv(in_act(x), W) + b + residual) on NHWC tensors.  x may carry more channels
-    than W has input channels (structural zero padding)."""
+    than W has input channels (structural zero padding).  With (u, v, sigma) given, W = weight/sigma
+    (spectral norm): the division happens inside the pack kernel and the gradient returned for
+    `weight` is the one w.r.t. weight_orig, through sigma."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, pad, in_act, out_act):
+    def forward(ctx, x, weight, bias, residual, stride, pad, in_act, out_act, u, v, sigma):
         n, hi, wi, cx = x.shape
         cout, cin, kh, kw = weight.shape
         if cx < cin:
             raise ValueError('input has %d channels, weight expects %d' % (cx, cin))
         ho = (hi + 2 * pad - kh) // stride + 1
         wo = (wi + 2 * pad - kw) // stride + 1
-        wp = pack_weight(weight, x.dtype, cx, False)
+        wp = pack_weight(weight, x.dtype, cx, False, sigma)
         b = None if bias is None else bias.detach().float().contiguous()
         y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act)
         ctx.cfg = (stride, pad, in_act, out_act, bias is not None, residual is not None)
-        ctx.save_for_backward(x, weight, y if out_act != ACT_NONE else None)
+        ctx.save_for_backward(x, weight, y if out_act != ACT_NONE else None, u, v, sigma)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, y = ctx.saved_tensors
+        x, weight, y, u, v, sigma = ctx.saved_tensors
         stride, pad, in_act, out_act, has_bias, has_res = ctx.cfg
         n, hi, wi, cx = x.shape
         cout, cin, kh, kw = weight.shape
@@ -213,20 +217,36 @@ class Conv2dFn(torch.autograd.Function):
             g = g2
         gx = gw = gb = gres = None
         if ctx.needs_input_grad[0]:
-            wpt = pack_weight(weight, x.dtype, cx, True)
+            wpt = pack_weight(weight, x.dtype, cx, True, sigma)
             gx = conv2d_raw(g, wpt, None, None, x if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
                             True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
         if ctx.needs_input_grad[1]:
-            gw = _unpack_dw(conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act), cout, cin, kh, kw, cx)
+            dwp = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act)
+            if sigma is None:
+                gw = _unpack_dw(dwp, cout, cin, kh, kw, cx)
+            else:
+                gw = torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
+                dot = torch.empty(1, dtype=torch.float32, device=x.device)
+                w32 = weight.detach()
+                L.check(L.lib().s2e_sn_weight_grad(_p(dwp), _p(w32), _p(u), _p(v), _p(sigma), _p(dot), _p(gw),
+                                                   cout, cin, kh, kw, cx, _stream()), 's2e_sn_weight_grad')
         if has_bias and ctx.needs_input_grad[2]:
             gb = colsum(g)
         if has_res and ctx.needs_input_grad[3]:
             gres = g
-        return gx, gw, gb, gres, None, None, None, None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, residual=None, stride=1, pad=0, in_act=ACT_NONE, out_act=ACT_NONE):
-    return Conv2dFn.apply(x, weight, bias, residual, stride, pad, in_act, out_act)
+def conv2d(x, weight, bias=None, residual=None, stride=1, pad=0, in_act=ACT_NONE, out_act=ACT_NONE, sn=None):
+    u, v, sigma = sn if sn is not None else (None, None, None)
+    return Conv2dFn.apply(x, weight, bias, residual, stride, pad, in_act, out_act, u, v, sigma)
+
+
+def conv2d_m(x, conv, residual=None, stride=1, pad=0, in_act=ACT_NONE, out_act=ACT_NONE):
+    """conv2d on an nn.Conv2d parameter container (spectral-normed or not)."""
+    from .spectral import conv_params
+    weight, bias, sn = conv_params(conv)
+    return conv2d(x, weight, bias, residual, stride, pad, in_act, out_act, sn)
 
 
 # ------------------------------------------------------------------------------ label-map convs

@@ -6,7 +6,7 @@ loss-log helpers and netG/netD/netE attributes.  Deliberate, documented differen
   * labels stay uint8 on the GPU (no one-hot tensor is materialised for G; D's 5-channel input is built
     by one kernel), and 3-D (N,H,W) labels are handled correctly for N > 1 (SURVEY F4);
   * the per-sample python loop over netE (pix2pix_model.py:280-290) is one batched call, with the
-    skipped spectral-norm power iterations made up first (encoder.extra_power_iterations);
+    same number of spectral-norm power iterations (ConvEncoder.forward(power_iterations=N));
   * netE is loaded whenever netG is (SURVEY F9);
   * D's weight gradients are not computed during the G step (the reference computes and then zeroes
     them, trainers/pix2pix_trainer.py:38) -- the parameters after the step are identical.
@@ -164,8 +164,7 @@ class Pix2PixModel(nn.Module):
         if real_image.dim() != 5:
             raise ValueError('real_image should have 5 dimensions')
         n, ns = real_image.shape[:2]
-        self.netE.extra_power_iterations(n - 1)
-        mu, _, feats = self.netE(real_image.reshape(n * ns, *real_image.shape[2:]))
+        mu, _, feats = self.netE(real_image.reshape(n * ns, *real_image.shape[2:]), power_iterations=n)
         return self._aggregate(mu.view(n, ns, -1)), feats
 
     def generate_fake_from_stylecode(self, seg, latent_style):

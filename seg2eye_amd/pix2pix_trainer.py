@@ -26,13 +26,16 @@ class Pix2PixTrainer:
         self.optimizer_G.zero_grad()
         g_losses, generated = self.pix2pix_model(data, mode='generator')
         sum(g_losses.values()).mean().backward()
-        self.g_losses, self.generated = g_losses, generated
+        # keep detached copies only: a live autograd graph would pin last iteration's AccumulateGrad nodes
+        # (and their stream), which breaks hipGraph capture
+        self.g_losses = {k: v.detach() for k, v in g_losses.items()}
+        self.generated = generated.detach()
 
     def _d_body(self, data):
         self.optimizer_D.zero_grad()
         d_losses = self.pix2pix_model(data, mode='discriminator')
         sum(d_losses.values()).mean().backward()
-        self.d_losses = d_losses
+        self.d_losses = {k: v.detach() for k, v in d_losses.items()}
 
     def run_generator_one_step(self, data):
         """trainers/pix2pix_trainer.py:26-35.  With opt.hip_graphs the body is one graph replay."""

@@ -1,0 +1,139 @@
+"""SpectralBank: fused spectral normalisation for every spectral-normed conv of one network.
+
+torch.nn.utils.spectral_norm stays registered on the conv modules -- it defines the state_dict layout
+(`weight_orig`, `weight_u`, `weight_v`) -- but its pre-forward hook is never run on the HIP path.
+Instead the owning network calls `bank.step(training)` once at the top of its forward: one batched
+power iteration (4 launches for all layers), after which each conv's sigma is a device scalar that
+the weight-pack kernel divides by on the fly.  Semantics are those of the hook (reference
+architecture.py:30-34, normalization.py:25-26): one iteration per forward in train
+mode updating u, v in place, none in eval mode.
+
+u and v of all layers are re-homed into one flat arena (like the parameters in optim.FlatAdam) so a
+single clone per forward snapshots the values the backward needs."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+SN_EPS = 1e-12
+_BR, _BC = 64, 256
+
+
+def sn_convs(root):
+    return [m for m in root.modules() if isinstance(m, torch.nn.Conv2d) and hasattr(m, 'weight_orig')]
+
+
+class SpectralBank:
+    def __init__(self, root):
+        self.root = root
+        self.convs = sn_convs(root)
+        self.n = len(self.convs)
+        for i, c in enumerate(self.convs):
+            c.__dict__['_sn_bank'] = self
+            c.__dict__['_sn_index'] = i
+        self._ptrs = None
+        self.sigma = None
+        self.uv_snap = None
+
+    # ------------------------------------------------------------------ device tables
+    def _build(self):
+        dev = self.convs[0].weight_orig.device
+        rows = [c.weight_orig.shape[0] for c in self.convs]
+        cols = [c.weight_orig[0].numel() for c in self.convs]
+        # flat arena for u | v of every layer; module buffers become views of it
+        sizes = []
+        for r, c_ in zip(rows, cols):
+            sizes += [r, c_]
+        offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])
+        arena = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
+        self.uv_off = []
+        with torch.no_grad():
+            for i, c in enumerate(self.convs):
+                ou, ov = int(offs[2 * i]), int(offs[2 * i + 1])
+                uview, vview = arena[ou:ou + rows[i]], arena[ov:ov + cols[i]]
+                uview.copy_(c.weight_u)
+                vview.copy_(c.weight_v)
+                c._buffers['weight_u'] = uview
+                c._buffers['weight_v'] = vview
+                self.uv_off.append((ou, ov))
+        self.uv_arena = arena
+        self.scratch = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)      # t | s, same offsets
+        table = (L.SnLayer * self.n)()
+        bm = []
+        for i, c in enumerate(self.convs):
+            ou, ov = self.uv_off[i]
+            table[i].w = c.weight_orig.data_ptr()
+            table[i].u = arena.data_ptr() + 4 * ou
+            table[i].v = arena.data_ptr() + 4 * ov
+            table[i].s = self.scratch.data_ptr() + 4 * ou
+            table[i].t = self.scratch.data_ptr() + 4 * ov
+            table[i].rows, table[i].cols = rows[i], cols[i]
+            for r0 in range(0, rows[i], _BR):
+                for c0 in range(0, cols[i], _BC):
+                    bm.append((i, r0, c0))
+        raw = np.frombuffer(bytes(table), dtype=np.uint8).copy()
+        self.table_dev = torch.from_numpy(raw).to(dev)
+        self.block_map = torch.tensor(bm, dtype=torch.int32, device=dev)
+        self.rows, self.cols = rows, cols
+        self._ptrs = self._current_ptrs()
+
+    def _current_ptrs(self):
+        return tuple((c.weight_orig.data_ptr(), c.weight_u.data_ptr(), c.weight_v.data_ptr()) for c in self.convs)
+
+    # ------------------------------------------------------------------ per-forward
+    def step(self, training, iterations=1):
+        """Run the power iteration(s) for every layer; afterwards sigma_of()/uv_of() serve this forward."""
+        if self.n == 0:
+            return
+        w = self.convs[0].weight_orig
+        if not w.is_cuda:
+            raise L.Seg2EyeHipError('spectral norm runs on the GPU only (no CPU fallback)')
+        if self._ptrs is None or self._ptrs != self._current_ptrs():
+            self._build()                                    # first use, or storage moved (.cuda(), optimizer arena)
+        self.sigma = torch.empty(self.n, dtype=torch.float32, device=w.device)
+        L.check(L.lib().s2e_sn_power_iteration(
+            self.table_dev.data_ptr(), self.n, self.block_map.data_ptr(), self.block_map.shape[0],
+            self.scratch.data_ptr(), self.scratch.numel() * 4, self.sigma.data_ptr(), int(bool(training)),
+            int(iterations), SN_EPS, torch.cuda.current_stream().cuda_stream), 's2e_sn_power_iteration')
+        # the backward of this forward needs u, v as they are NOW (later forwards update them in place)
+        self.uv_snap = self.uv_arena.clone() if torch.is_grad_enabled() else self.uv_arena
+
+    def handle(self, conv):
+        """(u, v, sigma) tensors for one conv, valid for the forward that called step()."""
+        i = conv._sn_index
+        ou, ov = self.uv_off[i]
+        return (self.uv_snap[ou:ou + self.rows[i]], self.uv_snap[ov:ov + self.cols[i]], self.sigma[i:i + 1])
+
+
+def sn_begin(root, iterations=1):
+    """Call at the top of a network's forward.  A module steps the bank only if it owns it, so a block
+    used stand-alone (tests) works, and inside a network the network's single step covers it."""
+    bank = root.__dict__.get('_sn_owned_bank')
+    convs = sn_convs(root)
+    if not convs:
+        return None
+    outer = convs[0].__dict__.get('_sn_bank')
+    if outer is not None and outer.root is not root and bank is None:
+        return outer                                         # an enclosing network owns and steps it
+    if bank is None:
+        bank = SpectralBank(root)
+        root.__dict__['_sn_owned_bank'] = bank
+    else:
+        for i, c in enumerate(bank.convs):                   # re-claim (a stand-alone use may have re-pointed them)
+            c.__dict__['_sn_bank'] = bank
+            c.__dict__['_sn_index'] = i
+    bank.step(root.training, iterations)
+    return bank
+
+
+def conv_params(conv):
+    """(weight, bias, sn) for ops.conv2d: sn = (u, v, sigma) when the conv is spectral-normed."""
+    bias = getattr(conv, 'bias', None)
+    if hasattr(conv, 'weight_orig'):
+        bank = conv.__dict__.get('_sn_bank')
+        if bank is None or bank.sigma is None:
+            raise RuntimeError('spectral-normed conv used before sn_begin() of its network')
+        return conv.weight_orig, bias, bank.handle(conv)
+    return conv.weight, bias, None

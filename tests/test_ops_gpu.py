@@ -301,3 +301,50 @@ def test_adam_flat_matches_torch():
         fa.step(grad_scale=0.5)                          # ... averaged inside the kernel
     assert float(fa.hyper[4]) == 4.0
     np.testing.assert_allclose(mine.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(16, 24, 3, 1, 1), (64, 130, 4, 2, 2), (8, 8, 1, 1, 0)])
+def test_fused_spectral_norm_conv_matches_torch(cfg, dtype):
+    """SpectralBank (batched power iteration) + sigma-in-the-pack-kernel + fused gradient through sigma
+    against torch.nn.utils.spectral_norm in fp64: train-mode forward (u, v updated), gradient w.r.t.
+    weight_orig, a second forward, eval-mode forward, and a 3-iteration step."""
+    import copy
+    from seg2eye_amd import ops
+    from seg2eye_amd.spectral import sn_begin
+    cin, cout, k, s, p = cfg
+    dev = _dev()
+    torch.manual_seed(7)
+    ref = torch.nn.utils.spectral_norm(torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, bias=True)).double()
+    mine = torch.nn.Sequential(copy.deepcopy(ref).float()).to(dev)
+    conv = mine[0]
+    x = _rnd((2, cin, 12, 12), 3, dtype)
+    xr = x.double().requires_grad_(True)
+    xg = nhwc(x).to(dev).requires_grad_(True)
+    for rnd, train in enumerate([True, True, False]):
+        ref.train(train)
+        mine.train(train)
+        ref.zero_grad()
+        yr = ref(xr)
+        gy = _rnd(tuple(yr.shape), 10 + rnd, dtype)
+        yr.backward(gy.double())
+        conv.zero_grad()
+        sn_begin(mine)
+        y = ops.conv2d_m(xg, conv, None, s, p)
+        y.backward(nhwc(gy).to(dev))
+        _close(nchw(y), yr, dtype, what='sn y (round %d)' % rnd)
+        _close(conv.weight_orig.grad, ref.weight_orig.grad, dtype, what='sn dW_orig (round %d)' % rnd)
+        _close(conv.bias.grad, ref.bias.grad, dtype, what='sn db')
+        _close(conv.weight_u, ref.weight_u, torch.float32, what='u (round %d)' % rnd)
+        _close(conv.weight_v, ref.weight_v, torch.float32, what='v (round %d)' % rnd)
+    # 3 iterations in one step == 3 train-mode forwards of the hook
+    ref.train()
+    mine.train()
+    with torch.no_grad():
+        for _ in range(3):
+            ref(xr)
+        sn_begin(mine, iterations=3)
+    _close(conv.weight_u, ref.weight_u, torch.float32, what='u (3 iters)')
+    _close(conv.weight_v, ref.weight_v, torch.float32, what='v (3 iters)')
+    sd = mine.state_dict()
+    assert set(sd) == {'0.bias', '0.weight_orig', '0.weight_u', '0.weight_v'}
