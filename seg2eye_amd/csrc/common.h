@@ -86,4 +86,10 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
+// Zero-fill as a KERNEL, never hipMemsetAsync: inside a captured hipGraph (ROCm 7.x) memset nodes were
+// observed to race with neighbouring kernel nodes (first replay fine, later replays corrupt), while
+// kernel nodes are strictly ordered.  bytes must be a multiple of 4; ptr 4-byte aligned.
+__global__ void s2e_zero_kernel(uint32_t* __restrict__ p, size_t n_words);
+int s2e_zero_async(void* ptr, size_t bytes, hipStream_t st);
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

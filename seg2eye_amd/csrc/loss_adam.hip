@@ -14,6 +14,25 @@ void s2e_set_error(const char* fmt, ...) {
 extern "C" const char* s2e_last_error(void) { return g_err; }
 extern "C" int s2e_version(void) { return 1; }
 
+// ------------------------------------------------------------------------------------ zero fill (see common.h)
+__global__ void s2e_zero_kernel(uint32_t* __restrict__ p, size_t n_words) {
+    const size_t nv = n_words / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x)
+        ((u32x4_t*)p)[i] = u32x4_t{0, 0, 0, 0};
+    for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+int s2e_zero_async(void* ptr, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return S2E_OK;
+    if (!ptr || (bytes & 3) || ((uintptr_t)ptr & 15))
+        S2E_FAIL(S2E_ERR_ARG, "s2e_zero_async: need a 16-byte aligned pointer and a size that is a multiple of 4");
+    const size_t words = bytes / 4;
+    size_t blocks = (words / 4 + 255) / 256 + 1;
+    if (blocks > 4096) blocks = 4096;
+    s2e_zero_kernel<<<(int)blocks, 256, 0, st>>>((uint32_t*)ptr, words);
+    S2E_CHECK_LAUNCH("s2e_zero_kernel");
+    return S2E_OK;
+}
+
 // ------------------------------------------------------------------------------------ loss reduce
 template <int MODE> __device__ __forceinline__ float loss_term(float a, float b) {
     if (MODE == S2E_LOSS_NEG_MEAN) return -a;

@@ -91,7 +91,7 @@ extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, 
     hipStream_t st = (hipStream_t)stream;
     const int iters = train ? iterations : 1;
     for (int it = 0; it < iters; ++it) {
-        if (hipMemsetAsync(scratch, 0, scratch_bytes, st) != hipSuccess) S2E_FAIL(S2E_ERR_LAUNCH, "s2e_sn_power_iteration: memset failed");
+        if (int zrc = s2e_zero_async(scratch, scratch_bytes, st)) return zrc;
         if (train) {
             sn_gemvT_kernel<<<n_blocks, 256, 0, st>>>(layers, block_map);
             sn_norm_v_kernel<<<n_layers, 256, 0, st>>>(layers, eps);
@@ -156,7 +156,7 @@ extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, con
     const size_t esz = dtype == S2E_BF16 ? 2 : 4;
     hipStream_t st = (hipStream_t)stream;
     // padding rows / columns (tile remainders, structural-zero channels) must read as zero
-    if (hipMemsetAsync(packed, 0, (size_t)rows * kpad * esz, st) != hipSuccess) S2E_FAIL(S2E_ERR_LAUNCH, "s2e_pack_conv_weight: memset failed");
+    if (int zrc = s2e_zero_async(packed, (size_t)rows * kpad * esz, st)) return zrc;
     if (!transposed) {
         dim3 grid(cout, ceil_div(cin, 64));
         const size_t lds = (size_t)64 * (taps + 1) * sizeof(float);
@@ -210,7 +210,7 @@ extern "C" int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, c
     if (!gw_packed || !w_orig || !u || !v || !sigma || !dot_ws || !gw_orig || cout <= 0 || cin <= 0 || cin_pad < cin)
         S2E_FAIL(S2E_ERR_ARG, "s2e_sn_weight_grad: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dot_ws, 0, sizeof(float), st) != hipSuccess) S2E_FAIL(S2E_ERR_LAUNCH, "s2e_sn_weight_grad: memset failed");
+    if (int zrc = s2e_zero_async(dot_ws, sizeof(float), st)) return zrc;
     const long total = (long)cout * cin * kh * kw;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     sn_grad_dot_kernel<<<grid, 256, 0, st>>>(gw_packed, w_orig, dot_ws, cout, cin, kh * kw, cin_pad);

@@ -79,11 +79,12 @@ class Pix2PixTrainer:
         m = self.pix2pix_model
         dev = m.device()
         self._static = {k: data[k].to(dev).clone() for k in ('label', 'style_image', 'target')}
-        # the warm-up passes run the spectral-norm power iterations for real: snapshot u, v and put them
-        # back afterwards so capturing does not change the training trajectory (weights are untouched:
-        # the bodies contain no optimizer step)
-        bufs = [b for net in (m.netG, m.netD, m.netE) for b in net.buffers()]
-        snap = [b.detach().clone() for b in bufs]
+        # the warm-up passes run the spectral-norm power iterations for real: snapshot every bank's u|v
+        # arena and put it back afterwards so capturing does not change the training trajectory (weights
+        # are untouched: the bodies contain no optimizer step)
+        from .spectral import ensure_bank
+        banks = [b for b in (ensure_bank(net) for net in (m.netG, m.netD, m.netE)) if b is not None]
+        snap = [b.uv_arena.clone() for b in banks]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -99,8 +100,8 @@ class Pix2PixTrainer:
         with torch.cuda.graph(self.graph_D, pool=self.graph_G.pool()):
             self._d_body(self._static)
         with torch.no_grad():
-            for b, s in zip(bufs, snap):
-                b.copy_(s)
+            for b, s0 in zip(banks, snap):
+                b.uv_arena.copy_(s0)
 
     def get_latest_losses(self, include_log_losses=False):
         losses = {**self.g_losses, **self.d_losses}

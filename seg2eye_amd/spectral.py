@@ -107,6 +107,20 @@ class SpectralBank:
         return (self.uv_snap[ou:ou + self.rows[i]], self.uv_snap[ov:ov + self.cols[i]], self.sigma[i:i + 1])
 
 
+def ensure_bank(root):
+    """Create (and build the device tables of) the bank a network would create on its first forward,
+    without running a power iteration.  Returns None for a network without spectral-normed convs."""
+    if not sn_convs(root):
+        return None
+    bank = root.__dict__.get('_sn_owned_bank')
+    if bank is None:
+        bank = SpectralBank(root)
+        root.__dict__['_sn_owned_bank'] = bank
+    if bank._ptrs is None or bank._ptrs != bank._current_ptrs():
+        bank._build()
+    return bank
+
+
 def sn_begin(root, iterations=1):
     """Call at the top of a network's forward.  A module steps the bank only if it owns it, so a block
     used stand-alone (tests) works, and inside a network the network's single step covers it."""

@@ -51,7 +51,7 @@ def test_generator_fp32_matches_reference(tag, ngf, crop, ar):
     onehot = torch.zeros(z['label'].shape[0], 4, *z['label'].shape[2:], device=DEV).scatter_(1, _label(z).long(), 1.0)
     with torch.no_grad():
         y2 = G(onehot, w)
-    assert torch.equal(y, y2)
+    assert float((y - y2).abs().max()) < 1e-5          # sigma is reduced with float atomics: not bit-reproducible
     # backward (eval mode): every parameter gradient vs the reference's checksums
     G.zero_grad()
     wt = w.clone().requires_grad_(True)
@@ -115,7 +115,7 @@ def test_discriminator_and_losses_fp32():
     onehot = torch.zeros(2, 4, 32, 32, device=DEV).scatter_(1, lab.long().unsqueeze(1), 1.0)
     xin = torch.cat([torch.cat([onehot, fake.detach()], 1), torch.cat([onehot, real], 1)], 0)
     pred2 = D(xin)
-    assert torch.equal(pred2[1][4], pred[1][4].detach())
+    assert float((pred2[1][4] - pred[1][4].detach()).abs().max()) < 1e-5
     crit = networks.GANLoss('hinge', opt=opt)
     pf = [[t[:2] for t in p] for p in pred]
     pr = [[t[2:] for t in p] for p in pred]
@@ -304,3 +304,35 @@ def test_resblk_matches_oracle_tight(fin, fout, name, hw):
     assert rel(wg.grad, wo.grad) < 1e-5
     for k, p in m.named_parameters():
         assert rel(p.grad, leaf['p.' + k].grad) < 2e-5, k
+
+
+def test_hip_graph_steps_match_eager():
+    """opt.hip_graphs: replaying the captured step bodies must follow the eager trajectory (same losses
+    over 3 iterations within float-atomics noise, capture itself leaves weights AND u, v untouched)."""
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    z = load_golden('trainer_ngf8_256')
+    res = {}
+    for graphs in (False, True):
+        opt = _opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='fp32', hip_graphs=graphs)
+        tr = Pix2PixTrainer(opt)
+        m = tr.pix2pix_model
+        for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+            sd = filled_state(z, tag)
+            with torch.no_grad():
+                for k, v in net.state_dict().items():
+                    v.copy_(sd[k])
+        data = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in _batch(2, 256, 256, 21).items()}
+        hist = []
+        for it in range(3):
+            tr.run_generator_one_step(dict(data))
+            tr.run_discriminator_one_step(dict(data))
+            hist.append({k: float(v.float().mean()) for k, v in tr.get_latest_losses().items()})
+        res[graphs] = (hist, {k: v.detach().float().cpu().clone() for k, v in m.netG.state_dict().items()})
+    for a, b in zip(res[False][0], res[True][0]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    ref = {k: float(z['it0_%s' % k.replace('/', '_')]) for k in res[True][0][0]}
+    for k, v in res[True][0][0].items():                      # and the graphed first iteration matches the real reference
+        assert abs(v - ref[k]) <= 2e-3 * max(1.0, abs(ref[k])), (k, v, ref[k])
+    for k, v in res[False][1].items():
+        assert float((v - res[True][1][k]).abs().max()) <= 2e-3 * max(1e-3, float(v.abs().max())), k
