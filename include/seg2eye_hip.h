@@ -87,8 +87,10 @@ int s2e_conv2d(int dtype, const void* x, const void* w_packed, const float* bias
 /* Weight gradient of the forward conv described by d (d->transposed must be 0):
  * dw[co][(ky*KW+kx)*Cin + ci] += sum_{n,oy,ox} gy[n,oy,ox,co] * in_act(x)[n, oy*s-p+ky, ox*s-p+kx, ci]
  * dw: fp32 (Cout x KH*KW*Cin), row-major, ACCUMULATED into (caller zeroes it); split over pixels
- * with fp32 atomics. */
-int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, const s2e_conv_desc* d, void* stream);
+ * with fp32 atomics.  dbias: NULL, or fp32 (Cout) ACCUMULATED with the bias gradient
+ * sum_{n,oy,ox} gy[n,oy,ox,co] from the gy tiles the kernel stages anyway (no extra pass over gy). */
+int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
+                     void* stream);
 
 /* ------------------------------------------------------------------ spectral normalisation
  * torch.nn.utils.spectral_norm as applied at architecture.py:30-34 and normalization.py:25-26

@@ -15,7 +15,7 @@
 #include "common.h"
 
 struct WgradParams {
-    const void* x; const void* gy; float* dw;
+    const void* x; const void* gy; float* dw; float* dbias;   // dbias != NULL: also accumulate sum_m gy[m][co]
     int N, Hi, Wi, Cin, Ho, Wo, Cout;
     int KH, KW, stride, pad, in_act;
     int Ktot, M, tiles_k, tiles_co, m_per_split;
@@ -73,6 +73,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         roy[i] = rem / p.Wo; rox[i] = rem - roy[i] * p.Wo;
     }
 
+    // bias gradient: the k-tile 0 workgroups also sum the gy vectors they stage (per thread: VEC channels of
+    // its rows), reduced across the block's row-threads through LDS at the end -> one atomic per channel
+    const bool do_bias = (p.dbias != nullptr) && (tk == 0);
+    float bsum[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) bsum[j] = 0.f;
     u32x4_t rg[NI], rx[NI];
     auto load_chunk = [&](int ch) __attribute__((always_inline)) {
         static_for<0, NI>([&](auto I) {
@@ -89,6 +95,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                 for (int j = 0; j < VEC; ++j)
                     f[j] = (mv && co0 + j < p.Cout) ? load1<T>(gg + (size_t)m * p.Cout + co0 + j) : 0.f;
                 rg[i] = pack16<T>(f);
+            }
+            if (do_bias) {
+                float f[VEC];
+                unpack16<T>(rg[i], f);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) bsum[j] += f[j];
             }
             // ---- xcol
             rx[i] = u32x4_t{0, 0, 0, 0};
@@ -204,6 +216,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     }
     compute((nch - 1) & 1);
 
+    if (p.dbias != nullptr && tk == 0) {                  // block-uniform
+        __syncthreads();
+        float* red = (float*)smem;                        // [RPT][128]
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) red[rb * 128 + c * VEC + j] = bsum[j];
+        __syncthreads();
+        if (tid < 128) {
+            float a = 0.f;
+            for (int r = 0; r < RPT; ++r) a += red[r * 128 + tid];
+            const int co = tco * 128 + tid;
+            if (co < p.Cout) atomicAdd(p.dbias + co, a);
+        }
+    }
     // ---- combine: lanes 0..31 of a register hold 32 consecutive k of one co row (128 B)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -217,14 +242,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             }
 }
 
-extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, const s2e_conv_desc* d, void* stream) {
+extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
+                                void* stream) {
     if (!x || !gy || !dw || !d) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: null pointer");
     if (d->transposed) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: describe the forward conv (transposed=0)");
     if (d->stride != 1 && d->stride != 2) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad: stride %d", d->stride);
     if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31))
         S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad: tensor too large for 32-bit pixel indices");
     WgradParams p;
-    p.x = x; p.gy = gy; p.dw = dw;
+    p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.in_act = d->in_act;
     p.Ktot = d->KH * d->KW * d->Cin;

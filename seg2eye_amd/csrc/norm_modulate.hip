@@ -171,7 +171,7 @@ extern "C" int s2e_colsum(int dtype, const void* g, long M, int C, float* out, v
         return S2E_OK;
     }
     const RowGeom rg = row_geom(C, vec);
-    const int rows_per_block = rg.rpp * 16;      // short slabs: >= 2k workgroups on the big maps
+    const int rows_per_block = rg.rpp * 64;      // long slabs: same-address atomics serialise, keep them few
     dim3 grid(ceil_div(M, rows_per_block), 1, rg.zblocks);
     if (dtype == S2E_BF16) colsum_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)g, out, M, C, rg.cg, rg.cgb, rg.rpp, rows_per_block);
     else colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)g, out, M, C, rg.cg, rg.cgb, rg.rpp, rows_per_block);

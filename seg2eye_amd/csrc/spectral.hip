@@ -106,30 +106,39 @@ extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, 
 // ------------------------------------------------------------------------------------ weight packers
 // OIHW fp32 -> MFMA B-operand layout in the compute dtype, divided by *sigma when sigma != NULL.
 // Both directions go through LDS so that global reads AND writes are contiguous runs.
-// forward pack : out[co][(tap)*cin_pad + ci]   one block = one co x 64 ci  (reads 64*taps contiguous floats)
+// Every element of the padded matrix is written exactly once per call (padding rows / channels / K tail as
+// zeros), so no separate zero-fill is needed.
+// forward pack : out[row][(tap)*cin_pad + ci]   one block = one row x 64 (padded) ci
 template <typename T>
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
                                                        int cout, int cin, int taps, int cin_pad, int kpad) {
     extern __shared__ float lds[];                          // [64][taps + 1]
-    const int co = blockIdx.x, ci0 = blockIdx.y * 64;
-    const int nci = min(64, cin - ci0);
+    const int row = blockIdx.x, ci0 = blockIdx.y * 64;
+    const bool valid = row < cout;
+    const int nci = valid ? max(0, min(64, cin - ci0)) : 0;       // real channels in this chunk
+    const int ncp = min(64, cin_pad - ci0);                        // channels incl. structural-zero padding
     const float inv = sigma ? 1.f / *sigma : 1.f;
-    const float* src = w + ((size_t)co * cin + ci0) * taps;
-    for (int i = threadIdx.x; i < nci * taps; i += 256) lds[(i / taps) * (taps + 1) + (i % taps)] = src[i] * inv;
-    __syncthreads();
-    T* dst = out + (size_t)co * kpad + ci0;
-    for (int i = threadIdx.x; i < nci * taps; i += 256) {
-        const int tap = i / nci, cil = i - tap * nci;
-        dst[(size_t)tap * cin_pad + cil] = (T)lds[cil * (taps + 1) + tap];
+    if (nci > 0) {
+        const float* src = w + ((size_t)row * cin + ci0) * taps;
+        for (int i = threadIdx.x; i < nci * taps; i += 256) lds[(i / taps) * (taps + 1) + (i % taps)] = src[i] * inv;
     }
+    __syncthreads();
+    T* dst = out + (size_t)row * kpad + ci0;
+    for (int i = threadIdx.x; i < ncp * taps; i += 256) {
+        const int tap = i / ncp, cil = i - tap * ncp;
+        dst[(size_t)tap * cin_pad + cil] = (T)(cil < nci ? lds[cil * (taps + 1) + tap] : 0.f);
+    }
+    if (blockIdx.y == 0)                                     // K tail [taps*cin_pad, kpad)
+        for (int k = taps * cin_pad + threadIdx.x; k < kpad; k += 256) out[(size_t)row * kpad + k] = (T)0.f;
 }
-// transposed pack: out[ci][(tap)*cout + co]     one block = 64 co x 8 ci
+// transposed pack: out[ci][(tap)*cout + co]     one block = 64 co x 8 (padded) ci rows
 template <typename T>
 __global__ __launch_bounds__(256) void pack_tr_kernel(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
-                                                      int cout, int cin, int taps, int kpad) {
+                                                      int cout, int cin, int taps, int rows_pad, int kpad) {
     extern __shared__ float lds[];                          // [64 co][8*taps + 1]
     const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 8;
-    const int nco = min(64, cout - co0), nci = min(8, cin - ci0);
+    const int nco = min(64, cout - co0);
+    const int nci = max(0, min(8, cin - ci0)), ncp = min(8, rows_pad - ci0);
     const int run = nci * taps, ld = 8 * taps + 1;
     const float inv = sigma ? 1.f / *sigma : 1.f;
     for (int i = threadIdx.x; i < nco * run; i += 256) {
@@ -137,11 +146,16 @@ __global__ __launch_bounds__(256) void pack_tr_kernel(const float* __restrict__ 
         lds[col * ld + r] = w[((size_t)(co0 + col) * cin + ci0) * taps + r] * inv;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nci * taps * nco; i += 256) {
+    for (int i = threadIdx.x; i < ncp * taps * nco; i += 256) {
         const int col = i % nco, rt = i / nco;               // rt = cil*taps + tap
         const int cil = rt / taps, tap = rt - cil * taps;
-        out[(size_t)(ci0 + cil) * kpad + (size_t)tap * cout + co0 + col] = (T)lds[col * ld + rt];
+        out[(size_t)(ci0 + cil) * kpad + (size_t)tap * cout + co0 + col] = (T)(cil < nci ? lds[col * ld + rt] : 0.f);
     }
+    if (blockIdx.x == 0)                                     // K tail [taps*cout, kpad) of this block's rows
+        for (int i = threadIdx.x; i < ncp * (kpad - taps * cout); i += 256) {
+            const int cil = i / (kpad - taps * cout), k = taps * cout + i % (kpad - taps * cout);
+            out[(size_t)(ci0 + cil) * kpad + k] = (T)0.f;
+        }
 }
 
 extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, const float* sigma, int cout, int cin, int kh, int kw,
@@ -153,20 +167,17 @@ extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, con
     if (taps > 64) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_pack_conv_weight: kernel %dx%d too large", kh, kw);
     const int rows = s2e_conv_cout_pad(transposed ? cin_pad : cout);
     const int kpad = s2e_conv_k_pad(dtype, taps * (transposed ? cout : cin_pad));
-    const size_t esz = dtype == S2E_BF16 ? 2 : 4;
     hipStream_t st = (hipStream_t)stream;
-    // padding rows / columns (tile remainders, structural-zero channels) must read as zero
-    if (int zrc = s2e_zero_async(packed, (size_t)rows * kpad * esz, st)) return zrc;
     if (!transposed) {
-        dim3 grid(cout, ceil_div(cin, 64));
+        dim3 grid(rows, ceil_div(cin_pad, 64));
         const size_t lds = (size_t)64 * (taps + 1) * sizeof(float);
         if (dtype == S2E_BF16) pack_fwd_kernel<bf16_t><<<grid, 256, lds, st>>>(w, (bf16_t*)packed, sigma, cout, cin, taps, cin_pad, kpad);
         else pack_fwd_kernel<float><<<grid, 256, lds, st>>>(w, (float*)packed, sigma, cout, cin, taps, cin_pad, kpad);
     } else {
-        dim3 grid(ceil_div(cout, 64), ceil_div(cin, 8));
+        dim3 grid(ceil_div(cout, 64), ceil_div(rows, 8));
         const size_t lds = (size_t)64 * (8 * taps + 1) * sizeof(float);
-        if (dtype == S2E_BF16) pack_tr_kernel<bf16_t><<<grid, 256, lds, st>>>(w, (bf16_t*)packed, sigma, cout, cin, taps, kpad);
-        else pack_tr_kernel<float><<<grid, 256, lds, st>>>(w, (float*)packed, sigma, cout, cin, taps, kpad);
+        if (dtype == S2E_BF16) pack_tr_kernel<bf16_t><<<grid, 256, lds, st>>>(w, (bf16_t*)packed, sigma, cout, cin, taps, rows, kpad);
+        else pack_tr_kernel<float><<<grid, 256, lds, st>>>(w, (float*)packed, sigma, cout, cin, taps, rows, kpad);
     }
     S2E_CHECK_LAUNCH("pack kernels");
     return S2E_OK;

@@ -85,8 +85,9 @@ class FC(nn.Module):
             self.bias = None
 
     def forward(self, x):
-        b = None if self.bias is None else self.bias * self.b_lrmul
-        return F.leaky_relu(F.linear(x.float(), self.weight * self.w_lrmul, b), 0.2)
+        w = self.weight if self.w_lrmul == 1.0 else self.weight * self.w_lrmul
+        b = None if self.bias is None else (self.bias if self.b_lrmul == 1.0 else self.bias * self.b_lrmul)
+        return F.leaky_relu(F.linear(x.float(), w, b), 0.2)
 
 
 class ApplyStyle(nn.Module):

@@ -119,15 +119,20 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     return y
 
 
-def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE):
+def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False):
+    """-> (dw, db): dw (Cout, KH*KW*Cin) fp32 in packed order; db (Cout) fp32 or None.  Both live in one
+    zero-filled buffer (a single fill launch)."""
     _need(x, gy)
     n, hi, wi, cin = x.shape
     _, ho, wo, cout = gy.shape
-    dw = torch.zeros(cout, kh * kw * cin, dtype=torch.float32, device=x.device)
+    k = kh * kw * cin
+    buf = torch.zeros(cout * k + (cout if want_bias else 0), dtype=torch.float32, device=x.device)
+    dw = buf[:cout * k].view(cout, k)
+    db = buf[cout * k:] if want_bias else None
     d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
     LaunchProfiler.run('conv_wgrad', 2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
-        L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), C.byref(d), _stream()), 's2e_conv2d_wgrad'))
-    return dw
+        L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), _p(db), C.byref(d), _stream()), 's2e_conv2d_wgrad'))
+    return dw, db
 
 
 def colsum(g):
@@ -220,8 +225,9 @@ class Conv2dFn(torch.autograd.Function):
             wpt = pack_weight(weight, x.dtype, cx, True, sigma)
             gx = conv2d_raw(g, wpt, None, None, x if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
                             True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
+        want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dwp = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act)
+            dwp, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b)
             if sigma is None:
                 gw = _unpack_dw(dwp, cout, cin, kh, kw, cx)
             else:
@@ -230,7 +236,7 @@ class Conv2dFn(torch.autograd.Function):
                 w32 = weight.detach()
                 L.check(L.lib().s2e_sn_weight_grad(_p(dwp), _p(w32), _p(u), _p(v), _p(sigma), _p(dot), _p(gw),
                                                    cout, cin, kh, kw, cx, _stream()), 's2e_sn_weight_grad')
-        if has_bias and ctx.needs_input_grad[2]:
+        elif want_b:
             gb = colsum(g)
         if has_res and ctx.needs_input_grad[3]:
             gres = g
@@ -273,8 +279,8 @@ class LabelConvFn(torch.autograd.Function):
             raise NotImplementedError('use SpadeParamFn for the ReLU variant (mask fused into the dgrad)')
         cout, ncls = weight.shape[0], weight.shape[1]
         oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
-        gw = _unpack_dw(conv2d_wgrad_raw(oh, g, 3, 3, 1, 1), cout, ncls, 3, 3, 8)
-        return None, gw, colsum(g), None, None, None, None
+        dwp, gb = conv2d_wgrad_raw(oh, g, 3, 3, 1, 1, ACT_NONE, True)
+        return None, _unpack_dw(dwp, cout, ncls, 3, 3, 8), gb, None, None, None, None
 
 
 def label_conv3x3(label, weight, bias, h, w, relu, dtype):
@@ -305,13 +311,13 @@ class SpadeParamFn(torch.autograd.Function):
         g = ggb.contiguous()
         c2, nh = w_gb.shape[0], w_gb.shape[1]
         ncls = w_sh.shape[1]
-        gw_gb = _unpack_dw(conv2d_wgrad_raw(actv, g, 3, 3, 1, 1), c2, nh, 3, 3, nh)
-        gb_gb = colsum(g)
+        dwp, gb_gb = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True)
+        gw_gb = _unpack_dw(dwp, c2, nh, 3, 3, nh)
         wpt = pack_weight(w_gb, g.dtype, nh, True)
         dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
         oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
-        gw_sh = _unpack_dw(conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1), nh, ncls, 3, 3, 8)
-        gb_sh = colsum(dactv)
+        dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True)
+        gw_sh = _unpack_dw(dwp, nh, ncls, 3, 3, 8)
         return None, gw_sh, gb_sh, gw_gb, gb_gb, None, None, None
 
 

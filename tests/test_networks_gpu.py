@@ -334,5 +334,7 @@ def test_hip_graph_steps_match_eager():
     ref = {k: float(z['it0_%s' % k.replace('/', '_')]) for k in res[True][0][0]}
     for k, v in res[True][0][0].items():                      # and the graphed first iteration matches the real reference
         assert abs(v - ref[k]) <= 2e-3 * max(1.0, abs(ref[k])), (k, v, ref[k])
+    # beta1 = 0: every Adam step moves a weight by ~ +-lr_G, so a near-zero gradient whose sign flips under
+    # float-atomic summation noise differs by up to 2*lr_G per step; 3 steps at lr_G = 1e-4
     for k, v in res[False][1].items():
-        assert float((v - res[True][1][k]).abs().max()) <= 2e-3 * max(1e-3, float(v.abs().max())), k
+        assert float((v - res[True][1][k]).abs().max()) <= 3 * 2 * 1e-4 + 1e-5, k
