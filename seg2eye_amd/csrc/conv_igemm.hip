@@ -17,6 +17,7 @@
 //   HBM layout: activations NHWC so a tap's Cin run is contiguous (one 16-B load = 8 bf16 channels);
 //   the 1-D grid is remapped so tiles sharing an A panel (same pixel rows) run on one XCD's L2.
 #include "common.h"
+#include <stdlib.h>
 
 struct ConvKParams {
     const void* x; const void* w; const float* bias; const void* res; const void* aux; void* y;
@@ -60,7 +61,16 @@ __device__ __forceinline__ u32x4_t apply_lrelu16(u32x4_t r) {
 // VECPATH: Cin is a multiple of the 16-B vector width, so every im2col chunk is one aligned 16-B load.
 // The any-Cin element-wise gather (tiny-K layers only: Cin = 1 or 5) is a separate instantiation so
 // its index arithmetic never bloats the hot kernel.
-template <typename T, int BN, bool VECPATH>
+// GLDS: stage both operands with LDS-DMA (global_load_lds, 16 B per lane) instead of global_load +
+// ds_write_b128.  A ds_write_b128 costs ~13 LDS cycles per wave-instruction; with 8 of them per wave per
+// K-tile the register-staged kernel is LDS-write-bound (64 writes + 128 reads ~ 1340 LDS cycles per CU per
+// K-tile pair vs 1024 MFMA cycles).  LDS-DMA writes lane-linear (M0 base + lane*16), so one instruction
+// fills 8 consecutive 128-B rows; the XOR swizzle moves to the SOURCE side (lane at physical chunk c loads
+// logical chunk c ^ swz(row)), and lanes whose tap reads padding fetch from a 16-byte zero page.
+// GLDS needs VECPATH and no input activation (nothing passes through registers).
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <typename T, int BN, bool VECPATH, bool GLDS>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p) {
     constexpr int BM = 128;
     constexpr int VEC = Vec<T>::N;
@@ -86,7 +96,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
 
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ wgt = (const T*)p.w;
-    const int c = tid & 7, r0 = tid >> 3;
+    // register staging: thread -> rows r0 + 32*i, physical chunk tid&7 (swizzled on the LDS write)
+    // LDS-DMA        : wave w, instruction i fills rows 8*(w + 4*i) .. +7; lane -> row offset lane>>3,
+    //                  physical chunk lane&7, i.e. LOGICAL chunk (lane&7) ^ swz(row).  swz(row) =
+    //                  (row>>1)&7 = (4*(w&1) + (lane>>4)) & 7 for every i, so one (tap, ci) state per thread.
+    const int r0 = GLDS ? 8 * wave + (lane >> 3) : tid >> 3;
+    const int c = GLDS ? ((lane & 7) ^ ((r0 >> 1) & 7)) : (tid & 7);
     const int swz_st = (c ^ ((r0 >> 1) & 7)) << 4;     // (r0+32i)>>1 & 7 == (r0>>1)&7
 
     int by[4], bx[4], nb[4];
@@ -129,8 +144,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
         const int k0 = kt0 * BK + c * VEC, tap = k0 / p.Cin;
         l_ci = k0 - tap * p.Cin; l_ky = tap / p.KW; l_kx = tap - l_ky * p.KW;
     }
-    u32x4_t ra[4], rb[NB];
-    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+    struct Stage { u32x4_t a[4]; u32x4_t b[NB]; };
+    auto load_tile = [&](int kt, Stage& S) __attribute__((always_inline)) {
+        u32x4_t (&ra)[4] = S.a;
+        u32x4_t (&rb)[NB] = S.b;
         const int k0 = kt * BK + c * VEC;
         if constexpr (VECPATH) {
             const bool kvalid = l_ky < p.KH;             // <=> k0 < Ktot
@@ -168,7 +185,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
             rb[j] = *(const u32x4_t*)(wgt + (size_t)(tn * BN + r0 + 32 * j) * p.Kpad + kt * BK + c * VEC);
         });
     };
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    auto store_tile = [&](int buf, const Stage& S) __attribute__((always_inline)) {
+        const u32x4_t (&ra)[4] = S.a;
+        const u32x4_t (&rb)[NB] = S.b;
         char* base = smem + buf * STAGE;
         static_for<0, 4>([&](auto I) {
             constexpr int i = decltype(I)::value;
@@ -214,18 +233,55 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
     };
 
     const int nk = kt1 - kt0;                       // >= 1 by construction of kt_per_split
-    load_tile(kt0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt + 1 < nk; ++kt) {           // steady state: prefetch kt+1 around the MFMAs of kt
-        const int cur = kt & 1;
-        load_tile(kt0 + kt + 1);
-        compute(cur);
-        store_tile(cur ^ 1);
+    if constexpr (!GLDS) {
+        Stage s0;
+        load_tile(kt0, s0);
+        store_tile(0, s0);
+        __syncthreads();
+        for (int kt = 0; kt + 1 < nk; ++kt) {       // steady state: prefetch kt+1 around the MFMAs of kt
+            const int cur = kt & 1;
+            load_tile(kt0 + kt + 1, s0);
+            compute(cur);
+            store_tile(cur ^ 1, s0);
+            __syncthreads();
+        }
+        compute((nk - 1) & 1);
+        __syncthreads();
+    } else {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        // rows r0 + 32*i of this thread land at LDS row 8*(wave + 4*i) + (lane>>3) = r0 + 32*i: same rows
+        auto dma_tile = [&](int kt, int buf) __attribute__((always_inline)) {
+            char* base = smem + buf * STAGE;
+            const bool kvalid = l_ky < p.KH;
+            static_for<0, 4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                int pix;
+                const bool v = src_pixel(i, l_ky, l_kx, pix) && kvalid;
+                const void* src = v ? (const void*)(xg + (size_t)pix * p.Cin + l_ci) : (const void*)g_zero16;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (8 * wave + 32 * i) * 128), 16, 0, 0);
+            });
+            l_ci += BK;
+            while (l_ci >= p.Cin) { l_ci -= p.Cin; if (++l_kx == p.KW) { l_kx = 0; ++l_ky; } }
+            static_for<0, NB>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const void* src = wgt + (size_t)(tn * BN + r0 + 32 * j) * p.Kpad + kt * BK + c * VEC;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + A_BYTES + (8 * wave + 32 * j) * 128), 16, 0, 0);
+            });
+        };
+        dma_tile(kt0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int cur = kt & 1;
+            dma_tile(kt0 + kt + 1, cur ^ 1);        // DMA into the other buffer while this one is read
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        compute((nk - 1) & 1);
         __syncthreads();
     }
-    compute((nk - 1) & 1);
-    __syncthreads();
 
     // ---- epilogue: acc -> LDS fp32 [BM][BN] -> coalesced rows
     float* Cs = (float*)smem;
@@ -385,8 +441,11 @@ extern "C" int s2e_conv_k_pad(int dtype, int k) { const int bk = dtype == S2E_BF
 template <typename T, int BN>
 static int launch_conv(const ConvKParams& p, hipStream_t st) {
     const int grid = p.tiles * p.splits;
-    if (p.Cin % Vec<T>::N == 0) conv_igemm_kernel<T, BN, true><<<grid, 256, 0, st>>>(p);
-    else conv_igemm_kernel<T, BN, false><<<grid, 256, 0, st>>>(p);
+    static const bool glds = [] { const char* e = getenv("S2E_IGEMM_GLDS"); return e ? atoi(e) != 0 : true; }();
+    if (p.Cin % Vec<T>::N == 0) {
+        if (glds && p.in_act == S2E_ACT_NONE) conv_igemm_kernel<T, BN, true, true><<<grid, 256, 0, st>>>(p);
+        else conv_igemm_kernel<T, BN, true, false><<<grid, 256, 0, st>>>(p);
+    } else conv_igemm_kernel<T, BN, false, false><<<grid, 256, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_igemm_kernel");
     if (p.splits > 1) {
         const long nvec = (long)p.M * p.Cout / Vec<T>::N + 1;

@@ -13,6 +13,7 @@
 // (split-K over workgroups to fill 256 CUs); partial tiles are combined with fp32 atomics in
 // 128-B row segments (the shape global float atomics run at full rate for).
 #include "common.h"
+#include <stdlib.h>
 
 struct WgradParams {
     const void* x; const void* gy; float* dw; float* dbias;   // dbias != NULL: also accumulate sum_m gy[m][co]
@@ -32,10 +33,9 @@ __device__ __forceinline__ u32x2_t lds_tr16_b64(const char* p) {
 
 // VECPATH: Cin and Cout are multiples of the 16-B vector width (every real layer except the 1- and
 // 5-channel heads); the element-wise gather lives in its own instantiation.
-template <typename T, bool VECPATH>
+template <typename T, bool VECPATH, int BR>              // BR = pixels per chunk (one barrier per chunk)
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int VEC = Vec<T>::N;
-    constexpr int BR = 32;                               // pixels per chunk
     constexpr int ROW = WgLds<T>::ROW;
     constexpr int OP_BYTES = BR * ROW;                   // one operand tile
     constexpr int STAGE = 2 * OP_BYTES;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         if constexpr (sizeof(T) == 2) {
             const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, g2 = (lane >> 4) & 1;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BR / 16; ++ks) {
                 const int r = 16 * ks + 8 * hh + q;
                 u32x4_t a[2], b[2];
 #pragma unroll
@@ -263,15 +263,19 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
     const int max_splits = ceil_div(p.M, 256);            // at least 8 chunks per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    p.m_per_split = ceil_div(ceil_div(p.M, splits), 32) * 32;
+    p.m_per_split = ceil_div(ceil_div(p.M, splits), 64) * 64;
     splits = ceil_div(p.M, p.m_per_split);
     hipStream_t st = (hipStream_t)stream;
+    static const int br = [] { const char* e = getenv("S2E_WGRAD_BR"); return e ? atoi(e) : 32; }();
+    const int g = tiles * splits;
     if (dtype == S2E_BF16) {
-        if (d->Cin % 8 == 0 && d->Cout % 8 == 0) conv_wgrad_kernel<bf16_t, true><<<tiles * splits, 256, 0, st>>>(p);
-        else conv_wgrad_kernel<bf16_t, false><<<tiles * splits, 256, 0, st>>>(p);
+        if (d->Cin % 8 == 0 && d->Cout % 8 == 0) {
+            if (br == 64) conv_wgrad_kernel<bf16_t, true, 64><<<g, 256, 0, st>>>(p);
+            else conv_wgrad_kernel<bf16_t, true, 32><<<g, 256, 0, st>>>(p);
+        } else conv_wgrad_kernel<bf16_t, false, 32><<<g, 256, 0, st>>>(p);
     } else if (dtype == S2E_F32) {
-        if (d->Cin % 4 == 0 && d->Cout % 4 == 0) conv_wgrad_kernel<float, true><<<tiles * splits, 256, 0, st>>>(p);
-        else conv_wgrad_kernel<float, false><<<tiles * splits, 256, 0, st>>>(p);
+        if (d->Cin % 4 == 0 && d->Cout % 4 == 0) conv_wgrad_kernel<float, true, 32><<<g, 256, 0, st>>>(p);
+        else conv_wgrad_kernel<float, false, 32><<<g, 256, 0, st>>>(p);
     } else S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: bad dtype %d", dtype);
     S2E_CHECK_LAUNCH("conv_wgrad_kernel");
     return S2E_OK;
