@@ -137,6 +137,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
         return v;
     };
 
+    // Fast addressing for the vector paths: in every mode the source pixel of tap (ky,kx) for row i is
+    //   rowbase[i] + tapoff(ky,kx)   with a ROW-INDEPENDENT tap offset
+    //     forward        : rowbase = nb + by*Wi + bx,            tapoff = ky*Wi + kx
+    //     dgrad stride 1 : rowbase = nb + by*Wi + bx,            tapoff = -(ky*Wi + kx)
+    //     dgrad stride 2 : rowbase = nb + (by>>1)*Wi + (bx>>1),  tapoff = -((ky>>1)*Wi + (kx>>1))
+    //       (on a valid tap by-ky is even, and then (by-ky)/2 == (by>>1) - (ky>>1))
+    // and validity is one bit per tap, computed once per row (KH*KW <= 32).
+    long rowoff[4];                                   // rowbase * Cin  (element offset; may be negative)
+    unsigned vmask[4];
+    if constexpr (VECPATH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // validity is separable: tap (ky,kx) is valid iff ky is valid for this row's y AND kx for its x
+            auto ok1 = [&](int b, int k, int lim) __attribute__((always_inline)) -> bool {
+                if (!p.transposed) return (unsigned)(b + k) < (unsigned)lim;
+                const int t = b - k;
+                if (t < 0) return false;
+                if (p.stride == 2) return ((t & 1) == 0) && (t >> 1) < lim;
+                return t < lim;
+            };
+            unsigned xm = 0;
+            for (int kx = 0; kx < p.KW; ++kx) xm |= ok1(bx[i], kx, p.Wi) ? (1u << kx) : 0u;
+            unsigned m = 0;
+            for (int ky = 0; ky < p.KH; ++ky) m |= ok1(by[i], ky, p.Hi) ? (xm << (ky * p.KW)) : 0u;
+            vmask[i] = m;
+            const int rb = (p.transposed && p.stride == 2) ? nb[i] + (by[i] >> 1) * p.Wi + (bx[i] >> 1)
+                                                           : nb[i] + by[i] * p.Wi + bx[i];
+            rowoff[i] = (long)rb * p.Cin;
+        }
+    }
+    const int tap_sy = p.transposed ? -p.Wi : p.Wi, tap_sx = p.transposed ? -1 : 1;
+    const int tap_sh = (p.transposed && p.stride == 2) ? 1 : 0;
+    // element offset of tap (ky,kx), channel ci relative to a row's base
+    auto tap_elem_off = [&](int ky, int kx, int ci) __attribute__((always_inline)) -> long {
+        return (long)((ky >> tap_sh) * tap_sy + (kx >> tap_sh) * tap_sx) * p.Cin + ci;
+    };
+
     // loader state of the vector path: (ky, kx, ci) of this thread's 16-B chunk in the NEXT K-tile,
     // advanced incrementally (no per-tile integer division)
     int l_ky, l_kx, l_ci;
@@ -151,12 +188,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
         const int k0 = kt * BK + c * VEC;
         if constexpr (VECPATH) {
             const bool kvalid = l_ky < p.KH;             // <=> k0 < Ktot
+            const int tbit = kvalid ? l_ky * p.KW + l_kx : 0;
+            const long koff = tap_elem_off(l_ky, l_kx, l_ci);
             static_for<0, 4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                int pix;
-                const bool v = src_pixel(i, l_ky, l_kx, pix) && kvalid;
+                const bool v = kvalid && ((vmask[i] >> tbit) & 1u);
                 ra[i] = u32x4_t{0, 0, 0, 0};
-                if (v) ra[i] = *(const u32x4_t*)(xg + (size_t)pix * p.Cin + l_ci);
+                if (v) ra[i] = *(const u32x4_t*)(xg + (rowoff[i] + koff));
             });
             l_ci += BK;
             while (l_ci >= p.Cin) { l_ci -= p.Cin; if (++l_kx == p.KW) { l_kx = 0; ++l_ky; } }
@@ -254,11 +292,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
         auto dma_tile = [&](int kt, int buf) __attribute__((always_inline)) {
             char* base = smem + buf * STAGE;
             const bool kvalid = l_ky < p.KH;
+            const int tbit = kvalid ? l_ky * p.KW + l_kx : 0;
+            const long koff = tap_elem_off(l_ky, l_kx, l_ci);
             static_for<0, 4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                int pix;
-                const bool v = src_pixel(i, l_ky, l_kx, pix) && kvalid;
-                const void* src = v ? (const void*)(xg + (size_t)pix * p.Cin + l_ci) : (const void*)g_zero16;
+                const bool v = kvalid && ((vmask[i] >> tbit) & 1u);
+                const void* src = v ? (const void*)(xg + (rowoff[i] + koff)) : (const void*)g_zero16;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (8 * wave + 32 * i) * 128), 16, 0, 0);
             });
             l_ci += BK;
@@ -465,7 +504,7 @@ static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tile
     *tiles = ceil_div(M, 128) * (*tiles_n);
     const int nk = s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin) / (dtype == S2E_BF16 ? 64 : 32);
     int s = 1;
-    if (*tiles < 256 && nk >= 8) {
+    if (*tiles < 512 && nk >= 8) {                   // fewer than 2 workgroups per CU
         s = ceil_div(512, *tiles);
         if (s > nk / 4) s = nk / 4;                  // at least 4 K-tiles per split
         if (s < 1) s = 1;
@@ -489,6 +528,7 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hi <= 0 || d->Wi <= 0)
         S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: bad shape");
     if (d->aux_mode != S2E_AUX_NONE && !aux) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: aux_mode without aux");
+    if (d->KH * d->KW > 32) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d: kernel %dx%d has more than 32 taps", d->KH, d->KW);
     if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31))
         S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d: tensor too large for 32-bit pixel indices");
     ConvKParams p;

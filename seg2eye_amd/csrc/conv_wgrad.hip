@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;             // 2x2 waves, each 64(co) x 64(k)
-    int bid = blockIdx.x;
+    // consecutive logical ids (= the (co,k) tiles of ONE pixel slice, which stream the same gy / x rows in
+    // lockstep) are placed on one XCD so they share that XCD's L2 instead of each L2 re-fetching the slice
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tk = bid % p.tiles_k; bid /= p.tiles_k;
     const int tco = bid % p.tiles_co; const int split = bid / p.tiles_co;
     const int m_begin = split * p.m_per_split;
@@ -242,6 +244,152 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             }
 }
 
+// ------------------------------------------------------------------------------------ bf16 LDS-DMA variant
+// Same decomposition, operands staged with global_load_lds (no VGPR round trip, no ds_write_b128 -- the
+// register-staged kernel spends more LDS cycles on its stores than the MFMAs take).  Rows are 256 B,
+// unpadded; LDS-DMA writes lane-linear, so one instruction fills 4 rows and the XOR swizzle
+//   physical 16-B chunk = logical chunk ^ ((row & 3) << 2)
+// is applied to the SOURCE address.  With it the four rows a ds_read_b64_tr_b16 block touches fall in four
+// disjoint 64-B bank ranges (conflict-free).  Out-of-range rows / channels / padding taps read a zero page.
+__device__ __attribute__((aligned(16))) const uint32_t g_wg_zero16[4] = {0u, 0u, 0u, 0u};
+
+__global__ __launch_bounds__(256, 4) void conv_wgrad_glds_kernel(const WgradParams p) {
+    typedef bf16_t T;
+    constexpr int BR = 32, ROW = 256, OP_BYTES = BR * ROW, STAGE = 2 * OP_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // consecutive logical ids (= the (co,k) tiles of ONE pixel slice, which stream the same gy / x rows in
+    // lockstep) are placed on one XCD so they share that XCD's L2 instead of each L2 re-fetching the slice
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tk = bid % p.tiles_k; bid /= p.tiles_k;
+    const int tco = bid % p.tiles_co; const int split = bid / p.tiles_co;
+    const int m_begin = split * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+    if (m_begin >= m_end) return;
+
+    const T* __restrict__ xg = (const T*)p.x;
+    const T* __restrict__ gg = (const T*)p.gy;
+    // DMA mapping: wave w, instruction j fills rows 4*(w + 4*j) .. +3; lane -> row offset lane>>4, physical
+    // chunk lane&15 = logical chunk ^ ((row&3)<<2), row&3 == (lane>>4)&3 for both j
+    const int rsub = lane >> 4;
+    const int c = (lane & 15) ^ ((rsub & 3) << 2);           // logical chunk this lane fetches
+    const int co0 = tco * 128 + c * 8;
+    const int k0 = tk * 128 + c * 8;
+    const int HoWo = p.Ho * p.Wo;
+    int t_ci, t_ky, t_kx;
+    { const int tap = k0 / p.Cin; t_ci = k0 - tap * p.Cin; t_ky = tap / p.KW; t_kx = tap - t_ky * p.KW; }
+    const bool k_valid = k0 < p.Ktot, co_valid = co0 < p.Cout;
+    int rn[2], roy[2], rox[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m_begin + 4 * wave + 16 * j + rsub;
+        rn[j] = m / HoWo; const int rem = m - rn[j] * HoWo;
+        roy[j] = rem / p.Wo; rox[j] = rem - roy[j] * p.Wo;
+    }
+    auto dma_chunk = [&](int ch, int buf) __attribute__((always_inline)) {
+        char* base = smem + buf * STAGE;
+        static_for<0, 2>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const int m = m_begin + ch * BR + 4 * wave + 16 * j + rsub;
+            const bool mv = m < m_end;
+            const void* gsrc = (mv && co_valid) ? (const void*)(gg + (size_t)m * p.Cout + co0) : (const void*)g_wg_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(base + (4 * wave + 16 * j) * ROW), 16, 0, 0);
+            const int iy = roy[j] * p.stride - p.pad + t_ky, ix = rox[j] * p.stride - p.pad + t_kx;
+            const bool xv = mv && k_valid && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const void* xsrc = xv ? (const void*)(xg + ((size_t)(rn[j] * p.Hi + iy) * p.Wi + ix) * p.Cin + t_ci)
+                                  : (const void*)g_wg_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)xsrc, (lptr_t)(base + OP_BYTES + (4 * wave + 16 * j) * ROW), 16, 0, 0);
+            rox[j] += BR;
+            while (rox[j] >= p.Wo) { rox[j] -= p.Wo; ++roy[j]; }
+            while (roy[j] >= p.Ho) { roy[j] -= p.Ho; ++rn[j]; }
+        });
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, g2 = (lane >> 4) & 1;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const char* Gs = smem + buf * STAGE;
+        const char* Xs = Gs + OP_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r = 16 * ks + 8 * hh + q;                      // r & 3 == q; (r + 4) & 3 == q
+            u32x4_t a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int chunk = (wm * 64 + mi * 32) / 8 + 2 * g2 + (pp >> 1);
+                const char* ptr = Gs + r * ROW + ((chunk ^ (q << 2)) << 4) + (pp & 1) * 8;
+                const u32x2_t lo = lds_tr16_b64(ptr), hi = lds_tr16_b64(ptr + 4 * ROW);
+                a[mi] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int chunk = (wn * 64 + ni * 32) / 8 + 2 * g2 + (pp >> 1);
+                const char* ptr = Xs + r * ROW + ((chunk ^ (q << 2)) << 4) + (pp & 1) * 8;
+                const u32x2_t lo = lds_tr16_b64(ptr), hi = lds_tr16_b64(ptr + 4 * ROW);
+                b[ni] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8_t, a[mi]), __builtin_bit_cast(bf16x8_t, b[ni]), acc[mi][ni], 0, 0, 0);
+        }
+    };
+    // bias gradient from the gy tile in LDS: thread t < 128 owns channel t of this tile
+    const bool do_bias = (p.dbias != nullptr) && (tk == 0);
+    float bsum = 0.f;
+    auto bias_from_lds = [&](int buf) __attribute__((always_inline)) {
+        if (do_bias && tid < 128) {
+            const char* Gs = smem + buf * STAGE;
+            const int ch = tid >> 3, sub = (tid & 7) * 2;
+#pragma unroll 8
+            for (int r = 0; r < BR; ++r)
+                bsum += bf16_bits_to_f32(*(const unsigned short*)(Gs + r * ROW + ((ch ^ ((r & 3) << 2)) << 4) + sub));
+        }
+    };
+
+    const int nch = (m_end - m_begin + BR - 1) / BR;
+    dma_chunk(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch = 0; ch + 1 < nch; ++ch) {
+        const int cur = ch & 1;
+        dma_chunk(ch + 1, cur ^ 1);
+        compute(cur);
+        bias_from_lds(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    compute((nch - 1) & 1);
+    bias_from_lds((nch - 1) & 1);
+    if (do_bias && tid < 128) {
+        const int co = tco * 128 + tid;
+        if (co < p.Cout) atomicAdd(p.dbias + co, bsum);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = tco * 128 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int k = tk * 128 + wn * 64 + ni * 32 + l31;
+                if (co < p.Cout && k < p.Ktot) atomicAdd(p.dw + (size_t)co * p.Ktot + k, acc[mi][ni][r]);
+            }
+}
+
 extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
                                 void* stream) {
     if (!x || !gy || !dw || !d) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: null pointer");
@@ -269,8 +417,10 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
     static const int br = [] { const char* e = getenv("S2E_WGRAD_BR"); return e ? atoi(e) : 32; }();
     const int g = tiles * splits;
     if (dtype == S2E_BF16) {
+        static const bool glds = [] { const char* e = getenv("S2E_WGRAD_GLDS"); return e ? atoi(e) != 0 : false; }();
         if (d->Cin % 8 == 0 && d->Cout % 8 == 0) {
-            if (br == 64) conv_wgrad_kernel<bf16_t, true, 64><<<g, 256, 0, st>>>(p);
+            if (glds && d->in_act == S2E_ACT_NONE) conv_wgrad_glds_kernel<<<g, 256, 0, st>>>(p);
+            else if (br == 64) conv_wgrad_kernel<bf16_t, true, 64><<<g, 256, 0, st>>>(p);
             else conv_wgrad_kernel<bf16_t, true, 32><<<g, 256, 0, st>>>(p);
         } else conv_wgrad_kernel<bf16_t, false, 32><<<g, 256, 0, st>>>(p);
     } else if (dtype == S2E_F32) {
