@@ -109,10 +109,15 @@ int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* 
                            void* scratch, size_t scratch_bytes, float* sigma, int train, int iterations,
                            float eps, void* stream);
 /* Gradient through W = W_orig / sigma (sigma = u^T W_orig v; u, v constants):
- *   gw_orig = gW / sigma - (<gW, W_orig> / sigma^2) * u v^T     in OIHW order,
- * with gW given in the packed order of s2e_conv2d_wgrad ([co][(tap)*cin_pad + ci]).  dot_ws: 1 float scratch. */
+ *   gw_orig (=|+=) gW / sigma - (<gW, W_orig> / sigma^2) * u v^T     in OIHW order,
+ * with gW given in the packed order of s2e_conv2d_wgrad ([co][(tap)*cin_pad + ci]).  dot_ws: 1 float scratch.
+ * accumulate != 0 adds into gw_orig (e.g. straight into the optimizer's gradient arena). */
 int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, const float* u, const float* v, const float* sigma,
-                       float* dot_ws, float* gw_orig, int cout, int cin, int kh, int kw, int cin_pad, void* stream);
+                       float* dot_ws, float* gw_orig, int cout, int cin, int kh, int kw, int cin_pad, int accumulate,
+                       void* stream);
+/* gw_oihw[co][ci][ky][kx] (=|+=) gw_packed[co][(ky*kw+kx)*cin_pad + ci]: packed weight gradient -> torch layout. */
+int s2e_unpack_weight_grad(const float* gw_packed, float* gw_oihw, int cout, int cin, int kh, int kw, int cin_pad,
+                           int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ InstanceNorm statistics
  * nn.InstanceNorm2d(affine=False) statistics, normalization.py:73 / :41 (biased variance, eps 1e-5).

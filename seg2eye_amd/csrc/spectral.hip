@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) void sn_grad_dot_kernel(const float* __restric
     if (threadIdx.x == 0) atomicAdd(dot, red[0] + red[1] + red[2] + red[3]);
 }
 __global__ __launch_bounds__(256) void sn_grad_apply_kernel(const float* __restrict__ gwp, const float* __restrict__ u, const float* __restrict__ v,
-        const float* __restrict__ sigma, const float* __restrict__ dot, float* __restrict__ out, int cout, int cin, int taps, int cin_pad) {
+        const float* __restrict__ sigma, const float* __restrict__ dot, float* __restrict__ out, int cout, int cin, int taps, int cin_pad,
+        int accumulate) {
     const long total = (long)cout * cin * taps;
     const float inv = 1.f / *sigma;
     const float c = *dot * inv * inv;
@@ -212,12 +213,36 @@ __global__ __launch_bounds__(256) void sn_grad_apply_kernel(const float* __restr
         const int tap = (int)(i % taps);
         const long r = i / taps;
         const int ci = (int)(r % cin), co = (int)(r / cin);
-        out[i] = gwp[(size_t)co * taps * cin_pad + (size_t)tap * cin_pad + ci] * inv - c * u[co] * v[(size_t)ci * taps + tap];
+        const float g = gwp[(size_t)co * taps * cin_pad + (size_t)tap * cin_pad + ci] * inv - c * u[co] * v[(size_t)ci * taps + tap];
+        out[i] = accumulate ? out[i] + g : g;
     }
 }
 
+// grad[co][ci][tap] (+)= gwp[co][tap*cin_pad + ci]: packed wgrad output -> OIHW gradient (no spectral norm)
+__global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restrict__ gwp, float* __restrict__ out, int cout, int cin, int taps,
+                                                          int cin_pad, int accumulate) {
+    const long total = (long)cout * cin * taps;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const long r = i / taps;
+        const int ci = (int)(r % cin), co = (int)(r / cin);
+        const float g = gwp[(size_t)co * taps * cin_pad + (size_t)tap * cin_pad + ci];
+        out[i] = accumulate ? out[i] + g : g;
+    }
+}
+extern "C" int s2e_unpack_weight_grad(const float* gw_packed, float* gw_oihw, int cout, int cin, int kh, int kw, int cin_pad,
+                                      int accumulate, void* stream) {
+    if (!gw_packed || !gw_oihw || cout <= 0 || cin <= 0 || cin_pad < cin) S2E_FAIL(S2E_ERR_ARG, "s2e_unpack_weight_grad: bad argument");
+    const long total = (long)cout * cin * kh * kw;
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    unpack_grad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gw_packed, gw_oihw, cout, cin, kh * kw, cin_pad, accumulate);
+    S2E_CHECK_LAUNCH("unpack_grad_kernel");
+    return S2E_OK;
+}
+
 extern "C" int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, const float* u, const float* v, const float* sigma,
-                                  float* dot_ws, float* gw_orig, int cout, int cin, int kh, int kw, int cin_pad, void* stream) {
+                                  float* dot_ws, float* gw_orig, int cout, int cin, int kh, int kw, int cin_pad, int accumulate,
+                                  void* stream) {
     if (!gw_packed || !w_orig || !u || !v || !sigma || !dot_ws || !gw_orig || cout <= 0 || cin <= 0 || cin_pad < cin)
         S2E_FAIL(S2E_ERR_ARG, "s2e_sn_weight_grad: bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -225,7 +250,7 @@ extern "C" int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, c
     const long total = (long)cout * cin * kh * kw;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     sn_grad_dot_kernel<<<grid, 256, 0, st>>>(gw_packed, w_orig, dot_ws, cout, cin, kh * kw, cin_pad);
-    sn_grad_apply_kernel<<<grid, 256, 0, st>>>(gw_packed, u, v, sigma, dot_ws, gw_orig, cout, cin, kh * kw, cin_pad);
+    sn_grad_apply_kernel<<<grid, 256, 0, st>>>(gw_packed, u, v, sigma, dot_ws, gw_orig, cout, cin, kh * kw, cin_pad, accumulate);
     S2E_CHECK_LAUNCH("sn_weight_grad kernels");
     return S2E_OK;
 }

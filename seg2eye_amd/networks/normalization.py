@@ -60,9 +60,14 @@ class SPADE(nn.Module):
 
     def gamma_beta(self, seg, h, w, dtype):
         """[gamma | beta] as one (N,h,w,2C) tensor."""
-        w_gb = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], 0)
-        b_gb = torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], 0)
-        return ops.spade_params(seg.label, self.mlp_shared[0].weight, self.mlp_shared[0].bias, w_gb, b_gb, h, w, dtype)
+        return ops.spade_params(seg.label, self.mlp_shared[0].weight, self.mlp_shared[0].bias,
+                                self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias,
+                                h, w, dtype)
+
+    def arena_order(self):
+        """Parameter order that makes [W_gamma; W_beta] and [b_gamma; b_beta] contiguous in a flat arena."""
+        return [self.mlp_shared[0].weight, self.mlp_shared[0].bias, self.mlp_gamma.weight, self.mlp_beta.weight,
+                self.mlp_gamma.bias, self.mlp_beta.bias]
 
 
 class FC(nn.Module):

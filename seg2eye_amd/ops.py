@@ -50,24 +50,24 @@ class LaunchProfiler:
     (torch's current stream).  bench.py turns it on to measure the dominant kernel's achieved rate
     live; off by default (zero overhead)."""
     enabled = False
-    records = []          # (family, algorithmic_flops, start_event, end_event)
+    records = []          # (family, algorithmic_flops, start_event, end_event, tag)
 
     @classmethod
-    def run(cls, family, flops, fn):
+    def run(cls, family, flops, fn, tag=''):
         if not cls.enabled:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         r = fn()
         e.record()
-        cls.records.append((family, flops, s, e))
+        cls.records.append((family, flops, s, e, tag))
         return r
 
     @classmethod
     def summary(cls):
         """family -> dict(launches, flops, ms); call after a device synchronize."""
         out = {}
-        for fam, fl, s, e in cls.records:
+        for fam, fl, s, e, _ in cls.records:
             d = out.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0))
             d['launches'] += 1
             d['flops'] += fl
@@ -119,20 +119,55 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     return y
 
 
-def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False):
+def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False, dbias_out=None):
     """-> (dw, db): dw (Cout, KH*KW*Cin) fp32 in packed order; db (Cout) fp32 or None.  Both live in one
-    zero-filled buffer (a single fill launch)."""
-    _need(x, gy)
+    zero-filled buffer (a single fill launch).  dbias_out: an fp32 (Cout) tensor to ACCUMULATE the bias
+    gradient into instead (e.g. the parameter's slice of the gradient arena); then db is None."""
+    _need(x, gy, dbias_out)
     n, hi, wi, cin = x.shape
     _, ho, wo, cout = gy.shape
     k = kh * kw * cin
-    buf = torch.zeros(cout * k + (cout if want_bias else 0), dtype=torch.float32, device=x.device)
+    own_b = want_bias and dbias_out is None
+    buf = torch.zeros(cout * k + (cout if own_b else 0), dtype=torch.float32, device=x.device)
     dw = buf[:cout * k].view(cout, k)
-    db = buf[cout * k:] if want_bias else None
+    db = buf[cout * k:] if own_b else None
+    dbp = db if own_b else dbias_out
     d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
     LaunchProfiler.run('conv_wgrad', 2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
-        L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), _p(db), C.byref(d), _stream()), 's2e_conv2d_wgrad'))
+        L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), _p(dbp), C.byref(d), _stream()), 's2e_conv2d_wgrad'),
+        tag='W n%d %dx%d c%d->%d k%d s%d' % (n, hi, wi, cin, cout, kh, stride))
     return dw, db
+
+
+def _grad_dst(p):
+    """The tensor a backward kernel may accumulate this parameter's gradient into directly: its .grad when
+    that already exists as a contiguous fp32 tensor (optim.FlatAdam keeps .grad as a view of the gradient
+    arena and zeroes it at the start of every step).  None -> return the gradient to autograd instead."""
+    g = getattr(p, 'grad', None)
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
+        return None
+    return g
+
+
+def _adjacent(a, b):
+    """b starts exactly where a ends in the same storage (both contiguous)."""
+    return (a is not None and b is not None and a.is_contiguous() and b.is_contiguous()
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel())
+
+
+def _span2(a, shape):
+    """View of `a`'s storage starting at a, with `shape` (covers a and the tensor laid out right after it)."""
+    strides, st = [], 1
+    for d in reversed(shape):
+        strides.append(st)
+        st *= d
+    return a.detach().as_strided(shape, tuple(reversed(strides)))
+
+
+def unpack_weight_grad_into(dwp, dst, cout, cin, kh, kw, cin_pad, accumulate=True):
+    L.check(L.lib().s2e_unpack_weight_grad(_p(dwp), _p(dst), cout, cin, kh, kw, cin_pad, int(accumulate), _stream()),
+            's2e_unpack_weight_grad')
 
 
 def colsum(g):
@@ -202,6 +237,8 @@ class Conv2dFn(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act)
         ctx.cfg = (stride, pad, in_act, out_act, bias is not None, residual is not None)
+        ctx.wdst = _grad_dst(weight)                       # direct accumulation targets (or None)
+        ctx.bdst = _grad_dst(bias) if bias is not None else None
         ctx.save_for_backward(x, weight, y if out_act != ACT_NONE else None, u, v, sigma)
         return y
 
@@ -227,15 +264,21 @@ class Conv2dFn(torch.autograd.Function):
                             True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
         want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dwp, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b)
+            bdst = ctx.bdst if want_b else None
+            dwp, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, bdst)
+            wdst = ctx.wdst
             if sigma is None:
-                gw = _unpack_dw(dwp, cout, cin, kh, kw, cx)
+                if wdst is not None:
+                    unpack_weight_grad_into(dwp, wdst, cout, cin, kh, kw, cx)
+                else:
+                    gw = _unpack_dw(dwp, cout, cin, kh, kw, cx)
             else:
-                gw = torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
+                acc = wdst is not None
+                out = wdst if acc else torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
                 dot = torch.empty(1, dtype=torch.float32, device=x.device)
-                w32 = weight.detach()
-                L.check(L.lib().s2e_sn_weight_grad(_p(dwp), _p(w32), _p(u), _p(v), _p(sigma), _p(dot), _p(gw),
-                                                   cout, cin, kh, kw, cx, _stream()), 's2e_sn_weight_grad')
+                L.check(L.lib().s2e_sn_weight_grad(_p(dwp), _p(weight.detach()), _p(u), _p(v), _p(sigma), _p(dot), _p(out),
+                                                   cout, cin, kh, kw, cx, int(acc), _stream()), 's2e_sn_weight_grad')
+                gw = None if acc else out
         elif want_b:
             gb = colsum(g)
         if has_res and ctx.needs_input_grad[3]:
@@ -267,6 +310,7 @@ class LabelConvFn(torch.autograd.Function):
         out = label_conv3x3_raw(label, _table_of(weight), bias.detach().float().contiguous(), n, H, W, h, w,
                                 weight.shape[0], relu, dtype)
         ctx.cfg = (h, w, relu)
+        ctx.wdst, ctx.bdst = _grad_dst(weight), _grad_dst(bias)
         ctx.save_for_backward(label, weight, out if relu else None)
         return out
 
@@ -279,7 +323,10 @@ class LabelConvFn(torch.autograd.Function):
             raise NotImplementedError('use SpadeParamFn for the ReLU variant (mask fused into the dgrad)')
         cout, ncls = weight.shape[0], weight.shape[1]
         oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
-        dwp, gb = conv2d_wgrad_raw(oh, g, 3, 3, 1, 1, ACT_NONE, True)
+        dwp, gb = conv2d_wgrad_raw(oh, g, 3, 3, 1, 1, ACT_NONE, True, ctx.bdst)
+        if ctx.wdst is not None:
+            unpack_weight_grad_into(dwp, ctx.wdst, cout, ncls, 3, 3, 8)
+            return None, None, gb, None, None, None, None
         return None, _unpack_dw(dwp, cout, ncls, 3, 3, 8), gb, None, None, None, None
 
 
@@ -289,40 +336,63 @@ def label_conv3x3(label, weight, bias, h, w, relu, dtype):
 
 class SpadeParamFn(torch.autograd.Function):
     """gb = conv3x3(ReLU(conv3x3(one_hot(label_h)))) : the SPADE branch that produces
-    [gamma | beta] (normalization.py:97-101) as one 2C-channel tensor.  w_gb = cat(mlp_gamma.weight,
-    mlp_beta.weight).  Backward: the ReLU mask is fused into the data-gradient epilogue, and the
-    mlp_shared weight gradient is an MFMA wgrad against the (tiny) 8-channel one-hot map."""
+    [gamma | beta] (normalization.py:97-101) as one 2C-channel tensor.
+    When mlp_gamma / mlp_beta weights (and biases) sit back to back in the optimizer arena (Pix2PixModel
+    orders them so), [W_gamma; W_beta] is a zero-copy view and the backward accumulates straight into
+    the gradient arena; otherwise they are concatenated and the gradients go back through autograd.
+    Backward: the ReLU mask is fused into the data-gradient epilogue; the mlp_shared weight gradient is an
+    MFMA wgrad against the (tiny) 8-channel one-hot map; bias gradients come out of the wgrad kernels."""
 
     @staticmethod
-    def forward(ctx, label, w_sh, b_sh, w_gb, b_gb, h, w, dtype):
+    def forward(ctx, label, w_sh, b_sh, w_g, b_g, w_b, b_b, h, w, dtype):
         n, H, W = label.shape
-        nh = w_sh.shape[0]
+        nh, C = w_sh.shape[0], w_g.shape[0]
+        fused = _adjacent(w_g, w_b) and _adjacent(b_g, b_b)
+        if fused:
+            w_gb, b_gb = _span2(w_g, (2 * C, nh, 3, 3)), _span2(b_g, (2 * C,))
+        else:
+            w_gb = torch.cat([w_g.detach(), w_b.detach()], 0)
+            b_gb = torch.cat([b_g.detach(), b_b.detach()], 0)
         actv = label_conv3x3_raw(label, _table_of(w_sh), b_sh.detach().float().contiguous(), n, H, W, h, w, nh, True, dtype)
         wp = pack_weight(w_gb, dtype, nh, False)
-        gb = conv2d_raw(actv, wp, b_gb.detach().float().contiguous(), None, None, (h, w, w_gb.shape[0]), 3, 3, 1, 1)
-        ctx.cfg = (h, w)
+        gb = conv2d_raw(actv, wp, b_gb.float().contiguous(), None, None, (h, w, 2 * C), 3, 3, 1, 1)
+        ctx.cfg = (h, w, C)
+        gwg, gwb, gbg, gbb = _grad_dst(w_g), _grad_dst(w_b), _grad_dst(b_g), _grad_dst(b_b)
+        ctx.gb_dst = (_span2(gwg, (2 * C, nh, 3, 3)), _span2(gbg, (2 * C,))) \
+            if (fused and _adjacent(gwg, gwb) and _adjacent(gbg, gbb)) else None
+        ctx.sh_dst = (_grad_dst(w_sh), _grad_dst(b_sh))
         ctx.save_for_backward(label, w_sh, w_gb, actv)
         return gb
 
     @staticmethod
     def backward(ctx, ggb):
         label, w_sh, w_gb, actv = ctx.saved_tensors
-        h, w = ctx.cfg
+        h, w, C = ctx.cfg
         g = ggb.contiguous()
         c2, nh = w_gb.shape[0], w_gb.shape[1]
         ncls = w_sh.shape[1]
-        dwp, gb_gb = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True)
-        gw_gb = _unpack_dw(dwp, c2, nh, 3, 3, nh)
+        gw_g = gb_g = gw_b = gb_b = gw_sh = gb_sh = None
+        if ctx.gb_dst is not None:
+            dwp, _ = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1])
+            unpack_weight_grad_into(dwp, ctx.gb_dst[0], c2, nh, 3, 3, nh)
+        else:
+            dwp, gb_gb = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True)
+            gw_gb = _unpack_dw(dwp, c2, nh, 3, 3, nh)
+            gw_g, gw_b, gb_g, gb_b = gw_gb[:C], gw_gb[C:], gb_gb[:C], gb_gb[C:]
         wpt = pack_weight(w_gb, g.dtype, nh, True)
         dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
         oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
-        dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True)
-        gw_sh = _unpack_dw(dwp, nh, ncls, 3, 3, 8)
-        return None, gw_sh, gb_sh, gw_gb, gb_gb, None, None, None
+        wdst, bdst = ctx.sh_dst
+        dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True, bdst)
+        if wdst is not None:
+            unpack_weight_grad_into(dwp, wdst, nh, ncls, 3, 3, 8)
+        else:
+            gw_sh = _unpack_dw(dwp, nh, ncls, 3, 3, 8)
+        return None, gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b, None, None, None
 
 
-def spade_params(label, w_sh, b_sh, w_gb, b_gb, h, w, dtype):
-    return SpadeParamFn.apply(label, w_sh, b_sh, w_gb, b_gb, h, w, dtype)
+def spade_params(label, w_sh, b_sh, w_g, b_g, w_b, b_b, h, w, dtype):
+    return SpadeParamFn.apply(label, w_sh, b_sh, w_g, b_g, w_b, b_b, h, w, dtype)
 
 
 # ------------------------------------------------------------------------------ modulation / IN

@@ -76,7 +76,16 @@ class Pix2PixModel(nn.Module):
 
     def create_optimizers(self, opt):
         """TTUR: betas (0, 0.9), lr_G = lr/2 over netG+netE, lr_D = 2*lr (pix2pix_model.py:92-110)."""
-        G_params = list(self.netG.parameters()) + list(self.netE.parameters())
+        # same parameter SET as the reference (netG + netE); the ORDER inside the flat arena puts each SPADE's
+        # gamma/beta conv weights (and biases) back to back so [gamma|beta] is one zero-copy matrix
+        from .networks.normalization import SPADE
+        G_params, seen = [], set()
+        for mod in self.netG.modules():
+            if isinstance(mod, SPADE):
+                for q in mod.arena_order():
+                    seen.add(id(q))
+                    G_params.append(q)
+        G_params += [q for q in self.netG.parameters() if id(q) not in seen] + list(self.netE.parameters())
         if opt.no_TTUR:
             beta1, beta2, G_lr, D_lr = opt.beta1, opt.beta2, opt.lr, opt.lr
         else:

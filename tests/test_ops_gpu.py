@@ -194,6 +194,7 @@ def test_spade_params_and_label_conv(cfg, dtype):
     b_sh = _rnd((128,), 22, torch.float32, 0.1)
     w_gb = _rnd((C2, 128, 3, 3), 23, torch.float32, 0.03)
     b_gb = _rnd((C2,), 24, torch.float32, 0.1)
+    Ch = C2 // 2
     ggb = _rnd((N, C2, h, w), 25, dtype)
     refs = [t.double().requires_grad_(True) for t in (w_sh, b_sh, w_gb.to(dtype), b_gb)]
     actv = F.relu(F.conv2d(seg_h, refs[0], refs[1], padding=1))
@@ -201,12 +202,28 @@ def test_spade_params_and_label_conv(cfg, dtype):
         actv = actv + (actv.detach().to(dtype).double() - actv.detach())      # the kernel stores actv in bf16
     gbr = F.conv2d(actv, refs[2], refs[3], padding=1)
     gbr.backward(ggb.double())
-    prm = [t.to(dev).requires_grad_(True) for t in (w_sh, b_sh, w_gb, b_gb)]
-    gb = ops.spade_params(lab.to(dev), prm[0], prm[1], prm[2], prm[3], h, w, dtype)
+    # (a) separate gamma / beta parameters -> concatenated inside, gradients through autograd
+    prm = [t.to(dev).requires_grad_(True) for t in (w_sh, b_sh, w_gb[:Ch].clone(), b_gb[:Ch].clone(), w_gb[Ch:].clone(), b_gb[Ch:].clone())]
+    gb = ops.spade_params(lab.to(dev), *prm, h, w, dtype)
     _close(nchw(gb), gbr, dtype, what='gb')
     gb.backward(nhwc(ggb).to(dev))
-    for name, a, b in zip(('dw_sh', 'db_sh', 'dw_gb', 'db_gb'), prm, refs):
-        _close(a.grad, b.grad, dtype, what=name)
+    _close(prm[0].grad, refs[0].grad, dtype, what='dw_sh')
+    _close(prm[1].grad, refs[1].grad, dtype, what='db_sh')
+    _close(torch.cat([prm[2].grad, prm[4].grad]), refs[2].grad, dtype, what='dw_gb')
+    _close(torch.cat([prm[3].grad, prm[5].grad]), refs[3].grad, dtype, what='db_gb')
+    # (b) parameters living in a flat arena (gamma/beta adjacent): zero-copy [gamma|beta], direct .grad accumulation
+    from seg2eye_amd.optim import FlatAdam
+    prm2 = [torch.nn.Parameter(t.to(dev)) for t in (w_sh, b_sh, w_gb[:Ch].clone(), w_gb[Ch:].clone(), b_gb[:Ch].clone(), b_gb[Ch:].clone())]
+    fa = FlatAdam(prm2, lr=1e-3)
+    for _ in range(2):                                   # twice: accumulation, not overwrite
+        gb2 = ops.spade_params(lab.to(dev), prm2[0], prm2[1], prm2[2], prm2[4], prm2[3], prm2[5], h, w, dtype)
+        gb2.backward(nhwc(ggb).to(dev))
+    _close(nchw(gb2), gbr, dtype, what='gb (arena)')
+    _close(prm2[0].grad, 2 * refs[0].grad, dtype, what='dw_sh (arena)')
+    _close(prm2[1].grad, 2 * refs[1].grad, dtype, what='db_sh (arena)')
+    _close(torch.cat([prm2[2].grad, prm2[3].grad]), 2 * refs[2].grad, dtype, what='dw_gb (arena)')
+    _close(torch.cat([prm2[4].grad, prm2[5].grad]), 2 * refs[3].grad, dtype, what='db_gb (arena)')
+    assert prm2[2].grad.data_ptr() >= fa.flat_g.data_ptr()
     # plain label conv (generator fc), no ReLU, wide Cout
     w_fc = _rnd((C2 * 2, 4, 3, 3), 26, torch.float32, 0.3)
     b_fc = _rnd((C2 * 2,), 27, torch.float32, 0.1)
