@@ -17,6 +17,7 @@
 //   HBM layout: activations NHWC so a tap's Cin run is contiguous (one 16-B load = 8 bf16 channels);
 //   the 1-D grid is remapped so tiles sharing an A panel (same pixel rows) run on one XCD's L2.
 #include "common.h"
+#include "conv_small.h"
 #include <stdlib.h>
 
 struct ConvKParams {
@@ -515,6 +516,7 @@ static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tile
 
 extern "C" size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d) {
     if (!d) return 0;
+    if (s2e_small_conv_kind(dtype, d) != SMALL_NONE) return 0;
     int tiles, tiles_n, splits, per;
     plan_splits(dtype, d, &tiles, &tiles_n, &splits, &per);
     return splits > 1 ? (size_t)splits * d->N * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
@@ -531,6 +533,15 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
     if (d->KH * d->KW > 32) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d: kernel %dx%d has more than 32 taps", d->KH, d->KW);
     if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31))
         S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d: tensor too large for 32-bit pixel indices");
+    if (const int kind = s2e_small_conv_kind(dtype, d)) {           // 1-channel heads: dedicated streaming kernels
+        SmallConvParams sp{};
+        sp.x = x; sp.w = w; sp.bias = bias; sp.res = res; sp.aux = aux; sp.y = y;
+        sp.N = d->N; sp.Hi = d->Hi; sp.Wi = d->Wi; sp.Cin = d->Cin; sp.Ho = d->Ho; sp.Wo = d->Wo; sp.Cout = d->Cout;
+        sp.KH = d->KH; sp.KW = d->KW; sp.stride = d->stride; sp.pad = d->pad;
+        sp.in_act = d->in_act; sp.out_act = d->out_act; sp.aux_mode = d->aux_mode;
+        sp.Kpad = s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin);
+        return s2e_small_conv_launch(dtype, kind, sp, (hipStream_t)stream);
+    }
     ConvKParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;

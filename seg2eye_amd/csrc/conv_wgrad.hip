@@ -13,6 +13,7 @@
 // (split-K over workgroups to fill 256 CUs); partial tiles are combined with fp32 atomics in
 // 128-B row segments (the shape global float atomics run at full rate for).
 #include "common.h"
+#include "conv_small.h"
 #include <stdlib.h>
 
 struct WgradParams {
@@ -397,6 +398,15 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
     if (d->stride != 1 && d->stride != 2) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad: stride %d", d->stride);
     if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31))
         S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad: tensor too large for 32-bit pixel indices");
+    if (const int kind = s2e_small_wgrad_kind(dtype, d)) {          // 1-channel heads: dedicated streaming kernels
+        SmallConvParams sp{};
+        sp.x = x; sp.gy = gy; sp.dw = dw;
+        sp.N = d->N; sp.Hi = d->Hi; sp.Wi = d->Wi; sp.Cin = d->Cin; sp.Ho = d->Ho; sp.Wo = d->Wo; sp.Cout = d->Cout;
+        sp.KH = d->KH; sp.KW = d->KW; sp.stride = d->stride; sp.pad = d->pad; sp.in_act = d->in_act;
+        if (int rc = s2e_small_wgrad_launch(dtype, kind, sp, (hipStream_t)stream)) return rc;
+        if (dbias) return s2e_colsum(dtype, gy, (long)d->N * d->Ho * d->Wo, d->Cout, dbias, stream);
+        return S2E_OK;
+    }
     WgradParams p;
     p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
