@@ -316,8 +316,11 @@ int s2e_small_wgrad_kind(int dtype, const s2e_conv_desc* d) {
 
 int s2e_small_wgrad_launch(int dtype, int kind, const SmallConvParams& p, hipStream_t st) {
     const long work = kind == SMALL_WGRAD_COUT1 ? (long)p.N * p.Hi * p.Wi : (long)p.N * p.Ho * p.Wo;
-    int grid = (int)(work / 2048 + 1);
-    if (grid > 1024) grid = 1024;
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    const int ppb = 256 / ((kind == SMALL_WGRAD_COUT1 ? p.Cin : p.Cout) / vec);     // pixels per pass of one block
+    long g = (work + (long)ppb * 8 - 1) / ((long)ppb * 8);                          // >= 8 passes per block ...
+    if (g > 256) g = 256;       // ... one block per CU at most: every block ends with atomics on the SAME small dW
+    const int grid = (int)(g < 1 ? 1 : g);
     if (dtype == S2E_BF16) {
         if (kind == SMALL_WGRAD_COUT1) wgrad_cout1_kernel<bf16_t><<<grid, 256, 0, st>>>(p);
         else wgrad_cin1_kernel<bf16_t><<<grid, 256, 0, st>>>(p);

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 
     // bias gradient: the k-tile 0 workgroups also sum the gy vectors they stage (per thread: VEC channels of
     // its rows), reduced across the block's row-threads through LDS at the end -> one atomic per channel
-    const bool do_bias = (p.dbias != nullptr) && (tk == 0);
+    // the bias sums are spread over the k-tile workgroups of a slice: chunk ch is summed by the
+    // workgroup with tk == ch % tiles_k (every gy row exactly once, no straggler tile)
+    const bool want_bias = p.dbias != nullptr;
     float bsum[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) bsum[j] = 0.f;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                     f[j] = (mv && co0 + j < p.Cout) ? load1<T>(gg + (size_t)m * p.Cout + co0 + j) : 0.f;
                 rg[i] = pack16<T>(f);
             }
-            if (do_bias) {
+            if (want_bias && (ch % p.tiles_k) == tk) {
                 float f[VEC];
                 unpack16<T>(rg[i], f);
 #pragma unroll
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     }
     compute((nch - 1) & 1);
 
-    if (p.dbias != nullptr && tk == 0) {                  // block-uniform
+    if (want_bias) {                                      // block-uniform
         __syncthreads();
         float* red = (float*)smem;                        // [RPT][128]
 #pragma unroll
@@ -349,10 +351,10 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_glds_kernel(const WgradPara
         }
     };
     // bias gradient from the gy tile in LDS: thread t < 128 owns channel t of this tile
-    const bool do_bias = (p.dbias != nullptr) && (tk == 0);
+    const bool do_bias = p.dbias != nullptr;
     float bsum = 0.f;
-    auto bias_from_lds = [&](int buf) __attribute__((always_inline)) {
-        if (do_bias && tid < 128) {
+    auto bias_from_lds = [&](int buf, int ch) __attribute__((always_inline)) {
+        if (do_bias && (ch % p.tiles_k) == tk && tid < 128) {
             const char* Gs = smem + buf * STAGE;
             const int ch = tid >> 3, sub = (tid & 7) * 2;
 #pragma unroll 8
@@ -369,12 +371,12 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_glds_kernel(const WgradPara
         const int cur = ch & 1;
         dma_chunk(ch + 1, cur ^ 1);
         compute(cur);
-        bias_from_lds(cur);
+        bias_from_lds(cur, ch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     compute((nch - 1) & 1);
-    bias_from_lds((nch - 1) & 1);
+    bias_from_lds((nch - 1) & 1, nch - 1);
     if (do_bias && tid < 128) {
         const int co = tco * 128 + tid;
         if (co < p.Cout) atomicAdd(p.dbias + co, bsum);

@@ -40,13 +40,18 @@ def checksum(t):
     return np.concatenate([[t.sum().item(), t.abs().sum().item()], t[idx].numpy()])
 
 
-def assert_checksum_close(t, ref, rtol, what=''):
+def assert_checksum_close(t, ref, rtol, what='', flip=0.0):
+    """`flip` is the size of ONE legitimate discrete difference per element (2*lr*steps for parameters
+    stepped by Adam with beta1 = 0: the first update is exactly -lr*sign(g), so a gradient within
+    float-summation noise of zero moves its weight by +lr in one implementation and -lr in the other).
+    The sums may absorb max(2, 1%) such elements, a sampled element one."""
     got = checksum(t)
     scale = max(ref[1] / max(t.numel(), 1), 1e-12)        # mean |x|
+    slack = flip * max(2, 0.01 * t.numel())
     # sum / abs-sum: compare relative to the abs-sum; samples: relative to mean |x|
-    assert abs(got[0] - ref[0]) <= rtol * max(ref[1], 1e-12), (what, got[0], ref[0])
-    assert abs(got[1] - ref[1]) <= rtol * max(ref[1], 1e-12), (what, got[1], ref[1])
-    np.testing.assert_allclose(got[2:], ref[2:], rtol=0, atol=rtol * 50 * scale + 1e-9, err_msg=what)
+    assert abs(got[0] - ref[0]) <= rtol * max(ref[1], 1e-12) + slack, (what, got[0], ref[0])
+    assert abs(got[1] - ref[1]) <= rtol * max(ref[1], 1e-12) + slack, (what, got[1], ref[1])
+    np.testing.assert_allclose(got[2:], ref[2:], rtol=0, atol=rtol * 50 * scale + 1e-9 + flip, err_msg=what)
 
 
 @pytest.fixture(scope='session')
