@@ -88,9 +88,14 @@ int s2e_conv2d(int dtype, const void* x, const void* w_packed, const float* bias
  * dw[co][(ky*KW+kx)*Cin + ci] += sum_{n,oy,ox} gy[n,oy,ox,co] * in_act(x)[n, oy*s-p+ky, ox*s-p+kx, ci]
  * dw: fp32 (Cout x KH*KW*Cin), row-major, ACCUMULATED into (caller zeroes it); split over pixels
  * with fp32 atomics.  dbias: NULL, or fp32 (Cout) ACCUMULATED with the bias gradient
- * sum_{n,oy,ox} gy[n,oy,ox,co] from the gy tiles the kernel stages anyway (no extra pass over gy). */
+ * sum_{n,oy,ox} gy[n,oy,ox,co] from the gy tiles the kernel stages anyway (no extra pass over gy).
+ * The 1-channel shapes (Cout == 1 or Cin == 1: conv_img, the PatchGAN heads, the encoder's first layer)
+ * run as HBM streams whose per-block partial rows go through `workspace` and are summed by a second
+ * kernel; s2e_conv2d_wgrad_workspace_bytes(d) is 0 for every other shape (workspace may then be NULL).
+ * The caller allocates; no initialisation needed. */
+size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_desc* d);
 int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
-                     void* stream);
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ spectral normalisation
  * torch.nn.utils.spectral_norm as applied at architecture.py:30-34 and normalization.py:25-26
@@ -110,7 +115,7 @@ int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* 
                            float eps, void* stream);
 /* Gradient through W = W_orig / sigma (sigma = u^T W_orig v; u, v constants):
  *   gw_orig (=|+=) gW / sigma - (<gW, W_orig> / sigma^2) * u v^T     in OIHW order,
- * with gW given in the packed order of s2e_conv2d_wgrad ([co][(tap)*cin_pad + ci]).  dot_ws: 1 float scratch.
+ * with gW given in the packed order of s2e_conv2d_wgrad ([co][(tap)*cin_pad + ci]).  dot_ws: 1 float of scratch, ZERO-FILLED by the caller.
  * accumulate != 0 adds into gw_orig (e.g. straight into the optimizer's gradient arena). */
 int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, const float* u, const float* v, const float* sigma,
                        float* dot_ws, float* gw_orig, int cout, int cin, int kh, int kw, int cin_pad, int accumulate,
@@ -121,7 +126,8 @@ int s2e_unpack_weight_grad(const float* gw_packed, float* gw_oihw, int cout, int
 
 /* ------------------------------------------------------------------ InstanceNorm statistics
  * nn.InstanceNorm2d(affine=False) statistics, normalization.py:73 / :41 (biased variance, eps 1e-5).
- * x (N, HW, C) -> stats (N, C, 2) fp32 = {mean, rstd}.  ws: N*C*2 doubles of scratch (zeroed here). */
+ * x (N, HW, C) -> stats (N, C, 2) fp32 = {mean, rstd}.  ws: N*C*2 doubles of scratch, ZERO-FILLED by the caller
+ * (one fill can serve all the scratch of a step: seg2eye_amd/ops.py::ZeroPool); dirty on return. */
 int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, void* stream);
 
 /* ------------------------------------------------------------------ SPADE+Style modulation / IN+LeakyReLU
@@ -136,7 +142,7 @@ int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* gb, const f
                      void* out, int N, int HW, int C, int lrelu, void* stream);
 /* Backward of the above given g = dL/dout.  Writes dx (N,HW,C), dgb (N,HW,2C) and ACCUMULATES
  * dstyle (N,2C) fp32 (SPADE_STYLE mode only; dgb/dstyle may be NULL in PLAIN_IN mode).
- * ws: N*C*4 doubles of scratch (zeroed here). */
+ * ws: N*C*4 doubles of scratch, ZERO-FILLED by the caller; dirty on return. */
 int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
                      const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                      int N, int HW, int C, int lrelu, void* stream);

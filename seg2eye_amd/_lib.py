@@ -46,7 +46,8 @@ SIGNATURES = {
     's2e_unpack_weight_grad': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     's2e_conv2d_workspace_bytes': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
-    's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp],
+    's2e_conv2d_wgrad_workspace_bytes': [_i, C.POINTER(ConvDesc)],
+    's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_in_stats': [_i, _vp, _i, _i, _i, _f, _vp, _vp, _vp],
     's2e_modulate_fwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     's2e_modulate_bwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -84,7 +85,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = (C.c_char_p if name == 's2e_last_error' else
-                          C.c_size_t if name == 's2e_conv2d_workspace_bytes' else C.c_int)
+                          C.c_size_t if name.endswith('_workspace_bytes') else C.c_int)
         _lib = L
     return _lib
 

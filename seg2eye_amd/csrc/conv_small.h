@@ -13,4 +13,6 @@ struct SmallConvParams {
 int s2e_small_conv_kind(int dtype, const s2e_conv_desc* d);
 int s2e_small_conv_launch(int dtype, int kind, const SmallConvParams& p, hipStream_t st);
 int s2e_small_wgrad_kind(int dtype, const s2e_conv_desc* d);
-int s2e_small_wgrad_launch(int dtype, int kind, const SmallConvParams& p, hipStream_t st);
+size_t s2e_small_wgrad_workspace_bytes(int dtype, int kind, const s2e_conv_desc* d);
+int s2e_small_wgrad_launch(int dtype, int kind, const s2e_conv_desc* d, const SmallConvParams& p, void* workspace,
+                           size_t workspace_bytes, hipStream_t st);

@@ -393,8 +393,15 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_glds_kernel(const WgradPara
             }
 }
 
+extern "C" size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_desc* d) {
+    if (!d || d->transposed) return 0;
+    if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31)) return 0;
+    const int kind = s2e_small_wgrad_kind(dtype, d);
+    return kind ? s2e_small_wgrad_workspace_bytes(dtype, kind, d) : 0;
+}
+
 extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
-                                void* stream) {
+                                void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !gy || !dw || !d) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: null pointer");
     if (d->transposed) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: describe the forward conv (transposed=0)");
     if (d->stride != 1 && d->stride != 2) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad: stride %d", d->stride);
@@ -405,7 +412,7 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
         sp.x = x; sp.gy = gy; sp.dw = dw;
         sp.N = d->N; sp.Hi = d->Hi; sp.Wi = d->Wi; sp.Cin = d->Cin; sp.Ho = d->Ho; sp.Wo = d->Wo; sp.Cout = d->Cout;
         sp.KH = d->KH; sp.KW = d->KW; sp.stride = d->stride; sp.pad = d->pad; sp.in_act = d->in_act;
-        if (int rc = s2e_small_wgrad_launch(dtype, kind, sp, (hipStream_t)stream)) return rc;
+        if (int rc = s2e_small_wgrad_launch(dtype, kind, d, sp, workspace, workspace_bytes, (hipStream_t)stream)) return rc;
         if (dbias) return s2e_colsum(dtype, gy, (long)d->N * d->Ho * d->Wo, d->Cout, dbias, stream);
         return S2E_OK;
     }

@@ -86,7 +86,6 @@ extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, floa
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_in_stats: bad dtype %d", dtype);
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_in_stats: C=%d not a multiple of %d", C, vec);
     hipStream_t st = (hipStream_t)stream;
-    if (int zrc = s2e_zero_async(ws, sizeof(double) * 2 * (size_t)N * C, st)) return zrc;
     const RowGeom g = row_geom(C, vec);
     dim3 grid(ceil_div(HW, g.rpp * kSlabIters), N, g.zblocks);
     if (dtype == S2E_BF16) in_stats_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, ws, HW, C, g.cg, g.cgb, g.rpp);
@@ -390,7 +389,6 @@ extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* 
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_bwd: C=%d not a multiple of %d", C, vec);
     hipStream_t st = (hipStream_t)stream;
-    if (int zrc = s2e_zero_async(ws, sizeof(double) * 4 * (size_t)N * C, st)) return zrc;
     const RowGeom rg = row_geom(C, vec);
     dim3 grid1(ceil_div(HW, rg.rpp * kSlabIters), N, rg.zblocks);
     const long nvec = (long)N * HW * rg.cg;

@@ -246,7 +246,6 @@ extern "C" int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, c
     if (!gw_packed || !w_orig || !u || !v || !sigma || !dot_ws || !gw_orig || cout <= 0 || cin <= 0 || cin_pad < cin)
         S2E_FAIL(S2E_ERR_ARG, "s2e_sn_weight_grad: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (int zrc = s2e_zero_async(dot_ws, sizeof(float), st)) return zrc;
     const long total = (long)cout * cin * kh * kw;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     sn_grad_dot_kernel<<<grid, 256, 0, st>>>(gw_packed, w_orig, dot_ws, cout, cin, kh * kw, cin_pad);

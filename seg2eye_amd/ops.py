@@ -79,6 +79,87 @@ class LaunchProfiler:
         cls.records = []
 
 
+# ------------------------------------------------------------------------------ zero-filled scratch
+class ZeroPool:
+    """Zero-initialised scratch for ONE trainer step, filled by ONE launch.
+
+    A G or D step needs ~200 small zero-filled buffers (packed weight-gradient accumulators, fp64
+    reduction scratch of the statistics / modulation kernels, the spectral-norm dot products).  Zeroing
+    each with its own 4-5 us launch cost ~1 ms of a 35 ms step.  Inside `with ZeroPool.scope(key)` they are
+    bump-allocated from one device buffer whose used prefix (the high-water mark of earlier scopes with
+    the same key) is cleared by a single fill at scope entry; a take beyond the cleared prefix clears its
+    own slice.  Outside a scope `take` is plain torch.zeros, so stand-alone ops and tests behave as
+    before.  Everything taken inside a scope must be dead when the next scope starts: true for the
+    scratch listed above, NOT for tensors handed to the caller (losses, parameter gradients) -- those
+    never come from the pool.  After `freeze()` (a hipGraph holds raw pointers into the buffer) the
+    buffer is never re-allocated; overflow falls back to torch.zeros."""
+    ALIGN = 256
+    buf = None
+    cap = 0            # bytes allocated
+    bump = 0           # bytes handed out in the current scope
+    clean = 0          # [bump, clean) is known to be zero
+    need = 0           # largest total any scope asked for (drives growth)
+    high = {}          # key -> high-water mark
+    key = None
+    frozen = False
+
+    @classmethod
+    def scope(cls, key, device):
+        return _ZeroScope(key, device)
+
+    @classmethod
+    def freeze(cls):
+        cls.frozen = True
+
+    @classmethod
+    def _begin(cls, key, device):
+        if cls.key is not None:
+            raise RuntimeError('ZeroPool scopes do not nest')
+        if not cls.frozen and cls.need > cls.cap:
+            cls.cap = (int(cls.need * 1.25) + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+            cls.buf = torch.zeros(cls.cap, dtype=torch.uint8, device=device)
+            cls.clean = cls.cap
+        else:
+            hw = min(cls.high.get(key, 0), cls.cap)
+            if hw:
+                cls.buf[:hw].zero_()
+            cls.clean = hw
+        cls.key, cls.bump = key, 0
+
+    @classmethod
+    def _end(cls):
+        cls.high[cls.key] = max(cls.high.get(cls.key, 0), cls.bump)
+        cls.need = max(cls.need, cls.bump)
+        cls.key = None
+
+    @classmethod
+    def take(cls, numel, dtype, device):
+        if cls.key is None:
+            return torch.zeros(numel, dtype=dtype, device=device)
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        off = cls.bump
+        end = off + (nbytes + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+        cls.bump = end                                   # counts overflow too: that is how the pool learns its size
+        if end > cls.cap or cls.buf.device != device:
+            return torch.zeros(numel, dtype=dtype, device=device)
+        if end > cls.clean:
+            cls.buf[max(off, cls.clean):end].zero_()
+            cls.clean = end
+        return cls.buf[off:off + nbytes].view(dtype)
+
+
+class _ZeroScope:
+    def __init__(self, key, device):
+        self.key, self.device = key, device
+
+    def __enter__(self):
+        ZeroPool._begin(self.key, self.device)
+
+    def __exit__(self, *exc):
+        ZeroPool._end()
+        return False
+
+
 # ------------------------------------------------------------------------------ raw launchers
 
 def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False, sigma=None):
@@ -115,26 +196,32 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     LaunchProfiler.run('conv_igemm', flops, lambda: L.check(
         L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _p(ws), wsb,
-                           _stream()), 's2e_conv2d'))
+                           _stream()), 's2e_conv2d'),
+        tag='%s n%d %dx%d c%d->%d k%d s%d' % ('D' if transposed else 'F', n, hi, wi, cin, cout, kh, stride))
     return y
 
 
 def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False, dbias_out=None):
     """-> (dw, db): dw (Cout, KH*KW*Cin) fp32 in packed order; db (Cout) fp32 or None.  Both live in one
-    zero-filled buffer (a single fill launch).  dbias_out: an fp32 (Cout) tensor to ACCUMULATE the bias
+    zero-filled buffer (ZeroPool scratch when the bias gradient is not returned).  dbias_out: an fp32 (Cout) tensor to ACCUMULATE the bias
     gradient into instead (e.g. the parameter's slice of the gradient arena); then db is None."""
     _need(x, gy, dbias_out)
     n, hi, wi, cin = x.shape
     _, ho, wo, cout = gy.shape
     k = kh * kw * cin
     own_b = want_bias and dbias_out is None
-    buf = torch.zeros(cout * k + (cout if own_b else 0), dtype=torch.float32, device=x.device)
-    dw = buf[:cout * k].view(cout, k)
-    db = buf[cout * k:] if own_b else None
+    if own_b:                                            # db goes back to autograd (may become a .grad): never pooled
+        buf = torch.zeros(cout * k + cout, dtype=torch.float32, device=x.device)
+        dw, db = buf[:cout * k].view(cout, k), buf[cout * k:]
+    else:
+        dw, db = ZeroPool.take(cout * k, torch.float32, x.device).view(cout, k), None
     dbp = db if own_b else dbias_out
     d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
+    wsb = L.lib().s2e_conv2d_wgrad_workspace_bytes(_dt(x), C.byref(d))    # > 0 only for the 1-channel shapes
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     LaunchProfiler.run('conv_wgrad', 2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
-        L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), _p(dbp), C.byref(d), _stream()), 's2e_conv2d_wgrad'),
+        L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), _p(dbp), C.byref(d), _p(ws), wsb, _stream()),
+        's2e_conv2d_wgrad'),
         tag='W n%d %dx%d c%d->%d k%d s%d' % (n, hi, wi, cin, cout, kh, stride))
     return dw, db
 
@@ -183,7 +270,7 @@ def in_stats(x):
     modulate_bwd, once per consumer of the statistics)."""
     _need(x)
     n, h, w, c = x.shape
-    ws = torch.empty(n * c * 2, dtype=torch.float64, device=x.device)
+    ws = ZeroPool.take(n * c * 2, torch.float64, x.device)
     stats = torch.empty(n, c, 2, dtype=torch.float32, device=x.device)
     L.check(L.lib().s2e_in_stats(_dt(x), _p(x), n, h * w, c, IN_EPS, _p(ws), _p(stats), _stream()), 's2e_in_stats')
     return stats
@@ -275,7 +362,7 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 acc = wdst is not None
                 out = wdst if acc else torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
-                dot = torch.empty(1, dtype=torch.float32, device=x.device)
+                dot = ZeroPool.take(1, torch.float32, x.device)
                 L.check(L.lib().s2e_sn_weight_grad(_p(dwp), _p(weight.detach()), _p(u), _p(v), _p(sigma), _p(dot), _p(out),
                                                    cout, cin, kh, kw, cx, int(acc), _stream()), 's2e_sn_weight_grad')
                 gw = None if acc else out
@@ -419,8 +506,8 @@ class ModulateFn(torch.autograd.Function):
         g = g.contiguous()
         dx = torch.empty_like(x)
         dgb = torch.empty_like(gb)
-        dstyle = torch.zeros_like(style)
-        ws = torch.empty(n * c * 4, dtype=torch.float64, device=x.device)
+        dstyle = ZeroPool.take(style.numel(), torch.float32, x.device).view(style.shape)
+        ws = ZeroPool.take(n * c * 4, torch.float64, x.device)
         L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_SPADE_STYLE, _p(g), _p(x), _p(gb), _p(stats), _p(style), _p(dx),
                                          _p(dgb), _p(dstyle), _p(ws), n, h * w, c, int(ctx.lrelu), _stream()),
                 's2e_modulate_bwd')
@@ -452,7 +539,7 @@ class InstanceNormFn(torch.autograd.Function):
         n, h, w, c = x.shape
         g = g.contiguous()
         dx = torch.empty_like(x)
-        ws = torch.empty(n * c * 4, dtype=torch.float64, device=x.device)
+        ws = ZeroPool.take(n * c * 4, torch.float64, x.device)
         L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_PLAIN_IN, _p(g), _p(x), None, _p(stats), None, _p(dx), None, None,
                                          _p(ws), n, h * w, c, int(ctx.lrelu), _stream()), 's2e_modulate_bwd')
         return dx, None

@@ -2,6 +2,7 @@
 runs one G step / one D step, LR decay, save.  Multi-GPU: when torch.distributed is initialised the
 flat gradient arenas are sum-all-reduced (RCCL) between backward and the Adam launch."""
 from .distributed import FlatGradSync, broadcast_flat
+from .ops import ZeroPool
 from .pix2pix_model import Pix2PixModel
 
 
@@ -24,8 +25,9 @@ class Pix2PixTrainer:
     # ---- step bodies: zero_grad + forward + backward (what a hipGraph captures) -------------------
     def _g_body(self, data):
         self.optimizer_G.zero_grad()
-        g_losses, generated = self.pix2pix_model(data, mode='generator')
-        sum(g_losses.values()).mean().backward()
+        with ZeroPool.scope('G', self.pix2pix_model.device()):   # all zero-filled scratch of the step: one fill
+            g_losses, generated = self.pix2pix_model(data, mode='generator')
+            sum(g_losses.values()).mean().backward()
         # keep detached copies only: a live autograd graph would pin last iteration's AccumulateGrad nodes
         # (and their stream), which breaks hipGraph capture
         self.g_losses = {k: v.detach() for k, v in g_losses.items()}
@@ -33,8 +35,9 @@ class Pix2PixTrainer:
 
     def _d_body(self, data):
         self.optimizer_D.zero_grad()
-        d_losses = self.pix2pix_model(data, mode='discriminator')
-        sum(d_losses.values()).mean().backward()
+        with ZeroPool.scope('D', self.pix2pix_model.device()):
+            d_losses = self.pix2pix_model(data, mode='discriminator')
+            sum(d_losses.values()).mean().backward()
         self.d_losses = {k: v.detach() for k, v in d_losses.items()}
 
     def run_generator_one_step(self, data):
@@ -93,6 +96,7 @@ class Pix2PixTrainer:
                 self._d_body(self._static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        ZeroPool.freeze()                                    # the graphs hold raw pointers into the pool
         self.graph_G = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_G):
             self._g_body(self._static)

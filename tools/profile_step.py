@@ -25,5 +25,5 @@ for fam in ('conv_igemm', 'conv_wgrad'):
     items = sorted(((k, v) for k, v in agg.items() if k[0] == fam), key=lambda kv: -kv[1][1])
     tot = sum(v[1] for _, v in items) / N
     print('== %s total %.2f ms/step' % (fam, tot))
-    for (f, tag), v in items[:22]:
+    for (f, tag), v in items[:40]:
         print('  %-34s x%4.1f  %6.3f ms/step  %7.1f TF' % (tag, v[0] / N, v[1] / N, v[2] / (v[1] * 1e-3) / 1e12))
