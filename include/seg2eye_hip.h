@@ -76,6 +76,21 @@ int s2e_conv_k_pad(int dtype, int k);            /* columns of a packed weight m
  * transposed = 1: packed[ci][(ky*kw+kx)*cout + co]              (cout_pad(cin_pad) x k_pad(kh*kw*cout)) */
 int s2e_pack_conv_weight(int dtype, const float* w_oihw, void* packed, const float* sigma, int cout, int cin,
                          int kh, int kw, int cin_pad, int transposed, void* stream);
+/* Batched weight pack: every conv of a network in ONE launch (a network packs 20-50 weight matrices per
+ * forward; as separate 8 us launches that was 1.6 ms of a 35 ms step).  jobs / block_map are DEVICE arrays the
+ * caller builds once: fill a host s2e_pack_job array, call s2e_pack_block_map to count (block_map_host NULL)
+ * and then fill the {job, bx, by} triples, upload both.  sigma_index >= 0 divides by sigma_base[sigma_index]
+ * (the sigma array s2e_sn_power_iteration wrote for this forward).  Outputs as s2e_pack_conv_weight. */
+typedef struct s2e_pack_job {
+    const float* w;          /* OIHW fp32 */
+    void* out;               /* packed matrix, compute dtype, s2e_conv_cout_pad(rows) x s2e_conv_k_pad(...) */
+    int sigma_index;         /* or -1 */
+    int cout, cin, taps, cin_pad, transposed;
+} s2e_pack_job;
+long s2e_pack_block_map(int dtype, const s2e_pack_job* jobs_host, int n_jobs, int* block_map_host);
+int s2e_pack_conv_weights(int dtype, const s2e_pack_job* jobs, const int* block_map, int n_blocks, int max_taps,
+                          const float* sigma_base, void* stream);
+
 /* Layers that cannot fill the chip from their output tiling alone (small N*Ho*Wo, large K) are
  * split over K: each split writes an fp32 partial slab into `workspace` and a finishing kernel sums
  * the slabs and applies the epilogue (deterministic; no atomics).  workspace_bytes(d) is 0 for
@@ -139,13 +154,16 @@ int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, doub
  *     out = (x-mean)*rstd            (gb, style unused; may be NULL)
  * lrelu != 0 applies LeakyReLU(0.2) to out. */
 int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* gb, const float* stats, const float* style,
-                     void* out, int N, int HW, int C, int lrelu, void* stream);
+                     void* out, int N, int HW, int C, int lrelu, int style_ld, void* stream);
 /* Backward of the above given g = dL/dout.  Writes dx (N,HW,C), dgb (N,HW,2C) and ACCUMULATES
  * dstyle (N,2C) fp32 (SPADE_STYLE mode only; dgb/dstyle may be NULL in PLAIN_IN mode).
+ * style_ld (both calls): floats between consecutive samples' rows of style AND dstyle; 0 = dense (2C).  A
+ * generator keeps the style codes of all its SPADE+Style layers as column slices of ONE (N, sum 2C) matrix
+ * (one GEMM for all style FCs, networks/stylebank.py), hence the leading dimension.
  * ws: N*C*4 doubles of scratch, ZERO-FILLED by the caller; dirty on return. */
 int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
                      const float* style, void* dx, void* dgb, float* dstyle, double* ws,
-                     int N, int HW, int C, int lrelu, void* stream);
+                     int N, int HW, int C, int lrelu, int style_ld, void* stream);
 /* out[c] += sum_m g[m][c]  (conv bias gradient).  g (M, C); out fp32 (C). */
 int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream);
 

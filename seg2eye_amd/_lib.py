@@ -32,6 +32,12 @@ class SnLayer(C.Structure):
                 ('rows', C.c_int), ('cols', C.c_int)]
 
 
+class PackJob(C.Structure):
+    """s2e_pack_job"""
+    _fields_ = [('w', C.c_void_p), ('out', C.c_void_p), ('sigma_index', C.c_int), ('cout', C.c_int), ('cin', C.c_int),
+                ('taps', C.c_int), ('cin_pad', C.c_int), ('transposed', C.c_int)]
+
+
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 # name -> argtypes; every entry returns int except the two noted below.  Must list EVERY symbol
 # declared in include/seg2eye_hip.h (tests/test_abi.py checks header <-> table <-> .so).
@@ -44,13 +50,15 @@ SIGNATURES = {
     's2e_sn_power_iteration': [_vp, _i, _vp, _i, _vp, C.c_size_t, _vp, _i, _i, _f, _vp],
     's2e_sn_weight_grad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     's2e_unpack_weight_grad': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    's2e_pack_block_map': [_i, _vp, _i, _vp],
+    's2e_pack_conv_weights': [_i, _vp, _vp, _i, _i, _vp, _vp],
     's2e_conv2d_workspace_bytes': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_conv2d_wgrad_workspace_bytes': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_in_stats': [_i, _vp, _i, _i, _i, _f, _vp, _vp, _vp],
-    's2e_modulate_fwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    's2e_modulate_bwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    's2e_modulate_fwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    's2e_modulate_bwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     's2e_colsum': [_i, _vp, _l, _i, _vp, _vp],
     's2e_label_conv3x3': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     's2e_onehot_nhwc': [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -85,7 +93,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = (C.c_char_p if name == 's2e_last_error' else
-                          C.c_size_t if name.endswith('_workspace_bytes') else C.c_int)
+                          C.c_size_t if name.endswith('_workspace_bytes') else
+                          C.c_long if name == 's2e_pack_block_map' else C.c_int)
         _lib = L
     return _lib
 

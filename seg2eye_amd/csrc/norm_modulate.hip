@@ -9,6 +9,17 @@
 #include "common.h"
 
 static constexpr int kSlabIters = 16;     // row passes per block in the row-walking kernels
+// Row passes per block of the row-walking reduction kernels.  Every block ends with one fp64 atomic per
+// (channel, sum) on addresses shared by all blocks of the sample, and contended atomics are what these kernels
+// were bound by (measured: in_stats of (8,256,256,128) 115 us with 2048 blocks, 30 us with 256): aim for
+// S2E_SLAB_BLOCKS (default 384) blocks in total, never fewer than 16 passes per block.
+static int slab_iters_for(int HW, int rpp, int N, int zblocks) {
+    static const int target = [] { const char* e = getenv("S2E_SLAB_BLOCKS"); return e ? atoi(e) : 384; }();
+    const int per_n = target / (N * zblocks) > 1 ? target / (N * zblocks) : 1;
+    int it = ceil_div(HW, (long)rpp * per_n);
+    if (it < kSlabIters) it = kSlabIters;
+    return it;
+}
 
 struct RowGeom {       // how a 256-thread block maps onto [rows][C/VEC channel groups]
     int cg;            // channel groups in total (C / VEC)
@@ -28,7 +39,7 @@ static RowGeom row_geom(int C, int vec) {
 // ------------------------------------------------------------------------------------ in_stats
 template <typename T>
 __global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restrict__ x, double* __restrict__ ws,
-                                                               int HW, int C, int cg, int cgb, int rpp) {
+                                                               int HW, int C, int cg, int cgb, int rpp, int iters) {
     constexpr int VEC = Vec<T>::N;
     __shared__ float red[256 * VEC * 2];
     const int tid = threadIdx.x;
@@ -40,16 +51,28 @@ __global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restri
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; }
     if (active) {
-        const int row0 = blockIdx.x * rpp * kSlabIters;
+        const int row0 = blockIdx.x * rpp * iters;
+        const int rend = min(HW, row0 + rpp * iters);
         const T* base = x + (size_t)n * HW * C + (size_t)g * VEC;
-        for (int it = 0; it < kSlabIters; ++it) {
-            const int row = row0 + it * rpp + ty;
-            if (row < HW) {
-                float f[VEC];
-                unpack16<T>(*(const u32x4_t*)(base + (size_t)row * C), f);
+        int row = row0 + ty;
+        for (; row + 3 * rpp < rend; row += 4 * rpp) {              // 4 independent 16-B loads in flight
+            const u32x4_t r0 = *(const u32x4_t*)(base + (size_t)row * C);
+            const u32x4_t r1 = *(const u32x4_t*)(base + (size_t)(row + rpp) * C);
+            const u32x4_t r2 = *(const u32x4_t*)(base + (size_t)(row + 2 * rpp) * C);
+            const u32x4_t r3 = *(const u32x4_t*)(base + (size_t)(row + 3 * rpp) * C);
+            float f0[VEC], f1[VEC], f2[VEC], f3[VEC];
+            unpack16<T>(r0, f0); unpack16<T>(r1, f1); unpack16<T>(r2, f2); unpack16<T>(r3, f3);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+            for (int j = 0; j < VEC; ++j) {
+                s[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
+                q[j] += (f0[j] * f0[j] + f1[j] * f1[j]) + (f2[j] * f2[j] + f3[j] * f3[j]);
             }
+        }
+        for (; row < rend; row += rpp) {
+            float f[VEC];
+            unpack16<T>(*(const u32x4_t*)(base + (size_t)row * C), f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
         }
     }
 #pragma unroll
@@ -87,9 +110,10 @@ extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, floa
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_in_stats: C=%d not a multiple of %d", C, vec);
     hipStream_t st = (hipStream_t)stream;
     const RowGeom g = row_geom(C, vec);
-    dim3 grid(ceil_div(HW, g.rpp * kSlabIters), N, g.zblocks);
-    if (dtype == S2E_BF16) in_stats_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, ws, HW, C, g.cg, g.cgb, g.rpp);
-    else in_stats_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)x, ws, HW, C, g.cg, g.cgb, g.rpp);
+    const int iters = slab_iters_for(HW, g.rpp, N, g.zblocks);
+    dim3 grid(ceil_div(HW, g.rpp * iters), N, g.zblocks);
+    if (dtype == S2E_BF16) in_stats_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, ws, HW, C, g.cg, g.cgb, g.rpp, iters);
+    else in_stats_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)x, ws, HW, C, g.cg, g.cgb, g.rpp, iters);
     S2E_CHECK_LAUNCH("in_stats_partial_kernel");
     in_stats_finalize_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(ws, stats, N * C, HW, eps);
     S2E_CHECK_LAUNCH("in_stats_finalize_kernel");
@@ -184,7 +208,7 @@ extern "C" int s2e_colsum(int dtype, const void* g, long M, int C, float* out, v
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gb,
                                                            const float* __restrict__ stats, const float* __restrict__ style,
-                                                           T* __restrict__ out, long nvec, int HW, int C, int cg, int lrelu) {
+                                                           T* __restrict__ out, long nvec, int HW, int C, int cg, int lrelu, int sld) {
     constexpr int VEC = Vec<T>::N;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
         const long row = v / cg;
@@ -198,7 +222,7 @@ __global__ __launch_bounds__(256) void modulate_fwd_kernel(const T* __restrict__
             float ga[VEC], be[VEC];
             unpack16<T>(*(const u32x4_t*)(gb + (size_t)row * 2 * C + c0), ga);
             unpack16<T>(*(const u32x4_t*)(gb + (size_t)row * 2 * C + C + c0), be);
-            const float* s0 = style + (size_t)n * 2 * C + c0;
+            const float* s0 = style + (size_t)n * sld + c0;
             const float* s1 = s0 + C;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -218,17 +242,18 @@ __global__ __launch_bounds__(256) void modulate_fwd_kernel(const T* __restrict__
 }
 
 extern "C" int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* gb, const float* stats, const float* style,
-                                void* out, int N, int HW, int C, int lrelu, void* stream) {
+                                void* out, int N, int HW, int C, int lrelu, int style_ld, void* stream) {
     if (!x || !stats || !out || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_fwd: bad argument");
     if (mode == S2E_NORM_SPADE_STYLE && (!gb || !style)) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_fwd: SPADE_STYLE needs gb and style");
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_fwd: bad dtype %d", dtype);
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_fwd: C=%d not a multiple of %d", C, vec);
     const int cg = C / vec;
+    const int sld = style_ld > 0 ? style_ld : 2 * C;
     const long nvec = (long)N * HW * cg;
     const int grid = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
     hipStream_t st = (hipStream_t)stream;
-#define S2E_LAUNCH_MOD(TT, MM) modulate_fwd_kernel<TT, MM><<<grid, 256, 0, st>>>((const TT*)x, (const TT*)gb, stats, style, (TT*)out, nvec, HW, C, cg, lrelu)
+#define S2E_LAUNCH_MOD(TT, MM) modulate_fwd_kernel<TT, MM><<<grid, 256, 0, st>>>((const TT*)x, (const TT*)gb, stats, style, (TT*)out, nvec, HW, C, cg, lrelu, sld)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_MOD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_MOD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_MOD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_MOD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_MOD
@@ -244,7 +269,7 @@ extern "C" int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __restrict__ gin, const T* __restrict__ x,
         const T* __restrict__ gb, const float* __restrict__ stats, const float* __restrict__ style,
-        T* __restrict__ dgb, double* __restrict__ ws, int HW, int C, int cg, int cgb, int rpp, int lrelu) {
+        T* __restrict__ dgb, double* __restrict__ ws, int HW, int C, int cg, int cgb, int rpp, int lrelu, int sld, int iters) {
     constexpr int VEC = Vec<T>::N;
     constexpr int NS = (MODE == S2E_NORM_SPADE_STYLE) ? 4 : 2;
     __shared__ float red[256 * VEC * NS];
@@ -266,22 +291,21 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
             mu[j] = stats[((size_t)n * C + c0 + j) * 2];
             rs[j] = stats[((size_t)n * C + c0 + j) * 2 + 1];
             if (MODE == S2E_NORM_SPADE_STYLE) {
-                a[j] = 1.f + style[(size_t)n * 2 * C + c0 + j];
-                b[j] = style[(size_t)n * 2 * C + C + c0 + j];
+                a[j] = 1.f + style[(size_t)n * sld + c0 + j];
+                b[j] = style[(size_t)n * sld + C + c0 + j];
             }
         }
-        const int row0 = blockIdx.x * rpp * kSlabIters;
-        for (int it = 0; it < kSlabIters; ++it) {
-            const int pr = row0 + it * rpp + ty;
-            if (pr >= HW) break;
-            const size_t row = (size_t)n * HW + pr;
+        const int row0 = blockIdx.x * rpp * iters;
+        const int pend = min(HW, row0 + rpp * iters);
+        // one row: everything after the loads (the loads of TWO rows are issued before either is consumed)
+        auto consume = [&](size_t row, u32x4_t rx, u32x4_t rg, u32x4_t rga, u32x4_t rbe) __attribute__((always_inline)) {
             float f[VEC], gg[VEC];
-            unpack16<T>(*(const u32x4_t*)(x + row * C + c0), f);
-            unpack16<T>(*(const u32x4_t*)(gin + row * C + c0), gg);
+            unpack16<T>(rx, f);
+            unpack16<T>(rg, gg);
             if (MODE == S2E_NORM_SPADE_STYLE) {
                 float ga[VEC], be[VEC], dga[VEC], dbe[VEC];
-                unpack16<T>(*(const u32x4_t*)(gb + row * 2 * C + c0), ga);
-                unpack16<T>(*(const u32x4_t*)(gb + row * 2 * C + C + c0), be);
+                unpack16<T>(rga, ga);
+                unpack16<T>(rbe, be);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const float xh = (f[j] - mu[j]) * rs[j];
@@ -307,6 +331,26 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
                     S[0][j] += go; S[1][j] += go * xh;
                 }
             }
+        };
+        const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+        int pr = row0 + ty;
+        for (; pr + rpp < pend; pr += 2 * rpp) {
+            const size_t r0 = (size_t)n * HW + pr, r1 = r0 + rpp;
+            const u32x4_t x0 = *(const u32x4_t*)(x + r0 * C + c0), x1 = *(const u32x4_t*)(x + r1 * C + c0);
+            const u32x4_t g0 = *(const u32x4_t*)(gin + r0 * C + c0), g1 = *(const u32x4_t*)(gin + r1 * C + c0);
+            u32x4_t a0 = zero4, b0 = zero4, a1 = zero4, b1 = zero4;
+            if (MODE == S2E_NORM_SPADE_STYLE) {
+                a0 = *(const u32x4_t*)(gb + r0 * 2 * C + c0); b0 = *(const u32x4_t*)(gb + r0 * 2 * C + C + c0);
+                a1 = *(const u32x4_t*)(gb + r1 * 2 * C + c0); b1 = *(const u32x4_t*)(gb + r1 * 2 * C + C + c0);
+            }
+            consume(r0, x0, g0, a0, b0);
+            consume(r1, x1, g1, a1, b1);
+        }
+        if (pr < pend) {
+            const size_t r0 = (size_t)n * HW + pr;
+            u32x4_t a0 = zero4, b0 = zero4;
+            if (MODE == S2E_NORM_SPADE_STYLE) { a0 = *(const u32x4_t*)(gb + r0 * 2 * C + c0); b0 = *(const u32x4_t*)(gb + r0 * 2 * C + C + c0); }
+            consume(r0, *(const u32x4_t*)(x + r0 * C + c0), *(const u32x4_t*)(gin + r0 * C + c0), a0, b0);
         }
     }
 #pragma unroll
@@ -329,7 +373,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __restrict__ gin, const T* __restrict__ x,
         const T* __restrict__ gb, const T* __restrict__ dgb, const float* __restrict__ stats, const float* __restrict__ style,
-        const double* __restrict__ ws, T* __restrict__ dx, long nvec, int HW, int C, int cg, int lrelu) {
+        const double* __restrict__ ws, T* __restrict__ dx, long nvec, int HW, int C, int cg, int lrelu, int sld) {
     constexpr int VEC = Vec<T>::N;
     const float inv_hw = 1.f / (float)HW;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
@@ -345,7 +389,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
             float ga[VEC], dbe[VEC];
             unpack16<T>(*(const u32x4_t*)(gb + (size_t)row * 2 * C + c0), ga);
             unpack16<T>(*(const u32x4_t*)(dgb + (size_t)row * 2 * C + C + c0), dbe);
-            const float* s0 = style + (size_t)n * 2 * C + c0;
+            const float* s0 = style + (size_t)n * sld + c0;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float rs = stp[2 * j + 1];
@@ -371,17 +415,18 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
     }
 }
 
-__global__ void modulate_bwd_style_kernel(const double* __restrict__ ws, float* __restrict__ dstyle, int N, int C) {
+__global__ void modulate_bwd_style_kernel(const double* __restrict__ ws, float* __restrict__ dstyle, int N, int C, int sld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
-    dstyle[(size_t)n * 2 * C + c] += 0.5f * (float)ws[(size_t)i * 4 + 2];
-    dstyle[(size_t)n * 2 * C + C + c] += 0.5f * (float)ws[(size_t)i * 4 + 3];
+    dstyle[(size_t)n * sld + c] += 0.5f * (float)ws[(size_t)i * 4 + 2];
+    dstyle[(size_t)n * sld + C + c] += 0.5f * (float)ws[(size_t)i * 4 + 3];
 }
 
 extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
                                 const float* style, void* dx, void* dgb, float* dstyle, double* ws,
-                                int N, int HW, int C, int lrelu, void* stream) {
+                                int N, int HW, int C, int lrelu, int style_ld, void* stream) {
+    const int sld = style_ld > 0 ? style_ld : 2 * C;
     if (!g || !x || !stats || !dx || !ws || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: bad argument");
     if (mode == S2E_NORM_SPADE_STYLE && (!gb || !style || !dgb || !dstyle))
         S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: SPADE_STYLE needs gb, style, dgb, dstyle");
@@ -390,18 +435,19 @@ extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* 
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_bwd: C=%d not a multiple of %d", C, vec);
     hipStream_t st = (hipStream_t)stream;
     const RowGeom rg = row_geom(C, vec);
-    dim3 grid1(ceil_div(HW, rg.rpp * kSlabIters), N, rg.zblocks);
+    const int iters = slab_iters_for(HW, rg.rpp, N, rg.zblocks);
+    dim3 grid1(ceil_div(HW, rg.rpp * iters), N, rg.zblocks);
     const long nvec = (long)N * HW * rg.cg;
     const int grid2 = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
 #define S2E_LAUNCH_BWD(TT, MM) do { \
-    modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu); \
-    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, stats, style, ws, (TT*)dx, nvec, HW, C, rg.cg, lrelu); } while (0)
+    modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters); \
+    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, stats, style, ws, (TT*)dx, nvec, HW, C, rg.cg, lrelu, sld); } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_BWD
     S2E_CHECK_LAUNCH("modulate_bwd kernels");
     if (mode == S2E_NORM_SPADE_STYLE) {
-        modulate_bwd_style_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(ws, dstyle, N, C);
+        modulate_bwd_style_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(ws, dstyle, N, C, sld);
         S2E_CHECK_LAUNCH("modulate_bwd_style_kernel");
     }
     return S2E_OK;

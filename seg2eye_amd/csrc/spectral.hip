@@ -51,10 +51,15 @@ __global__ __launch_bounds__(256) void sn_gemv_kernel(const s2e_sn_layer* __rest
     const float vj = cv ? L.v[col] : 0.f;
     const float* wp = L.w + (size_t)row0 * L.cols + col;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int r = 0; r < nr; ++r, wp += L.cols) {
-        float p = cv ? *wp * vj : 0.f;
-        p = wave_sum(p);
-        if (lane == 0) red[r][wave] = p;
+    for (int r = 0; r < nr; r += 8, wp += (size_t)8 * L.cols) {      // 8 independent row loads in flight (nr <= SN_BR)
+        float p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = (cv && r + k < nr) ? wp[(size_t)k * L.cols] * vj : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float q = wave_sum(p[k]);
+            if (lane == 0) red[r + k][wave] = q;
+        }
     }
     __syncthreads();
     if (threadIdx.x < nr) atomicAdd(L.s + row0 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
@@ -108,54 +113,85 @@ extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, 
 // Both directions go through LDS so that global reads AND writes are contiguous runs.
 // Every element of the padded matrix is written exactly once per call (padding rows / channels / K tail as
 // zeros), so no separate zero-fill is needed.
-// forward pack : out[row][(tap)*cin_pad + ci]   one block = one row x 64 (padded) ci
+// Thread mapping as in the gradient re-layout kernels below: no per-element integer division.
+// forward pack : out[row][(tap)*cin_pad + ci]   one block = 4 rows (one per wave) x 64 (padded) ci
 template <typename T>
-__global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
-                                                       int cout, int cin, int taps, int cin_pad, int kpad) {
-    extern __shared__ float lds[];                          // [64][taps + 1]
-    const int row = blockIdx.x, ci0 = blockIdx.y * 64;
+__device__ __forceinline__ void pack_fwd_block(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
+                                               int cout, int cin, int taps, int cin_pad, int kpad, int bx, int by, float* lds) {
+    // lds: [4][64 * taps]
+    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = bx * 4 + r, ci0 = by * 64;             // padded row count is a multiple of 32
     const bool valid = row < cout;
     const int nci = valid ? max(0, min(64, cin - ci0)) : 0;       // real channels in this chunk
     const int ncp = min(64, cin_pad - ci0);                        // channels incl. structural-zero padding
     const float inv = sigma ? 1.f / *sigma : 1.f;
-    if (nci > 0) {
-        const float* src = w + ((size_t)row * cin + ci0) * taps;
-        for (int i = threadIdx.x; i < nci * taps; i += 256) lds[(i / taps) * (taps + 1) + (i % taps)] = src[i] * inv;
-    }
+    float* my = lds + r * 64 * taps;
+    const float* src = w + ((size_t)row * cin + ci0) * taps;
+    for (int k = lane; k < nci * taps; k += 64) my[k] = src[k] * inv;
     __syncthreads();
-    T* dst = out + (size_t)row * kpad + ci0;
-    for (int i = threadIdx.x; i < ncp * taps; i += 256) {
-        const int tap = i / ncp, cil = i - tap * ncp;
-        dst[(size_t)tap * cin_pad + cil] = (T)(cil < nci ? lds[cil * (taps + 1) + tap] : 0.f);
-    }
-    if (blockIdx.y == 0)                                     // K tail [taps*cin_pad, kpad)
-        for (int k = taps * cin_pad + threadIdx.x; k < kpad; k += 256) out[(size_t)row * kpad + k] = (T)0.f;
+    T* dst = out + (size_t)row * kpad + ci0 + lane;
+    if (lane < ncp)
+        for (int tap = 0; tap < taps; ++tap) dst[(size_t)tap * cin_pad] = (T)(lane < nci ? my[lane * taps + tap] : 0.f);
+    if (by == 0)                                             // K tail [taps*cin_pad, kpad)
+        for (int k = taps * cin_pad + lane; k < kpad; k += 64) out[(size_t)row * kpad + k] = (T)0.f;
 }
 // transposed pack: out[ci][(tap)*cout + co]     one block = 64 co x 8 (padded) ci rows
 template <typename T>
-__global__ __launch_bounds__(256) void pack_tr_kernel(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
-                                                      int cout, int cin, int taps, int rows_pad, int kpad) {
-    extern __shared__ float lds[];                          // [64 co][8*taps + 1]
-    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 8;
+__device__ __forceinline__ void pack_tr_block(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
+                                              int cout, int cin, int taps, int rows_pad, int kpad, int bx, int by, float* lds) {
+    // lds: [64 co][8*taps + 1]
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int co0 = bx * 64, ci0 = by * 8;
     const int nco = min(64, cout - co0);
     const int nci = max(0, min(8, cin - ci0)), ncp = min(8, rows_pad - ci0);
     const int run = nci * taps, ld = 8 * taps + 1;
     const float inv = sigma ? 1.f / *sigma : 1.f;
-    for (int i = threadIdx.x; i < nco * run; i += 256) {
-        const int col = i / run, r = i - col * run;
-        lds[col * ld + r] = w[((size_t)(co0 + col) * cin + ci0) * taps + r] * inv;
+    for (int m = q; m < nco; m += 4) {                       // wave q stages co rows q, q+4, ...: contiguous runs
+        const float* src = w + ((size_t)(co0 + m) * cin + ci0) * taps;
+        for (int k = lane; k < run; k += 64) lds[m * ld + k] = src[k] * inv;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ncp * taps * nco; i += 256) {
-        const int col = i % nco, rt = i / nco;               // rt = cil*taps + tap
-        const int cil = rt / taps, tap = rt - cil * taps;
-        out[(size_t)(ci0 + cil) * kpad + (size_t)tap * cout + co0 + col] = (T)(cil < nci ? lds[col * ld + rt] : 0.f);
-    }
-    if (blockIdx.x == 0)                                     // K tail [taps*cout, kpad) of this block's rows
-        for (int i = threadIdx.x; i < ncp * (kpad - taps * cout); i += 256) {
-            const int cil = i / (kpad - taps * cout), k = taps * cout + i % (kpad - taps * cout);
-            out[(size_t)(ci0 + cil) * kpad + k] = (T)0.f;
+    if (lane < nco)
+        for (int cil = 0; cil < ncp; ++cil) {
+            T* dst = out + (size_t)(ci0 + cil) * kpad + co0 + lane;
+            for (int tap = q; tap < taps; tap += 4)          // wave q writes taps q, q+4, ...: 64 consecutive co each
+                dst[(size_t)tap * cout] = (T)(cil < nci ? lds[lane * ld + cil * taps + tap] : 0.f);
         }
+    if (bx == 0) {                                           // K tail [taps*cout, kpad) of this block's rows
+        const int tail = kpad - taps * cout;
+        for (int cil = q; cil < ncp; cil += 4)
+            for (int k = lane; k < tail; k += 64) out[(size_t)(ci0 + cil) * kpad + taps * cout + k] = (T)0.f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
+                                                       int cout, int cin, int taps, int cin_pad, int kpad) {
+    extern __shared__ float lds[];
+    pack_fwd_block<T>(w, out, sigma, cout, cin, taps, cin_pad, kpad, blockIdx.x, blockIdx.y, lds);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pack_tr_kernel(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
+                                                      int cout, int cin, int taps, int rows_pad, int kpad) {
+    extern __shared__ float lds[];
+    pack_tr_block<T>(w, out, sigma, cout, cin, taps, rows_pad, kpad, blockIdx.x, blockIdx.y, lds);
+}
+// every conv of a network in one launch: block_map = {job, bx, by} per block (s2e_pack_block_map)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const s2e_pack_job* __restrict__ jobs, const int* __restrict__ block_map,
+                                                         const float* __restrict__ sigma_base, int dtype) {
+    extern __shared__ float lds[];
+    const int* bm = block_map + 3 * blockIdx.x;
+    const s2e_pack_job J = jobs[bm[0]];
+    const float* sg = J.sigma_index >= 0 ? sigma_base + J.sigma_index : nullptr;
+    if (!J.transposed) {
+        const int kpad = (J.taps * J.cin_pad + (dtype == S2E_BF16 ? 63 : 31)) / (dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
+        pack_fwd_block<T>(J.w, (T*)J.out, sg, J.cout, J.cin, J.taps, J.cin_pad, kpad, bm[1], bm[2], lds);
+    } else {
+        const int kpad = (J.taps * J.cout + (dtype == S2E_BF16 ? 63 : 31)) / (dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
+        const int rows = J.cin_pad <= 32 ? 32 : (J.cin_pad <= 64 ? 64 : (J.cin_pad + 127) / 128 * 128);
+        pack_tr_block<T>(J.w, (T*)J.out, sg, J.cout, J.cin, J.taps, rows, kpad, bm[1], bm[2], lds);
+    }
 }
 
 extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, const float* sigma, int cout, int cin, int kh, int kw,
@@ -169,8 +205,8 @@ extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, con
     const int kpad = s2e_conv_k_pad(dtype, taps * (transposed ? cout : cin_pad));
     hipStream_t st = (hipStream_t)stream;
     if (!transposed) {
-        dim3 grid(rows, ceil_div(cin_pad, 64));
-        const size_t lds = (size_t)64 * (taps + 1) * sizeof(float);
+        dim3 grid(rows / 4, ceil_div(cin_pad, 64));
+        const size_t lds = (size_t)4 * 64 * taps * sizeof(float);
         if (dtype == S2E_BF16) pack_fwd_kernel<bf16_t><<<grid, 256, lds, st>>>(w, (bf16_t*)packed, sigma, cout, cin, taps, cin_pad, kpad);
         else pack_fwd_kernel<float><<<grid, 256, lds, st>>>(w, (float*)packed, sigma, cout, cin, taps, cin_pad, kpad);
     } else {
@@ -180,6 +216,39 @@ extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, con
         else pack_tr_kernel<float><<<grid, 256, lds, st>>>(w, (float*)packed, sigma, cout, cin, taps, rows, kpad);
     }
     S2E_CHECK_LAUNCH("pack kernels");
+    return S2E_OK;
+}
+
+extern "C" long s2e_pack_block_map(int dtype, const s2e_pack_job* jobs_host, int n_jobs, int* block_map_host) {
+    (void)dtype;
+    if (!jobs_host || n_jobs < 0) return S2E_ERR_ARG;
+    long nb = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const s2e_pack_job& J = jobs_host[j];
+        int gx, gy;
+        if (!J.transposed) { gx = s2e_conv_cout_pad(J.cout) / 4; gy = ceil_div(J.cin_pad, 64); }
+        else               { gx = ceil_div(J.cout, 64);      gy = ceil_div(s2e_conv_cout_pad(J.cin_pad), 8); }
+        if (block_map_host)
+            for (int y = 0; y < gy; ++y)
+                for (int x = 0; x < gx; ++x) {
+                    int* e = block_map_host + 3 * (nb + (long)y * gx + x);
+                    e[0] = j; e[1] = x; e[2] = y;
+                }
+        nb += (long)gx * gy;
+    }
+    return nb;
+}
+
+extern "C" int s2e_pack_conv_weights(int dtype, const s2e_pack_job* jobs, const int* block_map, int n_blocks, int max_taps,
+                                     const float* sigma_base, void* stream) {
+    if (!jobs || !block_map || n_blocks <= 0 || max_taps <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_pack_conv_weights: bad argument");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_pack_conv_weights: bad dtype %d", dtype);
+    if (max_taps > 16) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_pack_conv_weights: more than 16 taps");
+    const size_t lds = (size_t)64 * (8 * max_taps + 1) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) pack_batch_kernel<bf16_t><<<n_blocks, 256, lds, st>>>(jobs, block_map, sigma_base, dtype);
+    else pack_batch_kernel<float><<<n_blocks, 256, lds, st>>>(jobs, block_map, sigma_base, dtype);
+    S2E_CHECK_LAUNCH("batched pack kernel");
     return S2E_OK;
 }
 
@@ -218,6 +287,70 @@ __global__ __launch_bounds__(256) void sn_grad_apply_kernel(const float* __restr
     }
 }
 
+// Tiled variants for taps > 1: the packed gradient is [co][tap][ci] while W_orig / the output are [co][ci][tap].  A tile
+// of SNG_ROWS co rows x 64 ci goes through LDS so that BOTH sides move as contiguous runs; thread (wave r, lane) owns
+// row r: its lane index is the ci on the packed side and the flat run index (lane + 64 j) on the OIHW side, so no
+// per-element integer division is needed (the element-wise kernels above spend ~150 instructions per element on
+// 64-bit / and %: they were ALU-bound, not HBM-bound).  Blocks loop over tiles.
+static constexpr int SNG_ROWS = 4;     // co rows per tile = waves per block
+__global__ __launch_bounds__(256) void sn_grad_dot_tiled_kernel(const float* __restrict__ gwp, const float* __restrict__ w, float* __restrict__ dot,
+                                                                int cout, int cin, int taps, int cin_pad) {
+    extern __shared__ float lds[];                          // [SNG_ROWS][64 * taps]
+    __shared__ float red[4];
+    const int chunks = (cin + 63) / 64, rgroups = (cout + SNG_ROWS - 1) / SNG_ROWS, tiles = rgroups * chunks;
+    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* my = lds + r * 64 * taps;
+    float q = 0.f;
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int rg = t / chunks, ci0 = (t - rg * chunks) * 64, co = rg * SNG_ROWS + r;
+        const int nci = min(64, cin - ci0), run = nci * taps;
+        const bool rv = co < cout;
+        const float* wrow = w + ((size_t)co * cin + ci0) * taps;
+        const float* grow = gwp + (size_t)co * taps * cin_pad + ci0 + lane;
+        __syncthreads();
+        if (rv)
+            for (int k = lane; k < run; k += 64) my[k] = wrow[k];
+        __syncthreads();
+        if (rv && lane < nci)
+            for (int tap = 0; tap < taps; ++tap) q += grow[(size_t)tap * cin_pad] * my[lane * taps + tap];
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[r] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dot, red[0] + red[1] + red[2] + red[3]);
+}
+// out[co][ci][tap] (+)= gwp[co][tap][ci] / sigma - (dot / sigma^2) u[co] v[ci*taps + tap];   u == NULL: plain re-layout
+__global__ __launch_bounds__(256) void grad_unpack_tiled_kernel(const float* __restrict__ gwp, const float* __restrict__ u, const float* __restrict__ v,
+        const float* __restrict__ sigma, const float* __restrict__ dot, float* __restrict__ out, int cout, int cin, int taps, int cin_pad,
+        int accumulate) {
+    extern __shared__ float lds[];                          // [SNG_ROWS][64 * taps]
+    const int chunks = (cin + 63) / 64, rgroups = (cout + SNG_ROWS - 1) / SNG_ROWS, tiles = rgroups * chunks;
+    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* my = lds + r * 64 * taps;
+    const float inv = u ? 1.f / *sigma : 1.f;
+    const float c = u ? *dot * inv * inv : 0.f;
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int rg = t / chunks, ci0 = (t - rg * chunks) * 64, co = rg * SNG_ROWS + r;
+        const int nci = min(64, cin - ci0), run = nci * taps;
+        const bool rv = co < cout;
+        const float* grow = gwp + (size_t)co * taps * cin_pad + ci0 + lane;
+        __syncthreads();
+        if (rv && lane < nci)
+            for (int tap = 0; tap < taps; ++tap) my[lane * taps + tap] = grow[(size_t)tap * cin_pad];
+        __syncthreads();
+        if (rv) {
+            float* orow = out + ((size_t)co * cin + ci0) * taps;
+            const float cu = u ? c * u[co] : 0.f;
+            const float* vrow = v + (size_t)ci0 * taps;
+            for (int k = lane; k < run; k += 64) {
+                float gg = my[k] * inv;
+                if (u) gg -= cu * vrow[k];
+                orow[k] = accumulate ? orow[k] + gg : gg;
+            }
+        }
+    }
+}
+
 // grad[co][ci][tap] (+)= gwp[co][tap*cin_pad + ci]: packed wgrad output -> OIHW gradient (no spectral norm)
 __global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restrict__ gwp, float* __restrict__ out, int cout, int cin, int taps,
                                                           int cin_pad, int accumulate) {
@@ -235,7 +368,13 @@ extern "C" int s2e_unpack_weight_grad(const float* gw_packed, float* gw_oihw, in
     if (!gw_packed || !gw_oihw || cout <= 0 || cin <= 0 || cin_pad < cin) S2E_FAIL(S2E_ERR_ARG, "s2e_unpack_weight_grad: bad argument");
     const long total = (long)cout * cin * kh * kw;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    unpack_grad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gw_packed, gw_oihw, cout, cin, kh * kw, cin_pad, accumulate);
+    const int taps = kh * kw;
+    if (taps > 1 && taps <= 64) {
+        const int tiles = ceil_div(cout, SNG_ROWS) * ceil_div(cin, 64);
+        grad_unpack_tiled_kernel<<<tiles < 2048 ? tiles : 2048, 256, (size_t)SNG_ROWS * 64 * taps * sizeof(float), (hipStream_t)stream>>>(
+            gw_packed, nullptr, nullptr, nullptr, nullptr, gw_oihw, cout, cin, taps, cin_pad, accumulate);
+    } else
+        unpack_grad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gw_packed, gw_oihw, cout, cin, taps, cin_pad, accumulate);
     S2E_CHECK_LAUNCH("unpack_grad_kernel");
     return S2E_OK;
 }
@@ -248,8 +387,16 @@ extern "C" int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, c
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)cout * cin * kh * kw;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    sn_grad_dot_kernel<<<grid, 256, 0, st>>>(gw_packed, w_orig, dot_ws, cout, cin, kh * kw, cin_pad);
-    sn_grad_apply_kernel<<<grid, 256, 0, st>>>(gw_packed, u, v, sigma, dot_ws, gw_orig, cout, cin, kh * kw, cin_pad, accumulate);
+    const int taps = kh * kw;
+    if (taps > 1 && taps <= 64) {
+        const int tiles = ceil_div(cout, SNG_ROWS) * ceil_div(cin, 64);
+        const size_t lds = (size_t)SNG_ROWS * 64 * taps * sizeof(float);
+        sn_grad_dot_tiled_kernel<<<tiles < 1024 ? tiles : 1024, 256, lds, st>>>(gw_packed, w_orig, dot_ws, cout, cin, taps, cin_pad);
+        grad_unpack_tiled_kernel<<<tiles < 2048 ? tiles : 2048, 256, lds, st>>>(gw_packed, u, v, sigma, dot_ws, gw_orig, cout, cin, taps, cin_pad, accumulate);
+    } else {
+        sn_grad_dot_kernel<<<grid, 256, 0, st>>>(gw_packed, w_orig, dot_ws, cout, cin, taps, cin_pad);
+        sn_grad_apply_kernel<<<grid, 256, 0, st>>>(gw_packed, u, v, sigma, dot_ws, gw_orig, cout, cin, taps, cin_pad, accumulate);
+    }
     S2E_CHECK_LAUNCH("sn_weight_grad kernels");
     return S2E_OK;
 }

@@ -5,6 +5,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_NONE, ACT_LRELU
+from .. import packing
 from ..spectral import sn_begin
 from .base_network import BaseNetwork, compute_dtype_of
 from .normalization import get_nonspade_norm_layer
@@ -100,11 +101,12 @@ class MultiscaleDiscriminator(BaseNetwork):
         self.require_gpu(input)
         x = input if (input.dim() == 4 and input.shape[-1] == D_CPAD and input.shape[1] != self.opt.label_nc + self.opt.output_nc) \
             else to_d_input(input, self.cdtype)
-        sn_begin(self)                  # one batched power iteration for both scales' SN convs
-        result = []
-        keep_all = not self.opt.no_ganFeat_loss
-        for name, D in self.named_children():
-            feats = [f.permute(0, 3, 1, 2) for f in D.forward_nhwc(x)]
-            result.append(feats if keep_all else [feats[-1]])
-            x = ops.avgpool3x3s2(x)                    # F.avg_pool2d(3, 2, 1, count_include_pad=False)
-        return result
+        bank = sn_begin(self)                  # one batched power iteration for both scales' SN convs
+        with packing.network_scope(self, bank):    # all weight packs of this forward: one launch
+            result = []
+            keep_all = not self.opt.no_ganFeat_loss
+            for name, D in self.named_children():
+                feats = [f.permute(0, 3, 1, 2) for f in D.forward_nhwc(x)]
+                result.append(feats if keep_all else [feats[-1]])
+                x = ops.avgpool3x3s2(x)                    # F.avg_pool2d(3, 2, 1, count_include_pad=False)
+            return result

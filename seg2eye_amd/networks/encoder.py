@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import packing
 from ..spectral import sn_begin
 from .base_network import BaseNetwork, compute_dtype_of
 from .normalization import get_nonspade_norm_layer
@@ -39,19 +40,20 @@ class ConvEncoder(BaseNetwork):
         Pix2PixModel passes N so u, v follow the same trajectory.  Layer outputs are unaffected beyond
         eps effects: InstanceNorm follows each conv and removes the 1/sigma scale."""
         self.require_gpu(x)
-        sn_begin(self, power_iterations)
-        if x.size(2) != 256 or x.size(3) != 256:
-            x = F.interpolate(x.float(), size=(256, 256), mode='bilinear')
-        h = x.permute(0, 2, 3, 1).contiguous().to(self.cdtype)          # (M,256,256,1): same memory order as NCHW
-        feats = []
-        for i in range(self.len_sequence):
-            blk = getattr(self, 'layer%d' % i)
-            conv = blk[0] if isinstance(blk, nn.Sequential) else blk
-            h = ops.conv2d_m(h, conv, None, 2, 1)
-            if isinstance(blk, nn.Sequential):
-                h = ops.instance_norm(h, lrelu=False)
-            feats.append(h.permute(0, 3, 1, 2))
-        out = F.leaky_relu(feats[-1].float(), 0.2).reshape(h.shape[0], -1)     # NCHW flatten order, encoder.py:68
-        mu = self.fc_mu(out)
-        logvar = self.fc_var(out)
-        return mu, logvar, feats
+        bank = sn_begin(self, power_iterations)
+        with packing.network_scope(self, bank):    # all weight packs of this forward: one launch
+            if x.size(2) != 256 or x.size(3) != 256:
+                x = F.interpolate(x.float(), size=(256, 256), mode='bilinear')
+            h = x.permute(0, 2, 3, 1).contiguous().to(self.cdtype)          # (M,256,256,1): same memory order as NCHW
+            feats = []
+            for i in range(self.len_sequence):
+                blk = getattr(self, 'layer%d' % i)
+                conv = blk[0] if isinstance(blk, nn.Sequential) else blk
+                h = ops.conv2d_m(h, conv, None, 2, 1)
+                if isinstance(blk, nn.Sequential):
+                    h = ops.instance_norm(h, lrelu=False)
+                feats.append(h.permute(0, 3, 1, 2))
+            out = F.leaky_relu(feats[-1].float(), 0.2).reshape(h.shape[0], -1)     # NCHW flatten order, encoder.py:68
+            mu = self.fc_mu(out)
+            logvar = self.fc_var(out)
+            return mu, logvar, feats

@@ -5,6 +5,8 @@ import torch.nn as nn
 from .. import ops
 from .._lib import ACT_LRELU, ACT_TANH
 from ..options import latent_size
+from .. import packing
+from . import stylebank
 from ..spectral import sn_begin
 from .architecture import SPADE_STYLE_ResnetBlock
 from .base_network import BaseNetwork, compute_dtype_of
@@ -47,18 +49,19 @@ class SPADESTYLEGenerator(BaseNetwork):
         if (H, W) != (self.sh * f, self.sw * f):
             raise ValueError('label map is %dx%d but this generator emits %dx%d (SURVEY F5)' % (H, W, self.sh * f, self.sw * f))
         w = w.float()
-        sn_begin(self)          # one batched power iteration for all 18 spectral-normed convs
-        # F.interpolate(seg, (sh, sw)) + fc conv, generator.py:72-73
-        x = ops.label_conv3x3(seg.label, self.fc.weight, self.fc.bias, self.sh, self.sw, False, self.cdtype)
-        x = self.head_0(x, seg, w)
-        x = ops.upsample2x(x)
-        x = self.G_middle_0(x, seg, w)
-        if self.opt.num_upsampling_layers == 'more':
+        bank = sn_begin(self)          # one batched power iteration for all 18 spectral-normed convs
+        with packing.network_scope(self, bank), stylebank.scope(self, w):   # all weight packs: one launch; all style FCs: one GEMM
+            # F.interpolate(seg, (sh, sw)) + fc conv, generator.py:72-73
+            x = ops.label_conv3x3(seg.label, self.fc.weight, self.fc.bias, self.sh, self.sw, False, self.cdtype)
+            x = self.head_0(x, seg, w)
             x = ops.upsample2x(x)
-        x = self.G_middle_1(x, seg, w)
-        for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
-            x = ops.upsample2x(x)
-            x = blk(x, seg, w)
-        # conv_img(leaky_relu(x)) + tanh, generator.py:99-100: one launch
-        y = ops.conv2d(x, self.conv_img.weight, self.conv_img.bias, None, 1, 1, ACT_LRELU, ACT_TANH)
-        return y.permute(0, 3, 1, 2)
+            x = self.G_middle_0(x, seg, w)
+            if self.opt.num_upsampling_layers == 'more':
+                x = ops.upsample2x(x)
+            x = self.G_middle_1(x, seg, w)
+            for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
+                x = ops.upsample2x(x)
+                x = blk(x, seg, w)
+            # conv_img(leaky_relu(x)) + tanh, generator.py:99-100: one launch
+            y = ops.conv2d(x, self.conv_img.weight, self.conv_img.bias, None, 1, 1, ACT_LRELU, ACT_TANH)
+            return y.permute(0, 3, 1, 2)

@@ -118,9 +118,13 @@ class SPADE_STYLE_Block(nn.Module):
         seg = SegMap.of(segmap)
         n, h, w, c = x.shape
         gb = self.spade.gamma_beta(seg, h, w, x.dtype)
-        style = self.adain.linear(latent_style)                     # (N, 2C) fp32
         if stats is None:
             stats = ops.in_stats(x.detach())
+        from . import stylebank
+        sb = stylebank.current()                                    # inside a generator: all style FCs were one GEMM
+        if sb is not None and id(self.adain.linear) in sb[0]:
+            return ops.spade_style_modulate(x, gb, sb[1], stats, lrelu, off=sb[0][id(self.adain.linear)], dbig=sb[2])
+        style = self.adain.linear(latent_style)                     # (N, 2C) fp32
         return ops.spade_style_modulate(x, gb, style, stats, lrelu)
 
 

@@ -12,6 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from . import packing
 from ._lib import (ConvDesc, ACT_NONE, ACT_LRELU, ACT_TANH, AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD,
                    NORM_SPADE_STYLE, NORM_PLAIN_IN, LOSS_NEG_MEAN, LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_L1)
 
@@ -181,6 +182,19 @@ def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False, sigma=None):
     return out
 
 
+def packed_weight(w, dtype, cin_pad, transposed, sigma, plan, generation=None, stable=True):
+    """The packed matrix from the network's PackPlan (packing.py) when it has one for THIS forward, else an
+    individual pack -- which also teaches the plan, so the next forward packs it in the batched launch.
+    stable=False: `w` is a temporary (its address means nothing next time): never recorded."""
+    if plan is not None and stable:
+        wp = plan.lookup(w, dtype, cin_pad, transposed, generation)
+        if wp is not None:
+            return wp
+        if generation is None or generation == plan.generation:
+            plan.record(w, dtype, cin_pad, transposed, sigma)
+    return pack_weight(w, dtype, cin_pad, transposed, sigma)
+
+
 def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transposed=False,
                in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE):
     _need(x, wp, bias, residual, aux)
@@ -320,7 +334,9 @@ class Conv2dFn(torch.autograd.Function):
             raise ValueError('input has %d channels, weight expects %d' % (cx, cin))
         ho = (hi + 2 * pad - kh) // stride + 1
         wo = (wi + 2 * pad - kw) // stride + 1
-        wp = pack_weight(weight, x.dtype, cx, False, sigma)
+        plan = packing.current()
+        wp = packed_weight(weight, x.dtype, cx, False, sigma, plan)
+        ctx.plan, ctx.plan_gen = plan, (plan.generation if plan is not None else None)
         b = None if bias is None else bias.detach().float().contiguous()
         y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act)
         ctx.cfg = (stride, pad, in_act, out_act, bias is not None, residual is not None)
@@ -346,7 +362,7 @@ class Conv2dFn(torch.autograd.Function):
             g = g2
         gx = gw = gb = gres = None
         if ctx.needs_input_grad[0]:
-            wpt = pack_weight(weight, x.dtype, cx, True, sigma)
+            wpt = packed_weight(weight, x.dtype, cx, True, sigma, ctx.plan, ctx.plan_gen)
             gx = conv2d_raw(g, wpt, None, None, x if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
                             True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
         want_b = has_bias and ctx.needs_input_grad[2]
@@ -441,7 +457,9 @@ class SpadeParamFn(torch.autograd.Function):
             w_gb = torch.cat([w_g.detach(), w_b.detach()], 0)
             b_gb = torch.cat([b_g.detach(), b_b.detach()], 0)
         actv = label_conv3x3_raw(label, _table_of(w_sh), b_sh.detach().float().contiguous(), n, H, W, h, w, nh, True, dtype)
-        wp = pack_weight(w_gb, dtype, nh, False)
+        plan = packing.current()
+        wp = packed_weight(w_gb, dtype, nh, False, None, plan, stable=fused)
+        ctx.plan, ctx.plan_gen, ctx.fused = plan, (plan.generation if plan is not None else None), fused
         gb = conv2d_raw(actv, wp, b_gb.float().contiguous(), None, None, (h, w, 2 * C), 3, 3, 1, 1)
         ctx.cfg = (h, w, C)
         gwg, gwb, gbg, gbb = _grad_dst(w_g), _grad_dst(w_b), _grad_dst(b_g), _grad_dst(b_b)
@@ -466,7 +484,7 @@ class SpadeParamFn(torch.autograd.Function):
             dwp, gb_gb = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True)
             gw_gb = _unpack_dw(dwp, c2, nh, 3, 3, nh)
             gw_g, gw_b, gb_g, gb_b = gw_gb[:C], gw_gb[C:], gb_gb[:C], gb_gb[C:]
-        wpt = pack_weight(w_gb, g.dtype, nh, True)
+        wpt = packed_weight(w_gb, g.dtype, nh, True, None, ctx.plan, ctx.plan_gen, stable=ctx.fused)
         dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
         oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
         wdst, bdst = ctx.sh_dst
@@ -486,16 +504,23 @@ def spade_params(label, w_sh, b_sh, w_g, b_g, w_b, b_b, h, w, dtype):
 
 class ModulateFn(torch.autograd.Function):
     """SPADE+Style modulation (optionally + LeakyReLU).  stats come from in_stats(x) and may be
-    shared between consumers (norm_0 and norm_s normalise the same x, architecture.py:44-59)."""
+    shared between consumers (norm_0 and norm_s normalise the same x, architecture.py:44-59).
+
+    style: this layer's (N,2C) fp32 style code -- or, with `off` given, the generator's (N,S) matrix of ALL
+    layers' codes (networks/stylebank.py) of which columns [off, off+2C) are this layer's.  In that mode the
+    backward ADDS this layer's style gradient into the same columns of `dbig` (the bank's gradient
+    accumulator) and hands autograd nothing for `style`: the bank's own backward picks dbig up."""
 
     @staticmethod
-    def forward(ctx, x, gb, style, stats, lrelu):
+    def forward(ctx, x, gb, style, stats, lrelu, off=None, dbig=None):
         _need(x, gb, style, stats)
         n, h, w, c = x.shape
         out = torch.empty_like(x)
-        L.check(L.lib().s2e_modulate_fwd(_dt(x), NORM_SPADE_STYLE, _p(x), _p(gb), _p(stats), _p(style), _p(out),
-                                         n, h * w, c, int(lrelu), _stream()), 's2e_modulate_fwd')
-        ctx.lrelu = lrelu
+        ld = 0 if off is None else style.shape[1]
+        sp = style.data_ptr() + 4 * (off or 0)
+        L.check(L.lib().s2e_modulate_fwd(_dt(x), NORM_SPADE_STYLE, _p(x), _p(gb), _p(stats), sp, _p(out),
+                                         n, h * w, c, int(lrelu), ld, _stream()), 's2e_modulate_fwd')
+        ctx.lrelu, ctx.off, ctx.dbig = lrelu, off, dbig
         ctx.save_for_backward(x, gb, style, stats)
         return out
 
@@ -506,16 +531,25 @@ class ModulateFn(torch.autograd.Function):
         g = g.contiguous()
         dx = torch.empty_like(x)
         dgb = torch.empty_like(gb)
-        dstyle = ZeroPool.take(style.numel(), torch.float32, x.device).view(style.shape)
+        if ctx.off is None:
+            dstyle = ZeroPool.take(style.numel(), torch.float32, x.device).view(style.shape)
+            dsp, ld = dstyle.data_ptr(), 0
+        else:
+            if ctx.dbig is None:
+                raise RuntimeError('ModulateFn: banked style without a gradient accumulator')
+            dstyle, dsp, ld = None, ctx.dbig.data_ptr() + 4 * ctx.off, style.shape[1]
+        sp = style.data_ptr() + 4 * (ctx.off or 0)
         ws = ZeroPool.take(n * c * 4, torch.float64, x.device)
-        L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_SPADE_STYLE, _p(g), _p(x), _p(gb), _p(stats), _p(style), _p(dx),
-                                         _p(dgb), _p(dstyle), _p(ws), n, h * w, c, int(ctx.lrelu), _stream()),
+        L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_SPADE_STYLE, _p(g), _p(x), _p(gb), _p(stats), sp, _p(dx),
+                                         _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()),
                 's2e_modulate_bwd')
-        return dx, dgb, dstyle, None, None
+        return dx, dgb, dstyle, None, None, None, None
 
 
-def spade_style_modulate(x, gb, style, stats, lrelu):
-    return ModulateFn.apply(x, gb, style.float().contiguous(), stats, lrelu)
+def spade_style_modulate(x, gb, style, stats, lrelu, off=None, dbig=None):
+    if off is None:
+        style = style.float().contiguous()
+    return ModulateFn.apply(x, gb, style, stats, lrelu, off, dbig)
 
 
 class InstanceNormFn(torch.autograd.Function):
@@ -528,7 +562,7 @@ class InstanceNormFn(torch.autograd.Function):
         stats = in_stats(x)
         out = torch.empty_like(x)
         L.check(L.lib().s2e_modulate_fwd(_dt(x), NORM_PLAIN_IN, _p(x), None, _p(stats), None, _p(out),
-                                         n, h * w, c, int(lrelu), _stream()), 's2e_modulate_fwd')
+                                         n, h * w, c, int(lrelu), 0, _stream()), 's2e_modulate_fwd')
         ctx.lrelu = lrelu
         ctx.save_for_backward(x, stats)
         return out
@@ -541,7 +575,7 @@ class InstanceNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         ws = ZeroPool.take(n * c * 4, torch.float64, x.device)
         L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_PLAIN_IN, _p(g), _p(x), None, _p(stats), None, _p(dx), None, None,
-                                         _p(ws), n, h * w, c, int(ctx.lrelu), _stream()), 's2e_modulate_bwd')
+                                         _p(ws), n, h * w, c, int(ctx.lrelu), 0, _stream()), 's2e_modulate_bwd')
         return dx, None
 
 

@@ -85,6 +85,13 @@ class Pix2PixModel(nn.Module):
                 for q in mod.arena_order():
                     seen.add(id(q))
                     G_params.append(q)
+        # ... and the style FCs of all SPADE+Style layers back to back (weights, then biases): one GEMM for all
+        # of them (networks/stylebank.py)
+        from .networks.normalization import SPADE_STYLE_Block
+        fcs = [m.adain.linear for m in self.netG.modules() if isinstance(m, SPADE_STYLE_Block)]
+        for q in [f.weight for f in fcs] + [f.bias for f in fcs if f.bias is not None]:
+            seen.add(id(q))
+            G_params.append(q)
         G_params += [q for q in self.netG.parameters() if id(q) not in seen] + list(self.netE.parameters())
         if opt.no_TTUR:
             beta1, beta2, G_lr, D_lr = opt.beta1, opt.beta2, opt.lr, opt.lr

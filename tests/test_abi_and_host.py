@@ -54,6 +54,26 @@ def test_argument_errors_are_reported_without_a_gpu():
         _lib.check(-1, 'x')
 
 
+def test_pack_block_map_is_host_only():
+    """s2e_pack_block_map is pure host code: grid of a forward pack = rows_pad/4 x ceil(cin_pad/64), of a
+    transposed pack = ceil(cout/64) x ceil(rows_pad/8); triples are {job, bx, by}."""
+    from seg2eye_amd import _lib
+    L = _lib.lib()
+    jobs = (_lib.PackJob * 2)()
+    jobs[0].cout, jobs[0].cin, jobs[0].taps, jobs[0].cin_pad, jobs[0].transposed = 100, 70, 9, 72, 0
+    jobs[1].cout, jobs[1].cin, jobs[1].taps, jobs[1].cin_pad, jobs[1].transposed = 100, 70, 9, 72, 1
+    n0 = L.s2e_pack_block_map(_lib.S2E_BF16, ctypes.byref(jobs), 1, None)
+    n = L.s2e_pack_block_map(_lib.S2E_BF16, ctypes.byref(jobs), 2, None)
+    assert n0 == 128 // 4 * 2 and n == n0 + 2 * (128 // 8)
+    bm = np.zeros(3 * n, dtype=np.int32)
+    assert L.s2e_pack_block_map(_lib.S2E_BF16, ctypes.byref(jobs), 2, bm.ctypes.data) == n
+    bm = bm.reshape(-1, 3)
+    assert (bm[:n0, 0] == 0).all() and (bm[n0:, 0] == 1).all()
+    assert bm[:n0, 1].max() == 31 and bm[:n0, 2].max() == 1 and bm[n0:, 1].max() == 1 and bm[n0:, 2].max() == 15
+    assert len({tuple(r) for r in bm}) == n
+    assert L.s2e_pack_conv_weights(_lib.S2E_BF16, None, None, 0, 9, None, None) == -1
+
+
 def test_ops_refuse_cpu_tensors():
     from seg2eye_amd import ops, _lib, networks
     from seg2eye_amd.options import default_opt

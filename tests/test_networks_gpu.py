@@ -79,6 +79,54 @@ def test_generator_fp32_matches_reference(tag, ngf, crop, ar):
         np.testing.assert_allclose(sd[k].cpu().numpy(), z['uv_' + k], atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize('dt', ['fp32', 'bf16'])
+def test_pack_plan_matches_individual_packs(dt):
+    """The first forward/backward of a network packs every weight on its own and teaches the PackPlan;
+    later ones take all packs from ONE batched launch.  Same bits either way (eval mode: sigma fixed)."""
+    from seg2eye_amd import networks
+    z = load_golden('g_ngf16_128x64')
+    opt = _opt(ngf=16, crop_size=64, aspect_ratio=0.5, compute_dtype=dt)
+    G = _load(networks.define_G(opt), z, 'G').eval()
+    w = torch.from_numpy(z['w']).to(DEV)
+    runs = []
+    for it in range(3):
+        G.zero_grad()
+        wt = w.clone().requires_grad_(True)
+        y = G(_label(z), wt)
+        y.float().square().sum().backward()
+        runs.append((y.detach().float().clone(), wt.grad.clone(), [p.grad.clone() for p in G.parameters()]))
+        plan = G.__dict__['_pack_plan']
+        if it == 0:
+            assert plan.hits == 0 and len(plan.jobs) > 30          # learned fwd + transposed packs
+        if it == 1:
+            h1 = plan.hits
+            assert h1 >= len(plan.jobs) - 2, (h1, len(plan.jobs))
+    assert plan.hits >= 2 * h1
+    # the batched launch produced exactly the matrices the individual packs produce (same sigma array)
+    from seg2eye_amd import ops
+    sigma = G.__dict__['_sn_owned_bank'].sigma
+    for j in plan.jobs.values():
+        sg = None if j['sigma_index'] < 0 else sigma[j['sigma_index']:j['sigma_index'] + 1]
+        ref = ops.pack_weight(j['w'], j['dtype'], j['cin_pad'], j['transposed'], sg)
+        assert torch.equal(ref.view(torch.uint8), j['out'].view(torch.uint8)), (tuple(j['w'].shape), j['transposed'])
+    # sigma / wgrad atomics are not bit-reproducible; in bf16 a last-bit change of sigma flips weight roundings
+    tol = 1e-5 if dt == 'fp32' else 0.15
+    gtol = KINK_TOL                                                # ... and one flipped LeakyReLU mask moves a whole sample's gradient
+    for k in (1, 2):
+        assert float((runs[k][0] - runs[0][0]).abs().max()) <= tol
+        if dt == 'bf16':
+            # measured (tools/debug_plan2.py): with or without the plan two bf16 forwards of this random-weight net
+            # differ by ~0.05 -- the 1e-7 float-atomic noise of sigma flips bf16 weight roundings and the
+            # InstanceNorm chain amplifies them (fp32: 5e-6).  Gradients are not comparable run to run.
+            continue
+        assert float((runs[k][1] - runs[0][1]).abs().max()) <= gtol * max(1.0, float(runs[0][1].abs().max()))
+        for a, b in zip(runs[k][2], runs[0][2]):
+            assert float((a - b).abs().max()) <= gtol * max(1.0, float(b.abs().max()))
+    with torch.no_grad():                                          # forward-only: transposed packs skipped, still correct
+        y3 = G(_label(z), w).float()
+    assert float((y3 - runs[0][0]).abs().max()) <= tol
+
+
 def test_generator_bf16_close_to_fp32():
     from seg2eye_amd import networks
     z = load_golden('g_ngf16_128x64')
@@ -330,9 +378,11 @@ def test_hip_graph_steps_match_eager():
             tr.run_discriminator_one_step(dict(data))
             hist.append({k: float(v.float().mean()) for k, v in tr.get_latest_losses().items()})
         res[graphs] = (hist, {k: v.detach().float().cpu().clone() for k, v in m.netG.state_dict().items()})
-    for a, b in zip(res[False][0], res[True][0]):
+    # iteration 0 runs on identical weights: tight.  Later iterations have taken beta1 = 0 Adam steps (+-lr per
+    # weight, sign flips on near-zero gradients under float-atomic noise), so the trajectories drift a little.
+    for it, (a, b) in enumerate(zip(res[False][0], res[True][0])):
         for k in a:
-            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+            assert abs(a[k] - b[k]) <= (5e-4 if it == 0 else 1e-2) * max(1.0, abs(a[k])), (it, k, a[k], b[k])
     ref = {k: float(z['it0_%s' % k.replace('/', '_')]) for k in res[True][0][0]}
     for k, v in res[True][0][0].items():                      # and the graphed first iteration matches the real reference
         assert abs(v - ref[k]) <= 2e-3 * max(1.0, abs(ref[k])), (k, v, ref[k])
