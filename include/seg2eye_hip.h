@@ -119,7 +119,7 @@ int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float*
  *   train != 0 (per iteration): v = normalize(W^T u); u = normalize(W v); sigma = u . (W v)   (u, v updated in place)
  *   train == 0:                 sigma = u . (W v)                                              (u, v untouched)
  * layers: DEVICE array of n_layers descriptors.  block_map: DEVICE int32 [n_blocks][3] = {layer, row0, col0}
- * covering every layer with 64-row x 256-column blocks.  t (cols floats) and s (rows floats) of all layers
+ * covering every layer with 16-row x 256-column blocks.  t (cols floats) and s (rows floats) of all layers
  * live in `scratch` (zeroed here each iteration).  sigma: fp32 [n_layers] out. */
 typedef struct {
     const float* w; float* u; float* v; float* t; float* s;
@@ -169,11 +169,12 @@ int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream
 
 /* ------------------------------------------------------------------ label-map ops
  * conv3x3(pad 1) of the nearest-downsampled ONE-HOT label map, without materialising the one-hot:
- * out[n,y,x,co] = bias[co] + sum_{ky,kx in bounds} table[(ky*3+kx)*ncls + label_h[n,y+ky-1,x+kx-1]][co]
+ * out[n,y,x,co] = bias[co] + sum_{ky,kx in bounds} weight[co][label_h[n,y+ky-1,x+kx-1]][ky][kx]
  * with label_h[y][x] = label[y*(H/h)][x*(W/w)] (F.interpolate 'nearest', integer ratio), then ReLU
  * if relu != 0.  Replaces SPADE.mlp_shared (normalization.py:85-88,97-98) and the generator's
- * fc conv on the downsampled segmap (generator.py:72-73).  table: fp32 (9*ncls, Cout). */
-int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* table, const float* bias, void* out,
+ * fc conv on the downsampled segmap (generator.py:72-73).  weight: the conv's fp32 OIHW weight
+ * (Cout, ncls, 3, 3) as it sits in the parameter arena (each block gathers its table from it into LDS). */
+int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* weight, const float* bias, void* out,
                       int N, int H, int W, int h, int w, int ncls, int Cout, int relu, void* stream);
 /* out (N,h,w,cpad): channels [0,ncls) one-hot of the nearest-downsampled label, channel ncls =
  * img[n,y,x] when img != NULL (img is (N,h,w) of T), remaining channels 0.  Builds the

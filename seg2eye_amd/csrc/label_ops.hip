@@ -6,7 +6,7 @@
 // neighbour's class: zero MACs, 9 LDS row reads per 16-B output vector.  The [9*ncls][<=128] slice of
 // the table this block needs sits in LDS (<= 18 KiB for ncls = 4).
 template <typename T>
-__global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __restrict__ label, const float* __restrict__ table,
+__global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __restrict__ label, const float* __restrict__ weight,
         const float* __restrict__ bias, T* __restrict__ out, int N, int H, int W, int h, int w, int ncls, int Cout, int relu) {
     constexpr int VEC = Vec<T>::N;
     constexpr int CT = 128;                               // channels per block
@@ -14,9 +14,11 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
     const int cbase = blockIdx.y * CT;
     const int cw = min(CT, Cout - cbase);
     const int rows = 9 * ncls;
+    // gather table straight from the OIHW conv weight: tab[(tap*ncls + cls)][cc] = weight[cbase+cc][cls][tap]
     for (int i = threadIdx.x; i < rows * CT; i += blockDim.x) {
-        const int r = i / CT, cc = i - r * CT;
-        tab[i] = cc < cw ? table[(size_t)r * Cout + cbase + cc] : 0.f;
+        const int cc = i / rows, r = i - cc * rows;       // source-contiguous order: r = cls*9 + tap
+        const int cls = r / 9, tap = r - cls * 9;
+        tab[(tap * ncls + cls) * CT + cc] = cc < cw ? weight[(size_t)(cbase + cc) * rows + r] : 0.f;
     }
     for (int i = threadIdx.x; i < CT; i += blockDim.x) tab[rows * CT + i] = (bias && i < cw) ? bias[cbase + i] : 0.f;
     __syncthreads();
@@ -26,24 +28,32 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
     const int tx = threadIdx.x % cgb, ty = threadIdx.x / cgb;
     if (ty >= ppb) return;
     const int sy = H / h, sx = W / w;
-    const long npix = (long)N * h * w;
-    for (long pix = (long)blockIdx.x * ppb + ty; pix < npix; pix += (long)gridDim.x * ppb) {
-        const int n = (int)(pix / (h * w));
-        const int rem = (int)(pix - (long)n * h * w);
+    const int hw = h * w, npix = N * hw;                  // < 2^31 (checked by the launcher)
+    float bv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) bv[j] = tab[rows * CT + tx * VEC + j];
+    for (int pix = blockIdx.x * ppb + ty; pix < npix; pix += gridDim.x * ppb) {
+        const int n = pix / hw;
+        const int rem = pix - n * hw;
         const int y = rem / w, x = rem - y * w;
+        // the 9 neighbour classes: clamped addresses, all loads issued together; -1 marks padding
+        int cls[9];
+        const uint8_t* lb = label + (size_t)n * H * W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool ok = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+            const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy), xc = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+            const int v = lb[(size_t)yc * sy * W + (size_t)xc * sx];
+            cls[t] = ok ? v : -1;
+        }
         float acc[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = tab[rows * CT + tx * VEC + j];
+        for (int j = 0; j < VEC; ++j) acc[j] = bv[j];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int yy = y + ky - 1;
-            if ((unsigned)yy >= (unsigned)h) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xx = x + kx - 1;
-                if ((unsigned)xx >= (unsigned)w) continue;
-                const int cls = label[((size_t)n * H + (size_t)yy * sy) * W + (size_t)xx * sx];
-                const float* trow = tab + ((ky * 3 + kx) * ncls + cls) * CT + tx * VEC;
+        for (int t = 0; t < 9; ++t) {
+            if (cls[t] >= 0) {
+                const float* trow = tab + (t * ncls + cls[t]) * CT + tx * VEC;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[j] += trow[j];
             }
@@ -58,13 +68,14 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
     }
 }
 
-extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* table, const float* bias, void* out,
+extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* weight, const float* bias, void* out,
                                  int N, int H, int W, int h, int w, int ncls, int Cout, int relu, void* stream) {
-    if (!label || !table || !out || N <= 0 || h <= 0 || w <= 0 || Cout <= 0 || ncls <= 0 || ncls > 8)
+    if (!label || !weight || !out || N <= 0 || h <= 0 || w <= 0 || Cout <= 0 || ncls <= 0 || ncls > 8)
         S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3: bad argument");
     if (H % h || W % w) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_label_conv3x3: %dx%d is not an integer multiple of %dx%d", H, W, h, w);
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3: bad dtype %d", dtype);
     const long npix = (long)N * h * w;
+    if (npix >= (1L << 31)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_label_conv3x3: too many pixels for 32-bit indices");
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     const int cw = Cout < 128 ? Cout : 128;
     const int ppb = 256 / ((cw + vec - 1) / vec);
@@ -73,8 +84,8 @@ extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* t
     dim3 grid((unsigned)gx, ceil_div(Cout, 128));
     const size_t lds = (size_t)(9 * ncls + 1) * 128 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2E_BF16) label_conv3x3_kernel<bf16_t><<<grid, 256, lds, st>>>(label, table, bias, (bf16_t*)out, N, H, W, h, w, ncls, Cout, relu);
-    else label_conv3x3_kernel<float><<<grid, 256, lds, st>>>(label, table, bias, (float*)out, N, H, W, h, w, ncls, Cout, relu);
+    if (dtype == S2E_BF16) label_conv3x3_kernel<bf16_t><<<grid, 256, lds, st>>>(label, weight, bias, (bf16_t*)out, N, H, W, h, w, ncls, Cout, relu);
+    else label_conv3x3_kernel<float><<<grid, 256, lds, st>>>(label, weight, bias, (float*)out, N, H, W, h, w, ncls, Cout, relu);
     S2E_CHECK_LAUNCH("label_conv3x3_kernel");
     return S2E_OK;
 }

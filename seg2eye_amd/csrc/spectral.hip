@@ -10,7 +10,7 @@
 // W / sigma never exists in memory: the packers divide on the fly while converting to the MFMA layout.
 #include "common.h"
 
-static constexpr int SN_BR = 64;       // rows per block
+static constexpr int SN_BR = 16;       // rows per block: all of a block's row loads are in flight together
 static constexpr int SN_BC = 256;      // columns per block (one per thread)
 
 // ---- t += W^T u over a [SN_BR x SN_BC] block; block_map = {layer, row0, col0}
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void sn_gemvT_kernel(const s2e_sn_layer* __res
     const int rend = min(L.rows, row0 + SN_BR);
     float acc = 0.f;
     const float* wp = L.w + (size_t)row0 * L.cols + col;
-#pragma unroll 8
+#pragma unroll 16
     for (int r = row0; r < rend; ++r, wp += L.cols) acc += *wp * L.u[r];
     atomicAdd(L.t + col, acc);
 }
@@ -51,15 +51,13 @@ __global__ __launch_bounds__(256) void sn_gemv_kernel(const s2e_sn_layer* __rest
     const float vj = cv ? L.v[col] : 0.f;
     const float* wp = L.w + (size_t)row0 * L.cols + col;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int r = 0; r < nr; r += 8, wp += (size_t)8 * L.cols) {      // 8 independent row loads in flight (nr <= SN_BR)
-        float p[8];
+    float p[SN_BR];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] = (cv && r + k < nr) ? wp[(size_t)k * L.cols] * vj : 0.f;
+    for (int k = 0; k < SN_BR; ++k) p[k] = (cv && k < nr) ? wp[(size_t)k * L.cols] * vj : 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float q = wave_sum(p[k]);
-            if (lane == 0) red[r + k][wave] = q;
-        }
+    for (int k = 0; k < SN_BR; ++k) {
+        const float q = wave_sum(p[k]);
+        if (lane == 0) red[k][wave] = q;
     }
     __syncthreads();
     if (threadIdx.x < nr) atomicAdd(L.s + row0 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);

@@ -50,13 +50,25 @@ class NLayerDiscriminator(BaseNetwork):
             self.add_module('model' + str(n), nn.Sequential(*sequence[n]))
         self.n_groups = len(sequence)
 
-    def forward_nhwc(self, x):
-        """x: (M,H,W,8).  Returns the NHWC outputs of model0..model{n} (after their activations)."""
+    def forward_nhwc(self, x, feat_terms=None, feat_lambda=0.0):
+        """x: (M,H,W,8).  Returns the NHWC outputs of model0..model{n} (after their activations).
+        feat_terms: a list -> x is [fake | real] over the batch and every intermediate output is passed through
+        ops.feat_tap: its feature-matching term (x feat_lambda / numel of the fake half) is appended to the list,
+        its gradient is injected on the way back, and the returned intermediate features are detached."""
         sn_begin(self)                  # no-op when MultiscaleDiscriminator.forward already stepped
         feats = []
+
+        def tap(h):
+            if feat_terms is None:
+                feats.append(h)
+                return h
+            h, term = ops.feat_tap(h, feat_lambda / (h.numel() // 2))
+            feat_terms.append(term)
+            feats.append(h.detach())
+            return h
         first = self.model0[0]
         h = ops.conv2d(x, first.weight, first.bias, None, 2, self.padw, ACT_NONE, ACT_LRELU)   # conv + LeakyReLU, one launch
-        feats.append(h)
+        h = tap(h)
         for n in range(1, self.n_groups - 1):
             blk = getattr(self, 'model%d' % n)[0]
             if isinstance(blk, nn.Sequential):                     # SN conv (bias removed) -> InstanceNorm -> LeakyReLU
@@ -65,7 +77,7 @@ class NLayerDiscriminator(BaseNetwork):
                 h = ops.instance_norm(h, lrelu=True)
             else:                                                  # norm_D without a norm layer: conv -> LeakyReLU
                 h = ops.conv2d_m(h, blk, None, self.strides[n], self.padw, ACT_NONE, ACT_LRELU)
-            feats.append(h)
+            h = tap(h)
         last = getattr(self, 'model%d' % (self.n_groups - 1))[0]
         h = ops.conv2d(h, last.weight, last.bias, None, 1, self.padw)
         feats.append(h)
@@ -94,10 +106,13 @@ class MultiscaleDiscriminator(BaseNetwork):
         for i in range(opt.num_D):
             self.add_module('discriminator_%d' % i, NLayerDiscriminator(opt))
 
-    def forward(self, input):
+    def forward(self, input, feat_lambda=None):
         """input: (2N, label_nc+output_nc, H, W) as in the reference call (pix2pix_model.py:338), or
         the already-built (2N,H,W,8) NHWC tensor.  Returns list[num_D] of list[n_layers_D+1] tensors,
-        logical NCHW (NHWC storage); list[num_D][1] with --no_ganFeat_loss (discriminator.py:53-63)."""
+        logical NCHW (NHWC storage); list[num_D][1] with --no_ganFeat_loss (discriminator.py:53-63).
+        feat_lambda (not in the reference; used by Pix2PixModel's G step): the batch is [fake | real] and the GAN
+        feature-matching loss  lambda/num_D * sum_ij L1mean(fake_ij, real_ij.detach())  is computed on the way
+        (ops.feat_tap); returns (result, loss[1]) with the intermediate features of `result` detached."""
         self.require_gpu(input)
         x = input if (input.dim() == 4 and input.shape[-1] == D_CPAD and input.shape[1] != self.opt.label_nc + self.opt.output_nc) \
             else to_d_input(input, self.cdtype)
@@ -105,8 +120,13 @@ class MultiscaleDiscriminator(BaseNetwork):
         with packing.network_scope(self, bank):    # all weight packs of this forward: one launch
             result = []
             keep_all = not self.opt.no_ganFeat_loss
+            terms = [] if feat_lambda is not None else None
+            num_D = len(list(self.named_children()))
             for name, D in self.named_children():
-                feats = [f.permute(0, 3, 1, 2) for f in D.forward_nhwc(x)]
+                raw = D.forward_nhwc(x, terms, (feat_lambda or 0.0) / num_D)
+                feats = [f.permute(0, 3, 1, 2) for f in raw]
                 result.append(feats if keep_all else [feats[-1]])
                 x = ops.avgpool3x3s2(x)                    # F.avg_pool2d(3, 2, 1, count_include_pad=False)
-            return result
+            if terms is None:
+                return result
+            return result, torch.stack(terms).sum().view(1)

@@ -103,6 +103,7 @@ class ZeroPool:
     high = {}          # key -> high-water mark
     key = None
     frozen = False
+    step_cache = {}    # per-scope memo of derived read-only tensors (cleared at scope entry and exit)
 
     @classmethod
     def scope(cls, key, device):
@@ -126,12 +127,14 @@ class ZeroPool:
                 cls.buf[:hw].zero_()
             cls.clean = hw
         cls.key, cls.bump = key, 0
+        cls.step_cache = {}
 
     @classmethod
     def _end(cls):
         cls.high[cls.key] = max(cls.high.get(cls.key, 0), cls.bump)
         cls.need = max(cls.need, cls.bump)
         cls.key = None
+        cls.step_cache = {}
 
     @classmethod
     def take(cls, numel, dtype, device):
@@ -290,11 +293,12 @@ def in_stats(x):
     return stats
 
 
-def label_conv3x3_raw(label, table, bias, n, H, W, h, w, cout, relu, dtype):
-    _need(label, table, bias)
+def label_conv3x3_raw(label, weight, bias, n, H, W, h, w, cout, relu, dtype):
+    """weight: the (Cout, ncls, 3, 3) fp32 conv weight itself (the kernel gathers its table from it)."""
+    _need(label, weight, bias)
     out = torch.empty(n, h, w, cout, dtype=dtype, device=label.device)
-    ncls = table.shape[0] // 9
-    L.check(L.lib().s2e_label_conv3x3(_dt(out), _p(label), _p(table), _p(bias), _p(out), n, H, W, h, w, ncls, cout,
+    ncls = weight.shape[1]
+    L.check(L.lib().s2e_label_conv3x3(_dt(out), _p(label), _p(weight), _p(bias), _p(out), n, H, W, h, w, ncls, cout,
                                       int(relu), _stream()), 's2e_label_conv3x3')
     return out
 
@@ -302,15 +306,23 @@ def label_conv3x3_raw(label, table, bias, n, H, W, h, w, cout, relu, dtype):
 def onehot_nhwc_raw(label, img, h, w, ncls, cpad, dtype):
     _need(label, img)
     n, H, W = label.shape
+    # inside a trainer step the three SPADEs of a block (and both blocks of a resolution) ask for the same
+    # one-hot map in their backward: build it once per (label, resolution) per step
+    key = (label.data_ptr(), label._version, n, H, W, h, w, ncls, cpad, dtype) if (img is None and ZeroPool.key is not None) else None
+    if key is not None and key in ZeroPool.step_cache:
+        return ZeroPool.step_cache[key]
     out = torch.empty(n, h, w, cpad, dtype=dtype, device=label.device)
     L.check(L.lib().s2e_onehot_nhwc(_dt(out), _p(label), _p(img), _p(out), n, H, W, h, w, ncls, cpad, _stream()),
             's2e_onehot_nhwc')
+    if key is not None:
+        ZeroPool.step_cache[key] = out
     return out
 
 
 def _table_of(weight):
-    """(Cout, ncls, 3, 3) conv weight -> gather table (9*ncls, Cout) fp32."""
-    return weight.detach().float().permute(2, 3, 1, 0).reshape(-1, weight.shape[0]).contiguous()
+    """The fp32 OIHW weight of a label conv, as s2e_label_conv3x3 takes it."""
+    w = weight.detach()
+    return w if (w.dtype == torch.float32 and w.is_contiguous()) else w.float().contiguous()
 
 
 def _unpack_dw(dw, cout, cin, kh, kw, cin_pad):
@@ -679,6 +691,50 @@ class LossSumFn(torch.autograd.Function):
 
 def loss_sum(a, b, mode, scale):
     return LossSumFn.apply(a, b, mode, scale)
+
+
+class FeatTapFn(torch.autograd.Function):
+    """Identity on a discriminator feature map h = [fake | real] (2N,H,W,C) that also yields the GAN feature-
+    matching term  scale * sum |h[:N] - h[N:].detach()|  (pix2pix_model.py:231-241 of the reference).
+
+    Why not slice-then-loss: the slice's backward materialises a zero (2N,...) tensor, copies the half in and
+    autograd then ADDS it to the gradient arriving from the next layer -- three passes over every feature map
+    (~0.65 ms per G step).  Here the next layer's gradient arrives first (this node sits on the only path to
+    it) and the L1 gradient is accumulated into its fake half in place by s2e_loss_grad(accumulate=1)."""
+
+    @staticmethod
+    def forward(ctx, h, scale):
+        _need(h)
+        n = h.shape[0] // 2
+        a, b = h[:n], h[n:]
+        out = torch.zeros((), dtype=torch.float32, device=h.device)
+        L.check(L.lib().s2e_loss_reduce(_dt(h), LOSS_L1, _p(a), _p(b), a.numel(), float(scale), _p(out), _stream()),
+                's2e_loss_reduce')
+        ctx.scale = float(scale)
+        ctx.save_for_backward(h)
+        ctx.set_materialize_grads(False)
+        return h.view_as(h), out
+
+    @staticmethod
+    def backward(ctx, gh, gloss):
+        h, = ctx.saved_tensors
+        n = h.shape[0] // 2
+        if gloss is None:
+            return gh, None
+        if gh is None:
+            gh = torch.zeros_like(h)
+        elif not gh.is_contiguous():
+            gh = gh.contiguous()
+        a, b, ga = h[:n], h[n:], gh[:n]
+        gs = gloss.detach().float().contiguous()
+        L.check(L.lib().s2e_loss_grad(_dt(h), LOSS_L1, _p(a), _p(b), a.numel(), ctx.scale, _p(gs), _p(ga), 1, _stream()),
+                's2e_loss_grad')
+        return gh, None
+
+
+def feat_tap(h, scale):
+    """-> (h, term): see FeatTapFn."""
+    return FeatTapFn.apply(h, scale)
 
 
 # ------------------------------------------------------------------------------ optimizer

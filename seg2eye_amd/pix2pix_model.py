@@ -144,7 +144,9 @@ class Pix2PixModel(nn.Module):
         for p in d_params:                      # D's weight grads are dead in the G step
             p.requires_grad_(False)
         try:
-            pred_fake, pred_real = self.discriminate(seg, fake_image, target_image)
+            fused_feat = not self.opt.no_ganFeat_loss
+            out = self.discriminate(seg, fake_image, target_image, feat_lambda=self.opt.lambda_feat if fused_feat else None)
+            (pred_fake, pred_real), feat = (out if fused_feat else (out, None))
         finally:
             for p, f in zip(d_params, flags):
                 p.requires_grad_(f)
@@ -155,8 +157,10 @@ class Pix2PixModel(nn.Module):
             l1 = ops.loss_sum(a, b, LOSS_L1, 1.0 / a.numel()).view(1)
             G_losses['L1/weighted'] = l1 * self.opt.lambda_l1
             self.add_to_loss_log('L1/raw', l1.detach())
-        if not self.opt.no_ganFeat_loss:
-            G_losses['GAN_Feat'] = networks.feature_matching_loss(pred_fake, pred_real, self.opt.lambda_feat)
+        if fused_feat:
+            # == networks.feature_matching_loss(pred_fake, pred_real, lambda_feat), computed inside netD's forward so
+            # that its gradient is accumulated in place into the features' incoming gradients (ops.FeatTapFn)
+            G_losses['GAN_Feat'] = feat
         return G_losses, fake_image
 
     def compute_discriminator_loss(self, seg, real_image, target_image):
@@ -190,13 +194,16 @@ class Pix2PixModel(nn.Module):
         latent_style, feats = self.encode_w(style_image)
         return self.generate_fake_from_stylecode(seg, latent_style), latent_style, feats
 
-    def discriminate(self, seg, fake_image, real_image):
+    def discriminate(self, seg, fake_image, real_image, feat_lambda=None):
         """D on cat over the batch of [cat(seg, fake); cat(seg, real)] (pix2pix_model.py:328-342); the
         (2N,H,W,8) input is built by one kernel from the label map and the two image batches."""
         imgs = torch.cat([fake_image[:, 0].to(self.cdtype), real_image[:, 0].to(self.cdtype)], 0).contiguous()
         labels = torch.cat([seg.label, seg.label], 0)
-        out = self.netD(ops.seg_image_concat(labels, imgs, self.opt.label_nc, networks.discriminator.D_CPAD))
-        return self.divide_pred(out)
+        x = ops.seg_image_concat(labels, imgs, self.opt.label_nc, networks.discriminator.D_CPAD)
+        if feat_lambda is None:
+            return self.divide_pred(self.netD(x))
+        out, feat = self.netD(x, feat_lambda=feat_lambda)
+        return self.divide_pred(out), feat
 
     @staticmethod
     def divide_pred(pred):

@@ -18,7 +18,7 @@ import torch
 from . import _lib as L
 
 SN_EPS = 1e-12
-_BR, _BC = 64, 256
+_BR, _BC = 16, 256
 
 
 def sn_convs(root):

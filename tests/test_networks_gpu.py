@@ -185,6 +185,41 @@ def test_discriminator_and_losses_fp32():
         assert_checksum_close(g, z['gradD_' + k], KINK_TOL, k)
 
 
+@pytest.mark.parametrize('dt', ['fp32', 'bf16'])
+def test_fused_feature_matching_matches_unfused(dt):
+    """netD(x, feat_lambda=...) (the G step's path: feature-matching terms and their gradients produced inside
+    D's forward/backward by ops.feat_tap) == features + networks.feature_matching_loss afterwards."""
+    from seg2eye_amd import networks, ops
+    z = load_golden('d_ndf8_32')
+    opt = _opt(ndf=8, crop_size=32, compute_dtype=dt)
+    D = _load(networks.define_D(opt), z, 'D').eval()
+    for p in D.parameters():
+        p.requires_grad_(False)
+    lab = _label(z)[:, 0]
+    real = torch.from_numpy(z['real']).to(DEV)
+    crit = networks.GANLoss('hinge', opt=opt)
+    res = []
+    for fused in (False, True):
+        fake = torch.from_numpy(z['fake']).to(DEV).requires_grad_(True)
+        x = ops.seg_image_concat(torch.cat([lab, lab], 0), torch.cat([fake[:, 0], real[:, 0]], 0).to(D.cdtype))
+        if fused:
+            pred, feat = D(x, feat_lambda=10.0)
+        else:
+            pred = D(x)
+        pf = [[t[:2] for t in p] for p in pred]
+        pr = [[t[2:] for t in p] for p in pred]
+        if not fused:
+            feat = networks.feature_matching_loss(pf, pr, 10.0)
+        l_g = crit(pf, True, for_discriminator=False)
+        g, = torch.autograd.grad((l_g + feat).sum(), [fake])
+        res.append((float(feat), float(l_g), g.float().cpu()))
+    tol = 1e-5 if dt == 'fp32' else 2e-2
+    assert abs(res[0][0] - res[1][0]) <= tol * abs(res[0][0]) and abs(res[0][1] - res[1][1]) <= tol * max(1.0, abs(res[0][1]))
+    assert float((res[0][2] - res[1][2]).abs().max()) <= (1e-5 if dt == 'fp32' else 5e-2) * float(res[0][2].abs().max())
+    if dt == 'fp32':
+        np.testing.assert_allclose(res[1][0], float(z['l_feat']), rtol=2e-5, atol=2e-5)
+
+
 def test_encoder_fp32():
     from seg2eye_amd import networks
     z = load_golden('e_ngf8')
