@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
         const float* __restrict__ bias, T* __restrict__ out, int N, int H, int W, int h, int w, int ncls, int Cout, int relu) {
     constexpr int VEC = Vec<T>::N;
     constexpr int CT = 128;                               // channels per block
-    extern __shared__ __attribute__((aligned(16))) float tab[];   // [9*ncls][CT] then bias[CT]
+    extern __shared__ __attribute__((aligned(16))) float tab[];   // [9*ncls][CT], bias[CT], uni[ncls][CT]
     const int cbase = blockIdx.y * CT;
     const int cw = min(CT, Cout - cbase);
     const int rows = 9 * ncls;
@@ -21,6 +21,17 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
         tab[(tap * ncls + cls) * CT + cc] = cc < cw ? weight[(size_t)(cbase + cc) * rows + r] : 0.f;
     }
     for (int i = threadIdx.x; i < CT; i += blockDim.x) tab[rows * CT + i] = (bias && i < cw) ? bias[cbase + i] : 0.f;
+    __syncthreads();
+    // Label maps are piecewise constant: for an interior pixel whose 3x3 neighbourhood is ONE class the sum is a
+    // per-class constant.  uni[cls][cc] = bias + sum_tap tab[tap][cls] (same order as the general path below, so
+    // both paths give the same bits); such pixels cost one LDS vector read instead of nine.
+    float* uni = tab + (rows + 1) * CT;                   // [ncls][CT]
+    for (int i = threadIdx.x; i < ncls * CT; i += blockDim.x) {
+        const int cl = i / CT, cc = i - cl * CT;
+        float a = tab[rows * CT + cc];
+        for (int t = 0; t < 9; ++t) a += tab[(t * ncls + cl) * CT + cc];
+        uni[i] = a;
+    }
     __syncthreads();
 
     const int cgb = (cw + VEC - 1) / VEC;                 // channel groups handled by this block
@@ -47,15 +58,24 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
             const int v = lb[(size_t)yc * sy * W + (size_t)xc * sx];
             cls[t] = ok ? v : -1;
         }
+        bool same = true;
+#pragma unroll
+        for (int t = 1; t < 9; ++t) same = same && (cls[t] == cls[0]);
         float acc[VEC];
+        if (same && cls[0] >= 0) {
+            const float* u = uni + cls[0] * CT + tx * VEC;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = bv[j];
+            for (int j = 0; j < VEC; ++j) acc[j] = u[j];
+        } else {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (cls[t] >= 0) {
-                const float* trow = tab + (t * ncls + cls[t]) * CT + tx * VEC;
+            for (int j = 0; j < VEC; ++j) acc[j] = bv[j];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) acc[j] += trow[j];
+            for (int t = 0; t < 9; ++t) {
+                if (cls[t] >= 0) {
+                    const float* trow = tab + (t * ncls + cls[t]) * CT + tx * VEC;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] += trow[j];
+                }
             }
         }
         if (relu) {
@@ -82,7 +102,7 @@ extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* w
     long gx = (npix + ppb - 1) / ppb;
     if (gx > 2048) gx = 2048;
     dim3 grid((unsigned)gx, ceil_div(Cout, 128));
-    const size_t lds = (size_t)(9 * ncls + 1) * 128 * sizeof(float);
+    const size_t lds = (size_t)(9 * ncls + 1 + ncls) * 128 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16) label_conv3x3_kernel<bf16_t><<<grid, 256, lds, st>>>(label, weight, bias, (bf16_t*)out, N, H, W, h, w, ncls, Cout, relu);
     else label_conv3x3_kernel<float><<<grid, 256, lds, st>>>(label, weight, bias, (float*)out, N, H, W, h, w, ncls, Cout, relu);

@@ -498,6 +498,9 @@ class SpadeParamFn(torch.autograd.Function):
             gw_g, gw_b, gb_g, gb_b = gw_gb[:C], gw_gb[C:], gb_gb[:C], gb_gb[C:]
         wpt = packed_weight(w_gb, g.dtype, nh, True, None, ctx.plan, ctx.plan_gen, stable=ctx.fused)
         dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
+        # (a streaming class-bucket kernel for this gradient was tried twice -- LDS float atomics, then per-wave
+        # queues of boundary pixels -- and lost to the MFMA wgrad against the 8-channel one-hot map: 1.7 vs 0.75 ms
+        # per step; see DESIGN.md "tried and dropped")
         oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
         wdst, bdst = ctx.sh_dst
         dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True, bdst)
