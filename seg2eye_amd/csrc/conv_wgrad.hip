@@ -425,9 +425,23 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
     p.tiles_k = ceil_div(p.Ktot, 128);
     p.tiles_co = ceil_div(d->Cout, 128);
     const int tiles = p.tiles_k * p.tiles_co;
-    // split the pixels so that ~1024 workgroups exist (2 per CU resident x 2 waves of work)
-    int splits = ceil_div(1024, tiles);
-    const int max_splits = ceil_div(p.M, 256);            // at least 8 chunks per split
+    // Split the pixels over workgroups.  Two costs pull against each other (measured per shape, profiles/r01):
+    //   * long pixel loops want MANY workgroups: c128->256 @256^2 runs 476 / 497 / 558 TFLOP/s at 512 / 1024 / 2048;
+    //   * every split ends with one fp32 atomic per dW element on addresses shared by all splits of the tile: a big
+    //     dW with few pixels (1024->1024 @16^2: 9.4 M elements, 2048 pixels) loses 30 % going from 1 split to 4,
+    //     and a 1-tile dW (the 8-channel label maps) is best at ~512-deep contention, not 1024 or 2048.
+    // So: aim for S2E_WGRAD_WG (2048) workgroups, keep >= 32 pixel chunks per split (64 when dW is large), never more
+    // than 512 splits -- unless that leaves the chip under-filled (< 512 workgroups), then allow 16-chunk splits
+    // (8-chunk splits for a 1-2 tile dW, whose atomics are few).
+    static const int target_wg = [] { const char* e = getenv("S2E_WGRAD_WG"); return e ? atoi(e) : 2048; }();
+    int splits = ceil_div(target_wg, tiles);
+    int max_splits = p.M / (tiles >= 64 ? 2048 : 1024);
+    if (max_splits > 512) max_splits = 512;
+    if ((long)tiles * max_splits < 512) {
+        const int fill = ceil_div(512, tiles), cap = p.M / (tiles <= 2 ? 256 : 512);
+        max_splits = fill < cap ? fill : cap;
+    }
+    if (max_splits < 1) max_splits = 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     p.m_per_split = ceil_div(ceil_div(p.M, splits), 64) * 64;
