@@ -165,8 +165,17 @@ def main():
             d = prof[fam]
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
             args_steps = prof_steps
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, 'profiles', 'r01', 'pmc', 'hbm_traffic.json')
+            if os.path.exists(pmc):                       # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+                k = json.load(open(pmc)).get('kernels', {}).get(fam)
+                if k:
+                    traffic, traffic_src = k['hbm_bytes_per_launch'], 'profiles/r01/pmc/hbm_traffic.json'
             out['roofline'] = {'kernel': fam, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                               'frac': ach / peak, 'traffic': None,
+                               'frac': ach / peak, 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC, separate passes)',
+                               'traffic_source': traffic_src,
+                               'algorithmic_bytes_per_launch': d['bytes'] / d['launches'],
+                               'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                                'launches_per_step': d['launches'] / prof_steps, 'ms_per_step': d['ms'] / prof_steps,
                                'gflop_per_step': d['flops'] / prof_steps / 1e9,
                                'measured': 'HIP events around every launch, eager re-run of the timed step'}

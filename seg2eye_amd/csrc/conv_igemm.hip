@@ -26,6 +26,7 @@ struct ConvKParams {
     int KH, KW, stride, pad, transposed;
     int in_act, out_act, aux_mode;
     int Ktot, Kpad, M, tiles_n;
+    int tm_fast;                          // tile order: consecutive tile ids walk the pixel tiles of ONE weight panel (see s2e_conv2d)
     int tiles, splits, kt_per_split;      // split-K: grid = tiles * splits, split s owns K-tiles [s*per, (s+1)*per)
     float* partial;                       // splits > 1: fp32 slabs [splits][M][Cout], combined by conv_finish_kernel
 };
@@ -90,7 +91,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int split = wg / p.tiles, tile = wg - split * p.tiles;
-    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int tiles_m = p.tiles / p.tiles_n;
+    const int tn = p.tm_fast ? tile / tiles_m : tile % p.tiles_n;
+    const int tm = p.tm_fast ? tile - tn * tiles_m : tile / p.tiles_n;
     const int nk_all = p.Kpad / BK;
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_all, kt0 + p.kt_per_split);
@@ -552,6 +555,17 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
     p.M = d->N * d->Ho * d->Wo;
     const int bn = bn_for(d->Cout);
     plan_splits(dtype, d, &p.tiles, &p.tiles_n, &p.splits, &p.kt_per_split);
+    // Tile order.  xcd_remap hands each XCD a contiguous range of tile ids, and whatever operand panel those tiles do
+    // NOT share is fetched into that XCD's L2 once per XCD.  Default: Cout tiles fastest (neighbours share the
+    // im2col panel).  The PMC pass shows the price on the small-M, 1024-channel layers: 80-190 MB fetched per launch
+    // against ~25 MB of operands (the weight matrix arrives in all 8 L2s).  Walking the pixel tiles fastest instead
+    // (S2E_IGEMM_TMFAST=1: one weight panel per XCD, the small activation replicated) was measured and changes
+    // nothing on 1024->1024 @16^2 (577 vs 579 TFLOP/s) and costs 8 % on 128->2048: the re-reads are served by the
+    // Infinity Cache and are not what bounds these launches.  Kept as a switch, off.
+    {
+        static const int force = [] { const char* e = getenv("S2E_IGEMM_TMFAST"); return e ? atoi(e) : 0; }();
+        p.tm_fast = force > 0 && p.tiles_n > 1;
+    }
     p.partial = (float*)workspace;
     if (p.splits > 1 && (!workspace || workspace_bytes < s2e_conv2d_workspace_bytes(dtype, d)))
         S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: this shape needs %zu bytes of workspace (s2e_conv2d_workspace_bytes)",

@@ -51,27 +51,28 @@ class LaunchProfiler:
     (torch's current stream).  bench.py turns it on to measure the dominant kernel's achieved rate
     live; off by default (zero overhead)."""
     enabled = False
-    records = []          # (family, algorithmic_flops, start_event, end_event, tag)
+    records = []          # (family, algorithmic_flops, start_event, end_event, tag, algorithmic_bytes)
 
     @classmethod
-    def run(cls, family, flops, fn, tag=''):
+    def run(cls, family, flops, fn, tag='', nbytes=0.0):
         if not cls.enabled:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         r = fn()
         e.record()
-        cls.records.append((family, flops, s, e, tag))
+        cls.records.append((family, flops, s, e, tag, nbytes))
         return r
 
     @classmethod
     def summary(cls):
         """family -> dict(launches, flops, ms); call after a device synchronize."""
         out = {}
-        for fam, fl, s, e, _ in cls.records:
-            d = out.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0))
+        for fam, fl, s, e, _, nb in cls.records:
+            d = out.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
             d['launches'] += 1
             d['flops'] += fl
+            d['bytes'] += nb
             d['ms'] += s.elapsed_time(e)
         return out
 
@@ -214,7 +215,10 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     LaunchProfiler.run('conv_igemm', flops, lambda: L.check(
         L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _p(ws), wsb,
                            _stream()), 's2e_conv2d'),
-        tag='%s n%d %dx%d c%d->%d k%d s%d' % ('D' if transposed else 'F', n, hi, wi, cin, cout, kh, stride))
+        tag='%s n%d %dx%d c%d->%d k%d s%d' % ('D' if transposed else 'F', n, hi, wi, cin, cout, kh, stride),
+        # algorithmic bytes: every operand once (x, packed w, y, + residual / mask tensor when present)
+        nbytes=float((x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0)
+                      + (aux.numel() if aux is not None else 0)) * x.element_size()))
     return y
 
 
@@ -239,7 +243,8 @@ def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=Fals
     LaunchProfiler.run('conv_wgrad', 2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
         L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), _p(dbp), C.byref(d), _p(ws), wsb, _stream()),
         's2e_conv2d_wgrad'),
-        tag='W n%d %dx%d c%d->%d k%d s%d' % (n, hi, wi, cin, cout, kh, stride))
+        tag='W n%d %dx%d c%d->%d k%d s%d' % (n, hi, wi, cin, cout, kh, stride),
+        nbytes=float((x.numel() + gy.numel()) * x.element_size() + dw.numel() * 4))
     return dw, db
 
 

@@ -19,7 +19,7 @@ N = 3
 for _ in range(N): step()
 torch.cuda.synchronize(); ops.LaunchProfiler.enabled = False
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-for fam, fl, s, e, tag in ops.LaunchProfiler.records:
+for fam, fl, s, e, tag, _nb in ops.LaunchProfiler.records:
     a = agg[(fam, tag)]; a[0] += 1; a[1] += s.elapsed_time(e); a[2] += fl
 for fam in ('conv_igemm', 'conv_wgrad'):
     items = sorted(((k, v) for k, v in agg.items() if k[0] == fam), key=lambda kv: -kv[1][1])
