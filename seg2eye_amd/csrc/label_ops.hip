@@ -15,8 +15,10 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
     const int cw = min(CT, Cout - cbase);
     const int rows = 9 * ncls;
     // gather table straight from the OIHW conv weight: tab[(tap*ncls + cls)][cc] = weight[cbase+cc][cls][tap]
+    // (lanes walk the channel: LDS writes are conflict-free; walking the source-contiguous index instead puts all 64
+    // lanes of a write on one bank and made this preamble, not the pixel loop, the cost of the small launches)
     for (int i = threadIdx.x; i < rows * CT; i += blockDim.x) {
-        const int cc = i / rows, r = i - cc * rows;       // source-contiguous order: r = cls*9 + tap
+        const int r = i / CT, cc = i - r * CT;            // r = cls*9 + tap in the OIHW weight
         const int cls = r / 9, tap = r - cls * 9;
         tab[(tap * ncls + cls) * CT + cc] = cc < cw ? weight[(size_t)(cbase + cc) * rows + r] : 0.f;
     }
@@ -34,45 +36,42 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
     }
     __syncthreads();
 
-    const int cgb = (cw + VEC - 1) / VEC;                 // channel groups handled by this block
-    const int ppb = 256 / cgb;                            // pixels per pass
-    const int tx = threadIdx.x % cgb, ty = threadIdx.x / cgb;
-    if (ty >= ppb) return;
+    const int cgb = (cw + VEC - 1) / VEC;                 // lanes per pixel
     const int sy = H / h, sx = W / w;
     const int hw = h * w, npix = N * hw;                  // < 2^31 (checked by the launcher)
-    float bv[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) bv[j] = tab[rows * CT + tx * VEC + j];
-    for (int pix = blockIdx.x * ppb + ty; pix < npix; pix += gridDim.x * ppb) {
-        const int n = pix / hw;
-        const int rem = pix - n * hw;
+    // word of a pixel: its 9 neighbour classes, 3 bits each (7 = padding); bit 27 = "all nine are the same class"
+    auto load_word = [&](int pix) __attribute__((always_inline)) -> unsigned {
+        const int n = pix / hw, rem = pix - n * hw;
         const int y = rem / w, x = rem - y * w;
-        // the 9 neighbour classes: clamped addresses, all loads issued together; -1 marks padding
-        int cls[9];
         const uint8_t* lb = label + (size_t)n * H * W;
+        unsigned wd = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
             const bool ok = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
             const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy), xc = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-            const int v = lb[(size_t)yc * sy * W + (size_t)xc * sx];
-            cls[t] = ok ? v : -1;
+            const unsigned v = lb[(size_t)yc * sy * W + (size_t)xc * sx];
+            wd |= (ok ? (v & 7u) : 7u) << (3 * t);
         }
-        bool same = true;
-#pragma unroll
-        for (int t = 1; t < 9; ++t) same = same && (cls[t] == cls[0]);
+        const unsigned c0 = wd & 7u;
+        if (c0 != 7u && wd == c0 * 0x1249249u) wd |= 1u << 27;      // 0x1249249 = sum of 8^t, t < 9
+        return wd;
+    };
+    // emit one pixel's 16-byte channel group given its word
+    auto emit = [&](unsigned word, int pix, int tx) __attribute__((always_inline)) {
         float acc[VEC];
-        if (same && cls[0] >= 0) {
-            const float* u = uni + cls[0] * CT + tx * VEC;
+        if (word & (1u << 27)) {
+            const float* u = uni + (word & 7u) * CT + tx * VEC;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[j] = u[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) acc[j] = bv[j];
+            for (int j = 0; j < VEC; ++j) acc[j] = tab[rows * CT + tx * VEC + j];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                if (cls[t] >= 0) {
-                    const float* trow = tab + (t * ncls + cls[t]) * CT + tx * VEC;
+                const unsigned c = (word >> (3 * t)) & 7u;
+                if (c != 7u) {
+                    const float* trow = tab + (t * ncls + c) * CT + tx * VEC;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) acc[j] += trow[j];
                 }
@@ -85,12 +84,36 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
         T* o = out + (size_t)pix * Cout + cbase + tx * VEC;
         if ((Cout % VEC) == 0) *(u32x4_t*)o = pack16<T>(acc);
         else for (int j = 0; j < VEC && cbase + tx * VEC + j < Cout; ++j) store1<T>(o + j, acc[j]);
+    };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((64 % cgb) == 0 && npix >= 65536) {               // (small maps: too few 256-pixel blocks to fill the chip)
+        // A wave owns 64 consecutive pixels per pass: every lane fetches the word of ITS pixel (nine byte loads, no
+        // redundancy across the pixel's lanes), then the wave emits the 64 pixels in cgb sub-steps of 64/cgb pixels,
+        // each lane pulling the word it needs with one shuffle.  The coordinate arithmetic and the label loads are
+        // thus paid once per 64 pixels instead of once per 64/cgb: the loop was VALU-issue-bound (~150 wave
+        // instructions per KB stored), not HBM-bound.
+        const int ppw = 64 / cgb;
+        const int tx = lane % cgb, sub = lane / cgb;
+        for (int base = (blockIdx.x * 4 + wave) * 64; base < npix; base += gridDim.x * 256) {
+            const int mine = base + lane;
+            const unsigned wmine = mine < npix ? load_word(mine) : 0u;
+            for (int k = 0; k < cgb; ++k) {
+                const int src = k * ppw + sub;
+                const unsigned word = __shfl(wmine, src, 64);
+                if (base + src < npix) emit(word, base + src, tx);
+            }
+        }
+    } else {
+        const int ppb = 256 / cgb;
+        const int tx = threadIdx.x % cgb, ty = threadIdx.x / cgb;
+        if (ty >= ppb) return;
+        for (int pix = blockIdx.x * ppb + ty; pix < npix; pix += gridDim.x * ppb) emit(load_word(pix), pix, tx);
     }
 }
 
 extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* weight, const float* bias, void* out,
                                  int N, int H, int W, int h, int w, int ncls, int Cout, int relu, void* stream) {
-    if (!label || !weight || !out || N <= 0 || h <= 0 || w <= 0 || Cout <= 0 || ncls <= 0 || ncls > 8)
+    if (!label || !weight || !out || N <= 0 || h <= 0 || w <= 0 || Cout <= 0 || ncls <= 0 || ncls > 7)
         S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3: bad argument");
     if (H % h || W % w) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_label_conv3x3: %dx%d is not an integer multiple of %dx%d", H, W, h, w);
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3: bad dtype %d", dtype);
@@ -98,9 +121,11 @@ extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* w
     if (npix >= (1L << 31)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_label_conv3x3: too many pixels for 32-bit indices");
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     const int cw = Cout < 128 ? Cout : 128;
-    const int ppb = 256 / ((cw + vec - 1) / vec);
+    const int cgb_h = (cw + vec - 1) / vec;
+    const int ppb = ((64 % cgb_h) == 0 && npix >= 65536) ? 256 : 256 / cgb_h;       // pixels per block per pass
     long gx = (npix + ppb - 1) / ppb;
-    if (gx > 2048) gx = 2048;
+    static const long cap = [] { const char* e = getenv("S2E_LABEL_GRID"); return e ? atol(e) : 1024L; }();
+    if (gx > cap) gx = cap;
     dim3 grid((unsigned)gx, ceil_div(Cout, 128));
     const size_t lds = (size_t)(9 * ncls + 1 + ncls) * 128 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;

@@ -30,3 +30,20 @@ for (n, hw, c) in [(8, 256, 128), (8, 256, 64), (8, 128, 256), (8, 64, 512), (8,
     g = torch.randn_like(out)
     t = timeit(lambda: torch.autograd.grad(out, [x, gb, style], g, retain_graph=True))
     print('mod_bwd   n%d %dx%d c%d: %7.1f us  %6.2f TB/s (10 units; reduce+apply+style)' % (n, hw, hw, c, t, 10 * mb / t))
+from seg2eye_amd import synthetic as syn
+lab = torch.from_numpy(syn.ellipse_labels(8, 256, 256, seed=1)).to(dev)[:, 0].contiguous()
+wsh = torch.randn(128, 4, 3, 3, device=dev) * 0.3
+bsh = torch.randn(128, device=dev) * 0.1
+for hw in (256, 128, 64, 16):
+    t = timeit(lambda: ops.label_conv3x3_raw(lab, wsh, bsh, 8, 256, 256, hw, hw, 128, True, torch.bfloat16))
+    mb = 8 * hw * hw * 128 * 2 / 1e6
+    print('label_conv n8 %dx%d -> 128ch: %7.1f us  %6.2f TB/s (write only)' % (hw, hw, t, mb / t))
+lab0 = torch.zeros_like(lab)
+t = timeit(lambda: ops.label_conv3x3_raw(lab0, wsh, bsh, 8, 256, 256, 256, 256, 128, True, torch.bfloat16))
+print('label_conv uniform labels 256: %7.1f us' % t)
+labr = torch.randint(0, 4, lab.shape, device=dev, dtype=torch.uint8)
+t = timeit(lambda: ops.label_conv3x3_raw(labr, wsh, bsh, 8, 256, 256, 256, 256, 128, True, torch.bfloat16))
+print('label_conv random labels 256: %7.1f us' % t)
+out = torch.empty(8, 256, 256, 128, device=dev, dtype=torch.bfloat16)
+t = timeit(lambda: out.fill_(1.0))
+print('torch fill 134MB: %7.1f us' % t)
