@@ -370,57 +370,74 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
     }
 }
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __restrict__ gin, const T* __restrict__ x,
-        const T* __restrict__ gb, const T* __restrict__ dgb, const float* __restrict__ stats, const float* __restrict__ style,
-        const double* __restrict__ ws, T* __restrict__ dx, long nvec, int HW, int C, int cg, int lrelu, int sld) {
-    constexpr int VEC = Vec<T>::N;
-    const float inv_hw = 1.f / (float)HW;
-    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
-        const long row = v / cg;
-        const int g = (int)(v - row * cg);
-        const int n = (int)(row / HW);
-        const int c0 = g * VEC;
-        float f[VEC], o[VEC];
-        unpack16<T>(*(const u32x4_t*)(x + (size_t)row * C + c0), f);
-        const float* stp = stats + ((size_t)n * C + c0) * 2;
-        const double* wsp = ws + ((size_t)n * C + c0) * 4;
-        if (MODE == S2E_NORM_SPADE_STYLE) {
-            float ga[VEC], dbe[VEC];
-            unpack16<T>(*(const u32x4_t*)(gb + (size_t)row * 2 * C + c0), ga);
-            unpack16<T>(*(const u32x4_t*)(dgb + (size_t)row * 2 * C + C + c0), dbe);
-            const float* s0 = style + (size_t)n * sld + c0;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float rs = stp[2 * j + 1];
-                const float xh = (f[j] - stp[2 * j]) * rs;
-                const float gn = dbe[j] * (1.f + ga[j]);                 // 0.5*go*G
-                const float m0 = (float)wsp[4 * j] * inv_hw, m1 = (float)wsp[4 * j + 1] * inv_hw;
-                o[j] = dbe[j] * (1.f + s0[j]) + rs * (gn - m0 - xh * m1);
-            }
-        } else {
-            float gg[VEC];
-            unpack16<T>(*(const u32x4_t*)(gin + (size_t)row * C + c0), gg);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float rs = stp[2 * j + 1];
-                const float xh = (f[j] - stp[2 * j]) * rs;
-                float go = gg[j];
-                if (lrelu) go *= (xh > 0.f ? 1.f : 0.2f);
-                const float m0 = (float)wsp[4 * j] * inv_hw, m1 = (float)wsp[4 * j + 1] * inv_hw;
-                o[j] = rs * (go - m0 - xh * m1);
-            }
-        }
-        *(u32x4_t*)(dx + (size_t)row * C + c0) = pack16<T>(o);
-    }
-}
-
-__global__ void modulate_bwd_style_kernel(const double* __restrict__ ws, float* __restrict__ dstyle, int N, int C, int sld) {
+// Per-(n,c) coefficients of pass 2, computed once by modulate_bwd_coef_kernel and stored as one float4 over the first
+// 16 bytes of the channel's 32-byte fp64 slot in ws (each thread reads its whole slot first):
+//   SPADE_STYLE: dx = dbeta*(P + R*gamma) - Q - x*S     P = 1 + s0 + rstd, R = rstd
+//   PLAIN_IN   : dx = R*go - Q - x*S                    P = mean (for the LeakyReLU mask: xhat > 0 <=> x > mean)
+//   both       : Q = rstd*(S0 - mean*rstd*S1)/HW,  S = rstd^2*S1/HW
+// The element-wise pass then needs 16 B of constants per channel instead of 32 B of doubles + stats + style and no
+// fp64 conversions: it was VALU-issue-bound (22 loads and ~350 instructions per 16-byte vector), not HBM-bound.
+template <int MODE>
+__global__ void modulate_bwd_coef_kernel(double* __restrict__ ws, const float* __restrict__ stats, const float* __restrict__ style,
+                                         float* __restrict__ dstyle, int N, int C, int HW, int sld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
-    dstyle[(size_t)n * sld + c] += 0.5f * (float)ws[(size_t)i * 4 + 2];
-    dstyle[(size_t)n * sld + C + c] += 0.5f * (float)ws[(size_t)i * 4 + 3];
+    const double s0d = ws[(size_t)i * 4], s1d = ws[(size_t)i * 4 + 1];
+    const float mean = stats[2 * i], rs = stats[2 * i + 1];
+    const float inv_hw = 1.f / (float)HW;
+    const float m0 = (float)s0d * inv_hw, m1 = (float)s1d * inv_hw;
+    f32x4_t k;
+    if (MODE == S2E_NORM_SPADE_STYLE) {
+        const double s2d = ws[(size_t)i * 4 + 2], s3d = ws[(size_t)i * 4 + 3];
+        dstyle[(size_t)n * sld + c] += 0.5f * (float)s2d;
+        dstyle[(size_t)n * sld + C + c] += 0.5f * (float)s3d;
+        k[0] = 1.f + style[(size_t)n * sld + c] + rs;
+    } else {
+        k[0] = mean;
+    }
+    k[1] = rs;
+    k[2] = rs * (m0 - mean * rs * m1);
+    k[3] = rs * rs * m1;
+    *(f32x4_t*)(ws + (size_t)i * 4) = k;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __restrict__ gin, const T* __restrict__ x,
+        const T* __restrict__ gb, const T* __restrict__ dgb, const double* __restrict__ ws, T* __restrict__ dx,
+        int vps, int HW, int C, int cg, int cg_shift, int lrelu) {
+    constexpr int VEC = Vec<T>::N;
+    const int n = blockIdx.y;                              // one sample per grid row: 32-bit indices, no 64-bit division
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < vps; v += gridDim.x * blockDim.x) {
+        const int prow = cg_shift >= 0 ? v >> cg_shift : v / cg;
+        const int g = v - prow * cg;
+        const size_t row = (size_t)n * HW + prow;
+        const int c0 = g * VEC;
+        float f[VEC], o[VEC];
+        unpack16<T>(*(const u32x4_t*)(x + row * C + c0), f);
+        const f32x4_t* kp = (const f32x4_t*)(ws + ((size_t)n * C + c0) * 4);      // stride 32 B per channel
+        if (MODE == S2E_NORM_SPADE_STYLE) {
+            float ga[VEC], dbe[VEC];
+            unpack16<T>(*(const u32x4_t*)(gb + row * 2 * C + c0), ga);
+            unpack16<T>(*(const u32x4_t*)(dgb + row * 2 * C + C + c0), dbe);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const f32x4_t k = kp[2 * j];
+                o[j] = dbe[j] * (k[0] + k[1] * ga[j]) - k[2] - f[j] * k[3];
+            }
+        } else {
+            float gg[VEC];
+            unpack16<T>(*(const u32x4_t*)(gin + row * C + c0), gg);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const f32x4_t k = kp[2 * j];
+                float go = gg[j];
+                if (lrelu) go *= (f[j] > k[0] ? 1.f : 0.2f);
+                o[j] = k[1] * go - k[2] - f[j] * k[3];
+            }
+        }
+        *(u32x4_t*)(dx + row * C + c0) = pack16<T>(o);
+    }
 }
 
 extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
@@ -437,18 +454,22 @@ extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* 
     const RowGeom rg = row_geom(C, vec);
     const int iters = slab_iters_for(HW, rg.rpp, N, rg.zblocks);
     dim3 grid1(ceil_div(HW, rg.rpp * iters), N, rg.zblocks);
-    const long nvec = (long)N * HW * rg.cg;
-    const int grid2 = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    if ((long)HW * rg.cg >= (1L << 31)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_bwd: sample too large for 32-bit indices");
+    const int vps = HW * rg.cg;                            // 16-byte vectors per sample
+    int gx = (vps + 255) / 256;
+    const int gx_cap = 8192 / N > 1 ? 8192 / N : 1;
+    if (gx > gx_cap) gx = gx_cap;
+    dim3 grid2(gx, N);
+    int cg_shift = -1;
+    for (int b = 0; b < 31; ++b) if ((1 << b) == rg.cg) cg_shift = b;
+    const int gridc = ceil_div((long)N * C, 256);
 #define S2E_LAUNCH_BWD(TT, MM) do { \
     modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters); \
-    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, stats, style, ws, (TT*)dx, nvec, HW, C, rg.cg, lrelu, sld); } while (0)
+    modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, stats, style, dstyle, N, C, HW, sld); \
+    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, ws, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu); } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_BWD
     S2E_CHECK_LAUNCH("modulate_bwd kernels");
-    if (mode == S2E_NORM_SPADE_STYLE) {
-        modulate_bwd_style_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(ws, dstyle, N, C, sld);
-        S2E_CHECK_LAUNCH("modulate_bwd_style_kernel");
-    }
     return S2E_OK;
 }
