@@ -508,9 +508,13 @@ static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tile
     *tiles = ceil_div(M, 128) * (*tiles_n);
     const int nk = s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin) / (dtype == S2E_BF16 ? 64 : 32);
     int s = 1;
-    if (*tiles < 512 && nk >= 8) {                   // fewer than 2 workgroups per CU
-        s = ceil_div(512, *tiles);
-        if (s > nk / 4) s = nk / 4;                  // at least 4 K-tiles per split
+    static const int target = [] { const char* e = getenv("S2E_IGEMM_WG"); return e ? atoi(e) : 512; }();
+    if (*tiles < target && nk >= 8) {                // fewer than 2 workgroups per CU
+        s = ceil_div(target, *tiles);
+        // at least 4 K-tiles per split; a SHORT K (Cin = 128: 18 tiles) over >= 256 tiles is not worth splitting at all
+        // (128->2048 @16^2: 259 -> 302 TFLOP/s unsplit; the 64-tile 8x8 layer still is: it would leave 3/4 of the CUs idle)
+        const int min_per = (nk < 32 && *tiles >= 256) ? 16 : 4;
+        if (s > nk / min_per) s = nk / min_per;
         if (s < 1) s = 1;
     }
     *per = ceil_div(nk, s);
