@@ -138,6 +138,23 @@ int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, const float*
 /* gw_oihw[co][ci][ky][kx] (=|+=) gw_packed[co][(ky*kw+kx)*cin_pad + ci]: packed weight gradient -> torch layout. */
 int s2e_unpack_weight_grad(const float* gw_packed, float* gw_oihw, int cout, int cin, int kh, int kw, int cin_pad,
                            int accumulate, void* stream);
+/* The two calls above for EVERY conv of a step in two launches (a step has ~95 of them, most a few microseconds of
+ * work: as separate launches they cost 1.2 ms).  jobs / block_map are DEVICE arrays (host side: fill s2e_grad_job[],
+ * s2e_grad_block_map to count with block_map_host NULL and then to fill {job, first tile, tiles} triples, upload).
+ * w_orig != NULL marks a spectral-normed layer (u, v, sigma, dot_index must then be set; dots: zero-filled scratch with
+ * one float per such layer).  Every job ACCUMULATES into its out. */
+typedef struct s2e_grad_job {
+    const float* gw_packed;      /* [cout][taps*cin_pad] fp32 from s2e_conv2d_wgrad */
+    float* out;                  /* OIHW fp32 gradient (e.g. the parameter's slice of the gradient arena) */
+    const float* w_orig;         /* spectral norm: weight_orig (OIHW); NULL: plain re-layout */
+    const float* u;
+    const float* v;
+    const float* sigma;
+    int cout, cin, taps, cin_pad, dot_index, reserved;
+} s2e_grad_job;
+long s2e_grad_block_map(const s2e_grad_job* jobs_host, int n_jobs, int* block_map_host);
+int s2e_weight_grads_batched(const s2e_grad_job* jobs, const int* block_map, int n_blocks, int max_taps, int any_sn,
+                             float* dots, void* stream);
 
 /* ------------------------------------------------------------------ InstanceNorm statistics
  * nn.InstanceNorm2d(affine=False) statistics, normalization.py:73 / :41 (biased variance, eps 1e-5).

@@ -38,6 +38,13 @@ class PackJob(C.Structure):
                 ('taps', C.c_int), ('cin_pad', C.c_int), ('transposed', C.c_int)]
 
 
+class GradJob(C.Structure):
+    """s2e_grad_job"""
+    _fields_ = [('gw_packed', C.c_void_p), ('out', C.c_void_p), ('w_orig', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p),
+                ('sigma', C.c_void_p), ('cout', C.c_int), ('cin', C.c_int), ('taps', C.c_int), ('cin_pad', C.c_int),
+                ('dot_index', C.c_int), ('reserved', C.c_int)]
+
+
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 # name -> argtypes; every entry returns int except the two noted below.  Must list EVERY symbol
 # declared in include/seg2eye_hip.h (tests/test_abi.py checks header <-> table <-> .so).
@@ -49,6 +56,8 @@ SIGNATURES = {
     's2e_pack_conv_weight': [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     's2e_sn_power_iteration': [_vp, _i, _vp, _i, _vp, C.c_size_t, _vp, _i, _i, _f, _vp],
     's2e_sn_weight_grad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    's2e_grad_block_map': [_vp, _i, _vp],
+    's2e_weight_grads_batched': [_vp, _vp, _i, _i, _i, _vp, _vp],
     's2e_unpack_weight_grad': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     's2e_pack_block_map': [_i, _vp, _i, _vp],
     's2e_pack_conv_weights': [_i, _vp, _vp, _i, _i, _vp, _vp],
@@ -94,7 +103,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = (C.c_char_p if name == 's2e_last_error' else
                           C.c_size_t if name.endswith('_workspace_bytes') else
-                          C.c_long if name == 's2e_pack_block_map' else C.c_int)
+                          C.c_long if name in ('s2e_pack_block_map', 's2e_grad_block_map') else C.c_int)
         _lib = L
     return _lib
 

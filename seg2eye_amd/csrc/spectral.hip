@@ -349,6 +349,95 @@ __global__ __launch_bounds__(256) void grad_unpack_tiled_kernel(const float* __r
     }
 }
 
+// ---- all layers of a step at once: block_map = {job, first tile, number of tiles}; same tile bodies as above
+__global__ __launch_bounds__(256) void grad_dot_batch_kernel(const s2e_grad_job* __restrict__ jobs, const int* __restrict__ block_map, float* __restrict__ dots) {
+    extern __shared__ float lds[];
+    __shared__ float red[4];
+    const int* bm = block_map + 3 * blockIdx.x;
+    const s2e_grad_job J = jobs[bm[0]];
+    if (!J.w_orig) return;                                  // plain re-layout job: nothing to reduce
+    const int taps = J.taps, cin = J.cin, cout = J.cout, cin_pad = J.cin_pad;
+    const int chunks = (cin + 63) / 64;
+    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* my = lds + r * 64 * taps;
+    float q = 0.f;
+    for (int t = bm[1]; t < bm[1] + bm[2]; ++t) {
+        const int rg = t / chunks, ci0 = (t - rg * chunks) * 64, co = rg * SNG_ROWS + r;
+        const int nci = min(64, cin - ci0), run = nci * taps;
+        const bool rv = co < cout;
+        const float* wrow = J.w_orig + ((size_t)co * cin + ci0) * taps;
+        const float* grow = J.gw_packed + (size_t)co * taps * cin_pad + ci0 + lane;
+        __syncthreads();
+        if (rv)
+            for (int k = lane; k < run; k += 64) my[k] = wrow[k];
+        __syncthreads();
+        if (rv && lane < nci)
+            for (int tap = 0; tap < taps; ++tap) q += grow[(size_t)tap * cin_pad] * my[lane * taps + tap];
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[r] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dots + J.dot_index, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void grad_unpack_batch_kernel(const s2e_grad_job* __restrict__ jobs, const int* __restrict__ block_map, const float* __restrict__ dots) {
+    extern __shared__ float lds[];
+    const int* bm = block_map + 3 * blockIdx.x;
+    const s2e_grad_job J = jobs[bm[0]];
+    const int taps = J.taps, cin = J.cin, cout = J.cout, cin_pad = J.cin_pad;
+    const int chunks = (cin + 63) / 64;
+    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* my = lds + r * 64 * taps;
+    const bool sn = J.w_orig != nullptr;
+    const float inv = sn ? 1.f / *J.sigma : 1.f;
+    const float c = sn ? dots[J.dot_index] * inv * inv : 0.f;
+    for (int t = bm[1]; t < bm[1] + bm[2]; ++t) {
+        const int rg = t / chunks, ci0 = (t - rg * chunks) * 64, co = rg * SNG_ROWS + r;
+        const int nci = min(64, cin - ci0), run = nci * taps;
+        const bool rv = co < cout;
+        const float* grow = J.gw_packed + (size_t)co * taps * cin_pad + ci0 + lane;
+        __syncthreads();
+        if (rv && lane < nci)
+            for (int tap = 0; tap < taps; ++tap) my[lane * taps + tap] = grow[(size_t)tap * cin_pad];
+        __syncthreads();
+        if (rv) {
+            float* orow = J.out + ((size_t)co * cin + ci0) * taps;
+            const float cu = sn ? c * J.u[co] : 0.f;
+            const float* vrow = sn ? J.v + (size_t)ci0 * taps : nullptr;
+            for (int k = lane; k < run; k += 64) {
+                float gg = my[k] * inv;
+                if (sn) gg -= cu * vrow[k];
+                orow[k] += gg;
+            }
+        }
+    }
+}
+static constexpr int GRAD_TILES_PER_BLOCK = 8;
+extern "C" long s2e_grad_block_map(const s2e_grad_job* jobs_host, int n_jobs, int* block_map_host) {
+    if (!jobs_host || n_jobs < 0) return S2E_ERR_ARG;
+    long nb = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const s2e_grad_job& J = jobs_host[j];
+        const int tiles = ceil_div(J.cout, SNG_ROWS) * ceil_div(J.cin, 64);
+        for (int t0 = 0; t0 < tiles; t0 += GRAD_TILES_PER_BLOCK, ++nb)
+            if (block_map_host) {
+                int* e = block_map_host + 3 * nb;
+                e[0] = j; e[1] = t0; e[2] = tiles - t0 < GRAD_TILES_PER_BLOCK ? tiles - t0 : GRAD_TILES_PER_BLOCK;
+            }
+    }
+    return nb;
+}
+extern "C" int s2e_weight_grads_batched(const s2e_grad_job* jobs, const int* block_map, int n_blocks, int max_taps, int any_sn,
+                                        float* dots, void* stream) {
+    if (!jobs || !block_map || n_blocks <= 0 || max_taps <= 0 || (any_sn && !dots)) S2E_FAIL(S2E_ERR_ARG, "s2e_weight_grads_batched: bad argument");
+    if (max_taps > 64) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_weight_grads_batched: more than 64 taps");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)SNG_ROWS * 64 * max_taps * sizeof(float);
+    if (any_sn) grad_dot_batch_kernel<<<n_blocks, 256, lds, st>>>(jobs, block_map, dots);
+    grad_unpack_batch_kernel<<<n_blocks, 256, lds, st>>>(jobs, block_map, dots);
+    S2E_CHECK_LAUNCH("batched weight-gradient kernels");
+    return S2E_OK;
+}
+
 // grad[co][ci][tap] (+)= gwp[co][tap*cin_pad + ci]: packed wgrad output -> OIHW gradient (no spectral norm)
 __global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restrict__ gwp, float* __restrict__ out, int cout, int cin, int taps,
                                                           int cin_pad, int accumulate) {

@@ -161,8 +161,67 @@ class _ZeroScope:
         ZeroPool._begin(self.key, self.device)
 
     def __exit__(self, *exc):
+        if exc[0] is None:
+            GradSink.flush()                                 # all queued weight-gradient re-layouts: two launches
+        else:
+            GradSink.jobs = []
         ZeroPool._end()
         return False
+
+
+# ------------------------------------------------------------------------------ deferred weight-gradient re-layout
+class GradSink:
+    """Inside a ZeroPool scope (a trainer step) the per-layer "packed dW -> OIHW gradient arena" conversions -- plain
+    re-layout, or the spectral-norm chain rule dW_orig = (dW - <dW, W_sn> u v^T)/sigma -- are not launched one by one
+    (~95 launches of a few microseconds of work each, 1.2 ms per step) but queued and done by TWO launches at scope
+    exit (`s2e_weight_grads_batched`).  The packed buffers are ZeroPool slices, alive until the next scope.  The
+    device job table is cached by content: in steady state (and always under a hipGraph) every pointer repeats."""
+    jobs = []
+    tables = {}
+
+    @classmethod
+    def push(cls, dwp, dst, cout, cin, taps, cin_pad, w_orig=None, u=None, v=None, sigma=None):
+        """True if queued (caller must not touch dst until flush); False: no scope active, do it now."""
+        if ZeroPool.key is None:
+            return False
+        cls.jobs.append((dwp, dst, w_orig, u, v, sigma, int(cout), int(cin), int(taps), int(cin_pad)))
+        return True
+
+    @classmethod
+    def flush(cls):
+        if not cls.jobs:
+            return
+        jobs, cls.jobs = cls.jobs, []
+        key = tuple((j[0].data_ptr(), j[1].data_ptr()) + tuple(0 if t is None else t.data_ptr() for t in j[2:6]) + j[6:] for j in jobs)
+        dev = jobs[0][0].device
+        ent = cls.tables.get(key)
+        if ent is None:
+            arr = (L.GradJob * len(jobs))()
+            nsn = 0
+            for i, (dwp, dst, w, u, v, sg, cout, cin, taps, cin_pad) in enumerate(jobs):
+                a = arr[i]
+                a.gw_packed, a.out = dwp.data_ptr(), dst.data_ptr()
+                a.cout, a.cin, a.taps, a.cin_pad = cout, cin, taps, cin_pad
+                if w is not None:
+                    a.w_orig, a.u, a.v, a.sigma, a.dot_index = w.data_ptr(), u.data_ptr(), v.data_ptr(), sg.data_ptr(), nsn
+                    nsn += 1
+                else:
+                    a.dot_index = -1
+            import numpy as np
+            nb = L.lib().s2e_grad_block_map(C.byref(arr), len(jobs), None)
+            bm = np.zeros(3 * nb, dtype=np.int32)
+            L.lib().s2e_grad_block_map(C.byref(arr), len(jobs), bm.ctypes.data)
+            jobs_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+            map_dev = torch.from_numpy(bm).to(dev)
+            ent = (jobs_dev, map_dev, int(nb), max(j[8] for j in jobs), nsn)
+            if len(cls.tables) > 8:
+                cls.tables.clear()
+            cls.tables[key] = ent
+        jobs_dev, map_dev, nb, max_taps, nsn = ent
+        dots = ZeroPool.take(max(nsn, 1), torch.float32, dev)
+        L.check(L.lib().s2e_weight_grads_batched(jobs_dev.data_ptr(), map_dev.data_ptr(), nb, max_taps, int(nsn > 0),
+                                                 dots.data_ptr(), _stream()), 's2e_weight_grads_batched')
+        cls.keepalive = jobs                                 # the tensors of this flush stay referenced until the next one
 
 
 # ------------------------------------------------------------------------------ raw launchers
@@ -275,6 +334,8 @@ def _span2(a, shape):
 
 
 def unpack_weight_grad_into(dwp, dst, cout, cin, kh, kw, cin_pad, accumulate=True):
+    if accumulate and GradSink.push(dwp, dst, cout, cin, kh * kw, cin_pad):
+        return
     L.check(L.lib().s2e_unpack_weight_grad(_p(dwp), _p(dst), cout, cin, kh, kw, cin_pad, int(accumulate), _stream()),
             's2e_unpack_weight_grad')
 
@@ -394,11 +455,12 @@ class Conv2dFn(torch.autograd.Function):
                     gw = _unpack_dw(dwp, cout, cin, kh, kw, cx)
             else:
                 acc = wdst is not None
-                out = wdst if acc else torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
-                dot = ZeroPool.take(1, torch.float32, x.device)
-                L.check(L.lib().s2e_sn_weight_grad(_p(dwp), _p(weight.detach()), _p(u), _p(v), _p(sigma), _p(dot), _p(out),
-                                                   cout, cin, kh, kw, cx, int(acc), _stream()), 's2e_sn_weight_grad')
-                gw = None if acc else out
+                if not (acc and GradSink.push(dwp, wdst, cout, cin, kh * kw, cx, weight.detach(), u, v, sigma)):
+                    out = wdst if acc else torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
+                    dot = ZeroPool.take(1, torch.float32, x.device)
+                    L.check(L.lib().s2e_sn_weight_grad(_p(dwp), _p(weight.detach()), _p(u), _p(v), _p(sigma), _p(dot), _p(out),
+                                                       cout, cin, kh, kw, cx, int(acc), _stream()), 's2e_sn_weight_grad')
+                    gw = None if acc else out
         elif want_b:
             gb = colsum(g)
         if has_res and ctx.needs_input_grad[3]:

@@ -36,6 +36,8 @@ class SpectralBank:
         self._ptrs = None
         self.sigma = None
         self.uv_snap = None
+        self._snap_buf = None
+        self._sigma_buf = None
 
     # ------------------------------------------------------------------ device tables
     def _build(self):
@@ -92,13 +94,33 @@ class SpectralBank:
             raise L.Seg2EyeHipError('spectral norm runs on the GPU only (no CPU fallback)')
         if self._ptrs is None or self._ptrs != self._current_ptrs():
             self._build()                                    # first use, or storage moved (.cuda(), optimizer arena)
-        self.sigma = torch.empty(self.n, dtype=torch.float32, device=w.device)
+        # Inside a trainer step (ops.ZeroPool scope) sigma and the u|v snapshot live in PERSISTENT buffers: same addresses
+        # every step, which the batched gradient kernels (device job tables cached by pointer) and hipGraphs need.  They
+        # then hold the values of the LATEST forward -- the trainer always runs a network's backward before its next
+        # forward.  Anywhere else every forward gets its own sigma / snapshot, so an older forward can still be
+        # differentiated after a newer one.
+        from .ops import ZeroPool
+        persistent = ZeroPool.key is not None
+        if persistent:
+            if self._sigma_buf is None or self._sigma_buf.device != w.device:
+                self._sigma_buf = torch.empty(self.n, dtype=torch.float32, device=w.device)
+            self.sigma = self._sigma_buf
+        else:
+            self.sigma = torch.empty(self.n, dtype=torch.float32, device=w.device)
         L.check(L.lib().s2e_sn_power_iteration(
             self.table_dev.data_ptr(), self.n, self.block_map.data_ptr(), self.block_map.shape[0],
             self.scratch.data_ptr(), self.scratch.numel() * 4, self.sigma.data_ptr(), int(bool(training)),
             int(iterations), SN_EPS, torch.cuda.current_stream().cuda_stream), 's2e_sn_power_iteration')
         # the backward of this forward needs u, v as they are NOW (later forwards update them in place)
-        self.uv_snap = self.uv_arena.clone() if torch.is_grad_enabled() else self.uv_arena
+        if not torch.is_grad_enabled():
+            self.uv_snap = self.uv_arena
+        elif persistent:
+            if self._snap_buf is None or self._snap_buf.shape != self.uv_arena.shape or self._snap_buf.device != self.uv_arena.device:
+                self._snap_buf = torch.empty_like(self.uv_arena)
+            self._snap_buf.copy_(self.uv_arena)
+            self.uv_snap = self._snap_buf
+        else:
+            self.uv_snap = self.uv_arena.clone()
 
     def handle(self, conv):
         """(u, v, sigma) tensors for one conv, valid for the forward that called step()."""
