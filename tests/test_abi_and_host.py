@@ -74,6 +74,21 @@ def test_pack_block_map_is_host_only():
     assert L.s2e_pack_conv_weights(_lib.S2E_BF16, None, None, 0, 9, None, None) == -1
 
 
+def test_grad_block_map_is_host_only():
+    """s2e_grad_block_map: tiles of 4 co rows x 64 ci, up to 8 tiles per block, triples {job, first tile, tiles}."""
+    from seg2eye_amd import _lib
+    L = _lib.lib()
+    jobs = (_lib.GradJob * 2)()
+    jobs[0].cout, jobs[0].cin, jobs[0].taps, jobs[0].cin_pad = 10, 130, 9, 136      # 3 row groups x 3 chunks = 9 tiles
+    jobs[1].cout, jobs[1].cin, jobs[1].taps, jobs[1].cin_pad = 4, 64, 1, 64         # 1 tile
+    n = L.s2e_grad_block_map(ctypes.byref(jobs), 2, None)
+    assert n == 2 + 1
+    bm = np.zeros(3 * n, dtype=np.int32)
+    assert L.s2e_grad_block_map(ctypes.byref(jobs), 2, bm.ctypes.data) == n
+    assert bm.reshape(-1, 3).tolist() == [[0, 0, 8], [0, 8, 1], [1, 0, 1]]
+    assert L.s2e_weight_grads_batched(None, None, 0, 9, 0, None, None) == -1
+
+
 def test_ops_refuse_cpu_tensors():
     from seg2eye_amd import ops, _lib, networks
     from seg2eye_amd.options import default_opt
