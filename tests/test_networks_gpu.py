@@ -300,6 +300,34 @@ def test_model_modes_and_bf16_step():
         assert abs(losses[k] - ref[k]) < 0.05 * max(1.0, abs(ref[k])), (k, losses[k], ref[k])
 
 
+def test_trainer_nonsquare_batch3_runs():
+    """cfg5-like geometry (H = 1.667 W, odd batch): two graph-free trainer iterations stay finite, the fake has the
+    label's size, and every parameter moved."""
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    from seg2eye_amd.options import image_hw
+    from seg2eye_amd import synthetic as syn
+    opt = _opt(ngf=8, ndf=8, crop_size=384, aspect_ratio=0.6, batchSize=3, compute_dtype='bf16')   # crop < 256 breaks E (SURVEY F3)
+    h, w = image_hw(opt)
+    assert (h, w) == (640, 384)
+    tr = Pix2PixTrainer(opt)
+    m = tr.pix2pix_model
+    for net, seed in ((m.netG, 1), (m.netD, 2), (m.netE, 3)):
+        sd = syn.fill_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(torch.from_numpy(sd[k]))
+    before = tr.optimizer_G.flat_p.clone()
+    data = _batch(3, h, w, 5)
+    for _ in range(2):
+        tr.run_generator_one_step(dict(data))
+        tr.run_discriminator_one_step(dict(data))
+    losses = {k: float(v) for k, v in tr.get_latest_losses().items()}
+    assert all(np.isfinite(v) for v in losses.values()), losses
+    assert tuple(tr.get_latest_generated().shape) == (3, 1, h, w)
+    moved = (tr.optimizer_G.flat_p != before).float().mean()
+    assert float(moved) > 0.99, float(moved)
+
+
 def test_full_size_generator_fp32_pin():
     """Config 2 (BASELINE.json): ngf=64, 256x256, N=8, fp32 eval-mode G vs the reference's output
     (every 8th pixel + moments stored in the fixture)."""
