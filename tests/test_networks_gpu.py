@@ -453,3 +453,50 @@ def test_hip_graph_steps_match_eager():
     # float-atomic summation noise differs by up to 2*lr_G per step; 3 steps at lr_G = 1e-4
     for k, v in res[False][1].items():
         assert float((v - res[True][1][k]).abs().max()) <= 3 * 2 * 1e-4 + 1e-5, k
+
+
+def test_full_size_train_step_matches_oracle():
+    """The bench configuration's architecture (ngf = ndf = 64, 256x256) at batch 1: one G step + one D step through
+    Pix2PixTrainer on the HIP path in fp32 vs the CPU oracle on the same seeded weights and inputs -- the full-size
+    shapes exercise what the small fixtures cannot (split-K, 1024-channel tiles, the 1-channel stream kernels, the
+    batched pack / gradient re-layout at 100 M parameters) -- then the bf16 step against the fp32 one."""
+    from oracle import seg2eye_oracle as O
+    from seg2eye_amd import synthetic as syn
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    b = syn.make_batch(1, 256, 256, seed=33)
+    data = {'label': torch.from_numpy(b['label']), 'style_image': torch.from_numpy(b['style_image']),
+            'target': torch.from_numpy(b['target'])}
+    res, sds = {}, None
+    for dt in ('fp32', 'bf16'):
+        opt = _opt(ngf=64, ndf=64, crop_size=256, aspect_ratio=1.0, batchSize=1, compute_dtype=dt)
+        tr = Pix2PixTrainer(opt)
+        m = tr.pix2pix_model
+        if sds is None:
+            sds = {}
+            for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+                filled = syn.fill_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()])
+                sds[tag] = {k: torch.from_numpy(v) for k, v in filled.items()}
+        for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+            with torch.no_grad():
+                for k, v in net.state_dict().items():
+                    v.copy_(sds[tag][k])
+        tr.run_generator_one_step(dict(data))
+        tr.run_discriminator_one_step(dict(data))
+        res[dt] = ({k: float(v.detach().float().mean()) for k, v in tr.get_latest_losses().items()},
+                   tr.get_latest_generated().float().cpu())
+        del tr, m
+        torch.cuda.empty_cache()
+    opt = _opt(ngf=64, ndf=64, crop_size=256, aspect_ratio=1.0, batchSize=1, compute_dtype='fp32')
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    om = O.OracleModel(sds['G'], sds['D'], sds['E'], opt, 8, 8)
+    odata = {**data, 'label': data['label'].long()}
+    gl, fake = om.run_generator_one_step(odata)
+    dl = om.run_discriminator_one_step(odata)
+    err = float((res['fp32'][1] - fake).abs().max())
+    assert err < G_TOL, 'full-size fp32 generator output differs from the oracle by %.3e' % err
+    for k, v in {**gl, **dl}.items():
+        r = float(v.mean())
+        assert abs(res['fp32'][0][k] - r) <= 2e-3 * max(1.0, abs(r)), (k, res['fp32'][0][k], r)
+        assert abs(res['bf16'][0][k] - r) <= 0.05 * max(1.0, abs(r)), (k, res['bf16'][0][k], r)
+    d = (res['bf16'][1] - res['fp32'][1]).abs()
+    assert float(d.mean()) < 3e-2 and float(d.max()) < 0.5, (float(d.mean()), float(d.max()))
