@@ -29,6 +29,7 @@ struct ConvKParams {
     int tm_fast;                          // tile order: consecutive tile ids walk the pixel tiles of ONE weight panel (see s2e_conv2d)
     int tiles, splits, kt_per_split;      // split-K: grid = tiles * splits, split s owns K-tiles [s*per, (s+1)*per)
     float* partial;                       // splits > 1: fp32 slabs [splits][M][Cout], combined by conv_finish_kernel
+    int cls_tile0[5];                     // S2 kernels: first pixel-tile of each output-parity class (prefix sums)
 };
 
 template <typename T> struct Mfma;
@@ -72,7 +73,13 @@ __device__ __forceinline__ u32x4_t apply_lrelu16(u32x4_t r) {
 // GLDS needs VECPATH and no input activation (nothing passes through registers).
 __device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <typename T, int BN, bool VECPATH, bool GLDS>
+// S2: stride-2 DATA-GRADIENT by output-parity class.  In a stride-2 transposed conv an output pixel (oy, ox) only sees
+// the taps with ky = oy + pad (mod 2), kx = ox + pad (mod 2): a quarter of a 4x4 kernel.  Walking all taps with a
+// validity mask (the generic path) spends 3 of 4 MFMAs on structural zeros (measured 130-165 TFLOP/s).  Here the
+// pixel tiles are formed PER CLASS (oy & 1, ox & 1) -- cls_tile0[] holds the first tile of each class -- so a whole
+// tile shares its tap subset and the K loop walks only those taps (both operands: the weight matrix is addressed by
+// the loader's (ky, kx, ci) state instead of linearly).  Needs VECPATH + GLDS, no split-K.
+template <typename T, int BN, bool VECPATH, bool GLDS, bool S2 = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p) {
     constexpr int BM = 128;
     constexpr int VEC = Vec<T>::N;
@@ -85,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     constexpr int STAGE = A_BYTES + B_BYTES;
     static_assert(2 * STAGE >= BM * BN * 4, "epilogue staging must fit");
+    static_assert(!S2 || (VECPATH && GLDS), "the parity-class data-gradient exists for the vector LDS-DMA loader only");
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -94,9 +102,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
     const int tiles_m = p.tiles / p.tiles_n;
     const int tn = p.tm_fast ? tile / tiles_m : tile % p.tiles_n;
     const int tm = p.tm_fast ? tile - tn * tiles_m : tile / p.tiles_n;
-    const int nk_all = p.Kpad / BK;
+    // S2: this tile's output-parity class and its tap subset
+    int s2_tml = 0, s2_qy = 0, s2_qx = 0, s2_Hq = 1, s2_Wq = 1, s2_Mq = 0, ky0 = 0, kx0 = 0, nky = p.KH, nkx = p.KW;
+    if constexpr (S2) {
+        int cls = 0;
+        while (cls < 3 && tm >= p.cls_tile0[cls + 1]) ++cls;
+        s2_qy = cls >> 1; s2_qx = cls & 1;
+        s2_Hq = (p.Ho - s2_qy + 1) >> 1; s2_Wq = (p.Wo - s2_qx + 1) >> 1;
+        s2_Mq = p.N * s2_Hq * s2_Wq;
+        s2_tml = tm - p.cls_tile0[cls];
+        ky0 = (s2_qy + p.pad) & 1; kx0 = (s2_qx + p.pad) & 1;
+        nky = (p.KH - ky0 + 1) >> 1; nkx = (p.KW - kx0 + 1) >> 1;
+    }
+    const int nk_all = S2 ? (nky * nkx * p.Cin + BK - 1) / BK : p.Kpad / BK;
     const int kt0 = split * p.kt_per_split;
-    const int kt1 = min(nk_all, kt0 + p.kt_per_split);
+    const int kt1 = S2 ? nk_all : min(nk_all, kt0 + p.kt_per_split);
 
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ wgt = (const T*)p.w;
@@ -112,10 +132,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = tm * BM + r0 + 32 * i;
-        if (m < p.M) {
-            const int n = m / HoWo, rem = m - n * HoWo;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        int n = 0, oy = 0, ox = 0;
+        bool live;
+        if constexpr (S2) {
+            const int ml = s2_tml * BM + r0 + 32 * i;
+            live = ml < s2_Mq;
+            if (live) {
+                const int hw = s2_Hq * s2_Wq;
+                n = ml / hw;
+                const int rem = ml - n * hw, y2 = rem / s2_Wq;
+                oy = 2 * y2 + s2_qy; ox = 2 * (rem - y2 * s2_Wq) + s2_qx;
+            }
+        } else {
+            const int m = tm * BM + r0 + 32 * i;
+            live = m < p.M;
+            if (live) {
+                n = m / HoWo;
+                const int rem = m - n * HoWo;
+                oy = rem / p.Wo; ox = rem - oy * p.Wo;
+            }
+        }
+        if (live) {
             by[i] = p.transposed ? oy + p.pad : oy * p.stride - p.pad;
             bx[i] = p.transposed ? ox + p.pad : ox * p.stride - p.pad;
             nb[i] = n * p.Hi * p.Wi;
@@ -183,8 +220,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
     int l_ky, l_kx, l_ci;
     {
         const int k0 = kt0 * BK + c * VEC, tap = k0 / p.Cin;
-        l_ci = k0 - tap * p.Cin; l_ky = tap / p.KW; l_kx = tap - l_ky * p.KW;
+        l_ci = k0 - tap * p.Cin;
+        if constexpr (S2) {                              // tap = index into the class's (nky x nkx) tap subset
+            const int jy = tap / nkx;
+            l_ky = ky0 + 2 * jy; l_kx = kx0 + 2 * (tap - jy * nkx);
+        } else {
+            l_ky = tap / p.KW; l_kx = tap - l_ky * p.KW;
+        }
     }
+    auto advance_k = [&]() __attribute__((always_inline)) {
+        l_ci += BK;
+        if constexpr (S2) {
+            while (l_ci >= p.Cin) { l_ci -= p.Cin; l_kx += 2; if (l_kx >= p.KW) { l_kx = kx0; l_ky += 2; } }
+        } else {
+            while (l_ci >= p.Cin) { l_ci -= p.Cin; if (++l_kx == p.KW) { l_kx = 0; ++l_ky; } }
+        }
+    };
     struct Stage { u32x4_t a[4]; u32x4_t b[NB]; };
     auto load_tile = [&](int kt, Stage& S) __attribute__((always_inline)) {
         u32x4_t (&ra)[4] = S.a;
@@ -200,8 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
                 ra[i] = u32x4_t{0, 0, 0, 0};
                 if (v) ra[i] = *(const u32x4_t*)(xg + (rowoff[i] + koff));
             });
-            l_ci += BK;
-            while (l_ci >= p.Cin) { l_ci -= p.Cin; if (++l_kx == p.KW) { l_kx = 0; ++l_ky; } }
+            advance_k();
         } else {                                         // any-Cin fallback: element-wise gather
             static_for<0, 4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -304,11 +354,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
                 const void* src = v ? (const void*)(xg + (rowoff[i] + koff)) : (const void*)g_zero16;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (8 * wave + 32 * i) * 128), 16, 0, 0);
             });
-            l_ci += BK;
-            while (l_ci >= p.Cin) { l_ci -= p.Cin; if (++l_kx == p.KW) { l_kx = 0; ++l_ky; } }
+            // weight column of this thread's chunk: linear in k, except in S2 mode where k walks the class's tap subset
+            const long kb = S2 ? (kvalid ? (long)(l_ky * p.KW + l_kx) * p.Cin + l_ci : -1L) : (long)kt * BK + c * VEC;
+            advance_k();
             static_for<0, NB>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                const void* src = wgt + (size_t)(tn * BN + r0 + 32 * j) * p.Kpad + kt * BK + c * VEC;
+                const void* src = (S2 && kb < 0) ? (const void*)g_zero16
+                                                 : (const void*)(wgt + (size_t)(tn * BN + r0 + 32 * j) * p.Kpad + kb);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + A_BYTES + (8 * wave + 32 * j) * 128), 16, 0, 0);
             });
         };
@@ -363,7 +415,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
         return;
     }
     for (int row = tid / TPR; row < BM; row += RPP) {
-        const int m = tm * BM + row;
+        int m = tm * BM + row;
+        if constexpr (S2) {                              // class-local row -> output pixel
+            const int ml = s2_tml * BM + row;
+            if (ml >= s2_Mq) continue;
+            const int hw = s2_Hq * s2_Wq, n = ml / hw, rem = ml - n * hw, y2 = rem / s2_Wq;
+            m = (n * p.Ho + 2 * y2 + s2_qy) * p.Wo + 2 * (rem - y2 * s2_Wq) + s2_qx;
+        }
         if (m >= p.M || co >= p.Cout) continue;
         float v[VEC];
 #pragma unroll
@@ -482,8 +540,13 @@ extern "C" int s2e_conv_cout_pad(int cout) { const int bn = bn_for(cout); return
 extern "C" int s2e_conv_k_pad(int dtype, int k) { const int bk = dtype == S2E_BF16 ? 64 : 32; return ceil_div(k, bk) * bk; }
 
 template <typename T, int BN>
-static int launch_conv(const ConvKParams& p, hipStream_t st) {
+static int launch_conv(const ConvKParams& p, hipStream_t st, bool s2 = false) {
     const int grid = p.tiles * p.splits;
+    if (s2) {
+        conv_igemm_kernel<T, BN, true, true, true><<<grid, 256, 0, st>>>(p);
+        S2E_CHECK_LAUNCH("conv_igemm_kernel (stride-2 class mode)");
+        return S2E_OK;
+    }
     static const bool glds = [] { const char* e = getenv("S2E_IGEMM_GLDS"); return e ? atoi(e) != 0 : true; }();
     if (p.Cin % Vec<T>::N == 0) {
         if (glds && p.in_act == S2E_ACT_NONE) conv_igemm_kernel<T, BN, true, true><<<grid, 256, 0, st>>>(p);
@@ -499,6 +562,24 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
     return S2E_OK;
 }
 
+// Stride-2 data-gradients run per output-parity class (conv_igemm_kernel<..., S2 = true>) when the vector LDS-DMA
+// loader applies; S2E_IGEMM_S2CLASS=0 falls back to the masked all-taps walk.
+static bool s2_class_mode(int dtype, const s2e_conv_desc* d) {
+    static const bool on = [] { const char* e = getenv("S2E_IGEMM_S2CLASS"); return e ? atoi(e) != 0 : true; }();
+    static const bool glds = [] { const char* e = getenv("S2E_IGEMM_GLDS"); return e ? atoi(e) != 0 : true; }();
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    return on && glds && d->transposed && d->stride == 2 && d->in_act == S2E_ACT_NONE && d->Cin % vec == 0 && d->KH >= 2 && d->KW >= 2;
+}
+// pixel tiles of the four classes (oy & 1, ox & 1): prefix sums into t0[5]
+static void s2_class_tiles(const s2e_conv_desc* d, int* t0) {
+    t0[0] = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int qy = c >> 1, qx = c & 1;
+        const long mq = (long)d->N * ((d->Ho - qy + 1) / 2) * ((d->Wo - qx + 1) / 2);
+        t0[c + 1] = t0[c] + ceil_div(mq, 128);
+    }
+}
+
 // Split-K plan: layers whose output tiling cannot fill 256 CUs (small M, huge K: the 1024-channel
 // blocks at 8x8 / 16x16, the encoder tail) are split over K-tiles so ~512 workgroups exist.
 static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tiles_n, int* splits, int* per) {
@@ -507,6 +588,13 @@ static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tile
     *tiles_n = ceil_div(d->Cout, bn);
     *tiles = ceil_div(M, 128) * (*tiles_n);
     const int nk = s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin) / (dtype == S2E_BF16 ? 64 : 32);
+    if (s2_class_mode(dtype, d)) {                   // per-class tiles, never split (K shrinks to a quarter)
+        int t0[5];
+        s2_class_tiles(d, t0);
+        *tiles = t0[4] * (*tiles_n);
+        *per = nk; *splits = 1;
+        return;
+    }
     int s = 1;
     static const int target = [] { const char* e = getenv("S2E_IGEMM_WG"); return e ? atoi(e) : 512; }();
     if (*tiles < target && nk >= 8) {                // fewer than 2 workgroups per CU
@@ -559,6 +647,8 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
     p.M = d->N * d->Ho * d->Wo;
     const int bn = bn_for(d->Cout);
     plan_splits(dtype, d, &p.tiles, &p.tiles_n, &p.splits, &p.kt_per_split);
+    const bool s2 = s2_class_mode(dtype, d);
+    if (s2) s2_class_tiles(d, p.cls_tile0);
     // Tile order.  xcd_remap hands each XCD a contiguous range of tile ids, and whatever operand panel those tiles do
     // NOT share is fetched into that XCD's L2 once per XCD.  Default: Cout tiles fastest (neighbours share the
     // im2col panel).  The PMC pass shows the price on the small-M, 1024-channel layers: 80-190 MB fetched per launch
@@ -568,7 +658,7 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
     // Infinity Cache and are not what bounds these launches.  Kept as a switch, off.
     {
         static const int force = [] { const char* e = getenv("S2E_IGEMM_TMFAST"); return e ? atoi(e) : 0; }();
-        p.tm_fast = force > 0 && p.tiles_n > 1;
+        p.tm_fast = force > 0 && p.tiles_n > 1 && !s2;
     }
     p.partial = (float*)workspace;
     if (p.splits > 1 && (!workspace || workspace_bytes < s2e_conv2d_workspace_bytes(dtype, d)))
@@ -576,13 +666,13 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
                  s2e_conv2d_workspace_bytes(dtype, d));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16) {
-        if (bn == 128) return launch_conv<bf16_t, 128>(p, st);
-        if (bn == 64) return launch_conv<bf16_t, 64>(p, st);
-        return launch_conv<bf16_t, 32>(p, st);
+        if (bn == 128) return launch_conv<bf16_t, 128>(p, st, s2);
+        if (bn == 64) return launch_conv<bf16_t, 64>(p, st, s2);
+        return launch_conv<bf16_t, 32>(p, st, s2);
     } else if (dtype == S2E_F32) {
-        if (bn == 128) return launch_conv<float, 128>(p, st);
-        if (bn == 64) return launch_conv<float, 64>(p, st);
-        return launch_conv<float, 32>(p, st);
+        if (bn == 128) return launch_conv<float, 128>(p, st, s2);
+        if (bn == 64) return launch_conv<float, 64>(p, st, s2);
+        return launch_conv<float, 32>(p, st, s2);
     }
     S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: bad dtype %d", dtype);
 }
