@@ -196,27 +196,63 @@ def encoder_forward(sd, x, training=False, updates=None):
     return mu, logvar, feats
 
 
-def encode_w(sdE, style_image, aggr='mean', training=False, updates=None):
+def _aggregate(t, aggr, dim):
+    """_aggregate_tensor models/pix2pix_model.py:271-278."""
+    if aggr == 'mean':
+        return t.mean(dim=dim)
+    if aggr == 'max':
+        return t.max(dim=dim).values
+    raise ValueError('Aggregation method not found: %s' % aggr)
+
+
+def encode_w(sdE, style_image, aggr='mean', training=False, updates=None, with_features=False):
     """_compute_multiple_netE / _compute_aggregated_w / encode_w
-    models/pix2pix_model.py:271-314: netE is called once PER SAMPLE (a python
+    models/pix2pix_model.py:280-314: netE is called once PER SAMPLE (a python
     loop; each call is one spectral-norm power iteration in train mode), mu is
-    aggregated over the style dimension."""
-    mus = []
+    aggregated over the style dimension.  with_features: also the per-sample
+    list of per-layer feature maps, each aggregated over the style dimension
+    (pix2pix_model.py:297-303)."""
+    mus, feats_all = [], []
     cur = dict(sdE)
     for b in range(style_image.shape[0]):
         upd = {} if training else None
-        mu, _, _ = encoder_forward(cur, style_image[b], training, upd)
+        mu, _, feats = encoder_forward(cur, style_image[b], training, upd)
         if training:
             cur.update(upd)
             if updates is not None:
                 updates.update(upd)
         mus.append(mu)
+        feats_all.append([_aggregate(f, aggr, 0) for f in feats])
     multiple_w = torch.stack(mus, dim=0)                    # (bs, ns, w_dim)
-    if aggr == 'mean':
-        return multiple_w.mean(dim=1)
-    if aggr == 'max':
-        return multiple_w.max(dim=1).values
-    raise ValueError('Aggregation method not found: %s' % aggr)
+    w = _aggregate(multiple_w, aggr, 1)
+    return (w, feats_all) if with_features else w
+
+
+def gram_matrix(x):
+    """models/networks/loss.py:177-189."""
+    a, b, c, d = x.size()
+    f = x.reshape(a * b, c * d)
+    return torch.mm(f, f.t()).div(a * b * c * d)
+
+
+def style_consistency_losses(w_fake, feats_fake, w_real, feats_real, opt):
+    """The three optional terms of compute_generator_loss that re-encode the generated image
+    (models/pix2pix_model.py:162-184, 212-229; StyleLoss loss.py:192-199).  Note the reference's
+    `.detach()` calls there discard their result: gradients flow through BOTH encodings, except for the
+    gram target, which StyleLoss detaches."""
+    out = {}
+    n_maps = len(feats_fake[0])
+    stack = lambda feats, i: torch.stack([feats[b][i] for b in range(len(feats))])
+    if opt.lambda_style_w > 0:
+        out['style_w/weighted'] = F.mse_loss(w_fake, w_real) * opt.lambda_style_w
+    if opt.lambda_style_feat > 0:
+        raw = torch.sum(torch.stack([F.mse_loss(stack(feats_fake, i), stack(feats_real, i)) for i in range(n_maps)]))
+        out['style_feat/weighted'] = raw * opt.lambda_style_feat
+    if opt.lambda_gram > 0:
+        raw = torch.sum(torch.stack([F.mse_loss(gram_matrix(stack(feats_fake, i)), gram_matrix(stack(feats_real, i)).detach())
+                                     for i in range(n_maps)]))
+        out['gram/weighted'] = raw * opt.lambda_gram
+    return out
 
 
 # ----------------------------------------------------------------------------- losses
@@ -287,11 +323,12 @@ class OracleModel:
         return out
 
     # -- forward pieces (models/pix2pix_model.py:316-342) ----------------------
-    def generate_fake(self, G, E, seg, style, training, updG, updE):
-        w = encode_w(E, style, self.opt.style_aggr_method, training, updE)
+    def generate_fake(self, G, E, seg, style, training, updG, updE, with_features=False):
+        enc = encode_w(E, style, self.opt.style_aggr_method, training, updE, with_features)
+        w, feats = enc if with_features else (enc, None)
         fake = generator_forward(G, seg, w, self.sh, self.sw, training, updG,
                                  more=(self.opt.num_upsampling_layers == 'more'))
-        return fake, w
+        return (fake, w, feats) if with_features else (fake, w)
 
     def discriminate(self, D, seg, fake, real, training, updD):
         fake_and_real = torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, real], 1)], 0)
@@ -304,9 +341,19 @@ class OracleModel:
         lambdas: GAN + GAN_Feat)."""
         updG, updD, updE = ({}, {}, {}) if updates is None else updates
         seg = one_hot_labels(data['label'], self.opt.label_nc)
-        fake, _ = self.generate_fake(G, E, seg, data['style_image'], training, updG, updE)
+        opt = self.opt
+        style_terms = bool(getattr(opt, 'lambda_style_feat', 0) or getattr(opt, 'lambda_style_w', 0) or getattr(opt, 'lambda_gram', 0))
+        fake, w_real, feats_real = self.generate_fake(G, E, seg, data['style_image'], training, updG, updE, True)
         pred_fake, pred_real = self.discriminate(D, seg, fake, data['target'], training, updD)
         losses = {'GAN': gan_loss(pred_fake, True, for_discriminator=False)}
+        if getattr(opt, 'lambda_l2', 0):                                   # pix2pix_model.py:196-200
+            losses['L2/weighted'] = F.mse_loss(fake, data['target']) * opt.lambda_l2
+        if getattr(opt, 'lambda_l1', 0):                                   # :201-205
+            losses['L1/weighted'] = F.l1_loss(fake, data['target']) * opt.lambda_l1
+        if style_terms:                                                    # :212-229: second encode, u/v keep iterating
+            E2 = {**E, **updE} if training else E
+            w_fake, feats_fake = encode_w(E2, fake.unsqueeze(1), opt.style_aggr_method, training, updE, True)
+            losses.update(style_consistency_losses(w_fake, feats_fake, w_real, feats_real, opt))
         if not self.opt.no_ganFeat_loss:
             losses['GAN_Feat'] = feature_matching_loss(pred_fake, pred_real, self.opt.lambda_feat)
         return losses, fake

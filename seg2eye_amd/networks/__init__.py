@@ -8,7 +8,7 @@ from .base_network import BaseNetwork
 from .discriminator import MultiscaleDiscriminator, NLayerDiscriminator
 from .encoder import ConvEncoder
 from .generator import SPADESTYLEGenerator
-from .loss import GANLoss, feature_matching_loss
+from .loss import GANLoss, feature_matching_loss, gram_matrix
 from .normalization import SegMap
 
 

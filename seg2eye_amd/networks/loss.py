@@ -59,3 +59,10 @@ def feature_matching_loss(pred_fake, pred_real, lambda_feat):
             term = ops.loss_sum(a, b, LOSS_L1, lambda_feat / num_D / a.numel())
             total = term if total is None else total + term
     return total.view(1)
+
+
+def gram_matrix(x):
+    """(N,C,h,w) -> (N*C, N*C) Gram matrix / (N*C*h*w)  (reference models/networks/loss.py:177-189)."""
+    a, b, c, d = x.size()
+    f = x.reshape(a * b, c * d)
+    return torch.mm(f, f.t()).div(a * b * c * d)

@@ -104,6 +104,7 @@ class ZeroPool:
     high = {}          # key -> high-water mark
     key = None
     frozen = False
+    serial = 0         # scopes begun so far (lets per-scope state elsewhere notice a new step)
     step_cache = {}    # per-scope memo of derived read-only tensors (cleared at scope entry and exit)
 
     @classmethod
@@ -129,6 +130,7 @@ class ZeroPool:
             cls.clean = hw
         cls.key, cls.bump = key, 0
         cls.step_cache = {}
+        cls.serial += 1
 
     @classmethod
     def _end(cls):

@@ -13,6 +13,7 @@ loss-log helpers and netG/netD/netE attributes.  Deliberate, documented differen
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import checkpoint, networks, ops
 from ._lib import LOSS_L1
@@ -39,9 +40,9 @@ class Pix2PixModel(nn.Module):
             if not opt.no_vgg_loss:
                 raise NotImplementedError('VGGLoss does not exist in the reference either (SURVEY F1); '
                                           'keep --no_vgg_loss')
-            for name in ('lambda_l2', 'lambda_openeds', 'lambda_style_w', 'lambda_style_feat', 'lambda_gram'):
-                if getattr(opt, name, 0):
-                    raise NotImplementedError('%s != 0 is outside the hot path built so far' % name)
+            if getattr(opt, 'lambda_openeds', 0):
+                raise NotImplementedError('lambda_openeds != 0 needs the OpenEDS metric (SURVEY 8 f3: Tester/MSECalculator), '
+                                          'outside the hot path built so far')
             self.reset_loss_log()
 
     # ------------------------------------------------------------------ loss log (pix2pix_model.py:49-59)
@@ -138,7 +139,9 @@ class Pix2PixModel(nn.Module):
 
     def compute_generator_loss(self, seg, style_image, target_image):
         G_losses = {}
-        fake_image, _, _ = self.generate_fake(seg, style_image)
+        opt = self.opt
+        style_terms = bool(opt.lambda_style_feat or opt.lambda_style_w or opt.lambda_gram)
+        fake_image, latent_style_real, style_features_real = self.generate_fake(seg, style_image, aggregate_features=style_terms)
         d_params = list(self.netD.parameters())
         flags = [p.requires_grad for p in d_params]
         for p in d_params:                      # D's weight grads are dead in the G step
@@ -151,12 +154,35 @@ class Pix2PixModel(nn.Module):
             for p, f in zip(d_params, flags):
                 p.requires_grad_(f)
         G_losses['GAN'] = self.criterionGAN(pred_fake, True, for_discriminator=False)
+        if opt.lambda_l2:                                    # pix2pix_model.py:196-200 (nn.MSELoss)
+            l2 = F.mse_loss(fake_image.float(), target_image.float()).view(1)
+            G_losses['L2/weighted'] = l2 * opt.lambda_l2
+            self.add_to_loss_log('L2/raw', l2.detach())
         if self.opt.lambda_l1:
             a = fake_image.permute(0, 2, 3, 1)
             b = target_image.to(a.dtype).permute(0, 2, 3, 1).contiguous()
             l1 = ops.loss_sum(a, b, LOSS_L1, 1.0 / a.numel()).view(1)
             G_losses['L1/weighted'] = l1 * self.opt.lambda_l1
             self.add_to_loss_log('L1/raw', l1.detach())
+        if style_terms:
+            # Style consistency (pix2pix_model.py:162-184, 212-229): the generated image is encoded again and compared with
+            # the encoding of the style images -- latent code (MSE), per-layer feature maps (MSE), Gram matrices (MSE,
+            # target detached by StyleLoss).  The reference's other `.detach()` calls there discard their result, so
+            # gradients flow through both encodings; mirrored.  Features are aggregated over the style dimension.
+            latent_style_fake, style_features_fake = self.encode_w(fake_image.unsqueeze(1), aggregate_features=True)
+            if opt.lambda_style_w > 0:
+                raw = F.mse_loss(latent_style_fake.float(), latent_style_real.float()).view(1)
+                G_losses['style_w/weighted'] = raw * opt.lambda_style_w
+                self.add_to_loss_log('style_w/raw', raw.detach())
+            if opt.lambda_style_feat > 0:
+                raw = torch.stack([F.mse_loss(a.float(), b.float()) for a, b in zip(style_features_fake, style_features_real)]).sum().view(1)
+                G_losses['style_feat/weighted'] = raw * opt.lambda_style_feat
+                self.add_to_loss_log('style_feat/raw', raw.detach())
+            if opt.lambda_gram > 0:
+                raw = torch.stack([F.mse_loss(networks.gram_matrix(a.float()), networks.gram_matrix(b.float()).detach())
+                                   for a, b in zip(style_features_fake, style_features_real)]).sum().view(1)
+                G_losses['gram/weighted'] = raw * opt.lambda_gram
+                self.add_to_loss_log('gram/raw', raw.detach())
         if fused_feat:
             # == networks.feature_matching_loss(pred_fake, pred_real, lambda_feat), computed inside netD's forward so
             # that its gradient is accumulated in place into the features' incoming gradients (ops.FeatTapFn)
@@ -178,20 +204,24 @@ class Pix2PixModel(nn.Module):
             return torch.max(t, dim=dim).values
         raise ValueError('Aggregation method not found: %s' % self.opt.style_aggr_method)
 
-    def encode_w(self, real_image):
+    def encode_w(self, real_image, aggregate_features=False):
         """(N, input_ns, 1, h, w) style images -> w (N, w_dim) = aggregate over the style dimension of
-        netE's mu (pix2pix_model.py:271-314), as ONE batched netE call."""
+        netE's mu (pix2pix_model.py:271-314), as ONE batched netE call.
+        aggregate_features: the second result is the reference's `features_aggregated` (:297-303) as one (N,C,h,w) tensor
+        per encoder layer (aggregated over the style dimension); otherwise the raw (N*ns,C,h,w) layer outputs."""
         if real_image.dim() != 5:
             raise ValueError('real_image should have 5 dimensions')
         n, ns = real_image.shape[:2]
         mu, _, feats = self.netE(real_image.reshape(n * ns, *real_image.shape[2:]), power_iterations=n)
+        if aggregate_features:
+            feats = [self._aggregate(f.unflatten(0, (n, ns)), dim=1) for f in feats]
         return self._aggregate(mu.view(n, ns, -1)), feats
 
     def generate_fake_from_stylecode(self, seg, latent_style):
         return self.netG(seg, latent_style)
 
-    def generate_fake(self, seg, style_image):
-        latent_style, feats = self.encode_w(style_image)
+    def generate_fake(self, seg, style_image, aggregate_features=False):
+        latent_style, feats = self.encode_w(style_image, aggregate_features)
         return self.generate_fake_from_stylecode(seg, latent_style), latent_style, feats
 
     def discriminate(self, seg, fake_image, real_image, feat_lambda=None):

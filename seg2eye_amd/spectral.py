@@ -36,8 +36,8 @@ class SpectralBank:
         self._ptrs = None
         self.sigma = None
         self.uv_snap = None
-        self._snap_buf = None
-        self._sigma_buf = None
+        self._snap_bufs, self._sigma_bufs = [], []
+        self._scope_serial, self._scope_calls = -1, 0
 
     # ------------------------------------------------------------------ device tables
     def _build(self):
@@ -102,9 +102,19 @@ class SpectralBank:
         from .ops import ZeroPool
         persistent = ZeroPool.key is not None
         if persistent:
-            if self._sigma_buf is None or self._sigma_buf.device != w.device:
-                self._sigma_buf = torch.empty(self.n, dtype=torch.float32, device=w.device)
-            self.sigma = self._sigma_buf
+            # a network may run more than once per step (netE encodes the real styles and, with the style-consistency
+            # losses on, the generated image): the i-th forward of a step gets the i-th persistent buffer pair
+            if self._scope_serial != ZeroPool.serial:
+                self._scope_serial, self._scope_calls = ZeroPool.serial, 0
+            i = self._scope_calls
+            self._scope_calls += 1
+            while len(self._sigma_bufs) <= i:
+                self._sigma_bufs.append(torch.empty(self.n, dtype=torch.float32, device=w.device))
+                self._snap_bufs.append(torch.empty_like(self.uv_arena))
+            if self._sigma_bufs[i].device != w.device or self._snap_bufs[i].shape != self.uv_arena.shape:
+                self._sigma_bufs[i] = torch.empty(self.n, dtype=torch.float32, device=w.device)
+                self._snap_bufs[i] = torch.empty_like(self.uv_arena)
+            self.sigma = self._sigma_bufs[i]
         else:
             self.sigma = torch.empty(self.n, dtype=torch.float32, device=w.device)
         L.check(L.lib().s2e_sn_power_iteration(
@@ -115,10 +125,8 @@ class SpectralBank:
         if not torch.is_grad_enabled():
             self.uv_snap = self.uv_arena
         elif persistent:
-            if self._snap_buf is None or self._snap_buf.shape != self.uv_arena.shape or self._snap_buf.device != self.uv_arena.device:
-                self._snap_buf = torch.empty_like(self.uv_arena)
-            self._snap_buf.copy_(self.uv_arena)
-            self.uv_snap = self._snap_buf
+            self._snap_bufs[i].copy_(self.uv_arena)
+            self.uv_snap = self._snap_bufs[i]
         else:
             self.uv_snap = self.uv_arena.clone()
 

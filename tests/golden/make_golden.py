@@ -81,10 +81,48 @@ def checksum(t):
     return np.concatenate([[t.sum().item(), t.abs().sum().item()], t[idx].numpy()])
 
 
+def style_trainer_fixture(args, syn):
+    """T2: the reference's own training recipe switches the optional losses on (scripts/current_runs_spadestyle.sh,
+    run name '..._l2_15_lambda_w_0.5_lambda_feat_0.001_lambda_gram_10000_...'): L2 + the three style-consistency terms
+    that re-encode the generated image (pix2pix_model.py:196-229).  One G step + one D step, ngf=ndf=8, 256x256, N=2."""
+    class FloatAdam(torch.optim.Adam):           # SURVEY F6
+        def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), **kw):
+            super().__init__(params, lr=lr, betas=(float(betas[0]), float(betas[1])), **kw)
+    torch.optim.Adam = FloatAdam
+    from trainers.pix2pix_trainer import Pix2PixTrainer
+    opt = ref_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, init_type='normal',
+                  lambda_l2=15.0, lambda_l1=2.0, lambda_style_w=0.5, lambda_style_feat=0.001, lambda_gram=10000.0)
+    opt.checkpoints_dir = '/tmp/s2e_golden_ckpt'
+    trainer = Pix2PixTrainer(opt)
+    model = trainer.pix2pix_model
+    mG, mD, mE = load_filled(model.netG), load_filled(model.netD), load_filled(model.netE)
+    batch = syn.make_batch(2, 256, 256, seed=23)
+
+    def tdata():
+        return {'label': torch.from_numpy(batch['label'].astype(np.int64)),
+                'style_image': torch.from_numpy(batch['style_image']),
+                'target': torch.from_numpy(batch['target']), 'filename': batch['filename']}
+    rec = {}
+    trainer.run_generator_one_step(tdata())
+    for k, v in trainer.g_losses.items():
+        rec['it0_%s' % k.replace('/', '_')] = v.detach().numpy().reshape(-1)
+    rec['it0_fake_sub'] = trainer.generated.detach()[:, :, ::8, ::8].numpy()
+    trainer.run_discriminator_one_step(tdata())
+    for k, v in trainer.d_losses.items():
+        rec['it0_%s' % k.replace('/', '_')] = v.detach().numpy().reshape(-1)
+    for tag, net in (('G', model.netG), ('D', model.netD), ('E', model.netE)):
+        for k, v in net.state_dict().items():
+            rec['it0_ck_%s.%s' % (tag, k)] = checksum(v)
+    np.savez_compressed(os.path.join(args.out, 'trainer_style_ngf8_256.npz'), **rec,
+                        **manifest_arrays('G', mG), **manifest_arrays('D', mD), **manifest_arrays('E', mE))
+    print('style trainer ok', {k: float(v.reshape(-1)[0]) for k, v in rec.items() if k.startswith('it0_') and v.size == 1})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=HERE)
     ap.add_argument('--full', action='store_true', help='also the ngf=64 256x256 N=8 pin (slow)')
+    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture)")
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -102,6 +140,10 @@ def main():
     def onehot(label):
         lab = torch.from_numpy(label.astype(np.int64))
         return torch.zeros(lab.shape[0], 4, *lab.shape[2:]).scatter_(1, lab, 1.0)
+
+    if args.only == 'style':
+        style_trainer_fixture(args, syn)
+        return
 
     # ---- G1/G2: generator, ngf=8 (64x64) and ngf=16 (128x128 portrait-ish 128x64) -------
     for tag, ngf, crop, ar, n in (('g_ngf8_64', 8, 64, 1.0, 2), ('g_ngf16_128x64', 16, 64, 0.5, 2)):

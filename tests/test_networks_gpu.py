@@ -271,6 +271,43 @@ def test_trainer_two_iterations_fp32_match_reference():
                 assert_checksum_close(v, z['it%d_ck_%s.%s' % (it, tag, k)], 2e-3, 'it%d %s.%s' % (it, tag, k), flip=flip)
 
 
+STYLE_LAMBDAS = dict(lambda_l2=15.0, lambda_l1=2.0, lambda_style_w=0.5, lambda_style_feat=0.001, lambda_gram=10000.0)
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_trainer_optional_losses_fp32_match_reference(graphs):
+    """T2: the reference's own training recipe -- L2/L1 + the style-consistency terms that re-encode the generated
+    image (netE runs twice in the G step) -- one G step + one D step on the HIP path vs the REAL reference's losses
+    and parameter checksums; eager and as hipGraph replays."""
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    z = load_golden('trainer_style_ngf8_256')
+    opt = _opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='fp32', hip_graphs=graphs, **STYLE_LAMBDAS)
+    tr = Pix2PixTrainer(opt)
+    m = tr.pix2pix_model
+    for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+        sd = filled_state(z, tag)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(sd[k])
+    data = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in _batch(2, 256, 256, 23).items()}
+    tr.run_generator_one_step(dict(data))
+    tr.run_discriminator_one_step(dict(data))
+    losses = tr.get_latest_losses()
+    assert set(losses) == {'GAN', 'L2/weighted', 'L1/weighted', 'style_w/weighted', 'style_feat/weighted', 'gram/weighted',
+                           'GAN_Feat', 'D/Fake', 'D/real'}
+    for k, v in losses.items():
+        ref = z['it0_%s' % k.replace('/', '_')]
+        np.testing.assert_allclose(v.detach().cpu().numpy().reshape(ref.shape), ref, rtol=2e-3, atol=2e-4, err_msg=k)
+    sub = tr.get_latest_generated().detach()[:, :, ::8, ::8].float().cpu().numpy()
+    assert np.abs(sub - z['it0_fake_sub']).max() < G_TOL
+    if not graphs:           # (capture runs warm-up iterations on the weights' spectral-norm state restored afterwards;
+        for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):      # parameters are compared on the eager run)
+            for k, v in net.state_dict().items():
+                lr = opt.lr * 2 if tag == 'D' else opt.lr / 2
+                flip = 2 * lr if v.dtype.is_floating_point and not k.endswith(('_u', '_v')) else 0.0
+                assert_checksum_close(v, z['it0_ck_%s.%s' % (tag, k)], 2e-3, '%s.%s' % (tag, k), flip=flip)
+
+
 def test_model_modes_and_bf16_step():
     from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
     z = load_golden('trainer_ngf8_256')

@@ -147,3 +147,27 @@ def test_trainer_two_iterations():
             for k, v in sd.items():
                 assert_checksum_close(v, z['it%d_ck_%s.%s' % (it, tag, k)], 1e-4 if it == 0 else 5e-4,
                                       'it%d %s.%s' % (it, tag, k))
+
+
+STYLE_LAMBDAS = dict(lambda_l2=15.0, lambda_l1=2.0, lambda_style_w=0.5, lambda_style_feat=0.001, lambda_gram=10000.0)
+
+
+def test_trainer_optional_losses():
+    """T2: the reference's own training recipe (L2/L1 + the style-consistency terms that re-encode the generated
+    image, pix2pix_model.py:196-229): one G step + one D step against the real reference."""
+    z = load_golden('trainer_style_ngf8_256')
+    opt = default_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, **STYLE_LAMBDAS)
+    m = O.OracleModel(filled_state(z, 'G'), filled_state(z, 'D'), filled_state(z, 'E'), opt, 8, 8)
+    b = syn.make_batch(2, 256, 256, seed=23)
+    data = {'label': torch.from_numpy(b['label'].astype(np.int64)),
+            'style_image': torch.from_numpy(b['style_image']), 'target': torch.from_numpy(b['target'])}
+    gl, fake = m.run_generator_one_step(data)
+    dl = m.run_discriminator_one_step(data)
+    assert set(gl) == {'GAN', 'L2/weighted', 'L1/weighted', 'style_w/weighted', 'style_feat/weighted', 'gram/weighted', 'GAN_Feat'}
+    for k, v in list(gl.items()) + list(dl.items()):
+        ref = z['it0_%s' % k.replace('/', '_')]
+        np.testing.assert_allclose(v.numpy().reshape(-1), ref, rtol=2e-4, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(fake[:, :, ::8, ::8].numpy(), z['it0_fake_sub'], atol=1e-4, rtol=0)
+    for tag, sd in (('G', m.G), ('D', m.D), ('E', m.E)):
+        for k, v in sd.items():
+            assert_checksum_close(v, z['it0_ck_%s.%s' % (tag, k)], 1e-4, '%s.%s' % (tag, k))
