@@ -1,0 +1,41 @@
+"""Data sources for train.py / test.py.
+
+The reference trains on the OpenEDS H5 file (data/openeds_dataset.py, data/prepare_openeds.py) -- SURVEY 8 row f4, not
+built.  What is built is the data CONTRACT (openeds_dataset.py:103-118: keys `label` (N,1,H,W) int, `style_image`
+(N,ns,1,H,W) float in [-1,1], `target` (N,1,H,W) float in [-1,1], `filename`, `user`) served by a seeded synthetic
+source (nested-ellipse eye-region labels + smooth images, seg2eye_amd/synthetic.py), one fixed set of samples per
+epoch, sharded over data-parallel ranks."""
+import torch
+
+from . import synthetic as syn
+from .options import image_hw
+
+
+class SyntheticEyes:
+    """len(self) batches per epoch; batch i of epoch e is a pure function of (seed, rank, i)."""
+
+    def __init__(self, opt, rank=0, world=1, seed=1234):
+        if opt.dataset_mode != 'synthetic':
+            raise NotImplementedError("dataset_mode '%s': only 'synthetic' is built (the OpenEDS H5 pipeline is SURVEY 8 f4); "
+                                      "feed Pix2PixTrainer your own batches with the keys documented in seg2eye_amd/data.py"
+                                      % opt.dataset_mode)
+        self.opt, self.rank, self.world, self.seed = opt, rank, world, seed
+        self.h, self.w = image_hw(opt)
+        self.n_batches = max(1, int(getattr(opt, 'synthetic_size', 64)) // (opt.batchSize * world))
+
+    def __len__(self):
+        return self.n_batches
+
+    def batch(self, i):
+        b = syn.make_batch(self.opt.batchSize, self.h, self.w, self.opt.input_ns, seed=self.seed + 7919 * (i * self.world + self.rank))
+        return {'label': torch.from_numpy(b['label']), 'style_image': torch.from_numpy(b['style_image']),
+                'target': torch.from_numpy(b['target']), 'filename': b['filename'],
+                'user': ['synthetic'] * self.opt.batchSize}
+
+    def __iter__(self):
+        for i in range(self.n_batches):
+            yield self.batch(i)
+
+
+def create_dataloader(opt, rank=0, world=1):
+    return SyntheticEyes(opt, rank, world)

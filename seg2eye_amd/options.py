@@ -66,3 +66,80 @@ def image_hw(opt):
     sw, sh = latent_size(opt)
     f = 32 if opt.num_upsampling_layers == 'normal' else 64
     return sh * f, sw * f
+
+
+# ----------------------------------------------------------------------------------------- command line
+# Every flag of the reference's TrainOptions / TestOptions parsers (options/base_options.py:21-64,
+# options/train_options.py:13-51, options/test_options.py) with the reference's type and default -- checked against
+# tests/golden/reference_option_defaults.json, which make_golden.py dumped from the real parsers -- plus the four
+# model-specific flags added by modify_commandline_options and this build's own knobs.  Deliberate differences:
+#   norm_G        default 'spectralspadeinstance3x3' (reference: the BatchNorm variant, not built: SURVEY F2)
+#   dataset_mode  default 'synthetic' (reference: 'openeds', the H5 dataset of SURVEY 8 f4, not built)
+_F, _I, _S = float, int, str
+_CLI = [  # (name, type or 'flag', default, choices)
+    ('name', _S, '', None), ('gpu_ids', _S, '0', None), ('checkpoints_dir', _S, './checkpoints', None), ('model', _S, 'pix2pix', None),
+    ('norm_G', _S, 'spectralspadeinstance3x3', None), ('norm_D', _S, 'spectralinstance', None), ('norm_E', _S, 'spectralinstance', None),
+    ('batchSize', _I, 1, None),
+    ('preprocess_mode', _S, 'fixed', ['resize_and_crop', 'crop', 'scale_width', 'scale_width_and_crop', 'scale_shortside',
+                                       'scale_shortside_and_crop', 'fixed', 'none']),
+    ('load_size', _I, 256, None), ('crop_size', _I, 256, None), ('aspect_ratio', _F, 0.8, None),
+    ('label_nc', _I, 4, None), ('input_nc', _I, 1, None), ('output_nc', _I, 1, None), ('input_ns', _I, 4, None),
+    ('dataroot', _S, None, None), ('dataset_mode', _S, 'synthetic', None), ('dataset_key', _S, 'train', None),
+    ('serial_batches', 'flag', False, None), ('no_flip', 'flag', False, None), ('nThreads', _I, 0, None),
+    ('load_from_opt_file', 'flag', False, None), ('seg_file', _S, '', None),
+    ('style_ref', _S, 'datasets/0910_deeplab_top_image_indices_for_marcel.h5', None),
+    ('style_aggr_method', _S, 'mean', ['mean', 'max']),
+    ('style_sample_method', _S, 'random', ['random', 'first', 'ref_first', 'ref_random100']),
+    ('netG', _S, 'spadestyle', None), ('netD', _S, 'multiscale', None), ('netE', _S, 'conv', None),
+    ('ngf', _I, 64, None), ('ndf', _I, 64, None), ('nef', _I, 16, None), ('w_dim', _I, 16, None),
+    ('init_type', _S, 'xavier', None), ('init_variance', _F, 0.02, None),
+    ('validation_limit', _I, 250, None), ('write_error_log', 'flag', False, None),
+    # model-specific (generator.py:15-20, discriminator.py:16-28,69-72)
+    ('num_upsampling_layers', _S, 'normal', ['normal', 'more', 'most']), ('netD_subarch', _S, 'n_layer', None),
+    ('num_D', _I, 2, None), ('n_layers_D', _I, 4, None),
+    # build-only
+    ('compute_dtype', _S, 'bf16', ['bf16', 'fp32']), ('hip_graphs', 'flag', False, None),
+    ('synthetic_size', _I, 64, None),        # samples per epoch of the synthetic dataset
+]
+_CLI_TRAIN = [
+    ('display_freq', _I, 5000, None), ('print_freq', _I, 500, None), ('save_latest_freq', _I, 5000, None),
+    ('save_epoch_freq', _I, 1, None), ('full_val_freq', _I, 50000, None), ('no_html', 'flag', False, None), ('tf_log', 'flag', False, None),
+    ('continue_train', 'flag', False, None), ('which_epoch', _S, 'latest', None),
+    ('niter', _I, 14, None), ('niter_decay', _I, 7, None), ('optimizer', _S, 'adam', None),
+    ('beta1', _F, 0.5, None), ('beta2', _F, 0.999, None), ('lr', _F, 0.0002, None), ('D_steps_per_G', _I, 1, None),
+    ('weight_decay', _F, 0.0, None),
+    ('lambda_feat', _F, 10.0, None), ('lambda_vgg', _F, 10.0, None), ('lambda_l2', _F, 0, None), ('lambda_l1', _F, 0, None),
+    ('lambda_openeds', _F, 0, None), ('lambda_kld', _F, 0.05, None), ('lambda_style_w', _F, 0.0, None),
+    ('lambda_style_feat', _F, 0.0, None), ('lambda_gram', _F, 0.0, None),
+    ('no_ganFeat_loss', 'flag', False, None), ('no_vgg_loss', 'flag', True, None), ('gan_mode', _S, 'hinge', None), ('no_TTUR', 'flag', False, None),
+]
+_CLI_TEST = [
+    ('results_dir', _S, 'results/', None), ('which_epoch', _S, 'latest', None), ('how_many', _I, float('inf'), None),
+    ('produce_npy', 'flag', False, None),
+]
+
+
+def build_parser(is_train=True):
+    ap = argparse.ArgumentParser(description='seg2eye_amd %s options (flag-compatible with the reference)' % ('train' if is_train else 'test'))
+    for name, typ, default, choices in _CLI + (_CLI_TRAIN if is_train else _CLI_TEST):
+        if not is_train and name in ('serial_batches', 'no_flip'):
+            default = True                                 # options/test_options.py: parser.set_defaults(serial_batches=True, no_flip=True)
+        if typ == 'flag':
+            ap.add_argument('--' + name, action='store_true', default=default)
+        else:
+            ap.add_argument('--' + name, type=typ, default=default, choices=choices)
+    return ap
+
+
+def parse(argv=None, is_train=True):
+    """argv -> option Namespace with the reference's post-processing (options/base_options.py:139-160)."""
+    opt = build_parser(is_train).parse_args(argv)
+    opt.isTrain = is_train
+    opt.semantic_nc = opt.label_nc
+    opt.gpu_ids = [int(s) for s in str(opt.gpu_ids).split(',') if s.strip() and int(s) >= 0]
+    for k, v in _DEFAULTS.items():                      # fields the model reads that have no flag in this mode
+        if not hasattr(opt, k):
+            setattr(opt, k, v)
+    if not is_train:
+        opt.continue_train = False
+    return opt
