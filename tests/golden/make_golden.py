@@ -118,11 +118,28 @@ def style_trainer_fixture(args, syn):
     print('style trainer ok', {k: float(v.reshape(-1)[0]) for k, v in rec.items() if k.startswith('it0_') and v.size == 1})
 
 
+def options_fixture(args):
+    """reference_option_defaults.json: every flag of the reference's TrainOptions / TestOptions parsers
+    (options/base_options.py, train_options.py, test_options.py) with its default, type, action and choices."""
+    import json
+    from options.train_options import TrainOptions
+    from options.test_options import TestOptions
+    out = {}
+    for name, cls in (('train', TrainOptions), ('test', TestOptions)):
+        parser = cls().initialize(argparse.ArgumentParser())
+        out[name] = {a.dest: {'default': a.default, 'flags': a.option_strings,
+                              'type': getattr(a.type, '__name__', None) if a.type else None,
+                              'action': type(a).__name__, 'choices': list(a.choices) if a.choices else None}
+                     for a in parser._actions if a.dest != 'help'}
+    json.dump(out, open(os.path.join(args.out, 'reference_option_defaults.json'), 'w'), indent=0, sort_keys=True, default=str)
+    print('options ok', {k: len(v) for k, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=HERE)
     ap.add_argument('--full', action='store_true', help='also the ngf=64 256x256 N=8 pin (slow)')
-    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture)")
+    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture); 'options': only reference_option_defaults.json")
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -143,6 +160,9 @@ def main():
 
     if args.only == 'style':
         style_trainer_fixture(args, syn)
+        return
+    if args.only == 'options':
+        options_fixture(args)
         return
 
     # ---- G1/G2: generator, ngf=8 (64x64) and ngf=16 (128x128 portrait-ish 128x64) -------
