@@ -37,7 +37,8 @@ extern "C" {
 enum { S2E_F32 = 0, S2E_BF16 = 1 };
 enum { S2E_ACT_NONE = 0, S2E_ACT_LRELU = 1, S2E_ACT_TANH = 2 };          /* LeakyReLU slope 0.2 */
 enum { S2E_AUX_NONE = 0, S2E_AUX_RELU_MASK = 1, S2E_AUX_LRELU_GRAD = 2 }; /* y *= (aux>0 ? 1 : 0 | 0.2) */
-enum { S2E_NORM_SPADE_STYLE = 0, S2E_NORM_PLAIN_IN = 1 };
+enum { S2E_NORM_SPADE_STYLE = 0, S2E_NORM_PLAIN_IN = 1,
+       S2E_NORM_SPADE_STYLE_BATCH = 2 };   /* s2e_modulate_bwd only: stats are BATCH statistics (BatchNorm SPADE) */
 enum { S2E_LOSS_NEG_MEAN = 0, S2E_LOSS_HINGE_REAL = 1, S2E_LOSS_HINGE_FAKE = 2, S2E_LOSS_L1 = 3 };
 
 int s2e_version(void);
@@ -177,7 +178,9 @@ int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* gb, const f
  * style_ld (both calls): floats between consecutive samples' rows of style AND dstyle; 0 = dense (2C).  A
  * generator keeps the style codes of all its SPADE+Style layers as column slices of ONE (N, sum 2C) matrix
  * (one GEMM for all style FCs, networks/stylebank.py), hence the leading dimension.
- * ws: N*C*4 doubles of scratch, ZERO-FILLED by the caller; dirty on return. */
+ * ws: N*C*6 doubles of scratch (N*C*4 fp64 sums, then N*C float4 coefficients), the sums ZERO-FILLED by the caller;
+ * dirty on return.  mode S2E_NORM_SPADE_STYLE_BATCH: `stats` holds the same {mean, rstd} of the whole batch for every
+ * sample (param_free_norm = BatchNorm2d, normalization.py:74-75) and the normalisation's backward sums over N*HW. */
 int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
                      const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                      int N, int HW, int C, int lrelu, int style_ld, void* stream);

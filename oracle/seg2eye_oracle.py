@@ -88,9 +88,20 @@ def apply_style(sd, prefix, x, w):
     return x * (style[:, 0] + 1.0) + style[:, 1]
 
 
-def spade(sd, prefix, x, seg):
-    """SPADE.forward normalization.py:91-105."""
-    normalized = instance_norm(x)
+def spade(sd, prefix, x, seg, training=True, updates=None):
+    """SPADE.forward normalization.py:91-105.  param_free_norm is InstanceNorm2d (no state) or, when the state dict
+    carries `param_free_norm.running_mean`, BatchNorm2d(affine=False) (normalization.py:72-75): batch statistics and
+    a running-buffer update in train mode, the running buffers in eval mode."""
+    rm_key = prefix + '.param_free_norm.running_mean'
+    if rm_key in sd:
+        rm, rv = sd[rm_key].clone(), sd[prefix + '.param_free_norm.running_var'].clone()
+        normalized = F.batch_norm(x, rm, rv, None, None, training, 0.1, 1e-5)
+        if training and updates is not None:
+            updates[rm_key] = rm
+            updates[prefix + '.param_free_norm.running_var'] = rv
+            updates[prefix + '.param_free_norm.num_batches_tracked'] = sd[prefix + '.param_free_norm.num_batches_tracked'] + 1
+    else:
+        normalized = instance_norm(x)
     segmap = F.interpolate(seg, size=x.shape[2:], mode='nearest')
     actv = F.relu(F.conv2d(segmap, sd[prefix + '.mlp_shared.0.weight'],
                            sd[prefix + '.mlp_shared.0.bias'], padding=1))
@@ -99,9 +110,9 @@ def spade(sd, prefix, x, seg):
     return normalized * (1 + gamma) + beta
 
 
-def spade_style_block(sd, prefix, x, seg, w):
+def spade_style_block(sd, prefix, x, seg, w, training=True, updates=None):
     """SPADE_STYLE_Block.forward normalization.py:184-192."""
-    return (spade(sd, prefix + '.spade', x, seg) + apply_style(sd, prefix + '.adain', x, w)) / 2
+    return (spade(sd, prefix + '.spade', x, seg, training, updates) + apply_style(sd, prefix + '.adain', x, w)) / 2
 
 
 def spade_style_resblk(sd, prefix, x, seg, w, training, updates):
@@ -110,14 +121,14 @@ def spade_style_resblk(sd, prefix, x, seg, w, training, updates):
     learned = (prefix + '.conv_s.weight_orig') in sd
     if learned:
         ws = _sn_conv_weight(sd, prefix + '.conv_s', training, updates)
-        x_s = F.conv2d(spade_style_block(sd, prefix + '.norm_s', x, seg, w), ws)
+        x_s = F.conv2d(spade_style_block(sd, prefix + '.norm_s', x, seg, w, training, updates), ws)
     else:
         x_s = x
     w0 = _sn_conv_weight(sd, prefix + '.conv_0', training, updates)
-    dx = F.conv2d(F.leaky_relu(spade_style_block(sd, prefix + '.norm_0', x, seg, w), 0.2),
+    dx = F.conv2d(F.leaky_relu(spade_style_block(sd, prefix + '.norm_0', x, seg, w, training, updates), 0.2),
                   w0, sd[prefix + '.conv_0.bias'], padding=1)
     w1 = _sn_conv_weight(sd, prefix + '.conv_1', training, updates)
-    dx = F.conv2d(F.leaky_relu(spade_style_block(sd, prefix + '.norm_1', dx, seg, w), 0.2),
+    dx = F.conv2d(F.leaky_relu(spade_style_block(sd, prefix + '.norm_1', dx, seg, w, training, updates), 0.2),
                   w1, sd[prefix + '.conv_1.bias'], padding=1)
     return x_s + dx
 

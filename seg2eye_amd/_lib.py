@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libseg2eye_hip.so')
 S2E_F32, S2E_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD = 0, 1, 2
-NORM_SPADE_STYLE, NORM_PLAIN_IN = 0, 1
+NORM_SPADE_STYLE, NORM_PLAIN_IN, NORM_SPADE_STYLE_BATCH = 0, 1, 2
 LOSS_NEG_MEAN, LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_L1 = 0, 1, 2, 3
 
 

@@ -370,22 +370,28 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
     }
 }
 
-// Per-(n,c) coefficients of pass 2, computed once by modulate_bwd_coef_kernel and stored as one float4 over the first
-// 16 bytes of the channel's 32-byte fp64 slot in ws (each thread reads its whole slot first):
+// Per-(n,c) coefficients of pass 2, computed once by modulate_bwd_coef_kernel and stored as one float4 per channel in
+// the tail of ws (behind the N*C*4 fp64 sums):
 //   SPADE_STYLE: dx = dbeta*(P + R*gamma) - Q - x*S     P = 1 + s0 + rstd, R = rstd
 //   PLAIN_IN   : dx = R*go - Q - x*S                    P = mean (for the LeakyReLU mask: xhat > 0 <=> x > mean)
 //   both       : Q = rstd*(S0 - mean*rstd*S1)/HW,  S = rstd^2*S1/HW
 // The element-wise pass then needs 16 B of constants per channel instead of 32 B of doubles + stats + style and no
 // fp64 conversions: it was VALU-issue-bound (22 loads and ~350 instructions per 16-byte vector), not HBM-bound.
+// batch != 0 (BatchNorm SPADE: statistics over the whole batch): S0, S1 are summed over the samples and HW -> N*HW.
 template <int MODE>
-__global__ void modulate_bwd_coef_kernel(double* __restrict__ ws, const float* __restrict__ stats, const float* __restrict__ style,
-                                         float* __restrict__ dstyle, int N, int C, int HW, int sld) {
+__global__ void modulate_bwd_coef_kernel(const double* __restrict__ ws, f32x4_t* __restrict__ coef, const float* __restrict__ stats,
+                                         const float* __restrict__ style, float* __restrict__ dstyle, int N, int C, int HW, int sld, int batch) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
-    const double s0d = ws[(size_t)i * 4], s1d = ws[(size_t)i * 4 + 1];
+    double s0d = ws[(size_t)i * 4], s1d = ws[(size_t)i * 4 + 1];
+    float inv_hw = 1.f / (float)HW;
+    if (batch) {
+        s0d = 0.0; s1d = 0.0;
+        for (int m = 0; m < N; ++m) { s0d += ws[((size_t)m * C + c) * 4]; s1d += ws[((size_t)m * C + c) * 4 + 1]; }
+        inv_hw = 1.f / ((float)HW * (float)N);
+    }
     const float mean = stats[2 * i], rs = stats[2 * i + 1];
-    const float inv_hw = 1.f / (float)HW;
     const float m0 = (float)s0d * inv_hw, m1 = (float)s1d * inv_hw;
     f32x4_t k;
     if (MODE == S2E_NORM_SPADE_STYLE) {
@@ -399,12 +405,12 @@ __global__ void modulate_bwd_coef_kernel(double* __restrict__ ws, const float* _
     k[1] = rs;
     k[2] = rs * (m0 - mean * rs * m1);
     k[3] = rs * rs * m1;
-    *(f32x4_t*)(ws + (size_t)i * 4) = k;
+    coef[i] = k;
 }
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __restrict__ gin, const T* __restrict__ x,
-        const T* __restrict__ gb, const T* __restrict__ dgb, const double* __restrict__ ws, T* __restrict__ dx,
+        const T* __restrict__ gb, const T* __restrict__ dgb, const f32x4_t* __restrict__ coef, T* __restrict__ dx,
         int vps, int HW, int C, int cg, int cg_shift, int lrelu) {
     constexpr int VEC = Vec<T>::N;
     const int n = blockIdx.y;                              // one sample per grid row: 32-bit indices, no 64-bit division
@@ -415,14 +421,14 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
         const int c0 = g * VEC;
         float f[VEC], o[VEC];
         unpack16<T>(*(const u32x4_t*)(x + row * C + c0), f);
-        const f32x4_t* kp = (const f32x4_t*)(ws + ((size_t)n * C + c0) * 4);      // stride 32 B per channel
+        const f32x4_t* kp = coef + (size_t)n * C + c0;
         if (MODE == S2E_NORM_SPADE_STYLE) {
             float ga[VEC], dbe[VEC];
             unpack16<T>(*(const u32x4_t*)(gb + row * 2 * C + c0), ga);
             unpack16<T>(*(const u32x4_t*)(dgb + row * 2 * C + C + c0), dbe);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const f32x4_t k = kp[2 * j];
+                const f32x4_t k = kp[j];
                 o[j] = dbe[j] * (k[0] + k[1] * ga[j]) - k[2] - f[j] * k[3];
             }
         } else {
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
             unpack16<T>(*(const u32x4_t*)(gin + row * C + c0), gg);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const f32x4_t k = kp[2 * j];
+                const f32x4_t k = kp[j];
                 float go = gg[j];
                 if (lrelu) go *= (f[j] > k[0] ? 1.f : 0.2f);
                 o[j] = k[1] * go - k[2] - f[j] * k[3];
@@ -444,6 +450,8 @@ extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* 
                                 const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                                 int N, int HW, int C, int lrelu, int style_ld, void* stream) {
     const int sld = style_ld > 0 ? style_ld : 2 * C;
+    const int batch = mode == S2E_NORM_SPADE_STYLE_BATCH;
+    if (batch) mode = S2E_NORM_SPADE_STYLE;                // same passes; only the coefficient kernel sums over the batch
     if (!g || !x || !stats || !dx || !ws || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: bad argument");
     if (mode == S2E_NORM_SPADE_STYLE && (!gb || !style || !dgb || !dstyle))
         S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: SPADE_STYLE needs gb, style, dgb, dstyle");
@@ -463,10 +471,11 @@ extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* 
     int cg_shift = -1;
     for (int b = 0; b < 31; ++b) if ((1 << b) == rg.cg) cg_shift = b;
     const int gridc = ceil_div((long)N * C, 256);
+    f32x4_t* coef = (f32x4_t*)(ws + (size_t)N * C * 4);
 #define S2E_LAUNCH_BWD(TT, MM) do { \
     modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters); \
-    modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, stats, style, dstyle, N, C, HW, sld); \
-    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, ws, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu); } while (0)
+    modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, coef, stats, style, dstyle, N, C, HW, sld, batch); \
+    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu); } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_BWD

@@ -4,7 +4,7 @@ from torch.nn.utils import spectral_norm
 
 from .. import ops
 from ..spectral import sn_begin
-from .normalization import SPADE_STYLE_Block, SegMap
+from .normalization import SPADE_STYLE_Block, SegMap, spade_stats
 
 
 class SPADE_STYLE_ResnetBlock(nn.Module):
@@ -35,7 +35,7 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
     def forward(self, x, seg, latent_style):
         seg = SegMap.of(seg)
         sn_begin(self)                  # no-op inside a generator (its forward already stepped the bank)
-        stats = ops.in_stats(x.detach())
+        stats = spade_stats(x, [self.norm_0.spade] + ([self.norm_s.spade] if self.learned_shortcut else []))
         if self.learned_shortcut:
             x_s = ops.conv2d_m(self.norm_s(x, seg, latent_style, stats, lrelu=False), self.conv_s)
         else:

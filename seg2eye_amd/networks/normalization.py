@@ -39,20 +39,23 @@ class SegMap:
 
 
 class SPADE(nn.Module):
-    """Parameter holder for SPADE (normalization.py:63-105).  Only `instance` is built: it is the
-    variant the hot path is defined on; `batch` needs cross-sample statistics and is a
-    follow-up row."""
+    """Parameter holder for SPADE (normalization.py:63-105).  `instance` is the variant the hot path is defined on
+    (SURVEY F2); `batch` -- the reference's default `--norm_G spectralspadebatch3x3` -- normalises with the statistics of
+    the whole batch and keeps BatchNorm2d's running buffers (same state_dict keys: `param_free_norm.running_mean`,
+    `.running_var`, `.num_batches_tracked`, registered first like in the reference).  `syncbatch` raises there too."""
 
     def __init__(self, config_text, norm_nc, label_nc):
         super().__init__()
         assert config_text.startswith('spade')
         parsed = re.search(r'spade(\D+)(\d)x\d', config_text)
         kind, ks = str(parsed.group(1)), int(parsed.group(2))
-        if kind != 'instance':
-            raise ValueError('%s is not a param-free norm type this build supports in SPADE '
-                             '(only instance)' % kind)
+        if kind not in ('instance', 'batch'):
+            raise ValueError('%s is not a recognized param-free norm type in SPADE' % kind)
         if ks != 3:
             raise ValueError('SPADE kernel size %d not supported (3 only)' % ks)
+        self.kind = kind
+        if kind == 'batch':
+            self.param_free_norm = nn.BatchNorm2d(norm_nc, affine=False)
         nhidden = 128
         self.mlp_shared = nn.Sequential(nn.Conv2d(label_nc, nhidden, kernel_size=3, padding=1), nn.ReLU())
         self.mlp_gamma = nn.Conv2d(nhidden, norm_nc, kernel_size=3, padding=1)
@@ -68,6 +71,38 @@ class SPADE(nn.Module):
         """Parameter order that makes [W_gamma; W_beta] and [b_gamma; b_beta] contiguous in a flat arena."""
         return [self.mlp_shared[0].weight, self.mlp_shared[0].bias, self.mlp_gamma.weight, self.mlp_beta.weight,
                 self.mlp_gamma.bias, self.mlp_beta.bias]
+
+
+def spade_stats(x, spades):
+    """{mean, rstd} (N,C,2) fp32 of x for the SPADE modules that normalise it (norm_0 and norm_s of a block share x).
+    instance: per-sample statistics (one pass over x).  batch, train mode: statistics of the whole batch, combined from
+    the same pass's per-sample fp64 sums; every module's running buffers are updated like nn.BatchNorm2d does (momentum
+    0.1, unbiased running variance).  batch, eval mode: a module's own running statistics -- they differ between
+    modules, so this returns None when more than one is asked for (each block then calls again for itself)."""
+    sp = spades[0]
+    if sp.kind == 'instance':
+        return ops.in_stats(x.detach())
+    n, h, w, c = x.shape
+    if not sp.training:
+        if len(spades) > 1:
+            return None
+        bn = sp.param_free_norm
+        st = torch.stack([bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)], -1)
+        return st.unsqueeze(0).expand(n, c, 2).contiguous()
+    _, sums = ops.in_stats(x.detach(), return_sums=True)
+    cnt = float(n * h * w)
+    tot = sums.sum(0)                                             # (C,2) fp64
+    mean = tot[:, 0] / cnt
+    var = (tot[:, 1] / cnt - mean * mean).clamp_min(0.0)
+    with torch.no_grad():
+        for m in spades:
+            bn = m.param_free_norm
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+            bn.running_mean.mul_(1.0 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_((var * (cnt / max(cnt - 1.0, 1.0))).to(bn.running_var.dtype), alpha=mom)
+            bn.num_batches_tracked += 1
+    st = torch.stack([mean, torch.rsqrt(var + sp.param_free_norm.eps)], -1).float()
+    return st.unsqueeze(0).expand(n, c, 2).contiguous()
 
 
 class FC(nn.Module):
@@ -119,13 +154,14 @@ class SPADE_STYLE_Block(nn.Module):
         n, h, w, c = x.shape
         gb = self.spade.gamma_beta(seg, h, w, x.dtype)
         if stats is None:
-            stats = ops.in_stats(x.detach())
+            stats = spade_stats(x, [self.spade])
+        batch = self.spade.kind == 'batch'
         from . import stylebank
         sb = stylebank.current()                                    # inside a generator: all style FCs were one GEMM
         if sb is not None and id(self.adain.linear) in sb[0]:
-            return ops.spade_style_modulate(x, gb, sb[1], stats, lrelu, off=sb[0][id(self.adain.linear)], dbig=sb[2])
+            return ops.spade_style_modulate(x, gb, sb[1], stats, lrelu, off=sb[0][id(self.adain.linear)], dbig=sb[2], batch=batch)
         style = self.adain.linear(latent_style)                     # (N, 2C) fp32
-        return ops.spade_style_modulate(x, gb, style, stats, lrelu)
+        return ops.spade_style_modulate(x, gb, style, stats, lrelu, batch=batch)
 
 
 def get_nonspade_norm_layer(opt, norm_type='instance'):

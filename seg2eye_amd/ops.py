@@ -13,7 +13,7 @@ import torch
 
 from . import _lib as L
 from . import packing
-from ._lib import (ConvDesc, ACT_NONE, ACT_LRELU, ACT_TANH, AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD,
+from ._lib import (NORM_SPADE_STYLE_BATCH, ConvDesc, ACT_NONE, ACT_LRELU, ACT_TANH, AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD,
                    NORM_SPADE_STYLE, NORM_PLAIN_IN, LOSS_NEG_MEAN, LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_L1)
 
 IN_EPS = 1e-5      # nn.InstanceNorm2d default (models/networks/normalization.py:41,73)
@@ -350,15 +350,16 @@ def colsum(g):
     return out
 
 
-def in_stats(x):
+def in_stats(x, return_sums=False):
     """(N,H,W,C) -> (N,C,2) fp32 {mean, rstd}; not differentiated here (the IN backward lives in
-    modulate_bwd, once per consumer of the statistics)."""
+    modulate_bwd, once per consumer of the statistics).
+    return_sums: also the raw fp64 per-sample sums (N,C,2) {sum x, sum x^2} (BatchNorm SPADE combines them over the batch)."""
     _need(x)
     n, h, w, c = x.shape
     ws = ZeroPool.take(n * c * 2, torch.float64, x.device)
     stats = torch.empty(n, c, 2, dtype=torch.float32, device=x.device)
     L.check(L.lib().s2e_in_stats(_dt(x), _p(x), n, h * w, c, IN_EPS, _p(ws), _p(stats), _stream()), 's2e_in_stats')
-    return stats
+    return (stats, ws.view(n, c, 2)) if return_sums else stats
 
 
 def label_conv3x3_raw(label, weight, bias, n, H, W, h, w, cout, relu, dtype):
@@ -596,7 +597,7 @@ class ModulateFn(torch.autograd.Function):
     accumulator) and hands autograd nothing for `style`: the bank's own backward picks dbig up."""
 
     @staticmethod
-    def forward(ctx, x, gb, style, stats, lrelu, off=None, dbig=None):
+    def forward(ctx, x, gb, style, stats, lrelu, off=None, dbig=None, batch=False):
         _need(x, gb, style, stats)
         n, h, w, c = x.shape
         out = torch.empty_like(x)
@@ -604,7 +605,7 @@ class ModulateFn(torch.autograd.Function):
         sp = style.data_ptr() + 4 * (off or 0)
         L.check(L.lib().s2e_modulate_fwd(_dt(x), NORM_SPADE_STYLE, _p(x), _p(gb), _p(stats), sp, _p(out),
                                          n, h * w, c, int(lrelu), ld, _stream()), 's2e_modulate_fwd')
-        ctx.lrelu, ctx.off, ctx.dbig = lrelu, off, dbig
+        ctx.lrelu, ctx.off, ctx.dbig, ctx.batch = lrelu, off, dbig, bool(batch)
         ctx.save_for_backward(x, gb, style, stats)
         return out
 
@@ -623,17 +624,18 @@ class ModulateFn(torch.autograd.Function):
                 raise RuntimeError('ModulateFn: banked style without a gradient accumulator')
             dstyle, dsp, ld = None, ctx.dbig.data_ptr() + 4 * ctx.off, style.shape[1]
         sp = style.data_ptr() + 4 * (ctx.off or 0)
-        ws = ZeroPool.take(n * c * 4, torch.float64, x.device)
-        L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_SPADE_STYLE, _p(g), _p(x), _p(gb), _p(stats), sp, _p(dx),
+        ws = ZeroPool.take(n * c * 6, torch.float64, x.device)      # fp64 sums + float4 coefficients
+        L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_SPADE_STYLE_BATCH if ctx.batch else NORM_SPADE_STYLE, _p(g), _p(x), _p(gb), _p(stats), sp, _p(dx),
                                          _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()),
                 's2e_modulate_bwd')
-        return dx, dgb, dstyle, None, None, None, None
+        return dx, dgb, dstyle, None, None, None, None, None
 
 
-def spade_style_modulate(x, gb, style, stats, lrelu, off=None, dbig=None):
+def spade_style_modulate(x, gb, style, stats, lrelu, off=None, dbig=None, batch=False):
+    """batch: `stats` are batch statistics (BatchNorm SPADE) -- the same row for every sample."""
     if off is None:
         style = style.float().contiguous()
-    return ModulateFn.apply(x, gb, style, stats, lrelu, off, dbig)
+    return ModulateFn.apply(x, gb, style, stats, lrelu, off, dbig, batch)
 
 
 class InstanceNormFn(torch.autograd.Function):
@@ -657,7 +659,7 @@ class InstanceNormFn(torch.autograd.Function):
         n, h, w, c = x.shape
         g = g.contiguous()
         dx = torch.empty_like(x)
-        ws = ZeroPool.take(n * c * 4, torch.float64, x.device)
+        ws = ZeroPool.take(n * c * 6, torch.float64, x.device)      # fp64 sums + float4 coefficients
         L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_PLAIN_IN, _p(g), _p(x), None, _p(stats), None, _p(dx), None, None,
                                          _p(ws), n, h * w, c, int(ctx.lrelu), 0, _stream()), 's2e_modulate_bwd')
         return dx, None

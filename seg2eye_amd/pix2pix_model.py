@@ -32,8 +32,6 @@ class Pix2PixModel(nn.Module):
         super().__init__()
         self.opt = opt
         self.cdtype = compute_dtype_of(opt)
-        if 'batch' in opt.norm_G:
-            raise NotImplementedError('norm_G=%s: only the InstanceNorm SPADE variant is built (SURVEY F2)' % opt.norm_G)
         self.netG, self.netD, self.netE = self.initialize_networks(opt)
         if opt.isTrain:
             self.criterionGAN = networks.GANLoss(opt.gan_mode, opt=opt)

@@ -62,6 +62,12 @@ def fill_state_entry(name, shape, seed=0):
             if 'adain' in name:
                 return (hash_normal(name, shape, seed) * 0.25).astype(np.float32)
             return (hash_normal(name, shape, seed) / np.sqrt(shape[1])).astype(np.float32)
+    if leaf == 'running_mean':                        # BatchNorm SPADE buffers: plausible non-trivial running statistics
+        return hash_uniform(name, shape, seed, -0.2, 0.2)
+    if leaf == 'running_var':
+        return hash_uniform(name, shape, seed, 0.5, 1.5)
+    if leaf == 'num_batches_tracked':
+        return np.full(shape, 3, dtype=np.int64)
     raise ValueError('no fill rule for state entry %r with shape %r' % (name, shape))
 
 

@@ -118,6 +118,33 @@ def style_trainer_fixture(args, syn):
     print('style trainer ok', {k: float(v.reshape(-1)[0]) for k, v in rec.items() if k.startswith('it0_') and v.size == 1})
 
 
+def bn_generator_fixture(args, syn, onehot, SPADESTYLEGenerator):
+    """G3: the reference's DEFAULT --norm_G spectralspadebatch3x3 (BatchNorm SPADE): train-mode forward (batch statistics,
+    running buffers updated), every parameter gradient, then an eval-mode forward on the updated running buffers."""
+    opt = ref_opt(ngf=8, crop_size=64, aspect_ratio=1.0, norm_G='spectralspadebatch3x3')
+    netG = SPADESTYLEGenerator(opt)
+    man = load_filled(netG)
+    sd0 = {k: v.clone() for k, v in netG.state_dict().items()}
+    label = syn.ellipse_labels(3, 64, 64, seed=31)
+    w = syn.hash_normal('latent_w', (3, 16), seed=31)
+    proj = torch.from_numpy(syn.hash_uniform('g_proj', (3, 1, 64, 64), seed=9))
+    netG.train()
+    wt = torch.from_numpy(w).clone().requires_grad_(True)
+    y = netG(onehot(label), wt)
+    (y * proj).sum().backward()
+    rec = {'label': label, 'w': w, 'y_train': y.detach().numpy(), 'grad_w': wt.grad.numpy()}
+    for k, p in netG.named_parameters():
+        rec['grad_' + k] = checksum(p.grad)
+    for k, v in netG.state_dict().items():
+        if k.endswith(('weight_u', 'weight_v')) or 'param_free_norm' in k:
+            rec['buf_' + k] = v.detach().numpy().copy()
+    netG.eval()
+    with torch.no_grad():
+        rec['y_eval_after'] = netG(onehot(label), torch.from_numpy(w)).numpy()
+    np.savez_compressed(os.path.join(args.out, 'g_bn_ngf8_64.npz'), **rec, **manifest_arrays('G', man))
+    print('bn generator ok', float(y.std()), [k for k in rec if 'running_mean' in k][:1])
+
+
 def options_fixture(args):
     """reference_option_defaults.json: every flag of the reference's TrainOptions / TestOptions parsers
     (options/base_options.py, train_options.py, test_options.py) with its default, type, action and choices."""
@@ -139,7 +166,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=HERE)
     ap.add_argument('--full', action='store_true', help='also the ngf=64 256x256 N=8 pin (slow)')
-    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture); 'options': only reference_option_defaults.json")
+    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture); 'options': only reference_option_defaults.json; 'bn': only g_bn_ngf8_64.npz")
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -163,6 +190,9 @@ def main():
         return
     if args.only == 'options':
         options_fixture(args)
+        return
+    if args.only == 'bn':
+        bn_generator_fixture(args, syn, onehot, SPADESTYLEGenerator)
         return
 
     # ---- G1/G2: generator, ngf=8 (64x64) and ngf=16 (128x128 portrait-ish 128x64) -------

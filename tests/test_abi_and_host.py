@@ -124,8 +124,12 @@ def test_options_and_shapes():
     with pytest.raises(KeyError):
         default_opt(not_an_option=1)
     from seg2eye_amd.pix2pix_model import Pix2PixModel
+    bn = Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], norm_G='spectralspadebatch3x3'))     # the reference's default norm
+    assert len(bn.netG.state_dict()) == 270 and 'head_0.norm_0.spade.param_free_norm.running_mean' in bn.netG.state_dict()
+    with pytest.raises(ValueError):
+        Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], norm_G='spectralspadesyncbatch3x3'))
     with pytest.raises(NotImplementedError):
-        Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], norm_G='spectralspadebatch3x3'))
+        Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], lambda_openeds=1.0))
     with pytest.raises(NotImplementedError):
         Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], no_vgg_loss=False))
 

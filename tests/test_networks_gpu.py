@@ -127,6 +127,45 @@ def test_pack_plan_matches_individual_packs(dt):
     assert float((y3 - runs[0][0]).abs().max()) <= tol
 
 
+def test_generator_batchnorm_spade_fp32_matches_reference():
+    """G3: --norm_G spectralspadebatch3x3 (the reference's default): train-mode forward on batch statistics, parameter
+    gradients, the BatchNorm running buffers after the forward, then eval mode on those buffers -- vs the REAL reference."""
+    from seg2eye_amd import networks, synthetic as syn
+    z = load_golden('g_bn_ngf8_64')
+    opt = _opt(ngf=8, crop_size=64, aspect_ratio=1.0, compute_dtype='fp32', norm_G='spectralspadebatch3x3')
+    G = _load(networks.define_G(opt), z, 'G')
+    assert len(G.state_dict()) == 270
+    w = torch.from_numpy(z['w']).to(DEV)
+    G.train()
+    wt = w.clone().requires_grad_(True)
+    y = G(_label(z), wt)
+    err = float((y.detach().float().cpu() - torch.from_numpy(z['y_train'])).abs().max())
+    assert err < G_TOL, 'train-mode BN-SPADE output differs from the reference by %.3e' % err
+    proj = torch.from_numpy(syn.hash_uniform('g_proj', tuple(y.shape), seed=9)).to(DEV)
+    (y.float() * proj).sum().backward()
+    gw = z['grad_w']
+    assert float((wt.grad.cpu() - torch.from_numpy(gw)).abs().max()) < KINK_TOL * np.abs(gw).max()
+    for k, p in G.named_parameters():
+        assert_checksum_close(p.grad, z['grad_' + k], KINK_TOL, k)
+    sd = G.state_dict()
+    for k in [k[4:] for k in z.files if k.startswith('buf_')]:
+        np.testing.assert_allclose(sd[k].cpu().numpy(), z['buf_' + k], atol=2e-5, rtol=0, err_msg=k)
+    G.eval()
+    with torch.no_grad():
+        ye = G(_label(z), w)
+    err = float((ye.float().cpu() - torch.from_numpy(z['y_eval_after'])).abs().max())
+    assert err < G_TOL, 'eval-mode BN-SPADE output differs by %.3e' % err
+    # bf16 train step with the BatchNorm variant stays finite through Pix2PixTrainer (graphs on)
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    tr = Pix2PixTrainer(_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='bf16',
+                             norm_G='spectralspadebatch3x3', hip_graphs=True))
+    data = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in _batch(2, 256, 256, 3).items()}
+    for _ in range(2):
+        tr.run_generator_one_step(dict(data))
+        tr.run_discriminator_one_step(dict(data))
+    assert all(np.isfinite(float(v)) for v in tr.get_latest_losses().values())
+
+
 def test_generator_bf16_close_to_fp32():
     from seg2eye_amd import networks
     z = load_golden('g_ngf16_128x64')

@@ -171,3 +171,29 @@ def test_trainer_optional_losses():
     for tag, sd in (('G', m.G), ('D', m.D), ('E', m.E)):
         for k, v in sd.items():
             assert_checksum_close(v, z['it0_ck_%s.%s' % (tag, k)], 1e-4, '%s.%s' % (tag, k))
+
+
+def test_generator_batchnorm_spade():
+    """G3: the reference's default --norm_G spectralspadebatch3x3: train-mode forward (batch statistics), every parameter
+    gradient, the updated BatchNorm running buffers and u/v, then eval mode on the updated buffers."""
+    z = load_golden('g_bn_ngf8_64')
+    sd = filled_state(z, 'G')
+    seg, w = _onehot(z['label']), torch.from_numpy(z['w'])
+    leaf = {k: (v.clone().requires_grad_(True) if O.OracleModel.is_param(k) else v) for k, v in sd.items()}
+    wt = w.clone().requires_grad_(True)
+    upd = {}
+    y = O.generator_forward(leaf, seg, wt, 2, 2, training=True, updates=upd)
+    np.testing.assert_allclose(y.detach().numpy(), z['y_train'], atol=TOL, rtol=0)
+    proj = torch.from_numpy(syn.hash_uniform('g_proj', tuple(y.shape), seed=9))
+    (y * proj).sum().backward()
+    np.testing.assert_allclose(wt.grad.numpy(), z['grad_w'], atol=2e-4 * np.abs(z['grad_w']).max(), rtol=0)
+    for k, p in leaf.items():
+        if O.OracleModel.is_param(k):
+            assert_checksum_close(p.grad, z['grad_' + k], 2e-4, k)
+    bufs = [k[4:] for k in z.files if k.startswith('buf_')]
+    assert sorted(bufs) == sorted(upd)
+    for k in bufs:
+        np.testing.assert_allclose(upd[k].detach().numpy(), z['buf_' + k], atol=1e-6, rtol=0, err_msg=k)
+    with torch.no_grad():
+        ye = O.generator_forward({**sd, **{k: v.detach() for k, v in upd.items()}}, seg, w, 2, 2, training=False)
+    np.testing.assert_allclose(ye.numpy(), z['y_eval_after'], atol=TOL, rtol=0)
