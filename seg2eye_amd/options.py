@@ -72,13 +72,14 @@ def image_hw(opt):
 # Every flag of the reference's TrainOptions / TestOptions parsers (options/base_options.py:21-64,
 # options/train_options.py:13-51, options/test_options.py) with the reference's type and default -- checked against
 # tests/golden/reference_option_defaults.json, which make_golden.py dumped from the real parsers -- plus the four
-# model-specific flags added by modify_commandline_options and this build's own knobs.  Deliberate differences:
-#   norm_G        default 'spectralspadeinstance3x3' (reference: the BatchNorm variant, not built: SURVEY F2)
+# model-specific flags added by modify_commandline_options and this build's own knobs.  One deliberate difference:
 #   dataset_mode  default 'synthetic' (reference: 'openeds', the H5 dataset of SURVEY 8 f4, not built)
+# (norm_G defaults to the reference's BatchNorm SPADE here; default_opt() -- the Python helper the benchmark and the
+# parity tests use -- keeps the InstanceNorm variant the hot path is defined on)
 _F, _I, _S = float, int, str
 _CLI = [  # (name, type or 'flag', default, choices)
     ('name', _S, '', None), ('gpu_ids', _S, '0', None), ('checkpoints_dir', _S, './checkpoints', None), ('model', _S, 'pix2pix', None),
-    ('norm_G', _S, 'spectralspadeinstance3x3', None), ('norm_D', _S, 'spectralinstance', None), ('norm_E', _S, 'spectralinstance', None),
+    ('norm_G', _S, 'spectralspadebatch3x3', None), ('norm_D', _S, 'spectralinstance', None), ('norm_E', _S, 'spectralinstance', None),
     ('batchSize', _I, 1, None),
     ('preprocess_mode', _S, 'fixed', ['resize_and_crop', 'crop', 'scale_width', 'scale_width_and_crop', 'scale_shortside',
                                        'scale_shortside_and_crop', 'fixed', 'none']),

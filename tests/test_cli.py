@@ -10,8 +10,7 @@ import torch
 
 from conftest import ROOT
 
-DELIBERATE = {'norm_G': 'spectralspadeinstance3x3',      # reference: BatchNorm SPADE (not built)
-              'dataset_mode': 'synthetic'}               # reference: 'openeds' (H5 dataset)
+DELIBERATE = {'dataset_mode': 'synthetic'}               # reference: 'openeds' (H5 dataset)
 
 
 @pytest.mark.parametrize('mode', ['train', 'test'])
