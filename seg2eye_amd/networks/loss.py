@@ -21,14 +21,22 @@ class GANLoss(nn.Module):
 
     def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0, tensor=None, opt=None):
         super().__init__()
-        if gan_mode != 'hinge':
-            if gan_mode in ('ls', 'original', 'w'):
-                raise NotImplementedError("gan_mode '%s' is outside the hot path this build covers (hinge)" % gan_mode)
+        if gan_mode not in ('hinge', 'ls', 'original', 'w'):
             raise ValueError('Unexpected gan_mode {}'.format(gan_mode))
         self.gan_mode = gan_mode
+        self.real_label, self.fake_label = target_real_label, target_fake_label
         self.opt = opt
 
     def loss(self, input, target_is_real, for_discriminator=True):
+        if self.gan_mode != 'hinge':
+            # the non-default modes (loss.py:58-65, 78-83) act on the few-thousand-element PatchGAN outputs: plain torch
+            x = input.float()
+            if self.gan_mode == 'w':
+                return -x.mean() if target_is_real else x.mean()
+            target = torch.full_like(x, self.real_label if target_is_real else self.fake_label)
+            if self.gan_mode == 'original':
+                return torch.nn.functional.binary_cross_entropy_with_logits(x, target)
+            return torch.nn.functional.mse_loss(x, target)
         x = _flat(input)
         n = x.numel()
         if for_discriminator:

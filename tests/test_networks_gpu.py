@@ -259,6 +259,32 @@ def test_fused_feature_matching_matches_unfused(dt):
         np.testing.assert_allclose(res[1][0], float(z['l_feat']), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('mode', ['ls', 'original', 'w'])
+def test_non_hinge_gan_modes(mode):
+    """--gan_mode ls / original / w (loss.py:58-65, 78-83): the reference's formulas on the multiscale prediction lists,
+    and a trainer iteration with each."""
+    from seg2eye_amd import networks
+    import torch.nn.functional as F
+    opt = _opt(ndf=8, crop_size=32, compute_dtype='fp32', gan_mode=mode)
+    crit = networks.GANLoss(mode, opt=opt)
+    g = torch.Generator().manual_seed(5)
+    preds = [[torch.randn(2, 1, 7, 7, generator=g).to(DEV)], [torch.randn(2, 1, 4, 4, generator=g).to(DEV)]]
+    for real in (True, False):
+        want = 0
+        for (p,) in preds:
+            t = torch.full_like(p, 1.0 if real else 0.0)
+            want = want + {'ls': F.mse_loss(p, t), 'original': F.binary_cross_entropy_with_logits(p, t),
+                           'w': (-p.mean() if real else p.mean())}[mode]
+        got = crit(preds, real, for_discriminator=True)
+        assert abs(float(got) - float(want / 2)) < 1e-6
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    tr = Pix2PixTrainer(_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='bf16', gan_mode=mode))
+    data = _batch(2, 256, 256, 4)
+    tr.run_generator_one_step(dict(data))
+    tr.run_discriminator_one_step(dict(data))
+    assert all(np.isfinite(float(v)) for v in tr.get_latest_losses().values())
+
+
 def test_encoder_fp32():
     from seg2eye_amd import networks
     z = load_golden('e_ngf8')
