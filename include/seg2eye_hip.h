@@ -228,10 +228,10 @@ int s2e_loss_grad(int dtype, int mode, const void* a, const void* b, long n, flo
                   void* da, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
- * torch.optim.Adam step (pix2pix_model.py:92-110: TTUR betas (0, 0.9), eps 1e-8, no weight decay)
- * over one flat fp32 arena: m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+ * torch.optim.Adam step (pix2pix_model.py:92-110: TTUR betas (0, 0.9), eps 1e-8, --weight_decay as Adam's L2 term)
+ * over one flat fp32 arena: g = g*grad_scale + weight_decay*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
  * p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), bc1 = 1-b1^t, bc2 = 1-b2^t, t = steps+1.
- * hyper: 6 fp32 in DEVICE memory {lr, beta1, beta2, eps, completed steps, grad_scale}; the call
+ * hyper: 7 fp32 in DEVICE memory {lr, beta1, beta2, eps, completed steps, grad_scale, weight_decay}; the call
  * increments hyper[4].  Device-resident so a captured hipGraph replays with current values;
  * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float* hyper, void* stream);

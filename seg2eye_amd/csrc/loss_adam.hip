@@ -123,6 +123,7 @@ extern "C" int s2e_loss_grad(int dtype, int mode, const void* a, const void* b, 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
         float* __restrict__ v, long n, const float* __restrict__ hyper) {
     const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], t = hyper[4] + 1.f, grad_scale = hyper[5];
+    const float wd = hyper[6];                              // torch.optim.Adam's L2 term: g += weight_decay * p
     const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
     const float lr_bc1 = lr / bc1, rsqrt_bc2 = 1.f / sqrtf(bc2);
     const long nv = n / 4;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
         f32x4_t pp = ((f32x4_t*)p)[i], gg = ((const f32x4_t*)g)[i], mm = ((f32x4_t*)m)[i], vv = ((f32x4_t*)v)[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float gr = gg[j] * grad_scale;
+            const float gr = gg[j] * grad_scale + wd * pp[j];
             mm[j] = beta1 * mm[j] + (1.f - beta1) * gr;
             vv[j] = beta2 * vv[j] + (1.f - beta2) * gr * gr;
             pp[j] -= lr_bc1 * mm[j] / (sqrtf(vv[j]) * rsqrt_bc2 + eps);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
     }
     if (blockIdx.x == 0)
         for (long i = nv * 4 + threadIdx.x; i < n; i += blockDim.x) {
-            const float gr = g[i] * grad_scale;
+            const float gr = g[i] * grad_scale + wd * p[i];
             const float mi = beta1 * m[i] + (1.f - beta1) * gr;
             const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
             m[i] = mi; v[i] = vi;

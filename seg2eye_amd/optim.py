@@ -11,8 +11,6 @@ _ALIGN = 4          # elements; keeps every parameter 16-byte aligned inside the
 
 class FlatAdam:
     def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        if weight_decay:
-            raise NotImplementedError('weight_decay != 0 is outside the reference defaults this build covers')
         seen, plist = set(), []
         for p in params:
             if id(p) not in seen:
@@ -43,8 +41,8 @@ class FlatAdam:
         self.eps = float(eps)
         self.step_count = 0
         self.param_groups = [{'params': plist, 'lr': float(lr)}]         # update_learning_rate writes ['lr']
-        # device-resident hyper-parameters {lr, beta1, beta2, eps, completed steps, grad_scale}
-        self.hyper = torch.tensor([float(lr), self.betas[0], self.betas[1], self.eps, 0.0, 1.0],
+        # device-resident hyper-parameters {lr, beta1, beta2, eps, completed steps, grad_scale, weight_decay}
+        self.hyper = torch.tensor([float(lr), self.betas[0], self.betas[1], self.eps, 0.0, 1.0, float(weight_decay)],
                                   dtype=torch.float32, device=dev)
         self._hyper_host = (float(lr), 1.0)
 

@@ -163,8 +163,7 @@ def test_flat_adam_arena_aliases_parameters():
     assert float(opt.flat_g.abs().sum()) == 0
     with pytest.raises(Exception):
         opt.step()                                                                        # GPU-only kernel
-    with pytest.raises(NotImplementedError):
-        FlatAdam(list(torch.nn.Linear(2, 2).parameters()), lr=1e-3, weight_decay=0.1)
+    assert float(FlatAdam(list(torch.nn.Linear(2, 2).parameters()), lr=1e-3, weight_decay=0.1).hyper[6]) == pytest.approx(0.1)
 
 
 def test_checkpoint_roundtrip_and_module_prefix(tmp_path):

@@ -300,15 +300,16 @@ def test_losses(dtype, n):
         _close(ag.grad, ar.grad, dtype, what='loss grad %d' % mode)
 
 
-def test_adam_flat_matches_torch():
+@pytest.mark.parametrize('wd', [0.0, 0.05])
+def test_adam_flat_matches_torch(wd):
     from seg2eye_amd.optim import FlatAdam
     dev = _dev()
     n = 10007
     p0 = _rnd((n,), 51, torch.float32)
     ref = torch.nn.Parameter(p0.clone())
-    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.0, 0.9), eps=1e-8)
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.0, 0.9), eps=1e-8, weight_decay=wd)
     mine = torch.nn.Parameter(p0.to(dev).clone())
-    fa = FlatAdam([mine], lr=1e-3, betas=(0, 0.9))
+    fa = FlatAdam([mine], lr=1e-3, betas=(0, 0.9), weight_decay=wd)
     for step in range(1, 5):
         g = _rnd((n,), 60 + step, torch.float32)
         if step == 3:
