@@ -115,7 +115,7 @@ def test_pack_plan_matches_individual_packs(dt):
     for k in (1, 2):
         assert float((runs[k][0] - runs[0][0]).abs().max()) <= tol
         if dt == 'bf16':
-            # measured (tools/debug_plan2.py): with or without the plan two bf16 forwards of this random-weight net
+            # measured (tools/check_bf16_run_to_run.py): with or without the plan two bf16 forwards of this random-weight net
             # differ by ~0.05 -- the 1e-7 float-atomic noise of sigma flips bf16 weight roundings and the
             # InstanceNorm chain amplifies them (fp32: 5e-6).  Gradients are not comparable run to run.
             continue
