@@ -65,6 +65,8 @@ CONV_CASES = [
     (4, 16, 16, 256, 192, 3, 2, 1, False, False, 0, 0, None),    # split-K, stride 2, ragged Cout
     (2, 8, 8, 512, 1, 4, 1, 2, True, False, 0, 0, None),         # split-K with Cout = 1 (scalar finish)
     (2, 8, 8, 128, 256, 3, 1, 1, True, False, 1, 2, None),       # split-K + lrelu prologue + tanh epilogue
+    (1, 64, 64, 16, 128, 3, 1, 1, True, True, 0, 0, None),       # BN = 128 tile WITHOUT split-K (3 K-tiles): the big layers' path
+    (1, 48, 40, 32, 72, 3, 1, 1, True, False, 0, 0, None),       # ... and the 64 < Cout <= 128 ragged variant, 5 K-tiles
     (3, 15, 22, 24, 40, 4, 2, 2, True, False, 0, 0, None),       # stride-2 dgrad by parity class: odd x even, ragged channels
     (1, 13, 9, 16, 24, 3, 2, 1, False, False, 0, 0, None),       # ... 3x3: classes with 2x2, 2x1, 1x2, 1x1 taps
 ]
