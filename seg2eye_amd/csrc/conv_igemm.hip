@@ -18,6 +18,7 @@
 //   the 1-D grid is remapped so tiles sharing an A panel (same pixel rows) run on one XCD's L2.
 #include "common.h"
 #include "conv_small.h"
+#include "conv_patch.h"
 #include <stdlib.h>
 
 struct ConvKParams {
@@ -611,7 +612,7 @@ static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tile
 
 extern "C" size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d) {
     if (!d) return 0;
-    if (s2e_small_conv_kind(dtype, d) != SMALL_NONE) return 0;
+    if (s2e_small_conv_kind(dtype, d) != SMALL_NONE || s2e_conv_patch_plan(dtype, d)) return 0;
     int tiles, tiles_n, splits, per;
     plan_splits(dtype, d, &tiles, &tiles_n, &splits, &per);
     return splits > 1 ? (size_t)splits * d->N * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
@@ -637,6 +638,9 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
         sp.Kpad = s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin);
         return s2e_small_conv_launch(dtype, kind, sp, (hipStream_t)stream);
     }
+    if (const int tile_w = s2e_conv_patch_plan(dtype, d))          // big 3x3 stride-1 layers: patch-resident kernel
+        return s2e_conv_patch_launch(dtype, tile_w, x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin),
+                                     (hipStream_t)stream);
     ConvKParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;

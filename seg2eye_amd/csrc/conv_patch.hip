@@ -1,0 +1,355 @@
+// Patch-resident 3x3 stride-1 convolution (forward and data-gradient) for gfx950.
+//
+// Why a second conv kernel.  The generic implicit GEMM (conv_igemm.hip) re-gathers the im2col panel from L2 for every
+// tap: a 128 x 128 x 64 K-step moves 32 KB through the CU's vector-memory path for 2.1 MFLOP.  That path -- not the
+// MFMA pipe, not LDS, not HBM -- is what the large layers run against: with the MFMAs removed the same loop takes 80 %
+// of the full kernel's time (55 GB/s per CU, 14 TB/s chip-wide; the LDS-DMA gather ceiling measured for this chip is
+// 66-73 GB/s per CU), with the loads removed it runs at 1.2-1.5 PFLOP/s.  Deeper pipelines, more resident waves and a
+// 256-pixel tile at the same per-tap gather all measured flat, because none of them changes bytes per FLOP enough.
+//
+// Here a workgroup owns a RECTANGLE of 256 output pixels (4 x 64 or 8 x 32) and, per 64-channel chunk of Cin, brings
+// the input patch with its halo ((TH+2) x (TW+2) pixels x 128 B, <= 400 pixels = 50 KB) into LDS ONCE; the nine taps
+// are nine shifted views of that patch.  Per chunk and 256 pixels the vector-memory path carries 50 KB of activations
+// + 9 x 16 KB of weights = 194 KB instead of 9 x (32 + 16) = 432 KB at the same tile (576 KB as two 128-pixel tiles).
+//
+//   LDS        : 2 patch buffers (chunk c is read while c+1 lands, one 1-KiB piece per thread per tap) + 2 weight
+//                K-step buffers = 2 x 51,200 + 2 x 16,384 B = 135 KB -> one 512-thread workgroup per CU.
+//   patch image: pixel pp = py * PW + px at byte pp * 128, 16-B chunk index XORed with (pp >> 1) & 7 (source-side
+//                swizzle of the LDS-DMA, as in conv_igemm.hip).  An A fragment is 32 consecutive tx of one tile row =
+//                32 consecutive pp at ANY tap shift, so every ds_read_b128 stays conflict-free.
+//   waves      : 8 = 4 (pixels) x 2 (channels), wave tile 64 x BN/2, v_mfma_f32_32x32x16_bf16 (32x32x2 f32 for fp32).
+//   K order    : chunk-major, tap-minor; the packed weight matrix (row co, k = tap * Cin + ci) is used as it is.
+//   data-gradient (stride 1): the same kernel with the patch origin moved to o + pad - 2 and the taps mirrored.
+//   epilogue   : fp32 accumulators -> LDS in two 128-row halves -> 16-B row stores with bias / residual / activation /
+//                mask fused (same contract as conv_igemm.hip).
+#include "conv_patch.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __attribute__((aligned(16))) const uint32_t pz_zero16[4] = {0u, 0u, 0u, 0u};
+
+struct PatchParams {
+    const void* x; const void* w; const float* bias; const void* res; const void* aux; void* y;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout, Kpad;
+    int org;                      // patch origin = tile origin + org (forward: -pad; data-gradient: pad - (KS-1))
+    int flip;                     // data-gradient: patch offset t pairs with weight tap T-1-t
+    int out_act, aux_mode;
+    int tw_shift;                 // tile width 64 (6) or 32 (5); height = 256 / width
+    int tiles_x, tiles_y, tiles_n, tiles;
+};
+
+template <typename T> struct PMfma;
+template <> struct PMfma<bf16_t> {
+    static __device__ __forceinline__ void run(u32x4_t a, u32x4_t b, f32x16_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct PMfma<float> {           // same k permutation on both operands: exact contraction (see conv_igemm.hip)
+    static __device__ __forceinline__ void run(u32x4_t a, u32x4_t b, f32x16_t& acc) {
+        const f32x4_t fa = __builtin_bit_cast(f32x4_t, a), fb = __builtin_bit_cast(f32x4_t, b);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], acc, 0, 0, 0);
+    }
+};
+
+template <typename T, int BN, int KS>
+__global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p) {
+    constexpr int BM = 256, NW = 8, NT = 512;
+    constexpr int VEC = Vec<T>::N, BK = 8 * VEC;      // one 128-byte row of K per pixel / weight row
+    constexpr int TAPS = KS * KS;
+    constexpr int WN = 2, WM = NW / WN, WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int PPX = (KS == 3) ? 400 : 472;        // patch capacity in pixels: (4+KS-1) x (64+KS-1) rounded up to 8
+    constexpr int NPIECE = PPX / 8;                   // 1-KiB LDS-DMA pieces (8 pixels x 128 B) per patch
+    constexpr int NR = (NPIECE + NW - 1) / NW;        // pieces per thread per patch
+    constexpr int NBJ = BN / 64;                      // weight pieces per thread per K-step
+    constexpr int NBS = 3;                            // weight stages: K-step kt+2 is in flight while kt is multiplied
+    constexpr int P_BYTES = PPX * 128, B_BYTES = BN * 128;
+    constexpr int EP_ROWS = WTM;                      // epilogue staging: one wave row (64 pixels) per pass
+    static_assert(NR <= TAPS, "one patch piece per tap must cover the patch");
+    static_assert(EP_ROWS * BN * 4 <= P_BYTES, "epilogue staging must fit one patch buffer");
+    static_assert(2 * P_BYTES + NBS * B_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) char smem[2 * P_BYTES + NBS * B_BYTES];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int TW = 1 << p.tw_shift, TH = BM >> p.tw_shift;
+    const int PW = TW + KS - 1, PH = TH + KS - 1;
+    const T* __restrict__ xg = (const T*)p.x;
+    const T* __restrict__ wgt = (const T*)p.w;
+    T* __restrict__ yg = (T*)p.y;
+    const T* __restrict__ resg = (const T*)p.res;
+    const T* __restrict__ auxg = (const T*)p.aux;
+    const int nch = p.Cin / BK, nk = nch * TAPS;
+
+    // ---- tiles: the grid is persistent (one workgroup per CU); round k works tiles k*G .. k*G+G-1, handed out so that an
+    // XCD's workgroups hold a contiguous range (Cout tiles of one rectangle, then x, then y neighbours share L2 lines)
+    struct Tile { int tn, n, oy0, ox0; };
+    auto decode = [&](int id) __attribute__((always_inline)) -> Tile {
+        Tile q;
+        q.tn = id % p.tiles_n; id /= p.tiles_n;
+        q.ox0 = (id % p.tiles_x) << p.tw_shift; id /= p.tiles_x;
+        q.oy0 = (id % p.tiles_y) * TH;
+        q.n = id / p.tiles_y;
+        return q;
+    };
+    const int G = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, G);
+    int tile_id = slot;
+    if (tile_id >= p.tiles) return;
+
+    // ---- loads of one tile.  Patch piece q = r * NW + wave covers patch pixels 8q .. 8q+7; this lane brings the 16 bytes
+    // at physical chunk lane & 7 of pixel 8q + (lane >> 3), i.e. logical chunk (lane & 7) ^ swz(pixel).
+    long aoff[NR];                                    // element offset of those 16 B in chunk 0; < 0: zero page
+    const T* wrow;                                    // this lane's 16 B of weight row 8 * wave + (lane >> 3), k = 0
+    const int brow = 8 * wave + (lane >> 3);
+    auto aim = [&](const Tile& q) __attribute__((always_inline)) {
+        const int iy0 = q.oy0 + p.org, ix0 = q.ox0 + p.org;
+        static_for<0, NR>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            const int pp = 8 * (r * NW + wave) + (lane >> 3);
+            const int py = pp / PW, px = pp - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool ok = py < PH && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const int lc = (lane & 7) ^ ((pp >> 1) & 7);
+            aoff[r] = ok ? ((long)(q.n * p.Hi + iy) * p.Wi + ix) * p.Cin + lc * VEC : -1L;
+        });
+        wrow = wgt + (size_t)(q.tn * BN + brow) * p.Kpad + ((lane & 7) ^ ((brow >> 1) & 7)) * VEC;
+    };
+    auto dma_patch = [&](auto R, int chunk, int buf) __attribute__((always_inline)) -> int {
+        constexpr int r = decltype(R)::value;
+        if (r * NW + wave >= NPIECE) return 0;        // wave-uniform
+        const void* src = aoff[r] >= 0 ? (const void*)(xg + aoff[r] + chunk * BK) : (const void*)pz_zero16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * P_BYTES + (r * NW + wave) * 1024), 16, 0, 0);
+        return 1;
+    };
+    auto dma_w = [&](int kt, int stage) __attribute__((always_inline)) {     // K-step kt = chunk * TAPS + patch offset
+        const int chunk = kt / TAPS, tp = kt - chunk * TAPS;
+        const T* src = wrow + (p.flip ? TAPS - 1 - tp : tp) * p.Cin + chunk * BK;
+        static_for<0, NBJ>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            __builtin_amdgcn_global_load_lds((gptr_t)(const void*)(src + (size_t)(64 * j) * p.Kpad),
+                                             (lptr_t)(smem + 2 * P_BYTES + stage * B_BYTES + (8 * wave + 64 * j) * 128), 16, 0, 0);
+        });
+    };
+    auto prologue = [&](int pbuf) __attribute__((always_inline)) {
+        static_for<0, NR>([&](auto R) { dma_patch(R, 0, pbuf); });
+        dma_w(0, 0);
+        if (nk > 1) dma_w(1, 1);
+    };
+    auto wait_keep = [&](int n) __attribute__((always_inline)) {             // all but the n youngest loads have landed
+        if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    };
+    static_assert(NBJ + 1 <= 3, "wait_keep covers up to 3 loads per tap");
+
+    // patch pixel of this lane's fragment row at offset (0,0): 32 lanes = 32 consecutive tx of one tile row
+    int pp0[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int r = wm * WTM + mi * 32 + l31;
+        pp0[mi] = (r >> p.tw_shift) * PW + (r & (TW - 1));
+    }
+    int boff[TN], bq[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int row = wn * WTN + ni * 32 + l31;
+        boff[ni] = row * 128; bq[ni] = (row >> 1) & 7;
+    }
+    f32x16_t acc[TM][TN];
+    auto compute = [&](auto TAP, int pbuf, int stage) __attribute__((always_inline)) {
+        constexpr int tap = decltype(TAP)::value;
+        constexpr int dy = tap / KS, dx = tap % KS;
+        const char* Ps = smem + pbuf * P_BYTES;
+        const char* Bs = smem + 2 * P_BYTES + stage * B_BYTES;
+        int abase[TM], aq[TM];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            // opaque to the optimiser: otherwise all TAPS x 4 x TM fragment addresses are hoisted out of the chunk loop
+            // (loop-invariant) and 70 address registers push the accumulators into scratch
+            asm volatile("" : "+v"(pp0[mi]));
+            const int pp = pp0[mi] + dy * PW + dx;
+            abase[mi] = pp * 128; aq[mi] = (pp >> 1) & 7;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int chunk = 2 * s + h;
+            u32x4_t a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[mi] = *(const u32x4_t*)(Ps + abase[mi] + ((chunk ^ aq[mi]) << 4));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) b[ni] = *(const u32x4_t*)(Bs + boff[ni] + ((chunk ^ bq[ni]) << 4));
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) PMfma<T>::run(a[mi], b[ni], acc[mi][ni]);
+        }
+    };
+
+    constexpr int TPR = BN / VEC, RPP = NT / TPR;
+    const int cw = (tid % TPR) * VEC;
+    // fp32 accumulators -> LDS (one 64-pixel wave row per pass, staged in the patch buffer `sbuf`) -> 16-B row stores
+    auto epilogue = [&](const Tile& q, int sbuf) __attribute__((always_inline)) {
+        float* Cs = (float*)(smem + sbuf * P_BYTES);
+        const int co = q.tn * BN + cw;
+#pragma unroll
+        for (int ep = 0; ep < WM; ++ep) {
+            if (ep > 0) __syncthreads();
+            if (wm == ep) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            Cs[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wn * WTN + ni * 32 + l31] = acc[mi][ni][r];
+            }
+            __syncthreads();
+            for (int row = tid / TPR; row < EP_ROWS; row += RPP) {
+                const int tr = ep * EP_ROWS + row;
+                const int oy = q.oy0 + (tr >> p.tw_shift), ox = q.ox0 + (tr & (TW - 1));
+                if (oy >= p.Ho || ox >= p.Wo || co >= p.Cout) continue;
+                float v[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; j += 4) {
+                    const f32x4_t f = *(const f32x4_t*)(Cs + row * BN + cw + j);
+                    v[j] = f[0]; v[j + 1] = f[1]; v[j + 2] = f[2]; v[j + 3] = f[3];
+                }
+                const size_t o = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
+                if (p.bias) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j] += p.bias[co + j];
+                }
+                if (resg) {
+                    float rr[VEC];
+                    unpack16<T>(*(const u32x4_t*)(resg + o), rr);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j] += rr[j];
+                }
+                if (p.out_act == S2E_ACT_LRELU) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j] = lrelu02(v[j]);
+                } else if (p.out_act == S2E_ACT_TANH) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j] = tanhf(v[j]);
+                }
+                if (p.aux_mode != S2E_AUX_NONE) {
+                    float aa[VEC];
+                    unpack16<T>(*(const u32x4_t*)(auxg + o), aa);
+                    const float neg = (p.aux_mode == S2E_AUX_RELU_MASK) ? 0.f : 0.2f;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j] *= (aa[j] > 0.f ? 1.f : neg);
+                }
+                *(u32x4_t*)(yg + o) = pack16<T>(v);
+            }
+        }
+    };
+
+    Tile cur = decode(tile_id);
+    aim(cur);
+    int pb = 0;                                       // patch buffer of the current tile's chunk 0
+    prologue(pb);
+    for (;;) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        int kt = 0, stage = 0;
+        for (int c = 0; c < nch; ++c) {
+            const bool more = c + 1 < nch;
+            const int pcur = (pb + c) & 1;
+            static_for<0, TAPS>([&](auto TAP) {
+                constexpr int tap = decltype(TAP)::value;
+                int issued = 0;
+                if constexpr (tap < NR) { if (more) issued += dma_patch(TAP, c + 1, pcur ^ 1); }
+                if (kt + 2 < nk) { dma_w(kt + 2, stage == 0 ? 2 : stage - 1); issued += NBJ; }
+                compute(TAP, pcur, stage);
+                wait_keep(issued);                    // K-step kt+1 (and every older patch piece) has landed
+                __syncthreads();
+                ++kt; stage = stage == NBS - 1 ? 0 : stage + 1;
+            });
+        }
+        // every buffer is free now: start the next tile's loads, then write this tile out underneath them
+        const int pbn = (pb + nch) & 1;               // continues the alternation; the other one stages the epilogue
+        const int next_id = tile_id + G;
+        const bool has_next = next_id < p.tiles;
+        Tile nxt = cur;
+        if (has_next) { nxt = decode(next_id); aim(nxt); prologue(pbn); }
+        epilogue(cur, pbn ^ 1);
+        if (!has_next) break;
+        cur = nxt; tile_id = next_id; pb = pbn;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ host side
+// Shapes this kernel takes: 3x3, stride 1 (forward or data-gradient), no fused input activation, Cin a multiple of the
+// 128-byte K row, Cout a multiple of the 16-byte vector and > 32, and enough 256-pixel rectangles to fill the chip with
+// at least 80 % of their pixels inside the image.  Everything else stays on conv_igemm.hip.
+int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d) {
+    static const int min_tiles = [] { const char* e = getenv("S2E_CONV_PATCH"); return e ? atoi(e) : 224; }();
+    if (min_tiles <= 0) return 0;
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->in_act != S2E_ACT_NONE) return 0;
+    if (d->Cin % (8 * vec) != 0 || d->Cout % vec != 0 || d->Cout <= 32) return 0;
+    const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;
+    if (d->Ho != d->Hi + grow || d->Wo != d->Wi + grow) return 0;
+    const int bn = d->Cout > 64 ? 128 : 64;
+    int best = 0; double best_fill = 0.0;
+    for (int tw = 64; tw >= 32; tw >>= 1) {
+        const int th = 256 / tw;
+        const long covered = (long)ceil_div(d->Ho, th) * th * ceil_div(d->Wo, tw) * tw;
+        const double fill = (double)d->Ho * d->Wo / (double)covered;
+        if (fill > best_fill + 1e-9) { best_fill = fill; best = tw; }
+    }
+    if (best_fill < 0.8) return 0;
+    const long tiles = (long)d->N * ceil_div(d->Ho, 256 / best) * ceil_div(d->Wo, best) * ceil_div(d->Cout, bn);
+    return tiles >= min_tiles ? best : 0;
+}
+
+static int cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+template <typename T, int BN>
+static int launch_patch(const PatchParams& p, hipStream_t st) {
+    const int grid = p.tiles < cu_count() ? p.tiles : cu_count();      // persistent: one 135-151 KB workgroup per CU
+    conv_patch_kernel<T, BN, 3><<<grid, 512, 0, st>>>(p);
+    S2E_CHECK_LAUNCH("conv_patch_kernel");
+    return S2E_OK;
+}
+
+int s2e_conv_patch_launch(int dtype, int tile_w, const void* x, const void* w, const float* bias, const void* res,
+                          const void* aux, void* y, const s2e_conv_desc* d, int kpad, hipStream_t st) {
+    PatchParams p{};
+    p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
+    p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.Kpad = kpad;
+    p.org = d->transposed ? d->pad - 2 : -d->pad;
+    p.flip = d->transposed ? 1 : 0;
+    p.out_act = d->out_act; p.aux_mode = d->aux_mode;
+    p.tw_shift = tile_w == 64 ? 6 : 5;
+    const int bn = d->Cout > 64 ? 128 : 64;
+    p.tiles_x = ceil_div(d->Wo, tile_w); p.tiles_y = ceil_div(d->Ho, 256 / tile_w); p.tiles_n = ceil_div(d->Cout, bn);
+    p.tiles = p.N * p.tiles_y * p.tiles_x * p.tiles_n;
+    if (dtype == S2E_BF16) return bn == 128 ? launch_patch<bf16_t, 128>(p, st) : launch_patch<bf16_t, 64>(p, st);
+    if (dtype == S2E_F32) return bn == 128 ? launch_patch<float, 128>(p, st) : launch_patch<float, 64>(p, st);
+    S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: bad dtype %d", dtype);
+}
