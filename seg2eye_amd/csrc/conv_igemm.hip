@@ -415,6 +415,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
         }
         return;
     }
+    // the per-channel bias is the same for every row of this thread: fetch it once (inside the row loop it is re-loaded
+    // per row, because the stores may alias it, and every iteration then waits out a global-load round trip)
+    float bv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) bv[j] = (p.bias && cvec && co < p.Cout) ? p.bias[co + j] : 0.f;
     for (int row = tid / TPR; row < BM; row += RPP) {
         int m = tm * BM + row;
         if constexpr (S2) {                              // class-local row -> output pixel
@@ -432,10 +437,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKParams p)
         }
         const size_t o = (size_t)m * p.Cout + co;
         if (cvec) {
-            if (p.bias) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) v[j] += p.bias[co + j];
-            }
+            for (int j = 0; j < VEC; ++j) v[j] += bv[j];
             if (resg) {
                 float rr[VEC];
                 unpack16<T>(*(const u32x4_t*)(resg + o), rr);

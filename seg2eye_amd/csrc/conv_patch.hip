@@ -165,33 +165,48 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         boff[ni] = row * 128; bq[ni] = (row >> 1) & 7;
     }
     f32x16_t acc[TM][TN];
-    auto compute = [&](auto TAP, int pbuf, int stage) __attribute__((always_inline)) {
-        constexpr int tap = decltype(TAP)::value;
-        constexpr int dy = tap / KS, dx = tap % KS;
-        const char* Ps = smem + pbuf * P_BYTES;
-        const char* Bs = smem + 2 * P_BYTES + stage * B_BYTES;
-        int abase[TM], aq[TM];
+    // ---- the multiply loop is software-pipelined by hand.  Left to the compiler it reads one fragment set, waits for
+    // it (lgkmcnt(0)) and only then issues its MFMAs, so every LDS round trip is exposed, and __syncthreads() carries a
+    // vmcnt(0) that would drain the K-step-ahead loads at every barrier.  Here: two fragment sets (the reads of step s+1
+    // are issued before the MFMAs of step s wait for theirs), counted waits, a bare s_barrier, and the first fragment set
+    // of the NEXT K-step is requested right after the barrier, underneath the last four MFMAs of this one.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    u32x4_t fa[2][TM], fb[2][TN];
+    uint32_t a_addr[TM], b_addr[TN];                  // fragment addresses of the current K-step at s = 0; s flips bits 5-6
+    auto aim_frags = [&](int dy, int dx, int pbuf, int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
-            // opaque to the optimiser: otherwise all TAPS x 4 x TM fragment addresses are hoisted out of the chunk loop
-            // (loop-invariant) and 70 address registers push the accumulators into scratch
-            asm volatile("" : "+v"(pp0[mi]));
             const int pp = pp0[mi] + dy * PW + dx;
-            abase[mi] = pp * 128; aq[mi] = (pp >> 1) & 7;
+            a_addr[mi] = lds0 + pbuf * P_BYTES + pp * 128 + ((h ^ ((pp >> 1) & 7)) << 4);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int chunk = 2 * s + h;
-            u32x4_t a[TM], b[TN];
+        for (int ni = 0; ni < TN; ++ni) b_addr[ni] = lds0 + 2 * P_BYTES + stage * B_BYTES + boff[ni] + ((h ^ bq[ni]) << 4);
+    };
+    auto read_frags = [&](int set, int sstep) __attribute__((always_inline)) {     // logical chunk 2s + h = (h ^ q) ^ 2s
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) a[mi] = *(const u32x4_t*)(Ps + abase[mi] + ((chunk ^ aq[mi]) << 4));
+        for (int mi = 0; mi < TM; ++mi)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][mi]) : "v"(a_addr[mi] ^ (uint32_t)(sstep << 5)) : "memory");
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) b[ni] = *(const u32x4_t*)(Bs + boff[ni] + ((chunk ^ bq[ni]) << 4));
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) PMfma<T>::run(a[mi], b[ni], acc[mi][ni]);
+        for (int ni = 0; ni < TN; ++ni)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][ni]) : "v"(b_addr[ni] ^ (uint32_t)(sstep << 5)) : "memory");
+    };
+    // wait until only the NEWEST `TM + TN` LDS reads (or none) are outstanding; the fragment registers are operands so
+    // that no MFMA consuming them can be scheduled above the wait
+    auto frags_ready = [&](int set, bool all) __attribute__((always_inline)) {
+        static_assert(TM == 2 && (TN == 2 || TN == 1), "operand lists below");
+        if constexpr (TN == 2) {
+            if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fb[set][0]), "+v"(fb[set][1]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fb[set][0]), "+v"(fb[set][1]) :: "memory");
+        } else {
+            if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fb[set][0]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fb[set][0]) :: "memory");
         }
+    };
+    auto mfmas = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) PMfma<T>::run(fa[set][mi], fb[set][ni], acc[mi][ni]);
     };
 
     constexpr int TPR = BN / VEC, RPP = NT / TPR;
@@ -200,8 +215,29 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     auto epilogue = [&](const Tile& q, int sbuf) __attribute__((always_inline)) {
         float* Cs = (float*)(smem + sbuf * P_BYTES);
         const int co = q.tn * BN + cw;
+        const bool cok = co < p.Cout;
+        // the per-channel bias is the same for every row this thread writes: fetch it once (left in the row loop it is
+        // re-loaded per row -- the stores may alias it -- and every sweep then waits out a global-load round trip)
+        float bv[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) bv[j] = (p.bias && cok) ? p.bias[co + j] : 0.f;
+        constexpr int SWEEPS = EP_ROWS / RPP;
+        static_assert(EP_ROWS % RPP == 0, "whole sweeps");
 #pragma unroll
         for (int ep = 0; ep < WM; ++ep) {
+            // residual / mask operands of this pass are requested before the staging round trip, not after it
+            size_t o[SWEEPS]; bool live[SWEEPS];
+            u32x4_t rr[SWEEPS], aa[SWEEPS];
+#pragma unroll
+            for (int sw = 0; sw < SWEEPS; ++sw) {
+                const int tr = ep * EP_ROWS + sw * RPP + tid / TPR;
+                const int oy = q.oy0 + (tr >> p.tw_shift), ox = q.ox0 + (tr & (TW - 1));
+                live[sw] = cok && oy < p.Ho && ox < p.Wo;
+                o[sw] = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
+                rr[sw] = u32x4_t{0u, 0u, 0u, 0u}; aa[sw] = rr[sw];
+                if (live[sw] && resg) rr[sw] = *(const u32x4_t*)(resg + o[sw]);
+                if (live[sw] && p.aux_mode != S2E_AUX_NONE) aa[sw] = *(const u32x4_t*)(auxg + o[sw]);
+            }
             if (ep > 0) __syncthreads();
             if (wm == ep) {
 #pragma unroll
@@ -213,26 +249,21 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                             Cs[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wn * WTN + ni * 32 + l31] = acc[mi][ni][r];
             }
             __syncthreads();
-            for (int row = tid / TPR; row < EP_ROWS; row += RPP) {
-                const int tr = ep * EP_ROWS + row;
-                const int oy = q.oy0 + (tr >> p.tw_shift), ox = q.ox0 + (tr & (TW - 1));
-                if (oy >= p.Ho || ox >= p.Wo || co >= p.Cout) continue;
+#pragma unroll
+            for (int sw = 0; sw < SWEEPS; ++sw) {
+                if (!live[sw]) continue;
+                const int row = sw * RPP + tid / TPR;
                 float v[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; j += 4) {
                     const f32x4_t f = *(const f32x4_t*)(Cs + row * BN + cw + j);
-                    v[j] = f[0]; v[j + 1] = f[1]; v[j + 2] = f[2]; v[j + 3] = f[3];
-                }
-                const size_t o = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
-                if (p.bias) {
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) v[j] += p.bias[co + j];
+                    v[j] = f[0] + bv[j]; v[j + 1] = f[1] + bv[j + 1]; v[j + 2] = f[2] + bv[j + 2]; v[j + 3] = f[3] + bv[j + 3];
                 }
                 if (resg) {
-                    float rr[VEC];
-                    unpack16<T>(*(const u32x4_t*)(resg + o), rr);
+                    float t[VEC];
+                    unpack16<T>(rr[sw], t);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) v[j] += rr[j];
+                    for (int j = 0; j < VEC; ++j) v[j] += t[j];
                 }
                 if (p.out_act == S2E_ACT_LRELU) {
 #pragma unroll
@@ -242,13 +273,13 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                     for (int j = 0; j < VEC; ++j) v[j] = tanhf(v[j]);
                 }
                 if (p.aux_mode != S2E_AUX_NONE) {
-                    float aa[VEC];
-                    unpack16<T>(*(const u32x4_t*)(auxg + o), aa);
+                    float t[VEC];
+                    unpack16<T>(aa[sw], t);
                     const float neg = (p.aux_mode == S2E_AUX_RELU_MASK) ? 0.f : 0.2f;
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) v[j] *= (aa[j] > 0.f ? 1.f : neg);
+                    for (int j = 0; j < VEC; ++j) v[j] *= (t[j] > 0.f ? 1.f : neg);
                 }
-                *(u32x4_t*)(yg + o) = pack16<T>(v);
+                *(u32x4_t*)(yg + o[sw]) = pack16<T>(v);
             }
         }
     };
@@ -267,21 +298,36 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         int kt = 0, stage = 0;
+        aim_frags(0, 0, pb, 0);
+        read_frags(0, 0);
         for (int c = 0; c < nch; ++c) {
             const bool more = c + 1 < nch;
             const int pcur = (pb + c) & 1;
             static_for<0, TAPS>([&](auto TAP) {
                 constexpr int tap = decltype(TAP)::value;
+                constexpr int ntap = (tap + 1) % TAPS;
                 int issued = 0;
                 if constexpr (tap < NR) { if (more) issued += dma_patch(TAP, c + 1, pcur ^ 1); }
                 if (kt + 2 < nk) { dma_w(kt + 2, stage == 0 ? 2 : stage - 1); issued += NBJ; }
-                compute(TAP, pcur, stage);
-                wait_keep(issued);                    // K-step kt+1 (and every older patch piece) has landed
-                __syncthreads();
-                ++kt; stage = stage == NBS - 1 ? 0 : stage + 1;
+                read_frags(1, 1); frags_ready(0, false); mfmas(0);
+                read_frags(0, 2); frags_ready(1, false); mfmas(1);
+                read_frags(1, 3); frags_ready(0, false); mfmas(0);
+                // K-step kt+1 (and every older patch piece) has landed for this wave once all but this K-step's loads are
+                // back; every LDS read of K-step kt is back; then all waves meet
+                wait_keep(issued);
+                frags_ready(1, true);
+                __builtin_amdgcn_s_barrier();
+                stage = stage == NBS - 1 ? 0 : stage + 1;
+                ++kt;
+                if (kt < nk) {
+                    aim_frags(ntap / KS, ntap % KS, ntap == 0 ? pcur ^ 1 : pcur, stage);
+                    read_frags(0, 0);
+                }
+                mfmas(1);
             });
         }
-        // every buffer is free now: start the next tile's loads, then write this tile out underneath them
+        // every buffer is free now (the last barrier is behind every LDS read): start the next tile's loads, then write
+        // this tile out underneath them
         const int pbn = (pb + nch) & 1;               // continues the alternation; the other one stages the epilogue
         const int next_id = tile_id + G;
         const bool has_next = next_id < p.tiles;
