@@ -14,6 +14,7 @@
 // 128-B row segments (the shape global float atomics run at full rate for).
 #include "common.h"
 #include "conv_small.h"
+#include "conv_wgrad_patch.h"
 #include <stdlib.h>
 
 struct WgradParams {
@@ -416,6 +417,8 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
         if (dbias) return s2e_colsum(dtype, gy, (long)d->N * d->Ho * d->Wo, d->Cout, dbias, stream);
         return S2E_OK;
     }
+    if (const int slab_w = s2e_wgrad_patch_plan(dtype, d))          // big 3x3 stride-1 layers: patch-resident kernel
+        return s2e_wgrad_patch_launch(slab_w, x, gy, dw, dbias, d, (hipStream_t)stream);
     WgradParams p;
     p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;

@@ -1,0 +1,8 @@
+// Internal interface of the patch-resident 3x3 stride-1 weight-gradient kernel (conv_wgrad_patch.hip).
+#pragma once
+#include "common.h"
+
+// 0 = the generic kernel (conv_wgrad.hip) runs this shape; otherwise the pixel-slab width (32 or 64)
+int s2e_wgrad_patch_plan(int dtype, const s2e_conv_desc* d);
+int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
+                           hipStream_t st);

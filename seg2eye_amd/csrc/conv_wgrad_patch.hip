@@ -1,0 +1,281 @@
+// Patch-resident 3x3 stride-1 weight gradient for gfx950 (bf16, NHWC, fp32 accumulate).
+//
+//   dW[co][t * Cin + ci] += sum over pixels  gy[pixel][co] * x[pixel + tap t][ci]
+//
+// The generic kernel (conv_wgrad.hip) gives a workgroup a 128(co) x 128(k) tile of dW and streams, per 32 pixels,
+// 8 KB of gy and 8 KB of tap-shifted x for 1 MFLOP.  Like the forward gather this runs against the CU's
+// vector-memory path (see conv_patch.hip), at 65 FLOP per byte brought into LDS.  Here a workgroup owns
+// 128 co x 64 ci x ALL NINE TAPS (nine 128 x 64 accumulator tiles: 144 registers per lane over 8 waves) and walks
+// pixel slabs of 128 pixels (2 x 64 or 4 x 32): per slab it brings the gy rows (32 KB) and ONE x patch with its halo
+// (4 x 66 pixels x 128 B = 33 KB) into LDS; the nine taps are nine shifted views of the patch.  19 MFLOP per 65 KB:
+// 290 FLOP per byte, so the loop is paced by the matrix pipe instead of the load path.
+//
+//   operands   : the contraction runs over pixels, the slow index of both NHWC tensors, so tiles stay [pixel][channel]
+//                in LDS and fragments are fetched with ds_read_b64_tr_b16 (as in conv_wgrad.hip).  gy rows are 256 B
+//                with the 16-B chunk XORed by (row & 3) << 2; x rows are 128 B with chunk bit 2 XORed by bit 1 of the
+//                patch pixel index: any four consecutive rows -- at ANY tap shift -- then sit in four disjoint 64-B
+//                bank ranges.  Both swizzles are applied on the source side of the LDS-DMA.
+//   pipeline   : two stages of (patch + gy rows) = 2 x 66,560 B; the next slab's 65 one-KiB pieces are issued during
+//                the first five of the eight 16-pixel groups of the current slab; one barrier per slab.
+//   waves      : 8 = 4 (co blocks of 32) x 2 (ci blocks of 32); per 16-pixel group a wave reads one gy fragment and nine
+//                x fragments and issues nine MFMAs, the next fragment requested before each MFMA.
+//   bias grad  : sum over pixels of gy = gy^T x ones: one extra MFMA per group against a constant all-ones fragment,
+//                shared between the two ci waves (alternate groups) and between the ci-tile workgroups (alternate slabs).
+//   combine    : fp32 atomics in 128-B row segments, one per accumulator register, into the caller's dW.
+#include "conv_wgrad_patch.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __attribute__((aligned(16))) const uint32_t wz_zero16[4] = {0u, 0u, 0u, 0u};
+
+struct WpParams {
+    const void* x; const void* gy; float* dw; float* dbias;
+    int N, H, W, Cin, Cout, Ktot;
+    int tw_shift;                 // slab width 64 (6) or 32 (5); height = 128 / width
+    int sx, sy, nslabs;           // slabs per image in x and y; N * sy * sx
+    int per_split, tiles_co, tiles_ci;
+};
+
+// One MFMA operand = rows r and r+4 of a 4x16 transpose block (lane roles: conv_wgrad.hip).  The reads are inline asm with
+// hand-counted waits: through the builtin the compiler puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 that
+// follows an LDS-DMA (it cannot tell the DMA's destination stage from the stage being read), which serialises the next
+// slab's loads with this slab's MFMAs.
+struct TrFrag { u32x2_t lo, hi; };
+template <int HI_OFF>
+__device__ __forceinline__ void tr_issue(TrFrag& f, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(HI_OFF) : "memory");
+}
+// all but the newest KEEP LDS reads are back; a and b are operands so no MFMA on them can move above the wait
+template <int KEEP>
+__device__ __forceinline__ void tr_ready(TrFrag& a, TrFrag& b) {
+    static_assert(KEEP == 0 || KEEP == 2 || KEEP == 4, "counted waits used by the loop");
+    if constexpr (KEEP == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) :: "memory");
+    else if constexpr (KEEP == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) :: "memory");
+}
+__device__ __forceinline__ bf16x8_t tr_operand(const TrFrag& f) {
+    return __builtin_bit_cast(bf16x8_t, u32x4_t{f.lo.x, f.lo.y, f.hi.x, f.hi.y});
+}
+
+__global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams p) {
+    typedef bf16_t T;
+    constexpr int NW = 8;
+    constexpr int XPX = 264;                          // patch capacity: 4 x 66 (6 x 34 = 204 for the narrow slab)
+    constexpr int X_BYTES = XPX * 128, G_BYTES = 128 * 256, STAGE = X_BYTES + G_BYTES;
+    constexpr int NPI = 9;                            // pieces per thread per slab: 4 gy, 4 x, +1 x (wave 0)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave >> 1, cib = wave & 1;
+    // workgroups of one pixel split (all their co / ci tiles stream the same rows) sit on one XCD
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tci = bid % p.tiles_ci; bid /= p.tiles_ci;
+    const int tco = bid % p.tiles_co;
+    const int split = bid / p.tiles_co;
+    const int s0 = split * p.per_split, s1 = min(p.nslabs, s0 + p.per_split);
+    if (s0 >= s1) return;
+    const int TW = 1 << p.tw_shift, TH = 128 >> p.tw_shift, PW = TW + 2, PH = TH + 2;
+    const T* __restrict__ xg = (const T*)p.x;
+    const T* __restrict__ gg = (const T*)p.gy;
+
+    // ---- LDS-DMA pieces of this thread.  i < 4: gy piece q = 8 i + wave, rows (slab pixels) 4q .. 4q+3, 16 lanes per
+    // 256-B row; i >= 4: x piece xq = 8 (i - 4) + wave (xq = 32: wave 0 only), patch pixels 8 xq .. +7, 8 lanes per row.
+    int pdyx[NPI], pcol[NPI];                         // pixel offset from the slab origin (dy << 16 | dx + 1); channel (or -1: zero page)
+    static_for<0, NPI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < 4) {
+            const int j = 4 * (8 * i + wave) + (lane >> 4);
+            const int lch = (lane & 15) ^ ((j & 3) << 2);
+            const int co = tco * 128 + lch * 8;
+            pdyx[i] = ((j >> p.tw_shift) << 16) | ((j & (TW - 1)) + 1);
+            pcol[i] = co < p.Cout ? co : -1;
+        } else {
+            const int pp = 8 * (8 * (i - 4) + wave) + (lane >> 3);
+            const int py = pp / PW, px = pp - py * PW;
+            const int lch = (lane & 7) ^ (((pp >> 1) & 1) << 2);
+            pdyx[i] = ((py - 1) << 16) | px;
+            pcol[i] = (py < PH && pp < XPX) ? tci * 64 + lch * 8 : -1;
+        }
+    });
+    struct Slab { int n, y0, x0; };
+    auto decode = [&](int s) __attribute__((always_inline)) -> Slab {
+        Slab q;
+        q.x0 = (s % p.sx) << p.tw_shift; s /= p.sx;
+        q.y0 = (s % p.sy) * TH;
+        q.n = s / p.sy;
+        return q;
+    };
+    auto dma_piece = [&](auto I, const Slab& q, int buf) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        if (i == 8 && wave != 0) return;              // wave-uniform
+        const int y = q.y0 + (pdyx[i] >> 16), x = q.x0 + (pdyx[i] & 0xffff) - 1;
+        const bool ok = pcol[i] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const size_t pix = (size_t)(q.n * p.H + y) * p.W + x;
+        const void* src;
+        char* dst;
+        if constexpr (i < 4) {
+            src = ok ? (const void*)(gg + pix * p.Cout + pcol[i]) : (const void*)wz_zero16;
+            dst = smem + buf * STAGE + X_BYTES + (8 * i + wave) * 1024;
+        } else {
+            src = ok ? (const void*)(xg + pix * p.Cin + pcol[i]) : (const void*)wz_zero16;
+            dst = smem + buf * STAGE + (8 * (i - 4) + wave) * 1024;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    };
+
+    // ---- fragment addressing (see conv_wgrad.hip for the transpose-read lane roles)
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3, g2 = (lane >> 4) & 1;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    // gy: row 16 g + 8 hh + q4, chunk (cb * 4 + 2 g2 + (pq >> 1)) ^ (q4 << 2); row + 4 keeps row & 3
+    const uint32_t a_base = lds0 + X_BYTES + (8 * hh + q4) * 256 + (((cb * 4 + 2 * g2 + (pq >> 1)) ^ (q4 << 2)) << 4) + (pq & 1) * 8;
+    // x: patch row r, chunk (cib * 4 + 2 g2 + (pq >> 1)) with bit 2 flipped by bit 1 of r; row + 4 keeps that bit
+    const uint32_t x_const = ((cib * 4 + 2 * g2 + (pq >> 1)) << 4) + (pq & 1) * 8;
+    int x_row0 = 8 * hh + q4;
+    auto x_addr = [&](int buf, int row) __attribute__((always_inline)) -> uint32_t {
+        return lds0 + buf * STAGE + ((((uint32_t)row << 7) + x_const) ^ (((uint32_t)row & 2u) << 5));
+    };
+
+    f32x16_t acc[9], accb;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};     // bf16 1.0 x 8
+    const bool want_bias = p.dbias != nullptr;
+
+    Slab cur = decode(s0);
+    static_for<0, NPI>([&](auto I) { dma_piece(I, cur, 0); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        const bool has_next = s + 1 < s1;
+        Slab nxt = cur;
+        if (has_next) nxt = decode(s + 1);
+        const bool bias_slab = want_bias && (s % p.tiles_ci) == tci;
+        const uint32_t a_stage = a_base + buf * STAGE;
+        TrFrag A, B;
+        tr_issue<1024>(A, a_stage);
+        tr_issue<512>(B, x_addr(buf, x_row0));
+        static_for<0, 8>([&](auto Gq) {
+            constexpr int g = decltype(Gq)::value;
+            if (has_next) {
+                if constexpr (g < 4) { dma_piece(std::integral_constant<int, 2 * g>{}, nxt, buf ^ 1);
+                                       dma_piece(std::integral_constant<int, 2 * g + 1>{}, nxt, buf ^ 1); }
+                if constexpr (g == 4) dma_piece(std::integral_constant<int, 8>{}, nxt, buf ^ 1);
+            }
+            // patch row of this lane at tap (0,0): slab row (16 g) / TW, column (16 g) % TW.  (Opaque to the optimiser:
+            // otherwise all 72 fragment addresses of a slab are hoisted out of the slab loop and the accumulators spill.)
+            asm volatile("" : "+v"(x_row0));
+            const int row_g = ((16 * g) >> p.tw_shift) * PW + ((16 * g) & (TW - 1)) + x_row0;
+            static_for<0, 9>([&](auto Tq) {
+                constexpr int t = decltype(Tq)::value;
+                TrFrag An = A, Bn = B;
+                // the next fragment is requested before this MFMA waits for its own
+                if constexpr (t < 8) {
+                    tr_issue<512>(Bn, x_addr(buf, row_g + ((t + 1) / 3) * PW + (t + 1) % 3));
+                    tr_ready<2>(A, B);
+                } else if constexpr (g < 7) {
+                    const int row_n = ((16 * (g + 1)) >> p.tw_shift) * PW + ((16 * (g + 1)) & (TW - 1)) + x_row0;
+                    tr_issue<1024>(An, a_stage + (g + 1) * 4096);
+                    tr_issue<512>(Bn, x_addr(buf, row_n));
+                    tr_ready<4>(A, B);
+                } else {
+                    tr_ready<0>(A, B);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(A), tr_operand(B), acc[t], 0, 0, 0);
+                if constexpr (t == 0) {
+                    if (bias_slab && (g & 1) == cib)
+                        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(A), __builtin_bit_cast(bf16x8_t, ones), accb, 0, 0, 0);
+                }
+                A = An; B = Bn;
+            });
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur = nxt;
+    }
+
+    // ---- combine: lanes 0..31 of a register hold 32 consecutive ci of one (co, tap) row: one 128-B atomic segment
+    float* __restrict__ dw = p.dw;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = tco * 128 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int k = t * p.Cin + tci * 64 + cib * 32 + l31;
+            if (co < p.Cout) atomicAdd(dw + (size_t)co * p.Ktot + k, acc[t][r]);
+        }
+    // bias gradient: every column of accb holds the same sums, so lanes 0 and 32 carry a wave's 32 channels.  Gathered
+    // through LDS into ONE 128-lane atomic per workgroup: two-lane atomics from every wave of every workgroup onto the
+    // same 512 bytes cost ~0.1 ms per launch (same-row contention x 128 instructions per workgroup).
+    if (want_bias) {                                  // block-uniform; the last slab's barrier is behind every LDS read
+        float* red = (float*)smem;                    // [2 ci waves][128 co]
+        if (l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[cib * 128 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accb[r];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int co = tco * 128 + tid;
+            if (co < p.Cout) atomicAdd(p.dbias + co, red[tid] + red[128 + tid]);
+        }
+    }
+}
+
+static int wp_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+}  // namespace
+
+// Shapes this kernel takes: bf16, 3x3, stride 1, pad 1, no fused input activation, Cin a multiple of 64, Cout a
+// multiple of 8 and >= 64, slabs at least 80 % inside the image, and at least S2E_WGRAD_PATCH (default 1024)
+// slab x tile work items -- four per CU -- so that the one-workgroup-per-CU grid is not dominated by its ramp.
+int s2e_wgrad_patch_plan(int dtype, const s2e_conv_desc* d) {
+    static const int min_items = [] { const char* e = getenv("S2E_WGRAD_PATCH"); return e ? atoi(e) : 1024; }();
+    if (min_items <= 0 || dtype != S2E_BF16) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->in_act != S2E_ACT_NONE || d->transposed) return 0;
+    if (d->Ho != d->Hi || d->Wo != d->Wi || d->Cin % 64 != 0 || d->Cout % 8 != 0 || d->Cout < 64) return 0;
+    int best = 0; double best_fill = 0.0;
+    for (int tw = 64; tw >= 32; tw >>= 1) {
+        const int th = 128 / tw;
+        const long covered = (long)ceil_div(d->Ho, th) * th * ceil_div(d->Wo, tw) * tw;
+        const double fill = (double)d->Ho * d->Wo / (double)covered;
+        if (fill > best_fill + 1e-9) { best_fill = fill; best = tw; }
+    }
+    if (best_fill < 0.8) return 0;
+    const long items = (long)d->N * ceil_div(d->Ho, 128 / best) * ceil_div(d->Wo, best) * ceil_div(d->Cout, 128) * (d->Cin / 64);
+    return items >= min_items ? best : 0;
+}
+
+int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
+                           hipStream_t st) {
+    WpParams p{};
+    p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
+    p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Cin = d->Cin; p.Cout = d->Cout; p.Ktot = 9 * d->Cin;
+    p.tw_shift = slab_w == 64 ? 6 : 5;
+    p.sx = ceil_div(d->Wi, slab_w); p.sy = ceil_div(d->Hi, 128 / slab_w); p.nslabs = d->N * p.sy * p.sx;
+    p.tiles_co = ceil_div(d->Cout, 128); p.tiles_ci = d->Cin / 64;
+    const int tiles = p.tiles_co * p.tiles_ci;
+    int splits = wp_cu_count() / tiles;               // one workgroup per CU
+    if (splits < 1) splits = 1;
+    if (splits > p.nslabs) splits = p.nslabs;
+    p.per_split = ceil_div(p.nslabs, splits);
+    splits = ceil_div(p.nslabs, p.per_split);
+    conv_wgrad_patch_kernel<<<tiles * splits, 512, 0, st>>>(p);
+    S2E_CHECK_LAUNCH("conv_wgrad_patch_kernel");
+    return S2E_OK;
+}

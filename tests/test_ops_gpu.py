@@ -69,9 +69,9 @@ CONV_CASES = [
     (1, 48, 40, 32, 72, 3, 1, 1, True, False, 0, 0, None),       # ... and the 64 < Cout <= 128 ragged variant, 5 K-tiles
     (3, 15, 22, 24, 40, 4, 2, 2, True, False, 0, 0, None),       # stride-2 dgrad by parity class: odd x even, ragged channels
     (1, 13, 9, 16, 24, 3, 2, 1, False, False, 0, 0, None),       # ... 3x3: classes with 2x2, 2x1, 1x2, 1x1 taps
-    (2, 128, 128, 64, 256, 3, 1, 1, True, True, 0, 0, None),     # patch-resident kernel: 4x64 rectangles, BN = 128 (256 tiles)
-    (10, 62, 90, 128, 128, 3, 1, 1, True, False, 0, 0, None),    # ... 8x32 rectangles ragged in y and x, forward AND dgrad
-    (1, 250, 256, 64, 64, 3, 1, 1, True, False, 0, 2, None),     # ... BN = 64, ragged in y, tanh epilogue
+    (4, 128, 128, 64, 256, 3, 1, 1, True, True, 0, 0, None),     # patch-resident kernels (conv AND wgrad): 64-wide rectangles, BN = 128
+    (11, 62, 90, 128, 128, 3, 1, 1, True, False, 0, 0, None),    # ... 32-wide rectangles ragged in y and x; forward, dgrad, wgrad (2 ci tiles)
+    (3, 250, 256, 64, 64, 3, 1, 1, True, False, 0, 2, None),     # ... BN = 64 (wgrad: half-empty co tile), ragged in y, tanh epilogue
 ]
 
 
