@@ -47,13 +47,16 @@ __device__ __forceinline__ void tr_issue(TrFrag& f, uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(addr) : "memory");
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(HI_OFF) : "memory");
 }
-// all but the newest KEEP LDS reads are back; a and b are operands so no MFMA on them can move above the wait
+// all but the newest KEEP LDS reads are back; the fragments are operands so no MFMA on them can move above the wait
+template <int KEEP>
+__device__ __forceinline__ void tr_ready(TrFrag& b) {
+    static_assert(KEEP >= 0 && KEEP <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b.lo), "+v"(b.hi) : "n"(KEEP) : "memory");
+}
 template <int KEEP>
 __device__ __forceinline__ void tr_ready(TrFrag& a, TrFrag& b) {
-    static_assert(KEEP == 0 || KEEP == 2 || KEEP == 4, "counted waits used by the loop");
-    if constexpr (KEEP == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) :: "memory");
-    else if constexpr (KEEP == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) :: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) :: "memory");
+    static_assert(KEEP >= 0 && KEEP <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : "n"(KEEP) : "memory");
 }
 __device__ __forceinline__ bf16x8_t tr_operand(const TrFrag& f) {
     return __builtin_bit_cast(bf16x8_t, u32x4_t{f.lo.x, f.lo.y, f.hi.x, f.hi.y});
@@ -84,21 +87,22 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
 
     // ---- LDS-DMA pieces of this thread.  i < 4: gy piece q = 8 i + wave, rows (slab pixels) 4q .. 4q+3, 16 lanes per
     // 256-B row; i >= 4: x piece xq = 8 (i - 4) + wave (xq = 32: wave 0 only), patch pixels 8 xq .. +7, 8 lanes per row.
-    int pdyx[NPI], pcol[NPI];                         // pixel offset from the slab origin (dy << 16 | dx + 1); channel (or -1: zero page)
+    // The channel a lane fetches is the same for all its gy pieces and for all its x pieces (the swizzle term depends on
+    // the lane only); a piece that is never valid (channel tile past Cout, patch pixel past the patch) gets a row
+    // offset that fails every bounds check.
+    int pdyx[NPI];                                    // pixel offset from the slab origin: (dy << 16) | (dx + 1)
+    constexpr int NEVER = 0x4000 << 16;
+    const int g_col = tco * 128 + ((lane & 15) ^ (((lane >> 4) & 3) << 2)) * 8;
+    const int x_col = tci * 64 + ((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 8;
     static_for<0, NPI>([&](auto I) {
         constexpr int i = decltype(I)::value;
         if constexpr (i < 4) {
             const int j = 4 * (8 * i + wave) + (lane >> 4);
-            const int lch = (lane & 15) ^ ((j & 3) << 2);
-            const int co = tco * 128 + lch * 8;
-            pdyx[i] = ((j >> p.tw_shift) << 16) | ((j & (TW - 1)) + 1);
-            pcol[i] = co < p.Cout ? co : -1;
+            pdyx[i] = g_col < p.Cout ? (((j >> p.tw_shift) << 16) | ((j & (TW - 1)) + 1)) : NEVER;
         } else {
             const int pp = 8 * (8 * (i - 4) + wave) + (lane >> 3);
             const int py = pp / PW, px = pp - py * PW;
-            const int lch = (lane & 7) ^ (((pp >> 1) & 1) << 2);
-            pdyx[i] = ((py - 1) << 16) | px;
-            pcol[i] = (py < PH && pp < XPX) ? tci * 64 + lch * 8 : -1;
+            pdyx[i] = (py < PH && pp < XPX) ? (((py - 1) << 16) | px) : NEVER;
         }
     });
     struct Slab { int n, y0, x0; };
@@ -113,15 +117,15 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
         constexpr int i = decltype(I)::value;
         if (i == 8 && wave != 0) return;              // wave-uniform
         const int y = q.y0 + (pdyx[i] >> 16), x = q.x0 + (pdyx[i] & 0xffff) - 1;
-        const bool ok = pcol[i] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         const size_t pix = (size_t)(q.n * p.H + y) * p.W + x;
         const void* src;
         char* dst;
         if constexpr (i < 4) {
-            src = ok ? (const void*)(gg + pix * p.Cout + pcol[i]) : (const void*)wz_zero16;
+            src = ok ? (const void*)(gg + pix * p.Cout + g_col) : (const void*)wz_zero16;
             dst = smem + buf * STAGE + X_BYTES + (8 * i + wave) * 1024;
         } else {
-            src = ok ? (const void*)(xg + pix * p.Cin + pcol[i]) : (const void*)wz_zero16;
+            src = ok ? (const void*)(xg + pix * p.Cin + x_col) : (const void*)wz_zero16;
             dst = smem + buf * STAGE + (8 * (i - 4) + wave) * 1024;
         }
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
@@ -133,13 +137,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     // gy: row 16 g + 8 hh + q4, chunk (cb * 4 + 2 g2 + (pq >> 1)) ^ (q4 << 2); row + 4 keeps row & 3
     const uint32_t a_base = lds0 + X_BYTES + (8 * hh + q4) * 256 + (((cb * 4 + 2 * g2 + (pq >> 1)) ^ (q4 << 2)) << 4) + (pq & 1) * 8;
-    // x: patch row r, chunk (cib * 4 + 2 g2 + (pq >> 1)) with bit 2 flipped by bit 1 of r; row + 4 keeps that bit
+    // x: patch row r, chunk (cib * 4 + 2 g2 + (pq >> 1)) with bit 2 flipped by bit 1 of r; row + 4 keeps that bit.
+    // r = (lane row + tap offset) + R, with R = the 16-pixel group's first patch pixel -- even, so bit 1 of r is the XOR of
+    // the two parts' bit 1 and the address splits into a per-lane, per-tap constant and a wave-uniform part:
+    //   addr = (x_tap[t] ^ ((R & 2) << 5)) + (lds0 + stage + (R << 7))                one v_xad_u32 per fragment
     const uint32_t x_const = ((cib * 4 + 2 * g2 + (pq >> 1)) << 4) + (pq & 1) * 8;
-    int x_row0 = 8 * hh + q4;
-    auto x_addr = [&](int buf, int row) __attribute__((always_inline)) -> uint32_t {
-        return lds0 + buf * STAGE + ((((uint32_t)row << 7) + x_const) ^ (((uint32_t)row & 2u) << 5));
-    };
-
+    uint32_t x_tap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const uint32_t r = 8 * hh + q4 + (t / 3) * PW + t % 3;
+        x_tap[t] = ((r << 7) + x_const) ^ ((r & 2u) << 5);
+    }
     f32x16_t acc[9], accb;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -147,7 +155,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
-    const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};     // bf16 1.0 x 8
+    u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};           // bf16 1.0 x 8
+    asm volatile("" : "+v"(ones));                  // kept in registers (else rebuilt with three moves in front of every use)
     const bool want_bias = p.dbias != nullptr;
 
     Slab cur = decode(s0);
@@ -161,42 +170,55 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
         if (has_next) nxt = decode(s + 1);
         const bool bias_slab = want_bias && (s % p.tiles_ci) == tci;
         const uint32_t a_stage = a_base + buf * STAGE;
-        TrFrag A, B;
-        tr_issue<1024>(A, a_stage);
-        tr_issue<512>(B, x_addr(buf, x_row0));
-        static_for<0, 8>([&](auto Gq) {
-            constexpr int g = decltype(Gq)::value;
-            if (has_next) {
-                if constexpr (g < 4) { dma_piece(std::integral_constant<int, 2 * g>{}, nxt, buf ^ 1);
-                                       dma_piece(std::integral_constant<int, 2 * g + 1>{}, nxt, buf ^ 1); }
-                if constexpr (g == 4) dma_piece(std::integral_constant<int, 8>{}, nxt, buf ^ 1);
+        // 72 MFMA steps per slab (u = 9 g + t).  The x fragment of step u + FD and, at group boundaries, the gy fragment of
+        // the next group are requested at step u: one MFMA (32 cycles) of lookahead does not cover an LDS round trip.
+        constexpr int FD = 3, NSTEP = 72;
+        TrFrag Af[2], Bf[FD + 1];
+        uint32_t x_stage = lds0 + buf * STAGE;
+        auto x_addr = [&](auto U) __attribute__((always_inline)) -> uint32_t {
+            constexpr int u = decltype(U)::value, g = u / 9, t = u % 9;
+            const uint32_t R = ((16 * g) >> p.tw_shift) * PW + ((16 * g) & (TW - 1));      // wave-uniform
+            uint32_t flip = (R & 2u) << 5;
+            asm volatile("" : "+s"(flip));            // opaque: keeps the 18 (tap, flip) combinations from being hoisted and spilled
+            return (x_tap[t] ^ flip) + (x_stage + (R << 7));
+        };
+        tr_issue<1024>(Af[0], a_stage);
+        static_for<0, FD>([&](auto U) { tr_issue<512>(Bf[decltype(U)::value % (FD + 1)], x_addr(U)); });
+        static_for<0, NSTEP>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            constexpr int g = u / 9, t = u % 9;
+            if constexpr (t == 0) {
+                if (has_next) {
+                    if constexpr (g < 4) { dma_piece(std::integral_constant<int, 2 * g>{}, nxt, buf ^ 1);
+                                           dma_piece(std::integral_constant<int, 2 * g + 1>{}, nxt, buf ^ 1); }
+                    if constexpr (g == 4) dma_piece(std::integral_constant<int, 8>{}, nxt, buf ^ 1);
+                }
+                // opaque to the optimiser: otherwise the 72 fragment addresses of a slab are all formed up front and the
+                // accumulators spill
+                asm volatile("" : "+s"(x_stage));
             }
-            // patch row of this lane at tap (0,0): slab row (16 g) / TW, column (16 g) % TW.  (Opaque to the optimiser:
-            // otherwise all 72 fragment addresses of a slab are hoisted out of the slab loop and the accumulators spill.)
-            asm volatile("" : "+v"(x_row0));
-            const int row_g = ((16 * g) >> p.tw_shift) * PW + ((16 * g) & (TW - 1)) + x_row0;
-            static_for<0, 9>([&](auto Tq) {
-                constexpr int t = decltype(Tq)::value;
-                TrFrag An = A, Bn = B;
-                // the next fragment is requested before this MFMA waits for its own
-                if constexpr (t < 8) {
-                    tr_issue<512>(Bn, x_addr(buf, row_g + ((t + 1) / 3) * PW + (t + 1) % 3));
-                    tr_ready<2>(A, B);
-                } else if constexpr (g < 7) {
-                    const int row_n = ((16 * (g + 1)) >> p.tw_shift) * PW + ((16 * (g + 1)) & (TW - 1)) + x_row0;
-                    tr_issue<1024>(An, a_stage + (g + 1) * 4096);
-                    tr_issue<512>(Bn, x_addr(buf, row_n));
-                    tr_ready<4>(A, B);
-                } else {
-                    tr_ready<0>(A, B);
+            if constexpr (u + FD < NSTEP) {
+                if constexpr ((u + FD) % 9 == 0) tr_issue<1024>(Af[((u + FD) / 9) & 1], a_stage + ((u + FD) / 9) * 4096);
+                tr_issue<512>(Bf[(u + FD) % (FD + 1)], x_addr(std::integral_constant<int, u + FD>{}));
+            }
+            // reads issued after the ones this step consumes: steps u-FD+1 .. u, two per x fragment, two per gy fragment
+            constexpr int keep = [] {
+                int k = 0;
+                for (int v = u - FD + 1; v <= u; ++v) {
+                    if (v + FD >= NSTEP) continue;            // (v < 0: requested ahead of the loop, in the same order)
+                    k += 2 + (((v + FD) % 9 == 0) ? 2 : 0);
                 }
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(A), tr_operand(B), acc[t], 0, 0, 0);
-                if constexpr (t == 0) {
-                    if (bias_slab && (g & 1) == cib)
-                        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(A), __builtin_bit_cast(bf16x8_t, ones), accb, 0, 0, 0);
-                }
-                A = An; B = Bn;
-            });
+                return k;
+            }();
+            TrFrag& A = Af[g & 1];
+            TrFrag& B = Bf[u % (FD + 1)];
+            if constexpr (t == 0) tr_ready<keep>(A, B);       // the gy fragment was requested before this group's first x
+            else tr_ready<keep>(B);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(A), tr_operand(B), acc[t], 0, 0, 0);
+            if constexpr (t == 0) {
+                if (bias_slab && (g & 1) == cib)
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(A), __builtin_bit_cast(bf16x8_t, ones), accb, 0, 0, 0);
+            }
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
