@@ -32,7 +32,6 @@ __device__ __attribute__((aligned(16))) const uint32_t wz_zero16[4] = {0u, 0u, 0
 struct WpParams {
     const void* x; const void* gy; float* dw; float* dbias;
     int N, H, W, Cin, Cout, Ktot;
-    int tw_shift;                 // slab width 64 (6) or 32 (5); height = 128 / width
     int sx, sy, nslabs;           // slabs per image in x and y; N * sy * sx
     int per_split, tiles_co, tiles_ci;
 };
@@ -62,6 +61,7 @@ __device__ __forceinline__ bf16x8_t tr_operand(const TrFrag& f) {
     return __builtin_bit_cast(bf16x8_t, u32x4_t{f.lo.x, f.lo.y, f.hi.x, f.hi.y});
 }
 
+template <int TWS>                                // slab width 1 << TWS (64 or 32)
 __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams p) {
     typedef bf16_t T;
     constexpr int NW = 8;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
     const int split = bid / p.tiles_co;
     const int s0 = split * p.per_split, s1 = min(p.nslabs, s0 + p.per_split);
     if (s0 >= s1) return;
-    const int TW = 1 << p.tw_shift, TH = 128 >> p.tw_shift, PW = TW + 2, PH = TH + 2;
+    constexpr int TW = 1 << TWS, TH = 128 >> TWS, PW = TW + 2, PH = TH + 2;
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ gg = (const T*)p.gy;
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
         constexpr int i = decltype(I)::value;
         if constexpr (i < 4) {
             const int j = 4 * (8 * i + wave) + (lane >> 4);
-            pdyx[i] = g_col < p.Cout ? (((j >> p.tw_shift) << 16) | ((j & (TW - 1)) + 1)) : NEVER;
+            pdyx[i] = g_col < p.Cout ? (((j >> TWS) << 16) | ((j & (TW - 1)) + 1)) : NEVER;
         } else {
             const int pp = 8 * (8 * (i - 4) + wave) + (lane >> 3);
             const int py = pp / PW, px = pp - py * PW;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
     struct Slab { int n, y0, x0; };
     auto decode = [&](int s) __attribute__((always_inline)) -> Slab {
         Slab q;
-        q.x0 = (s % p.sx) << p.tw_shift; s /= p.sx;
+        q.x0 = (s % p.sx) << TWS; s /= p.sx;
         q.y0 = (s % p.sy) * TH;
         q.n = s / p.sy;
         return q;
@@ -140,13 +140,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
     // x: patch row r, chunk (cib * 4 + 2 g2 + (pq >> 1)) with bit 2 flipped by bit 1 of r; row + 4 keeps that bit.
     // r = (lane row + tap offset) + R, with R = the 16-pixel group's first patch pixel -- even, so bit 1 of r is the XOR of
     // the two parts' bit 1 and the address splits into a per-lane, per-tap constant and a wave-uniform part:
-    //   addr = (x_tap[t] ^ ((R & 2) << 5)) + (lds0 + stage + (R << 7))                one v_xad_u32 per fragment
+    //   addr = x_tap[bit 1 of R][t] + (lds0 + stage + (R << 7))                       one v_add_u32 per fragment
     const uint32_t x_const = ((cib * 4 + 2 * g2 + (pq >> 1)) << 4) + (pq & 1) * 8;
-    uint32_t x_tap[9];
+    uint32_t x_tap[2][9];                             // [bit 1 of R]
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const uint32_t r = 8 * hh + q4 + (t / 3) * PW + t % 3;
-        x_tap[t] = ((r << 7) + x_const) ^ ((r & 2u) << 5);
+        x_tap[0][t] = ((r << 7) + x_const) ^ ((r & 2u) << 5);
+        x_tap[1][t] = x_tap[0][t] ^ 64u;
     }
     f32x16_t acc[9], accb;
 #pragma unroll
@@ -177,10 +178,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
         uint32_t x_stage = lds0 + buf * STAGE;
         auto x_addr = [&](auto U) __attribute__((always_inline)) -> uint32_t {
             constexpr int u = decltype(U)::value, g = u / 9, t = u % 9;
-            const uint32_t R = ((16 * g) >> p.tw_shift) * PW + ((16 * g) & (TW - 1));      // wave-uniform
-            uint32_t flip = (R & 2u) << 5;
-            asm volatile("" : "+s"(flip));            // opaque: keeps the 18 (tap, flip) combinations from being hoisted and spilled
-            return (x_tap[t] ^ flip) + (x_stage + (R << 7));
+            constexpr uint32_t R = ((16 * g) >> TWS) * PW + ((16 * g) & (TW - 1));
+            return x_tap[(R >> 1) & 1][t] + (x_stage + (R << 7));
         };
         tr_issue<1024>(Af[0], a_stage);
         static_for<0, FD>([&](auto U) { tr_issue<512>(Bf[decltype(U)::value % (FD + 1)], x_addr(U)); });
@@ -288,7 +287,6 @@ int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw,
     WpParams p{};
     p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
     p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Cin = d->Cin; p.Cout = d->Cout; p.Ktot = 9 * d->Cin;
-    p.tw_shift = slab_w == 64 ? 6 : 5;
     p.sx = ceil_div(d->Wi, slab_w); p.sy = ceil_div(d->Hi, 128 / slab_w); p.nslabs = d->N * p.sy * p.sx;
     p.tiles_co = ceil_div(d->Cout, 128); p.tiles_ci = d->Cin / 64;
     const int tiles = p.tiles_co * p.tiles_ci;
@@ -297,7 +295,8 @@ int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw,
     if (splits > p.nslabs) splits = p.nslabs;
     p.per_split = ceil_div(p.nslabs, splits);
     splits = ceil_div(p.nslabs, p.per_split);
-    conv_wgrad_patch_kernel<<<tiles * splits, 512, 0, st>>>(p);
+    if (slab_w == 64) conv_wgrad_patch_kernel<6><<<tiles * splits, 512, 0, st>>>(p);
+    else conv_wgrad_patch_kernel<5><<<tiles * splits, 512, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_wgrad_patch_kernel");
     return S2E_OK;
 }
