@@ -107,8 +107,10 @@ int s2e_conv2d(int dtype, const void* x, const void* w_packed, const float* bias
  * sum_{n,oy,ox} gy[n,oy,ox,co] from the gy tiles the kernel stages anyway (no extra pass over gy).
  * The 1-channel shapes (Cout == 1 or Cin == 1: conv_img, the PatchGAN heads, the encoder's first layer)
  * run as HBM streams whose per-block partial rows go through `workspace` and are summed by a second
- * kernel; s2e_conv2d_wgrad_workspace_bytes(d) is 0 for every other shape (workspace may then be NULL).
- * The caller allocates; no initialisation needed. */
+ * kernel; the big bf16 3x3 stride-1 layers (patch-resident kernel, one workgroup per CU) store their per-workgroup
+ * partial tiles there too (<= 75 MB) and fold them into dw with a reduction pass.
+ * s2e_conv2d_wgrad_workspace_bytes(d) is 0 for every other shape (workspace may then be NULL; a patch-kernel shape
+ * given no workspace falls back to atomics).  The caller allocates; no initialisation needed. */
 size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_desc* d);
 int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
                      void* workspace, size_t workspace_bytes, void* stream);

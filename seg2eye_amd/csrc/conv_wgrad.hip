@@ -398,7 +398,9 @@ extern "C" size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_des
     if (!d || d->transposed) return 0;
     if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31)) return 0;
     const int kind = s2e_small_wgrad_kind(dtype, d);
-    return kind ? s2e_small_wgrad_workspace_bytes(dtype, kind, d) : 0;
+    if (kind) return s2e_small_wgrad_workspace_bytes(dtype, kind, d);
+    if (const int slab_w = s2e_wgrad_patch_plan(dtype, d)) return s2e_wgrad_patch_workspace_bytes(slab_w, d);
+    return 0;
 }
 
 extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
@@ -418,7 +420,7 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
         return S2E_OK;
     }
     if (const int slab_w = s2e_wgrad_patch_plan(dtype, d))          // big 3x3 stride-1 layers: patch-resident kernel
-        return s2e_wgrad_patch_launch(slab_w, x, gy, dw, dbias, d, (hipStream_t)stream);
+        return s2e_wgrad_patch_launch(slab_w, x, gy, dw, dbias, d, workspace, workspace_bytes, (hipStream_t)stream);
     WgradParams p;
     p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;

@@ -31,6 +31,7 @@ __device__ __attribute__((aligned(16))) const uint32_t wz_zero16[4] = {0u, 0u, 0
 
 struct WpParams {
     const void* x; const void* gy; float* dw; float* dbias;
+    float* ws;                    // per-workgroup partial tiles [wg][9][128][64] (NULL: atomics straight into dw)
     int N, H, W, Cin, Cout, Ktot;
     int sx, sy, nslabs;           // slabs per image in x and y; N * sy * sx
     int per_split, tiles_co, tiles_ci;
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave >> 1, cib = wave & 1;
     // workgroups of one pixel split (all their co / ci tiles stream the same rows) sit on one XCD
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int logical_id = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = logical_id;
     const int tci = bid % p.tiles_ci; bid /= p.tiles_ci;
     const int tco = bid % p.tiles_co;
     const int split = bid / p.tiles_co;
@@ -224,16 +226,28 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
         cur = nxt;
     }
 
-    // ---- combine: lanes 0..31 of a register hold 32 consecutive ci of one (co, tap) row: one 128-B atomic segment
-    float* __restrict__ dw = p.dw;
+    // ---- combine.  Lanes 0..31 of a register hold 32 consecutive ci of one (co, tap) row.  With a workspace the tile is
+    // written with plain stores ([tap][co][ci] per workgroup) and wgrad_patch_reduce_kernel folds the splits into dw: one
+    // workgroup per CU means 256 x 288 KB = 75 MB of partial sums per launch whatever the layer, 58 us as fp32 atomics
+    // (1.3 TB/s chip-wide) against ~30 us as a store plus a reduction pass.
+    if (p.ws) {
+        float* __restrict__ tile = p.ws + (size_t)logical_id * (9 * 128 * 64);
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = tco * 128 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const int k = t * p.Cin + tci * 64 + cib * 32 + l31;
-            if (co < p.Cout) atomicAdd(dw + (size_t)co * p.Ktot + k, acc[t][r]);
-        }
+            for (int r = 0; r < 16; ++r)
+                tile[(t * 128 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 64 + cib * 32 + l31] = acc[t][r];
+    } else {
+        float* __restrict__ dw = p.dw;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = tco * 128 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int k = t * p.Cin + tci * 64 + cib * 32 + l31;
+                if (co < p.Cout) atomicAdd(dw + (size_t)co * p.Ktot + k, acc[t][r]);
+            }
+    }
     // bias gradient: every column of accb holds the same sums, so lanes 0 and 32 carry a wave's 32 channels.  Gathered
     // through LDS into ONE 128-lane atomic per workgroup: two-lane atomics from every wave of every workgroup onto the
     // same 512 bytes cost ~0.1 ms per launch (same-row contention x 128 instructions per workgroup).
@@ -260,6 +274,34 @@ static int wp_cu_count() {
     return n;
 }
 
+// dw[co][t * Cin + ci] += sum over the splits of the (co tile, ci tile) of  ws[wg][t][co % 128][ci % 64].  One thread
+// per 4 consecutive ci; blockIdx.y takes every gridDim.y-th split (small dW: keeps the chip busy; the few partial sums
+// per element that result are combined with atomics).
+__global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout,
+                                                                 int Cin, int tiles_co, int tiles_ci, int splits) {
+    const int quads = 9 * Cin / 4;                                   // float4 groups per co row
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Cout * quads) return;
+    const int co = (int)(idx / quads), kq = (int)(idx - (long)co * quads);
+    const int k = kq * 4, t = k / Cin, ci = k - t * Cin;
+    const int tco = co >> 7, tci = ci >> 6;
+    const size_t in_tile = ((size_t)(t * 128 + (co & 127)) * 64 + (ci & 63));
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = blockIdx.y; s < splits; s += gridDim.y) {
+        const int wg = (s * tiles_co + tco) * tiles_ci + tci;        // the logical id the wgrad kernel decoded
+        const f32x4_t v = *(const f32x4_t*)(ws + (size_t)wg * (9 * 128 * 64) + in_tile);
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+    float* dst = dw + (size_t)co * (9 * Cin) + k;
+    if (gridDim.y == 1) {
+        f32x4_t o = *(f32x4_t*)dst;
+        o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3];
+        *(f32x4_t*)dst = o;
+    } else {
+        atomicAdd(dst, a[0]); atomicAdd(dst + 1, a[1]); atomicAdd(dst + 2, a[2]); atomicAdd(dst + 3, a[3]);
+    }
+}
+
 }  // namespace
 
 // Shapes this kernel takes: bf16, 3x3, stride 1, pad 1, no fused input activation, Cin a multiple of 64, Cout a
@@ -282,21 +324,45 @@ int s2e_wgrad_patch_plan(int dtype, const s2e_conv_desc* d) {
     return items >= min_items ? best : 0;
 }
 
-int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
-                           hipStream_t st) {
-    WpParams p{};
-    p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
+static void wp_plan(int slab_w, const s2e_conv_desc* d, WpParams& p, int& splits) {
     p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Cin = d->Cin; p.Cout = d->Cout; p.Ktot = 9 * d->Cin;
     p.sx = ceil_div(d->Wi, slab_w); p.sy = ceil_div(d->Hi, 128 / slab_w); p.nslabs = d->N * p.sy * p.sx;
     p.tiles_co = ceil_div(d->Cout, 128); p.tiles_ci = d->Cin / 64;
     const int tiles = p.tiles_co * p.tiles_ci;
-    int splits = wp_cu_count() / tiles;               // one workgroup per CU
+    splits = wp_cu_count() / tiles;                   // one workgroup per CU
     if (splits < 1) splits = 1;
     if (splits > p.nslabs) splits = p.nslabs;
     p.per_split = ceil_div(p.nslabs, splits);
     splits = ceil_div(p.nslabs, p.per_split);
-    if (slab_w == 64) conv_wgrad_patch_kernel<6><<<tiles * splits, 512, 0, st>>>(p);
-    else conv_wgrad_patch_kernel<5><<<tiles * splits, 512, 0, st>>>(p);
+}
+
+// the partial-tile workspace pays off from a few splits on; below that the atomics are few
+size_t s2e_wgrad_patch_workspace_bytes(int slab_w, const s2e_conv_desc* d) {
+    static const bool on = [] { const char* e = getenv("S2E_WGRAD_PATCH_WS"); return e ? atoi(e) != 0 : true; }();
+    WpParams p{}; int splits;
+    wp_plan(slab_w, d, p, splits);
+    if (!on || splits < 4) return 0;
+    return (size_t)p.tiles_co * p.tiles_ci * splits * (9 * 128 * 64) * sizeof(float);
+}
+
+int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
+                           void* workspace, size_t workspace_bytes, hipStream_t st) {
+    WpParams p{}; int splits;
+    wp_plan(slab_w, d, p, splits);
+    p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
+    const size_t need = s2e_wgrad_patch_workspace_bytes(slab_w, d);
+    p.ws = (need && workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
+    const int nwg = p.tiles_co * p.tiles_ci * splits;
+    if (slab_w == 64) conv_wgrad_patch_kernel<6><<<nwg, 512, 0, st>>>(p);
+    else conv_wgrad_patch_kernel<5><<<nwg, 512, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_wgrad_patch_kernel");
+    if (p.ws) {
+        const long threads = (long)d->Cout * (9 * d->Cin / 4);
+        const int bx = (int)((threads + 255) / 256);
+        int by = 1;
+        while (bx * by < 1024 && by * 2 <= splits) by *= 2;
+        wgrad_patch_reduce_kernel<<<dim3(bx, by), 256, 0, st>>>(p.ws, dw, d->Cout, d->Cin, p.tiles_co, p.tiles_ci, splits);
+        S2E_CHECK_LAUNCH("wgrad_patch_reduce_kernel");
+    }
     return S2E_OK;
 }
