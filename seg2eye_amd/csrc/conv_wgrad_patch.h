@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-// 0 = the generic kernel (conv_wgrad.hip) runs this shape; otherwise the pixel-slab width (32 or 64)
+// 0 = the generic kernel (conv_wgrad.hip) runs this shape; otherwise the pixel-slab width (16, 32 or 64)
 int s2e_wgrad_patch_plan(int dtype, const s2e_conv_desc* d);
 size_t s2e_wgrad_patch_workspace_bytes(int slab_w, const s2e_conv_desc* d);
 int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,

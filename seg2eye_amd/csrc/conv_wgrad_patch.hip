@@ -6,7 +6,7 @@
 // 8 KB of gy and 8 KB of tap-shifted x for 1 MFLOP.  Like the forward gather this runs against the CU's
 // vector-memory path (see conv_patch.hip), at 65 FLOP per byte brought into LDS.  Here a workgroup owns
 // 128 co x 64 ci x ALL NINE TAPS (nine 128 x 64 accumulator tiles: 144 registers per lane over 8 waves) and walks
-// pixel slabs of 128 pixels (2 x 64 or 4 x 32): per slab it brings the gy rows (32 KB) and ONE x patch with its halo
+// pixel slabs of 128 pixels (2 x 64, 4 x 32 or 8 x 16): per slab it brings the gy rows (32 KB) and ONE x patch with its halo
 // (4 x 66 pixels x 128 B = 33 KB) into LDS; the nine taps are nine shifted views of the patch.  19 MFLOP per 65 KB:
 // 290 FLOP per byte, so the loop is paced by the matrix pipe instead of the load path.
 //
@@ -62,7 +62,7 @@ __device__ __forceinline__ bf16x8_t tr_operand(const TrFrag& f) {
     return __builtin_bit_cast(bf16x8_t, u32x4_t{f.lo.x, f.lo.y, f.hi.x, f.hi.y});
 }
 
-template <int TWS>                                // slab width 1 << TWS (64 or 32)
+template <int TWS>                                // slab width 1 << TWS (64, 32 or 16)
 __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams p) {
     typedef bf16_t T;
     constexpr int NW = 8;
@@ -313,7 +313,7 @@ int s2e_wgrad_patch_plan(int dtype, const s2e_conv_desc* d) {
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->in_act != S2E_ACT_NONE || d->transposed) return 0;
     if (d->Ho != d->Hi || d->Wo != d->Wi || d->Cin % 64 != 0 || d->Cout % 8 != 0 || d->Cout < 64) return 0;
     int best = 0; double best_fill = 0.0;
-    for (int tw = 64; tw >= 32; tw >>= 1) {
+    for (int tw = 64; tw >= 16; tw >>= 1) {
         const int th = 128 / tw;
         const long covered = (long)ceil_div(d->Ho, th) * th * ceil_div(d->Wo, tw) * tw;
         const double fill = (double)d->Ho * d->Wo / (double)covered;
@@ -354,7 +354,8 @@ int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw,
     p.ws = (need && workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
     const int nwg = p.tiles_co * p.tiles_ci * splits;
     if (slab_w == 64) conv_wgrad_patch_kernel<6><<<nwg, 512, 0, st>>>(p);
-    else conv_wgrad_patch_kernel<5><<<nwg, 512, 0, st>>>(p);
+    else if (slab_w == 32) conv_wgrad_patch_kernel<5><<<nwg, 512, 0, st>>>(p);
+    else conv_wgrad_patch_kernel<4><<<nwg, 512, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_wgrad_patch_kernel");
     if (p.ws) {
         const long threads = (long)d->Cout * (9 * d->Cin / 4);

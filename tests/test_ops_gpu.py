@@ -71,6 +71,7 @@ CONV_CASES = [
     (1, 13, 9, 16, 24, 3, 2, 1, False, False, 0, 0, None),       # ... 3x3: classes with 2x2, 2x1, 1x2, 1x1 taps
     (4, 128, 128, 64, 256, 3, 1, 1, True, True, 0, 0, None),     # patch-resident kernels (conv AND wgrad): 64-wide rectangles, BN = 128
     (11, 62, 90, 128, 128, 3, 1, 1, True, False, 0, 0, None),    # ... 32-wide rectangles ragged in y and x; forward, dgrad, wgrad (2 ci tiles)
+    (16, 16, 16, 512, 512, 3, 1, 1, True, False, 0, 0, None),    # ... wgrad with 16-wide slabs (8 x 16), 8 ci tiles x 4 co tiles x 8 splits
     (3, 250, 256, 64, 64, 3, 1, 1, True, False, 0, 2, None),     # ... BN = 64 (wgrad: half-empty co tile), ragged in y, tanh epilogue
 ]
 
