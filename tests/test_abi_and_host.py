@@ -46,7 +46,10 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.s2e_conv2d(_lib.S2E_BF16, 1, 1, None, None, None, 1, ctypes.byref(d2), None, 0, None) == -1   # workspace missing
     d3 = _lib.ConvDesc(8, 256, 256, 128, 256, 256, 256, 3, 3, 1, 1, 0, 0, 0, 0)
     assert L.s2e_conv2d_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d3)) == 0
-    assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d3)) == 0
+    # big bf16 3x3 layer: patch-resident weight gradient, one workgroup per CU (256 when no device is visible), each
+    # storing its 9 x 128 x 64 fp32 partial tile; the fp32 build of the same shape stays on the generic (atomics) kernel
+    assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d3)) == 256 * 9 * 128 * 64 * 4
+    assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_F32, ctypes.byref(d3)) == 0
     d4 = _lib.ConvDesc(8, 256, 256, 64, 256, 256, 1, 3, 3, 1, 1, 0, 0, 0, 0)      # conv_img: 1-channel stream kernels
     assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d4)) == 1024 * 9 * 64 * 4
     assert L.s2e_conv2d_wgrad(_lib.S2E_BF16, 1, 1, 1, None, ctypes.byref(d4), None, 0, None) == -1        # workspace missing
