@@ -543,6 +543,18 @@ static int bn_for(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 extern "C" int s2e_conv_cout_pad(int cout) { const int bn = bn_for(cout); return ceil_div(cout, bn) * bn; }
 extern "C" int s2e_conv_k_pad(int dtype, int k) { const int bk = dtype == S2E_BF16 ? 64 : 32; return ceil_div(k, bk) * bk; }
 
+template <typename T>
+static int launch_finish_t(const ConvKParams& p, hipStream_t st) {
+    const long nvec = (long)p.M * p.Cout / Vec<T>::N + 1;
+    const int fgrid = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
+    conv_finish_kernel<T><<<fgrid, 256, 0, st>>>(p);
+    S2E_CHECK_LAUNCH("conv_finish_kernel");
+    return S2E_OK;
+}
+static int launch_finish(int dtype, const ConvKParams& p, hipStream_t st) {
+    return dtype == S2E_BF16 ? launch_finish_t<bf16_t>(p, st) : launch_finish_t<float>(p, st);
+}
+
 template <typename T, int BN>
 static int launch_conv(const ConvKParams& p, hipStream_t st, bool s2 = false) {
     const int grid = p.tiles * p.splits;
@@ -557,12 +569,7 @@ static int launch_conv(const ConvKParams& p, hipStream_t st, bool s2 = false) {
         else conv_igemm_kernel<T, BN, true, false><<<grid, 256, 0, st>>>(p);
     } else conv_igemm_kernel<T, BN, false, false><<<grid, 256, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_igemm_kernel");
-    if (p.splits > 1) {
-        const long nvec = (long)p.M * p.Cout / Vec<T>::N + 1;
-        const int fgrid = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
-        conv_finish_kernel<T><<<fgrid, 256, 0, st>>>(p);
-        S2E_CHECK_LAUNCH("conv_finish_kernel");
-    }
+    if (p.splits > 1) return launch_finish_t<T>(p, st);
     return S2E_OK;
 }
 
@@ -615,7 +622,8 @@ static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tile
 
 extern "C" size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d) {
     if (!d) return 0;
-    if (s2e_small_conv_kind(dtype, d) != SMALL_NONE || s2e_conv_patch_plan(dtype, d)) return 0;
+    if (s2e_small_conv_kind(dtype, d) != SMALL_NONE) return 0;
+    if (s2e_conv_patch_plan(dtype, d, nullptr)) return s2e_conv_patch_workspace_bytes(dtype, d);
     int tiles, tiles_n, splits, per;
     plan_splits(dtype, d, &tiles, &tiles_n, &splits, &per);
     return splits > 1 ? (size_t)splits * d->N * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
@@ -641,9 +649,20 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
         sp.Kpad = s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin);
         return s2e_small_conv_launch(dtype, kind, sp, (hipStream_t)stream);
     }
-    if (const int tile_w = s2e_conv_patch_plan(dtype, d))          // big 3x3 stride-1 layers: patch-resident kernel
-        return s2e_conv_patch_launch(dtype, tile_w, x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin),
-                                     (hipStream_t)stream);
+    int patch_splits = 1;
+    if (const int tile_w = s2e_conv_patch_plan(dtype, d, &patch_splits)) {     // big 3x3 stride-1 layers: patch-resident kernel
+        const size_t need = s2e_conv_patch_workspace_bytes(dtype, d);
+        if (need && (!workspace || workspace_bytes < need))
+            S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: this shape needs %zu bytes of workspace (s2e_conv2d_workspace_bytes)", need);
+        const int rc = s2e_conv_patch_launch(dtype, tile_w, patch_splits, x, w, bias, res, aux, y, d,
+                                             s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), (float*)workspace, (hipStream_t)stream);
+        if (rc != S2E_OK || patch_splits == 1) return rc;
+        ConvKParams f{};                             // split over channel chunks: combine the slabs, then the fused epilogue
+        f.bias = bias; f.res = res; f.aux = aux; f.y = y;
+        f.out_act = d->out_act; f.aux_mode = d->aux_mode;
+        f.M = d->N * d->Ho * d->Wo; f.Cout = d->Cout; f.splits = patch_splits; f.partial = (float*)workspace;
+        return launch_finish(dtype, f, (hipStream_t)stream);
+    }
     ConvKParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;

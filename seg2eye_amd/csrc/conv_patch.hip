@@ -7,7 +7,7 @@
 // 66-73 GB/s per CU), with the loads removed it runs at 1.2-1.5 PFLOP/s.  Deeper pipelines, more resident waves and a
 // 256-pixel tile at the same per-tap gather all measured flat, because none of them changes bytes per FLOP enough.
 //
-// Here a workgroup owns a RECTANGLE of 256 output pixels (4 x 64 or 8 x 32) and, per 64-channel chunk of Cin, brings
+// Here a workgroup owns a RECTANGLE of 256 output pixels (4 x 64, 8 x 32 or 16 x 16) and, per 64-channel chunk of Cin, brings
 // the input patch with its halo ((TH+2) x (TW+2) pixels x 128 B, <= 400 pixels = 50 KB) into LDS ONCE; the nine taps
 // are nine shifted views of that patch.  Per chunk and 256 pixels the vector-memory path carries 50 KB of activations
 // + 9 x 16 KB of weights = 194 KB instead of 9 x (32 + 16) = 432 KB at the same tile (576 KB as two 128-pixel tiles).
@@ -37,6 +37,8 @@ struct PatchParams {
     int out_act, aux_mode;
     int tw_shift;                 // tile width 64 (6) or 32 (5); height = 256 / width
     int tiles_x, tiles_y, tiles_n, tiles;
+    int splits, cps, tiles_out, M;    // split-K over channel chunks: split s owns chunks [s * cps, (s+1) * cps); tiles = tiles_out * splits
+    float* partial;                   // splits > 1: fp32 slabs [splits][M][Cout], combined by conv_finish_kernel (conv_igemm.hip)
 };
 
 template <typename T> struct PMfma;
@@ -86,13 +88,14 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     T* __restrict__ yg = (T*)p.y;
     const T* __restrict__ resg = (const T*)p.res;
     const T* __restrict__ auxg = (const T*)p.aux;
-    const int nch = p.Cin / BK, nk = nch * TAPS;
+    const int nch = p.cps, nk = nch * TAPS;           // channel chunks (and K-steps) of ONE work item
 
     // ---- tiles: the grid is persistent (one workgroup per CU); round k works tiles k*G .. k*G+G-1, handed out so that an
     // XCD's workgroups hold a contiguous range (Cout tiles of one rectangle, then x, then y neighbours share L2 lines)
-    struct Tile { int tn, n, oy0, ox0; };
+    struct Tile { int tn, n, oy0, ox0, split; };
     auto decode = [&](int id) __attribute__((always_inline)) -> Tile {
         Tile q;
+        q.split = id / p.tiles_out; id -= q.split * p.tiles_out;
         q.tn = id % p.tiles_n; id /= p.tiles_n;
         q.ox0 = (id % p.tiles_x) << p.tw_shift; id /= p.tiles_x;
         q.oy0 = (id % p.tiles_y) * TH;
@@ -118,9 +121,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
             const int iy = iy0 + py, ix = ix0 + px;
             const bool ok = py < PH && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             const int lc = (lane & 7) ^ ((pp >> 1) & 7);
-            aoff[r] = ok ? ((long)(q.n * p.Hi + iy) * p.Wi + ix) * p.Cin + lc * VEC : -1L;
+            aoff[r] = ok ? ((long)(q.n * p.Hi + iy) * p.Wi + ix) * p.Cin + q.split * p.cps * BK + lc * VEC : -1L;
         });
-        wrow = wgt + (size_t)(q.tn * BN + brow) * p.Kpad + ((lane & 7) ^ ((brow >> 1) & 7)) * VEC;
+        wrow = wgt + (size_t)(q.tn * BN + brow) * p.Kpad + q.split * p.cps * BK + ((lane & 7) ^ ((brow >> 1) & 7)) * VEC;
     };
     auto dma_patch = [&](auto R, int chunk, int buf) __attribute__((always_inline)) -> int {
         constexpr int r = decltype(R)::value;
@@ -235,8 +238,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                 live[sw] = cok && oy < p.Ho && ox < p.Wo;
                 o[sw] = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
                 rr[sw] = u32x4_t{0u, 0u, 0u, 0u}; aa[sw] = rr[sw];
-                if (live[sw] && resg) rr[sw] = *(const u32x4_t*)(resg + o[sw]);
-                if (live[sw] && p.aux_mode != S2E_AUX_NONE) aa[sw] = *(const u32x4_t*)(auxg + o[sw]);
+                if (live[sw] && resg && p.splits == 1) rr[sw] = *(const u32x4_t*)(resg + o[sw]);
+                if (live[sw] && p.aux_mode != S2E_AUX_NONE && p.splits == 1) aa[sw] = *(const u32x4_t*)(auxg + o[sw]);
             }
             if (ep > 0) __syncthreads();
             if (wm == ep) {
@@ -249,6 +252,18 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                             Cs[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wn * WTN + ni * 32 + l31] = acc[mi][ni][r];
             }
             __syncthreads();
+            if (p.splits > 1) {                       // split-K: raw fp32 partial tile -> this split's slab
+                float* slab = p.partial + (size_t)q.split * p.M * p.Cout;
+#pragma unroll
+                for (int sw = 0; sw < SWEEPS; ++sw) {
+                    if (!live[sw]) continue;
+                    const int row = sw * RPP + tid / TPR;
+#pragma unroll
+                    for (int j = 0; j < VEC; j += 4)
+                        *(f32x4_t*)(slab + o[sw] + j) = *(const f32x4_t*)(Cs + row * BN + cw + j);
+                }
+                continue;
+            }
 #pragma unroll
             for (int sw = 0; sw < SWEEPS; ++sw) {
                 if (!live[sw]) continue;
@@ -343,10 +358,26 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
 
 // ------------------------------------------------------------------------------------ host side
 // Shapes this kernel takes: 3x3, stride 1 (forward or data-gradient), no fused input activation, Cin a multiple of the
-// 128-byte K row, Cout a multiple of the 16-byte vector and > 32, and enough 256-pixel rectangles to fill the chip with
-// at least 80 % of their pixels inside the image.  Everything else stays on conv_igemm.hip.
-int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d) {
+// 128-byte K row, Cout a multiple of the 16-byte vector and > 32, rectangles (4 x 64, 8 x 32 or 16 x 16) with at least
+// 80 % of their pixels inside the image, and enough work items to fill the chip: >= S2E_CONV_PATCH (default 224) output
+// tiles, or fewer tiles with a long K that is split over channel chunks (>= 2 chunks per split) until >= 192 workgroups
+// exist.  Everything else stays on conv_igemm.hip.
+static int patch_tile_w(const s2e_conv_desc* d, double* fill_out) {
+    int best = 0; double best_fill = 0.0;
+    for (int tw = 64; tw >= 16; tw >>= 1) {
+        const int th = 256 / tw;
+        const long covered = (long)ceil_div(d->Ho, th) * th * ceil_div(d->Wo, tw) * tw;
+        const double fill = (double)d->Ho * d->Wo / (double)covered;
+        if (fill > best_fill + 1e-9) { best_fill = fill; best = tw; }
+    }
+    *fill_out = best_fill;
+    return best;
+}
+
+int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d, int* splits_out) {
     static const int min_tiles = [] { const char* e = getenv("S2E_CONV_PATCH"); return e ? atoi(e) : 224; }();
+    static const bool allow_split = [] { const char* e = getenv("S2E_CONV_PATCH_SPLIT"); return e ? atoi(e) != 0 : true; }();
+    if (splits_out) *splits_out = 1;
     if (min_tiles <= 0) return 0;
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->in_act != S2E_ACT_NONE) return 0;
@@ -354,16 +385,24 @@ int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d) {
     const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;
     if (d->Ho != d->Hi + grow || d->Wo != d->Wi + grow) return 0;
     const int bn = d->Cout > 64 ? 128 : 64;
-    int best = 0; double best_fill = 0.0;
-    for (int tw = 64; tw >= 32; tw >>= 1) {
-        const int th = 256 / tw;
-        const long covered = (long)ceil_div(d->Ho, th) * th * ceil_div(d->Wo, tw) * tw;
-        const double fill = (double)d->Ho * d->Wo / (double)covered;
-        if (fill > best_fill + 1e-9) { best_fill = fill; best = tw; }
-    }
-    if (best_fill < 0.8) return 0;
-    const long tiles = (long)d->N * ceil_div(d->Ho, 256 / best) * ceil_div(d->Wo, best) * ceil_div(d->Cout, bn);
-    return tiles >= min_tiles ? best : 0;
+    double fill;
+    const int tw = patch_tile_w(d, &fill);
+    if (fill < 0.8) return 0;
+    const long tiles = (long)d->N * ceil_div(d->Ho, 256 / tw) * ceil_div(d->Wo, tw) * ceil_div(d->Cout, bn);
+    if (tiles >= min_tiles) return tw;
+    if (!allow_split) return 0;
+    const int nch = d->Cin / (8 * vec);
+    int best = 0;
+    for (int s = 2; s <= nch / 2; ++s)               // a divisor of the chunk count, >= 2 chunks per split, <= ~one workgroup per CU
+        if (nch % s == 0 && tiles * s <= 256) best = s;
+    if (best && tiles * best >= 192) { if (splits_out) *splits_out = best; return tw; }
+    return 0;
+}
+
+size_t s2e_conv_patch_workspace_bytes(int dtype, const s2e_conv_desc* d) {
+    int splits = 1;
+    if (!s2e_conv_patch_plan(dtype, d, &splits) || splits == 1) return 0;
+    return (size_t)splits * d->N * d->Ho * d->Wo * d->Cout * sizeof(float);
 }
 
 static int cu_count() {
@@ -377,24 +416,27 @@ static int cu_count() {
 
 template <typename T, int BN>
 static int launch_patch(const PatchParams& p, hipStream_t st) {
-    const int grid = p.tiles < cu_count() ? p.tiles : cu_count();      // persistent: one 135-151 KB workgroup per CU
+    const int grid = p.tiles < cu_count() ? p.tiles : cu_count();      // persistent: one 127-151 KB workgroup per CU
     conv_patch_kernel<T, BN, 3><<<grid, 512, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_patch_kernel");
     return S2E_OK;
 }
 
-int s2e_conv_patch_launch(int dtype, int tile_w, const void* x, const void* w, const float* bias, const void* res,
-                          const void* aux, void* y, const s2e_conv_desc* d, int kpad, hipStream_t st) {
+int s2e_conv_patch_launch(int dtype, int tile_w, int splits, const void* x, const void* w, const float* bias, const void* res,
+                          const void* aux, void* y, const s2e_conv_desc* d, int kpad, float* partial, hipStream_t st) {
     PatchParams p{};
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.Kpad = kpad;
     p.org = d->transposed ? d->pad - 2 : -d->pad;
     p.flip = d->transposed ? 1 : 0;
     p.out_act = d->out_act; p.aux_mode = d->aux_mode;
-    p.tw_shift = tile_w == 64 ? 6 : 5;
+    p.tw_shift = tile_w == 64 ? 6 : (tile_w == 32 ? 5 : 4);
     const int bn = d->Cout > 64 ? 128 : 64;
     p.tiles_x = ceil_div(d->Wo, tile_w); p.tiles_y = ceil_div(d->Ho, 256 / tile_w); p.tiles_n = ceil_div(d->Cout, bn);
-    p.tiles = p.N * p.tiles_y * p.tiles_x * p.tiles_n;
+    p.tiles_out = p.N * p.tiles_y * p.tiles_x * p.tiles_n;
+    p.splits = splits; p.cps = d->Cin / (dtype == S2E_BF16 ? 64 : 32) / splits;
+    p.tiles = p.tiles_out * splits;
+    p.M = d->N * d->Ho * d->Wo; p.partial = partial;
     if (dtype == S2E_BF16) return bn == 128 ? launch_patch<bf16_t, 128>(p, st) : launch_patch<bf16_t, 64>(p, st);
     if (dtype == S2E_F32) return bn == 128 ? launch_patch<float, 128>(p, st) : launch_patch<float, 64>(p, st);
     S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: bad dtype %d", dtype);
