@@ -208,36 +208,52 @@ extern "C" int s2e_colsum(int dtype, const void* g, long M, int C, float* out, v
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gb,
                                                            const float* __restrict__ stats, const float* __restrict__ style,
-                                                           T* __restrict__ out, long nvec, int HW, int C, int cg, int lrelu, int sld) {
+                                                           T* __restrict__ out, int HW, int C, int cg, int cg_shift, int lrelu, int sld) {
     constexpr int VEC = Vec<T>::N;
-    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
-        const long row = v / cg;
-        const int g = (int)(v - row * cg);
-        const int n = (int)(row / HW);
-        const int c0 = g * VEC;
-        float f[VEC], o[VEC];
-        unpack16<T>(*(const u32x4_t*)(x + (size_t)row * C + c0), f);
+    // One sample per grid row (32-bit indices, no 64-bit divisions).  When the grid stride is a multiple of cg (cg a
+    // power of two <= 256: every real layer) a thread keeps its channel group over the whole loop, and its per-channel
+    // constants -- mean, rstd, 1 + s0, s1: 8 of the 11 loads of an iteration -- are loaded once.
+    const int n = blockIdx.y;
+    const int vps = HW * cg;                               // 16-byte vectors per sample
+    const bool fixed_g = cg_shift >= 0 && cg <= 256;
+    float mu[VEC], rs[VEC], sa[VEC], sb[VEC];
+    auto load_consts = [&](int c0) __attribute__((always_inline)) {
         const float* stp = stats + ((size_t)n * C + c0) * 2;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { mu[j] = stp[2 * j]; rs[j] = stp[2 * j + 1]; }
+        if (MODE == S2E_NORM_SPADE_STYLE) {
+            const float* s0 = style + (size_t)n * sld + c0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { sa[j] = 1.f + s0[j]; sb[j] = s0[C + j]; }
+        }
+    };
+    if (fixed_g) load_consts((threadIdx.x & (cg - 1)) * VEC);
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < vps; v += gridDim.x * blockDim.x) {
+        const int prow = cg_shift >= 0 ? v >> cg_shift : v / cg;
+        const int g = v - prow * cg;
+        const size_t row = (size_t)n * HW + prow;
+        const int c0 = g * VEC;
+        if (!fixed_g) load_consts(c0);
+        float f[VEC], o[VEC];
+        unpack16<T>(*(const u32x4_t*)(x + row * C + c0), f);
         if (MODE == S2E_NORM_SPADE_STYLE) {
             float ga[VEC], be[VEC];
-            unpack16<T>(*(const u32x4_t*)(gb + (size_t)row * 2 * C + c0), ga);
-            unpack16<T>(*(const u32x4_t*)(gb + (size_t)row * 2 * C + C + c0), be);
-            const float* s0 = style + (size_t)n * sld + c0;
-            const float* s1 = s0 + C;
+            unpack16<T>(*(const u32x4_t*)(gb + row * 2 * C + c0), ga);
+            unpack16<T>(*(const u32x4_t*)(gb + row * 2 * C + C + c0), be);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float xh = (f[j] - stp[2 * j]) * stp[2 * j + 1];
-                o[j] = 0.5f * (xh * (1.f + ga[j]) + be[j] + f[j] * (1.f + s0[j]) + s1[j]);
+                const float xh = (f[j] - mu[j]) * rs[j];
+                o[j] = 0.5f * (xh * (1.f + ga[j]) + be[j] + f[j] * sa[j] + sb[j]);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) o[j] = (f[j] - stp[2 * j]) * stp[2 * j + 1];
+            for (int j = 0; j < VEC; ++j) o[j] = (f[j] - mu[j]) * rs[j];
         }
         if (lrelu) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] = lrelu02(o[j]);
         }
-        *(u32x4_t*)(out + (size_t)row * C + c0) = pack16<T>(o);
+        *(u32x4_t*)(out + row * C + c0) = pack16<T>(o);
     }
 }
 
@@ -250,10 +266,16 @@ extern "C" int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* 
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_fwd: C=%d not a multiple of %d", C, vec);
     const int cg = C / vec;
     const int sld = style_ld > 0 ? style_ld : 2 * C;
-    const long nvec = (long)N * HW * cg;
-    const int grid = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    if ((long)HW * cg >= (1L << 31)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_fwd: sample too large for 32-bit indices");
+    const int vps = HW * cg;
+    int gx = (vps + 255) / 256;
+    const int gx_cap = 8192 / N > 1 ? 8192 / N : 1;
+    if (gx > gx_cap) gx = gx_cap;
+    const dim3 grid(gx, N);
+    int cg_shift = -1;
+    for (int b = 0; b < 31; ++b) if ((1 << b) == cg) cg_shift = b;
     hipStream_t st = (hipStream_t)stream;
-#define S2E_LAUNCH_MOD(TT, MM) modulate_fwd_kernel<TT, MM><<<grid, 256, 0, st>>>((const TT*)x, (const TT*)gb, stats, style, (TT*)out, nvec, HW, C, cg, lrelu, sld)
+#define S2E_LAUNCH_MOD(TT, MM) modulate_fwd_kernel<TT, MM><<<grid, 256, 0, st>>>((const TT*)x, (const TT*)gb, stats, style, (TT*)out, HW, C, cg, cg_shift, lrelu, sld)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_MOD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_MOD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_MOD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_MOD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_MOD
