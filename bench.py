@@ -8,8 +8,8 @@ fp32 accumulate, synthetic 4-class label maps + styles (BASELINE.json metric; co
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  Besides the driver contract it carries
-  roofline     : the dominant kernel family (implicit-GEMM conv, MFMA-bound): algorithmic FLOPs of its
-                 launches / their HIP-event durations, measured live in the timed steps;
+  roofline     : the dominant kernel (by GPU time: the patch-resident 3x3 conv kernel, MFMA-bound): algorithmic FLOPs
+                 of its launches / their HIP-event durations, measured live; `kernels` lists every conv kernel the same way;
   cpu_baseline : the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded
                  sample (one G+D step at batch 1 of the same 256x256 ngf=64 workload), rank 0, N=1 only.
 """

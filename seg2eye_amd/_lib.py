@@ -62,6 +62,8 @@ SIGNATURES = {
     's2e_pack_block_map': [_i, _vp, _i, _vp],
     's2e_pack_conv_weights': [_i, _vp, _vp, _i, _i, _vp, _vp],
     's2e_conv2d_workspace_bytes': [_i, C.POINTER(ConvDesc)],
+    's2e_conv2d_kernel_kind': [_i, C.POINTER(ConvDesc)],
+    's2e_conv2d_wgrad_kernel_kind': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_conv2d_wgrad_workspace_bytes': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],

@@ -629,6 +629,12 @@ extern "C" size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d) 
     return splits > 1 ? (size_t)splits * d->N * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
 }
 
+extern "C" int s2e_conv2d_kernel_kind(int dtype, const s2e_conv_desc* d) {
+    if (!d) return S2E_KERNEL_GENERIC;
+    if (s2e_small_conv_kind(dtype, d) != SMALL_NONE) return S2E_KERNEL_SMALL;
+    return s2e_conv_patch_plan(dtype, d, nullptr) ? S2E_KERNEL_PATCH : S2E_KERNEL_GENERIC;
+}
+
 extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* bias, const void* res,
                           const void* aux, void* y, const s2e_conv_desc* d, void* workspace, size_t workspace_bytes,
                           void* stream) {

@@ -403,6 +403,12 @@ extern "C" size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_des
     return 0;
 }
 
+extern "C" int s2e_conv2d_wgrad_kernel_kind(int dtype, const s2e_conv_desc* d) {
+    if (!d || d->transposed) return S2E_KERNEL_GENERIC;
+    if (s2e_small_wgrad_kind(dtype, d)) return S2E_KERNEL_SMALL;
+    return s2e_wgrad_patch_plan(dtype, d) ? S2E_KERNEL_PATCH : S2E_KERNEL_GENERIC;
+}
+
 extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
                                 void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !gy || !dw || !d) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: null pointer");

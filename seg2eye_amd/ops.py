@@ -260,6 +260,11 @@ def packed_weight(w, dtype, cin_pad, transposed, sigma, plan, generation=None, s
     return pack_weight(w, dtype, cin_pad, transposed, sigma)
 
 
+# profiler families = the kernel s2e_conv2d / s2e_conv2d_wgrad choose for the shape (S2E_KERNEL_GENERIC / SMALL / PATCH)
+_CONV_FAMILY = ('conv_igemm', 'conv_small', 'conv_patch')
+_WGRAD_FAMILY = ('conv_wgrad', 'conv_wgrad_small', 'conv_wgrad_patch')
+
+
 def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transposed=False,
                in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE):
     _need(x, wp, bias, residual, aux)
@@ -273,7 +278,7 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     flops = 2.0 * n * pix * cin * cout * kh * kw
     wsb = L.lib().s2e_conv2d_workspace_bytes(_dt(x), C.byref(d))          # > 0 only for split-K shapes
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
-    LaunchProfiler.run('conv_igemm', flops, lambda: L.check(
+    LaunchProfiler.run(_CONV_FAMILY[L.lib().s2e_conv2d_kernel_kind(_dt(x), C.byref(d))] if LaunchProfiler.enabled else 'conv_igemm', flops, lambda: L.check(
         L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _p(ws), wsb,
                            _stream()), 's2e_conv2d'),
         tag='%s n%d %dx%d c%d->%d k%d s%d' % ('D' if transposed else 'F', n, hi, wi, cin, cout, kh, stride),
@@ -301,7 +306,8 @@ def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=Fals
     d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
     wsb = L.lib().s2e_conv2d_wgrad_workspace_bytes(_dt(x), C.byref(d))    # > 0 only for the 1-channel shapes
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
-    LaunchProfiler.run('conv_wgrad', 2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
+    LaunchProfiler.run(_WGRAD_FAMILY[L.lib().s2e_conv2d_wgrad_kernel_kind(_dt(x), C.byref(d))] if LaunchProfiler.enabled else 'conv_wgrad',
+                       2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
         L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), _p(dbp), C.byref(d), _p(ws), wsb, _stream()),
         's2e_conv2d_wgrad'),
         tag='W n%d %dx%d c%d->%d k%d s%d' % (n, hi, wi, cin, cout, kh, stride),

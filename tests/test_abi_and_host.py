@@ -50,6 +50,17 @@ def test_argument_errors_are_reported_without_a_gpu():
     # storing its 9 x 128 x 64 fp32 partial tile; the fp32 build of the same shape stays on the generic (atomics) kernel
     assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d3)) == 256 * 9 * 128 * 64 * 4
     assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_F32, ctypes.byref(d3)) == 0
+    # which kernel the library picks is a function of the shape alone (0 generic, 1 one-channel stream, 2 patch-resident)
+    assert L.s2e_conv2d_kernel_kind(_lib.S2E_BF16, ctypes.byref(d3)) == 2
+    assert L.s2e_conv2d_kernel_kind(_lib.S2E_F32, ctypes.byref(d3)) == 2
+    assert L.s2e_conv2d_wgrad_kernel_kind(_lib.S2E_BF16, ctypes.byref(d3)) == 2
+    assert L.s2e_conv2d_wgrad_kernel_kind(_lib.S2E_F32, ctypes.byref(d3)) == 0
+    assert L.s2e_conv2d_kernel_kind(_lib.S2E_BF16, ctypes.byref(d2)) == 0                      # 8x8: rectangles would be 25 % full
+    d4 = _lib.ConvDesc(8, 256, 256, 64, 256, 256, 1, 3, 3, 1, 1, 0, 0, 0, 0)
+    assert L.s2e_conv2d_kernel_kind(_lib.S2E_BF16, ctypes.byref(d4)) == 1                      # conv_img: Cout = 1
+    d5 = _lib.ConvDesc(8, 16, 16, 1024, 16, 16, 1024, 3, 3, 1, 1, 0, 0, 0, 0)                  # few tiles, long K: patch kernel split 4x
+    assert L.s2e_conv2d_kernel_kind(_lib.S2E_BF16, ctypes.byref(d5)) == 2
+    assert L.s2e_conv2d_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d5)) == 4 * 8 * 16 * 16 * 1024 * 4
     d4 = _lib.ConvDesc(8, 256, 256, 64, 256, 256, 1, 3, 3, 1, 1, 0, 0, 0, 0)      # conv_img: 1-channel stream kernels
     assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d4)) == 1024 * 9 * 64 * 4
     assert L.s2e_conv2d_wgrad(_lib.S2E_BF16, 1, 1, 1, None, ctypes.byref(d4), None, 0, None) == -1        # workspace missing

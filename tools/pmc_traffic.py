@@ -7,9 +7,10 @@
     python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r01/pmc
 
 Counters are in KB; FETCH_SIZE is doubled (gfx950 counts a 128-B request as 64 B: MI355X_MICROARCH.md, HBM section).
-Families follow seg2eye_amd.ops.LaunchProfiler: every kernel launched inside s2e_conv2d is `conv_igemm`, inside
-s2e_conv2d_wgrad `conv_wgrad`; the per-family figure is total bytes / number of C-ABI calls (= launches of the
-family's MAIN kernels; helper kernels -- split-K finish, partial-tile reduction -- add bytes, not launches)."""
+Families follow seg2eye_amd.ops.LaunchProfiler (= s2e_conv2d_kernel_kind / s2e_conv2d_wgrad_kernel_kind): `conv_patch`,
+`conv_igemm` (generic), `conv_small`, and the same three for the weight gradient; the per-family figure is total bytes /
+number of C-ABI calls (= launches of the family's MAIN kernel; helper kernels -- split-K finish, partial-tile reduction --
+add bytes, not launches)."""
 import csv
 import glob
 import json
@@ -18,14 +19,15 @@ import sys
 from collections import defaultdict
 
 FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the family)
-    'conv_patch_kernel': ('conv_igemm', True),
+    'conv_patch_kernel': ('conv_patch', True),
     'conv_igemm_kernel': ('conv_igemm', True),
-    'conv_finish_kernel': ('conv_igemm', False),
-    'fwd_cout1_kernel': ('conv_igemm', True), 'fwd_cin1_kernel': ('conv_igemm', True), 'dgrad_cout1_kernel': ('conv_igemm', True),
-    'conv_wgrad_patch_kernel': ('conv_wgrad', True),
+    'conv_finish_kernel': ('conv_igemm', False),          # (also finishes the patch kernel's channel-chunk splits)
+    'fwd_cout1_kernel': ('conv_small', True), 'fwd_cin1_kernel': ('conv_small', True), 'dgrad_cout1_kernel': ('conv_small', True),
+    'conv_wgrad_patch_kernel': ('conv_wgrad_patch', True),
+    'wgrad_patch_reduce_kernel': ('conv_wgrad_patch', False),
     'conv_wgrad_kernel': ('conv_wgrad', True), 'conv_wgrad_glds_kernel': ('conv_wgrad', True),
-    'wgrad_patch_reduce_kernel': ('conv_wgrad', False),
-    'wgrad_cout1_kernel': ('conv_wgrad', True), 'wgrad_cin1_kernel': ('conv_wgrad', True), 'small_wgrad_reduce_kernel': ('conv_wgrad', False),
+    'wgrad_cout1_kernel': ('conv_wgrad_small', True), 'wgrad_cin1_kernel': ('conv_wgrad_small', True),
+    'small_wgrad_reduce_kernel': ('conv_wgrad_small', False),
 }
 
 
