@@ -112,16 +112,25 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     long aoff[NR];                                    // element offset of those 16 B in chunk 0; < 0: zero page
     const T* wrow;                                    // this lane's 16 B of weight row 8 * wave + (lane >> 3), k = 0
     const int brow = 8 * wave + (lane >> 3);
+    // the patch pixel a lane fetches for piece r (and its swizzled channel offset) does not depend on the tile: the two
+    // divisions per piece are done once per kernel, not once per tile (7 pieces: ~1.5k cycles of every tile's turnaround)
+    int ppyx[NR], pcol[NR];                           // (py << 16) | px, py >= PH for pixels past the patch; lc * VEC
+    static_for<0, NR>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const int pp = 8 * (r * NW + wave) + (lane >> 3);
+        const int py = pp / PW, px = pp - py * PW;
+        ppyx[r] = (py << 16) | px;
+        pcol[r] = ((lane & 7) ^ ((pp >> 1) & 7)) * VEC;
+    });
     auto aim = [&](const Tile& q) __attribute__((always_inline)) {
         const int iy0 = q.oy0 + p.org, ix0 = q.ox0 + p.org;
+        const long cbase = (long)q.split * p.cps * BK;
         static_for<0, NR>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            const int pp = 8 * (r * NW + wave) + (lane >> 3);
-            const int py = pp / PW, px = pp - py * PW;
+            const int py = ppyx[r] >> 16, px = ppyx[r] & 0xffff;
             const int iy = iy0 + py, ix = ix0 + px;
             const bool ok = py < PH && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            const int lc = (lane & 7) ^ ((pp >> 1) & 7);
-            aoff[r] = ok ? ((long)(q.n * p.Hi + iy) * p.Wi + ix) * p.Cin + q.split * p.cps * BK + lc * VEC : -1L;
+            aoff[r] = ok ? ((long)(q.n * p.Hi + iy) * p.Wi + ix) * p.Cin + cbase + pcol[r] : -1L;
         });
         wrow = wgt + (size_t)(q.tn * BN + brow) * p.Kpad + q.split * p.cps * BK + ((lane & 7) ^ ((brow >> 1) & 7)) * VEC;
     };
@@ -215,15 +224,20 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     constexpr int TPR = BN / VEC, RPP = NT / TPR;
     const int cw = (tid % TPR) * VEC;
     // fp32 accumulators -> LDS (one 64-pixel wave row per pass, staged in the patch buffer `sbuf`) -> 16-B row stores
+    // the per-channel bias is the same for every row this thread writes: fetched once per tile (left in the row loop it
+    // is re-loaded per row -- the stores may alias it -- and every sweep waits out a global-load round trip), and BEFORE
+    // the next tile's DMAs are issued: vector-memory data returns in order, so a bias load queued behind 50 KB of patch
+    // pieces is not back before they are (measured: the first sweep waited ~2k cycles for it)
+    float bv[VEC];
+    auto load_bias = [&](const Tile& q) __attribute__((always_inline)) {
+        const int co = q.tn * BN + cw;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) bv[j] = (p.bias && co < p.Cout) ? p.bias[co + j] : 0.f;
+    };
     auto epilogue = [&](const Tile& q, int sbuf) __attribute__((always_inline)) {
         float* Cs = (float*)(smem + sbuf * P_BYTES);
         const int co = q.tn * BN + cw;
         const bool cok = co < p.Cout;
-        // the per-channel bias is the same for every row this thread writes: fetch it once (left in the row loop it is
-        // re-loaded per row -- the stores may alias it -- and every sweep then waits out a global-load round trip)
-        float bv[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) bv[j] = (p.bias && cok) ? p.bias[co + j] : 0.f;
         constexpr int SWEEPS = EP_ROWS / RPP;
         static_assert(EP_ROWS % RPP == 0, "whole sweeps");
 #pragma unroll
@@ -347,6 +361,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         const int next_id = tile_id + G;
         const bool has_next = next_id < p.tiles;
         Tile nxt = cur;
+        load_bias(cur);
         if (has_next) { nxt = decode(next_id); aim(nxt); prologue(pbn); }
         epilogue(cur, pbn ^ 1);
         if (!has_next) break;
