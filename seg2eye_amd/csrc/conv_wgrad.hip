@@ -400,13 +400,14 @@ extern "C" size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_des
     const int kind = s2e_small_wgrad_kind(dtype, d);
     if (kind) return s2e_small_wgrad_workspace_bytes(dtype, kind, d);
     if (const int slab_w = s2e_wgrad_patch_plan(dtype, d)) return s2e_wgrad_patch_workspace_bytes(slab_w, d);
+    if (const int slab_w = s2e_wgrad_c8_plan(dtype, d)) return s2e_wgrad_c8_workspace_bytes(slab_w, d);
     return 0;
 }
 
 extern "C" int s2e_conv2d_wgrad_kernel_kind(int dtype, const s2e_conv_desc* d) {
     if (!d || d->transposed) return S2E_KERNEL_GENERIC;
     if (s2e_small_wgrad_kind(dtype, d)) return S2E_KERNEL_SMALL;
-    return s2e_wgrad_patch_plan(dtype, d) ? S2E_KERNEL_PATCH : S2E_KERNEL_GENERIC;
+    return (s2e_wgrad_patch_plan(dtype, d) || s2e_wgrad_c8_plan(dtype, d)) ? S2E_KERNEL_PATCH : S2E_KERNEL_GENERIC;
 }
 
 extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
@@ -427,6 +428,9 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
     }
     if (const int slab_w = s2e_wgrad_patch_plan(dtype, d))          // big 3x3 stride-1 layers: patch-resident kernel
         return s2e_wgrad_patch_launch(slab_w, x, gy, dw, dbias, d, workspace, workspace_bytes, (hipStream_t)stream);
+    if (const int slab_w = s2e_wgrad_c8_plan(dtype, d))             // 8-channel (label-map) input: B operand built from a 16-B/pixel patch
+        if (workspace && workspace_bytes >= s2e_wgrad_c8_workspace_bytes(slab_w, d))
+            return s2e_wgrad_c8_launch(slab_w, x, gy, dw, dbias, d, workspace, (hipStream_t)stream);
     WgradParams p;
     p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;

@@ -265,6 +265,186 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
     }
 }
 
+// ------------------------------------------------------------------------------------ Cin = 8 (the label-map convs)
+// dW[co][t * 8 + ci] += sum over pixels gy[pixel][co] * x[pixel + tap t][ci]  for an 8-channel x (the one-hot label
+// map of SPADE's mlp_shared and of the generator's first conv).  K = 72 is less than one 128-wide tile of the generic
+// kernel and its x operand is 16 bytes per pixel, so that kernel spends its time staging padding (100 / 43 / 24
+// TFLOP/s at 256^2 / 128^2 / 64^2) while the data would stream from HBM in a third of the time.  Here the x operand
+// never goes through a staged tile at all: the 3 x 32 columns (tap, ci) of the B fragment are assembled straight from
+// a 16-byte-per-pixel patch in LDS with eight ds_read_u16_d16(_hi) per fragment (consecutive pixels are 16 B apart, so
+// the eight reads are immediate offsets of one address); column 72 is a constant one and yields the bias gradient.
+// gy rows (128 pixels x 128 co, 32 KB per slab) come in by LDS-DMA as in the kernel above; four waves = four 32-co
+// blocks; per 16-pixel group a wave issues three MFMAs.  Per-workgroup partial tiles [128][80] go to the workspace and
+// are folded by wgrad_c8_reduce_kernel (every workgroup adding into the same 36 KB would serialise the atomics).
+struct WcParams {
+    const void* x; const void* gy; float* ws;
+    int N, H, W, Cout;
+    int sx, sy, nslabs, per_split;
+};
+
+// two bf16 from two LDS addresses into one register: the low half by ds_read_u16 (zero-extended), the high half by
+// ds_read_u16_d16_hi into a second register, OR-ed after the wait.  (A d16_hi read does NOT preserve the other half on
+// this target -- with SRAM ECC the destination's unused half is written as zero -- so the pair cannot share a register.)
+#define S2E_U16_PAIR(lo, hi, addr, off_lo, off_hi) \
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(off_lo) : "memory"); \
+    asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(off_hi) : "memory")
+
+template <int TWS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_c8_kernel(const WcParams p) {
+    typedef bf16_t T;
+    constexpr int TW = 1 << TWS, TH = 128 >> TWS, PW = TW + 2, PH = TH + 2;
+    constexpr int XPIECES = 5;                        // 64 pixels x 16 B per piece; 320 >= 4 x 66
+    constexpr int X_BYTES = XPIECES * 1024, G_BYTES = 128 * 256, STAGE = X_BYTES + G_BYTES;
+    static_assert(PH * PW <= XPIECES * 64, "patch capacity");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave;                              // 32-co block of this wave
+    const int split = blockIdx.x, tco = blockIdx.y;
+    const int s0 = split * p.per_split, s1 = min(p.nslabs, s0 + p.per_split);
+    const T* __restrict__ xg = (const T*)p.x;
+    const T* __restrict__ gg = (const T*)p.gy;
+    const int hh = lane >> 5, l31 = lane & 31;
+
+    f32x16_t acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    if (s0 < s1) {
+        // ---- pieces of this thread: i < 8: gy piece q = 4 i + wave (rows 4q .. 4q+3 of the slab, 16 lanes per row);
+        // i = 8: x piece `wave` (patch pixels 64 wave .. +63, one lane per pixel); i = 9: x piece 4 (wave 0 only)
+        constexpr int NEVER = 0x4000 << 16;
+        const int g_col = tco * 128 + ((lane & 15) ^ (((lane >> 4) & 3) << 2)) * 8;
+        int pdyx[10];
+        static_for<0, 10>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i < 8) {
+                const int j = 4 * (4 * i + wave) + (lane >> 4);
+                pdyx[i] = g_col < p.Cout ? (((j >> TWS) << 16) | ((j & (TW - 1)) + 1)) : NEVER;
+            } else {
+                const int pp = 64 * (i == 8 ? wave : 4) + lane;
+                const int py = pp / PW, px = pp - py * PW;
+                pdyx[i] = py < PH ? (((py - 1) << 16) | px) : NEVER;
+            }
+        });
+        struct Slab { int n, y0, x0; };
+        auto decode = [&](int s) __attribute__((always_inline)) -> Slab {
+            Slab q;
+            q.x0 = (s % p.sx) << TWS; s /= p.sx;
+            q.y0 = (s % p.sy) * TH;
+            q.n = s / p.sy;
+            return q;
+        };
+        auto dma_piece = [&](auto I, const Slab& q, int buf) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if (i == 9 && wave != 0) return;          // wave-uniform
+            const int y = q.y0 + (pdyx[i] >> 16), x = q.x0 + (pdyx[i] & 0xffff) - 1;
+            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            const size_t pix = (size_t)(q.n * p.H + y) * p.W + x;
+            const void* src;
+            char* dst;
+            if constexpr (i < 8) {
+                src = ok ? (const void*)(gg + pix * p.Cout + g_col) : (const void*)wz_zero16;
+                dst = smem + buf * STAGE + X_BYTES + (4 * i + wave) * 1024;
+            } else {
+                src = ok ? (const void*)(xg + pix * 8) : (const void*)wz_zero16;
+                dst = smem + buf * STAGE + (i == 8 ? wave : 4) * 1024;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        };
+
+        const int i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3, g2 = (lane >> 4) & 1;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+        const uint32_t a_base = lds0 + X_BYTES + (8 * hh + q4) * 256 + (((cb * 4 + 2 * g2 + (pq >> 1)) ^ (q4 << 2)) << 4) + (pq & 1) * 8;
+        // column j = 32 c + l31 of the B operand is (tap j >> 3, channel j & 7); this lane holds pixels 8 hh .. 8 hh + 7 of
+        // the group: bytes (R + tap offset + 8 hh + i) * 16 + 2 ci of the patch
+        uint32_t b_base[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int j = 32 * c + l31, tap = j >> 3;
+            b_base[c] = lds0 + (((tap / 3) * PW + tap % 3 + 8 * hh) << 4) + (j & 7) * 2;
+        }
+        const bool ones_lane = l31 == 8;              // column 72 (third block): the constant one of the bias gradient
+
+        Slab cur = decode(s0);
+        static_for<0, 10>([&](auto I) { dma_piece(I, cur, 0); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int s = s0; s < s1; ++s) {
+            const int buf = (s - s0) & 1;
+            const bool has_next = s + 1 < s1;
+            Slab nxt = cur;
+            if (has_next) nxt = decode(s + 1);
+            const uint32_t stage = buf * STAGE;
+            static_for<0, 8>([&](auto Gq) {
+                constexpr int g = decltype(Gq)::value;
+                if (has_next) {
+                    if constexpr (g < 5) { dma_piece(std::integral_constant<int, 2 * g>{}, nxt, buf ^ 1);
+                                           dma_piece(std::integral_constant<int, 2 * g + 1>{}, nxt, buf ^ 1); }
+                }
+                constexpr uint32_t R16 = (((16 * g) >> TWS) * PW + ((16 * g) & (TW - 1))) << 4;
+                TrFrag A;
+                tr_issue<1024>(A, a_base + stage + g * 4096);
+                uint32_t B[3][4], Bh[3][4];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t ad = b_base[c] + stage + R16;
+                    S2E_U16_PAIR(B[c][0], Bh[c][0], ad, 0, 16);
+                    S2E_U16_PAIR(B[c][1], Bh[c][1], ad, 32, 48);
+                    S2E_U16_PAIR(B[c][2], Bh[c][2], ad, 64, 80);
+                    S2E_U16_PAIR(B[c][3], Bh[c][3], ad, 96, 112);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(A.lo), "+v"(A.hi), "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[0][3]),
+                               "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[1][2]), "+v"(B[1][3]),
+                               "+v"(B[2][0]), "+v"(B[2][1]), "+v"(B[2][2]), "+v"(B[2][3]),
+                               "+v"(Bh[0][0]), "+v"(Bh[0][1]), "+v"(Bh[0][2]), "+v"(Bh[0][3]),
+                               "+v"(Bh[1][0]), "+v"(Bh[1][1]), "+v"(Bh[1][2]), "+v"(Bh[1][3]),
+                               "+v"(Bh[2][0]), "+v"(Bh[2][1]), "+v"(Bh[2][2]), "+v"(Bh[2][3]) :: "memory");
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) B[c][v] |= Bh[c][v];
+                if (ones_lane) { B[2][0] = 0x3F803F80u; B[2][1] = 0x3F803F80u; B[2][2] = 0x3F803F80u; B[2][3] = 0x3F803F80u; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(A),
+                             __builtin_bit_cast(bf16x8_t, u32x4_t{B[c][0], B[c][1], B[c][2], B[c][3]}), acc[c], 0, 0, 0);
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur = nxt;
+        }
+    }
+    // partial tile of this workgroup: [128 co][80] (72 weight columns, column 72 = bias sum); an idle split writes zeros
+    float* __restrict__ tile = p.ws + ((size_t)tco * gridDim.x + split) * (128 * 80);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = 32 * c + l31;
+            if (col < 80) tile[(cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 80 + col] = acc[c][r];
+        }
+}
+
+// dw[co][j] += sum over splits of ws[tco][split][co % 128][j], j < 72; dbias[co] += column 72.  blockIdx.y strides the
+// splits (a few partial sums per element, combined with atomics) so that the ~9k outputs still fill the chip.
+__global__ __launch_bounds__(256) void wgrad_c8_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                             float* __restrict__ dbias, int Cout, int splits) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * 73) return;
+    const int co = idx / 73, j = idx - co * 73;
+    const float* src = ws + ((size_t)(co >> 7) * splits) * (128 * 80) + (size_t)(co & 127) * 80 + j;
+    float a = 0.f;
+    for (int s = blockIdx.y; s < splits; s += gridDim.y) a += src[(size_t)s * (128 * 80)];
+    if (j < 72) atomicAdd(dw + (size_t)co * 72 + j, a);
+    else if (dbias) atomicAdd(dbias + co, a);
+}
+
 static int wp_cu_count() {
     static const int n = [] {
         int dev = 0, v = 0;
@@ -365,5 +545,59 @@ int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw,
         wgrad_patch_reduce_kernel<<<dim3(bx, by), 256, 0, st>>>(p.ws, dw, d->Cout, d->Cin, p.tiles_co, p.tiles_ci, splits);
         S2E_CHECK_LAUNCH("wgrad_patch_reduce_kernel");
     }
+    return S2E_OK;
+}
+
+// ---- Cin = 8: bf16, 3x3, stride 1, pad 1, no fused input activation, Cout a multiple of 128, slabs >= 80 % inside the
+// image and at least 256 of them (64^2 and up at batch 8); needs the workspace.
+int s2e_wgrad_c8_plan(int dtype, const s2e_conv_desc* d) {
+    static const bool on = [] { const char* e = getenv("S2E_WGRAD_C8"); return e ? atoi(e) != 0 : true; }();
+    if (!on || dtype != S2E_BF16) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->in_act != S2E_ACT_NONE || d->transposed) return 0;
+    if (d->Ho != d->Hi || d->Wo != d->Wi || d->Cin != 8 || d->Cout % 128 != 0) return 0;
+    int best = 0; double best_fill = 0.0;
+    for (int tw = 64; tw >= 16; tw >>= 1) {
+        const int th = 128 / tw;
+        const long covered = (long)ceil_div(d->Ho, th) * th * ceil_div(d->Wo, tw) * tw;
+        const double fill = (double)d->Ho * d->Wo / (double)covered;
+        if (fill > best_fill + 1e-9) { best_fill = fill; best = tw; }
+    }
+    if (best_fill < 0.8) return 0;
+    const long nslabs = (long)d->N * ceil_div(d->Ho, 128 / best) * ceil_div(d->Wo, best);
+    return nslabs >= 256 ? best : 0;
+}
+
+static void wc_plan(int slab_w, const s2e_conv_desc* d, WcParams& p, int& splits, int& tiles_co) {
+    p.N = d->N; p.H = d->Hi; p.W = d->Wi; p.Cout = d->Cout;
+    p.sx = ceil_div(d->Wi, slab_w); p.sy = ceil_div(d->Hi, 128 / slab_w); p.nslabs = d->N * p.sy * p.sx;
+    tiles_co = d->Cout / 128;
+    splits = 2 * wp_cu_count() / tiles_co;            // two 74-KB workgroups per CU
+    if (splits < 1) splits = 1;
+    if (splits > p.nslabs / 2) splits = p.nslabs / 2 > 0 ? p.nslabs / 2 : 1;
+    p.per_split = ceil_div(p.nslabs, splits);
+    splits = ceil_div(p.nslabs, p.per_split);
+}
+
+size_t s2e_wgrad_c8_workspace_bytes(int slab_w, const s2e_conv_desc* d) {
+    WcParams p{}; int splits, tiles_co;
+    wc_plan(slab_w, d, p, splits, tiles_co);
+    return (size_t)tiles_co * splits * (128 * 80) * sizeof(float);
+}
+
+int s2e_wgrad_c8_launch(int slab_w, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
+                        void* workspace, hipStream_t st) {
+    WcParams p{}; int splits, tiles_co;
+    wc_plan(slab_w, d, p, splits, tiles_co);
+    p.x = x; p.gy = gy; p.ws = (float*)workspace;
+    const dim3 grid(splits, tiles_co);
+    if (slab_w == 64) conv_wgrad_c8_kernel<6><<<grid, 256, 0, st>>>(p);
+    else if (slab_w == 32) conv_wgrad_c8_kernel<5><<<grid, 256, 0, st>>>(p);
+    else conv_wgrad_c8_kernel<4><<<grid, 256, 0, st>>>(p);
+    S2E_CHECK_LAUNCH("conv_wgrad_c8_kernel");
+    const int bx = ceil_div((long)d->Cout * 73, 256);
+    int by = 1;
+    while (bx * by < 512 && by * 2 <= splits) by *= 2;
+    wgrad_c8_reduce_kernel<<<dim3(bx, by), 256, 0, st>>>(p.ws, dw, dbias, d->Cout, splits);
+    S2E_CHECK_LAUNCH("wgrad_c8_reduce_kernel");
     return S2E_OK;
 }

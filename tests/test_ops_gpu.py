@@ -72,6 +72,8 @@ CONV_CASES = [
     (4, 128, 128, 64, 256, 3, 1, 1, True, True, 0, 0, None),     # patch-resident kernels (conv AND wgrad): 64-wide rectangles, BN = 128
     (11, 62, 90, 128, 128, 3, 1, 1, True, False, 0, 0, None),    # ... 32-wide rectangles ragged in y and x; forward, dgrad, wgrad (2 ci tiles)
     (16, 16, 16, 512, 512, 3, 1, 1, True, False, 0, 0, None),    # ... wgrad with 16-wide slabs (8 x 16), 8 ci tiles x 4 co tiles x 8 splits
+    (8, 64, 64, 8, 128, 3, 1, 1, True, False, 0, 0, None),       # 8-channel input (label-map convs): wgrad with the B operand built from a 16-B/pixel patch
+    (10, 60, 90, 8, 256, 3, 1, 1, True, False, 0, 0, None),      # ... 32-wide slabs, ragged, two co tiles
     (3, 250, 256, 64, 64, 3, 1, 1, True, False, 0, 2, None),     # ... BN = 64 (wgrad: half-empty co tile), ragged in y, tanh epilogue
 ]
 
