@@ -25,6 +25,7 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'fwd_cout1_kernel': ('conv_small', True), 'fwd_cin1_kernel': ('conv_small', True), 'dgrad_cout1_kernel': ('conv_small', True),
     'conv_wgrad_patch_kernel': ('conv_wgrad_patch', True),
     'wgrad_patch_reduce_kernel': ('conv_wgrad_patch', False),
+    'conv_wgrad_c8_kernel': ('conv_wgrad_patch', True), 'wgrad_c8_reduce_kernel': ('conv_wgrad_patch', False),
     'conv_wgrad_kernel': ('conv_wgrad', True), 'conv_wgrad_glds_kernel': ('conv_wgrad', True),
     'wgrad_cout1_kernel': ('conv_wgrad_small', True), 'wgrad_cin1_kernel': ('conv_wgrad_small', True),
     'small_wgrad_reduce_kernel': ('conv_wgrad_small', False),
