@@ -129,7 +129,8 @@ int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float*
  *   train == 0:                 sigma = u . (W v)                                              (u, v untouched)
  * layers: DEVICE array of n_layers descriptors.  block_map: DEVICE int32 [n_blocks][3] = {layer, row0, col0}
  * covering every layer with 16-row x 256-column blocks.  t (cols floats) and s (rows floats) of all layers
- * live in `scratch` (zeroed here each iteration).  sigma: fp32 [n_layers] out. */
+ * live in `scratch`, which must be ZERO on the first call (the kernels leave it zero again: no fill per iteration).
+ * sigma: fp32 [n_layers] out. */
 typedef struct {
     const float* w; float* u; float* v; float* t; float* s;
     int rows, cols;

@@ -38,6 +38,8 @@ __global__ __launch_bounds__(256) void sn_norm_v_kernel(const s2e_sn_layer* __re
     __syncthreads();
     const float inv = 1.f / fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), eps);
     for (int j = threadIdx.x; j < L.cols; j += 256) L.v[j] = L.t[j] * inv;
+    // s is accumulated (atomics) by the next launch: clear it here instead of a separate zero-fill launch per iteration
+    for (int i = threadIdx.x; i < L.rows; i += 256) L.s[i] = 0.f;
 }
 
 // ---- s += W v over a [SN_BR x SN_BC] block
@@ -84,6 +86,11 @@ __global__ __launch_bounds__(256) void sn_finalize_kernel(const s2e_sn_layer* __
     } else if (threadIdx.x == 0) {
         sigma[blockIdx.x] = tot;
     }
+    // leave both accumulators cleared for the next iteration / forward (each thread clears what it alone read): the
+    // scratch is zero at creation and stays zero between calls, so no zero-fill launch is needed per iteration
+    for (int i = threadIdx.x; i < L.rows; i += 256) L.s[i] = 0.f;
+    if (train)
+        for (int j = threadIdx.x; j < L.cols; j += 256) L.t[j] = 0.f;
 }
 
 extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map, int n_blocks,
@@ -93,8 +100,8 @@ extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, 
         S2E_FAIL(S2E_ERR_ARG, "s2e_sn_power_iteration: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int iters = train ? iterations : 1;
+    (void)scratch_bytes;                                     // the accumulators in `scratch` are cleared by the kernels themselves
     for (int it = 0; it < iters; ++it) {
-        if (int zrc = s2e_zero_async(scratch, scratch_bytes, st)) return zrc;
         if (train) {
             sn_gemvT_kernel<<<n_blocks, 256, 0, st>>>(layers, block_map);
             sn_norm_v_kernel<<<n_layers, 256, 0, st>>>(layers, eps);
