@@ -12,9 +12,10 @@ static constexpr int kSlabIters = 16;     // row passes per block in the row-wal
 // Row passes per block of the row-walking reduction kernels.  Every block ends with one fp64 atomic per
 // (channel, sum) on addresses shared by all blocks of the sample, and contended atomics are what these kernels
 // were bound by (measured: in_stats of (8,256,256,128) 115 us with 2048 blocks, 30 us with 256): aim for
-// S2E_SLAB_BLOCKS (default 384) blocks in total, never fewer than 16 passes per block.
+// S2E_SLAB_BLOCKS (default 256: 330.5 / 328.7 / 327.3 / 325.2 img/s at 256 / 384 / 512 / 1024 on one box, 318.0 / 316.9 /
+// 313.5 at 256 / 192 / 128 on another) blocks in total, never fewer than 16 passes per block.
 static int slab_iters_for(int HW, int rpp, int N, int zblocks) {
-    static const int target = [] { const char* e = getenv("S2E_SLAB_BLOCKS"); return e ? atoi(e) : 384; }();
+    static const int target = [] { const char* e = getenv("S2E_SLAB_BLOCKS"); return e ? atoi(e) : 256; }();
     const int per_n = target / (N * zblocks) > 1 ? target / (N * zblocks) : 1;
     int it = ceil_div(HW, (long)rpp * per_n);
     if (it < kSlabIters) it = kSlabIters;
