@@ -376,3 +376,18 @@ def test_fused_spectral_norm_conv_matches_torch(cfg, dtype):
     _close(conv.weight_v, ref.weight_v, torch.float32, what='v (3 iters)')
     sd = mine.state_dict()
     assert set(sd) == {'0.bias', '0.weight_orig', '0.weight_u', '0.weight_v'}
+
+
+@pytest.mark.parametrize('forced', [True, False])
+def test_conv2d_random_shapes(forced):
+    """60 random 3x3 stride-1 shapes (odd sizes, ragged channels, 8-channel inputs, bias / residual / activations, both
+    dtypes) through ops.conv2d forward + backward vs fp64 -- with the patch-resident kernels forced on for every eligible
+    shape (thresholds lowered to 1 in a child process) and with the shipped thresholds."""
+    import os, subprocess, sys
+    env = dict(os.environ, SEED='11' if forced else '12', N='30')
+    if forced:
+        env.update(S2E_CONV_PATCH='1', S2E_WGRAD_PATCH='1')
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_stress_conv.py')
+    out = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'done, mismatches: 0' in out.stdout, out.stdout[-2000:]
