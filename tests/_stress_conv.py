@@ -8,6 +8,7 @@ import torch, torch.nn.functional as F
 from seg2eye_amd import ops
 dev = torch.device('cuda:0')
 random.seed(int(os.environ.get('SEED', '1')))
+torch.manual_seed(int(os.environ.get('SEED', '1')))
 bad = 0
 for it in range(int(os.environ.get('N', '24'))):
     dt = random.choice([torch.bfloat16, torch.bfloat16, torch.float32])
@@ -20,17 +21,21 @@ for it in range(int(os.environ.get('N', '24'))):
     b = (0.1 * torch.randn(cout, device=dev)).requires_grad_(True) if has_b else None
     r = torch.randn(N, H, W, cout, device=dev).to(dt).requires_grad_(True) if has_r else None
     gy = torch.randn(N, H, W, cout, device=dev).to(dt)
-    y = ops.conv2d(x, w, b, r, 1, 1, 0, out_act)
-    y.backward(gy)
     # fp64 reference on the GPU
     xr = x.detach().double().permute(0, 3, 1, 2).requires_grad_(True); wr = w.detach().to(dt).double().requires_grad_(True)
     br = b.detach().double().requires_grad_(True) if has_b else None
     rr = r.detach().double().permute(0, 3, 1, 2).requires_grad_(True) if has_r else None
     yr = F.conv2d(xr, wr, br, padding=1)
     if has_r: yr = yr + rr
-    if out_act == 1: yr = F.leaky_relu(yr, 0.2)
+    if out_act == 1:
+        # LeakyReLU kink: a pre-activation within rounding of 0 may fall on either side in two implementations (and then
+        # the whole 0.8 * gy of that element differs); such elements carry no incoming gradient in this test
+        gy = gy * (yr.detach().abs() > 1e-3).permute(0, 2, 3, 1).to(gy.dtype)
+        yr = F.leaky_relu(yr, 0.2)
     if out_act == 2: yr = torch.tanh(yr)
     yr.backward(gy.double().permute(0, 3, 1, 2))
+    y = ops.conv2d(x, w, b, r, 1, 1, 0, out_act)
+    y.backward(gy)
     tol = 2e-2 if dt == torch.bfloat16 else 2e-4
     def chk(name, got, ref):
         global bad
