@@ -655,12 +655,13 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
         sp.Kpad = s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin);
         return s2e_small_conv_launch(dtype, kind, sp, (hipStream_t)stream);
     }
-    int patch_splits = 1;
-    if (const int tile_w = s2e_conv_patch_plan(dtype, d, &patch_splits)) {     // big 3x3 stride-1 layers: patch-resident kernel
+    s2e_patch_plan pplan;
+    if (s2e_conv_patch_plan(dtype, d, &pplan)) {      // big 3x3 / 4x4 stride-1 layers: patch-resident kernel
+        const int patch_splits = pplan.splits;
         const size_t need = s2e_conv_patch_workspace_bytes(dtype, d);
         if (need && (!workspace || workspace_bytes < need))
             S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: this shape needs %zu bytes of workspace (s2e_conv2d_workspace_bytes)", need);
-        const int rc = s2e_conv_patch_launch(dtype, tile_w, patch_splits, x, w, bias, res, aux, y, d,
+        const int rc = s2e_conv_patch_launch(dtype, &pplan, x, w, bias, res, aux, y, d,
                                              s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), (float*)workspace, (hipStream_t)stream);
         if (rc != S2E_OK || patch_splits == 1) return rc;
         ConvKParams f{};                             // split over channel chunks: combine the slabs, then the fused epilogue

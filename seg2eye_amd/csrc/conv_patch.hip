@@ -1,4 +1,4 @@
-// Patch-resident 3x3 stride-1 convolution (forward and data-gradient) for gfx950.
+// Patch-resident stride-1 convolution, 3x3 and 4x4 (forward and data-gradient) for gfx950.
 //
 // Why a second conv kernel.  The generic implicit GEMM (conv_igemm.hip) re-gathers the im2col panel from L2 for every
 // tap: a 128 x 128 x 64 K-step moves 32 KB through the CU's vector-memory path for 2.1 MFLOP.  That path -- not the
@@ -7,7 +7,7 @@
 // 66-73 GB/s per CU), with the loads removed it runs at 1.2-1.5 PFLOP/s.  Deeper pipelines, more resident waves and a
 // 256-pixel tile at the same per-tap gather all measured flat, because none of them changes bytes per FLOP enough.
 //
-// Here a workgroup owns a RECTANGLE of 256 output pixels (4 x 64, 8 x 32 or 16 x 16) and, per 64-channel chunk of Cin, brings
+// Here a workgroup owns a RECTANGLE of up to 256 output pixels (4 x 64, 8 x 32, 16 x 16, 7 x 34 ...: any width <= 64) and, per 64-channel chunk of Cin, brings
 // the input patch with its halo ((TH+2) x (TW+2) pixels x 128 B, <= 400 pixels = 50 KB) into LDS ONCE; the nine taps
 // are nine shifted views of that patch.  Per chunk and 256 pixels the vector-memory path carries 50 KB of activations
 // + 9 x 16 KB of weights = 194 KB instead of 9 x (32 + 16) = 432 KB at the same tile (576 KB as two 128-pixel tiles).
@@ -35,7 +35,7 @@ struct PatchParams {
     int org;                      // patch origin = tile origin + org (forward: -pad; data-gradient: pad - (KS-1))
     int flip;                     // data-gradient: patch offset t pairs with weight tap T-1-t
     int out_act, aux_mode;
-    int tw_shift;                 // tile width 64 (6) or 32 (5); height = 256 / width
+    int tw, th;                   // rectangle of output pixels: width (<= 64), height; tw * th <= 256 (rows past it idle)
     int tiles_x, tiles_y, tiles_n, tiles;
     int splits, cps, tiles_out, M;    // split-K over channel chunks: split s owns chunks [s * cps, (s+1) * cps); tiles = tiles_out * splits
     float* partial;                   // splits > 1: fp32 slabs [splits][M][Cout], combined by conv_finish_kernel (conv_igemm.hip)
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     constexpr int NPIECE = PPX / 8;                   // 1-KiB LDS-DMA pieces (8 pixels x 128 B) per patch
     constexpr int NR = (NPIECE + NW - 1) / NW;        // pieces per thread per patch
     constexpr int NBJ = BN / 64;                      // weight pieces per thread per K-step
-    constexpr int NBS = 3;                            // weight stages: K-step kt+2 is in flight while kt is multiplied
+    constexpr int NBS = (KS == 3) ? 3 : 2;            // weight stages (3x3: K-step kt+2 is in flight while kt is multiplied;
+    constexpr int PD = NBS - 1;                       //  4x4: the larger patch leaves room for two stages, one K-step ahead)
     constexpr int P_BYTES = PPX * 128, B_BYTES = BN * 128;
     constexpr int EP_ROWS = WTM;                      // epilogue staging: one wave row (64 pixels) per pass
     static_assert(NR <= TAPS, "one patch piece per tap must cover the patch");
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l31 = lane & 31;
-    const int TW = 1 << p.tw_shift, TH = BM >> p.tw_shift;
+    const int TW = p.tw, TH = p.th;
     const int PW = TW + KS - 1, PH = TH + KS - 1;
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ wgt = (const T*)p.w;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         Tile q;
         q.split = id / p.tiles_out; id -= q.split * p.tiles_out;
         q.tn = id % p.tiles_n; id /= p.tiles_n;
-        q.ox0 = (id % p.tiles_x) << p.tw_shift; id /= p.tiles_x;
+        q.ox0 = (id % p.tiles_x) * TW; id /= p.tiles_x;
         q.oy0 = (id % p.tiles_y) * TH;
         q.n = id / p.tiles_y;
         return q;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     auto prologue = [&](int pbuf) __attribute__((always_inline)) {
         static_for<0, NR>([&](auto R) { dma_patch(R, 0, pbuf); });
         dma_w(0, 0);
-        if (nk > 1) dma_w(1, 1);
+        if (PD > 1 && nk > 1) dma_w(1, 1);
     };
     auto wait_keep = [&](int n) __attribute__((always_inline)) {             // all but the n youngest loads have landed
         if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int r = wm * WTM + mi * 32 + l31;
-        pp0[mi] = (r >> p.tw_shift) * PW + (r & (TW - 1));
+        const int ty = r / TW;                        // (rows r >= TW * TH: no pixel; they read patch pixel 0 and are never stored)
+        pp0[mi] = r < TW * TH ? ty * PW + (r - ty * TW) : 0;
     }
     int boff[TN], bq[TN];
 #pragma unroll
@@ -248,8 +250,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
 #pragma unroll
             for (int sw = 0; sw < SWEEPS; ++sw) {
                 const int tr = ep * EP_ROWS + sw * RPP + tid / TPR;
-                const int oy = q.oy0 + (tr >> p.tw_shift), ox = q.ox0 + (tr & (TW - 1));
-                live[sw] = cok && oy < p.Ho && ox < p.Wo;
+                const int ty = tr / TW;
+                const int oy = q.oy0 + ty, ox = q.ox0 + (tr - ty * TW);
+                live[sw] = cok && tr < TW * TH && oy < p.Ho && ox < p.Wo;
                 o[sw] = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
                 rr[sw] = u32x4_t{0u, 0u, 0u, 0u}; aa[sw] = rr[sw];
                 if (live[sw] && resg && p.splits == 1) rr[sw] = *(const u32x4_t*)(resg + o[sw]);
@@ -337,13 +340,13 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                 constexpr int ntap = (tap + 1) % TAPS;
                 int issued = 0;
                 if constexpr (tap < NR) { if (more) issued += dma_patch(TAP, c + 1, pcur ^ 1); }
-                if (kt + 2 < nk) { dma_w(kt + 2, stage == 0 ? 2 : stage - 1); issued += NBJ; }
+                if (kt + PD < nk) { dma_w(kt + PD, stage == 0 ? NBS - 1 : stage - 1); issued += NBJ; }
                 read_frags(1, 1); frags_ready(0, false); mfmas(0);
                 read_frags(0, 2); frags_ready(1, false); mfmas(1);
                 read_frags(1, 3); frags_ready(0, false); mfmas(0);
                 // K-step kt+1 (and every older patch piece) has landed for this wave once all but this K-step's loads are
                 // back; every LDS read of K-step kt is back; then all waves meet
-                wait_keep(issued);
+                wait_keep(PD > 1 ? issued : 0);       // (one K-step ahead: what was just issued is needed next)
                 frags_ready(1, true);
                 __builtin_amdgcn_s_barrier();
                 stage = stage == NBS - 1 ? 0 : stage + 1;
@@ -372,52 +375,57 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
 }  // namespace
 
 // ------------------------------------------------------------------------------------ host side
-// Shapes this kernel takes: 3x3, stride 1 (forward or data-gradient), no fused input activation, Cin a multiple of the
-// 128-byte K row, Cout a multiple of the 16-byte vector and > 32, rectangles (4 x 64, 8 x 32 or 16 x 16) with at least
-// 80 % of their pixels inside the image, and enough work items to fill the chip: >= S2E_CONV_PATCH (default 224) output
-// tiles, or fewer tiles with a long K that is split over channel chunks (>= 2 chunks per split) until >= 192 workgroups
-// exist.  Everything else stays on conv_igemm.hip.
-static int patch_tile_w(const s2e_conv_desc* d, double* fill_out) {
-    int best = 0; double best_fill = 0.0;
-    for (int tw = 64; tw >= 16; tw >>= 1) {
-        const int th = 256 / tw;
-        const long covered = (long)ceil_div(d->Ho, th) * th * ceil_div(d->Wo, tw) * tw;
-        const double fill = (double)d->Ho * d->Wo / (double)covered;
-        if (fill > best_fill + 1e-9) { best_fill = fill; best = tw; }
+// Shapes this kernel takes: 3x3 or 4x4, stride 1 (forward or data-gradient), no fused input activation, Cin a multiple of
+// the 128-byte K row, Cout a multiple of the 16-byte vector and > 32, a rectangle of output pixels (any width <= 64, as
+// many rows as fit 256 pixels and the patch buffer) that keeps >= 80 % of the 256 accumulator rows on image pixels, and
+// enough work items to fill the chip: >= S2E_CONV_PATCH (default 224) output tiles, or fewer tiles with a long K that is
+// split over channel chunks (>= 2 chunks per split) until >= 192 workgroups exist.  Everything else: conv_igemm.hip.
+static double patch_rectangle(const s2e_conv_desc* d, int ks, int* tw_out, int* th_out) {
+    const int cap = ks == 3 ? 400 : 472;             // PPX of the kernel
+    double best_fill = 0.0;
+    for (int tw = 64; tw >= 8; --tw) {
+        int th = 256 / tw;
+        while (th > 1 && (th + ks - 1) * (tw + ks - 1) > cap) --th;
+        if ((th + ks - 1) * (tw + ks - 1) > cap) continue;
+        if (th > d->Ho) th = d->Ho;
+        const long tiles = (long)ceil_div(d->Ho, th) * ceil_div(d->Wo, tw);
+        const double fill = (double)d->Ho * d->Wo / (256.0 * tiles);
+        if (fill > best_fill + 1e-9) { best_fill = fill; *tw_out = tw; *th_out = th; }
     }
-    *fill_out = best_fill;
-    return best;
+    return best_fill;
 }
 
-int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d, int* splits_out) {
+int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan) {
     static const int min_tiles = [] { const char* e = getenv("S2E_CONV_PATCH"); return e ? atoi(e) : 224; }();
     static const bool allow_split = [] { const char* e = getenv("S2E_CONV_PATCH_SPLIT"); return e ? atoi(e) != 0 : true; }();
-    if (splits_out) *splits_out = 1;
+    static const bool allow_k4 = [] { const char* e = getenv("S2E_CONV_PATCH_K4"); return e ? atoi(e) != 0 : true; }();
+    s2e_patch_plan local;
+    if (!plan) plan = &local;
+    plan->tw = plan->th = 0; plan->splits = 1;
     if (min_tiles <= 0) return 0;
     const int vec = dtype == S2E_BF16 ? 8 : 4;
-    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->in_act != S2E_ACT_NONE) return 0;
+    const int ks = d->KH;
+    if (d->KW != ks || (ks != 3 && !(ks == 4 && allow_k4)) || d->stride != 1 || d->in_act != S2E_ACT_NONE) return 0;
     if (d->Cin % (8 * vec) != 0 || d->Cout % vec != 0 || d->Cout <= 32) return 0;
-    const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;
+    const int grow = d->transposed ? (ks - 1) - 2 * d->pad : 2 * d->pad - (ks - 1);
     if (d->Ho != d->Hi + grow || d->Wo != d->Wi + grow) return 0;
     const int bn = d->Cout > 64 ? 128 : 64;
-    double fill;
-    const int tw = patch_tile_w(d, &fill);
-    if (fill < 0.8) return 0;
-    const long tiles = (long)d->N * ceil_div(d->Ho, 256 / tw) * ceil_div(d->Wo, tw) * ceil_div(d->Cout, bn);
-    if (tiles >= min_tiles) return tw;
+    if (patch_rectangle(d, ks, &plan->tw, &plan->th) < 0.8) return 0;
+    const long tiles = (long)d->N * ceil_div(d->Ho, plan->th) * ceil_div(d->Wo, plan->tw) * ceil_div(d->Cout, bn);
+    if (tiles >= min_tiles) return 1;
     if (!allow_split) return 0;
     const int nch = d->Cin / (8 * vec);
     int best = 0;
     for (int s = 2; s <= nch / 2; ++s)               // a divisor of the chunk count, >= 2 chunks per split, <= ~one workgroup per CU
         if (nch % s == 0 && tiles * s <= 256) best = s;
-    if (best && tiles * best >= 192) { if (splits_out) *splits_out = best; return tw; }
+    if (best && tiles * best >= 192) { plan->splits = best; return 1; }
     return 0;
 }
 
 size_t s2e_conv_patch_workspace_bytes(int dtype, const s2e_conv_desc* d) {
-    int splits = 1;
-    if (!s2e_conv_patch_plan(dtype, d, &splits) || splits == 1) return 0;
-    return (size_t)splits * d->N * d->Ho * d->Wo * d->Cout * sizeof(float);
+    s2e_patch_plan plan;
+    if (!s2e_conv_patch_plan(dtype, d, &plan) || plan.splits == 1) return 0;
+    return (size_t)plan.splits * d->N * d->Ho * d->Wo * d->Cout * sizeof(float);
 }
 
 static int cu_count() {
@@ -430,29 +438,30 @@ static int cu_count() {
 }
 
 template <typename T, int BN>
-static int launch_patch(const PatchParams& p, hipStream_t st) {
-    const int grid = p.tiles < cu_count() ? p.tiles : cu_count();      // persistent: one 127-151 KB workgroup per CU
-    conv_patch_kernel<T, BN, 3><<<grid, 512, 0, st>>>(p);
+static int launch_patch(const PatchParams& p, int ks, hipStream_t st) {
+    const int grid = p.tiles < cu_count() ? p.tiles : cu_count();      // persistent: one 127-154 KB workgroup per CU
+    if (ks == 3) conv_patch_kernel<T, BN, 3><<<grid, 512, 0, st>>>(p);
+    else conv_patch_kernel<T, BN, 4><<<grid, 512, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_patch_kernel");
     return S2E_OK;
 }
 
-int s2e_conv_patch_launch(int dtype, int tile_w, int splits, const void* x, const void* w, const float* bias, const void* res,
+int s2e_conv_patch_launch(int dtype, const s2e_patch_plan* plan, const void* x, const void* w, const float* bias, const void* res,
                           const void* aux, void* y, const s2e_conv_desc* d, int kpad, float* partial, hipStream_t st) {
     PatchParams p{};
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.Kpad = kpad;
-    p.org = d->transposed ? d->pad - 2 : -d->pad;
+    p.org = d->transposed ? d->pad - (d->KH - 1) : -d->pad;
     p.flip = d->transposed ? 1 : 0;
     p.out_act = d->out_act; p.aux_mode = d->aux_mode;
-    p.tw_shift = tile_w == 64 ? 6 : (tile_w == 32 ? 5 : 4);
+    p.tw = plan->tw; p.th = plan->th;
     const int bn = d->Cout > 64 ? 128 : 64;
-    p.tiles_x = ceil_div(d->Wo, tile_w); p.tiles_y = ceil_div(d->Ho, 256 / tile_w); p.tiles_n = ceil_div(d->Cout, bn);
+    p.tiles_x = ceil_div(d->Wo, p.tw); p.tiles_y = ceil_div(d->Ho, p.th); p.tiles_n = ceil_div(d->Cout, bn);
     p.tiles_out = p.N * p.tiles_y * p.tiles_x * p.tiles_n;
-    p.splits = splits; p.cps = d->Cin / (dtype == S2E_BF16 ? 64 : 32) / splits;
-    p.tiles = p.tiles_out * splits;
+    p.splits = plan->splits; p.cps = d->Cin / (dtype == S2E_BF16 ? 64 : 32) / plan->splits;
+    p.tiles = p.tiles_out * plan->splits;
     p.M = d->N * d->Ho * d->Wo; p.partial = partial;
-    if (dtype == S2E_BF16) return bn == 128 ? launch_patch<bf16_t, 128>(p, st) : launch_patch<bf16_t, 64>(p, st);
-    if (dtype == S2E_F32) return bn == 128 ? launch_patch<float, 128>(p, st) : launch_patch<float, 64>(p, st);
+    if (dtype == S2E_BF16) return bn == 128 ? launch_patch<bf16_t, 128>(p, d->KH, st) : launch_patch<bf16_t, 64>(p, d->KH, st);
+    if (dtype == S2E_F32) return bn == 128 ? launch_patch<float, 128>(p, d->KH, st) : launch_patch<float, 64>(p, d->KH, st);
     S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: bad dtype %d", dtype);
 }
