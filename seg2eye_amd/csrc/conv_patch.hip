@@ -64,12 +64,12 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     constexpr int TAPS = KS * KS;
     constexpr int WN = 2, WM = NW / WN, WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int PPX = (KS == 3) ? 400 : 472;        // patch capacity in pixels: (4+KS-1) x (64+KS-1) rounded up to 8
+    constexpr int PPX = 400;                          // patch capacity in pixels: 6 x 66 (3x3, 4 x 64 rectangle), 11 x 35 (4x4, 8 x 32)
     constexpr int NPIECE = PPX / 8;                   // 1-KiB LDS-DMA pieces (8 pixels x 128 B) per patch
     constexpr int NR = (NPIECE + NW - 1) / NW;        // pieces per thread per patch
     constexpr int NBJ = BN / 64;                      // weight pieces per thread per K-step
-    constexpr int NBS = (KS == 3) ? 3 : 2;            // weight stages (3x3: K-step kt+2 is in flight while kt is multiplied;
-    constexpr int PD = NBS - 1;                       //  4x4: the larger patch leaves room for two stages, one K-step ahead)
+    constexpr int NBS = 3;                            // weight stages: K-step kt+2 is in flight while kt is multiplied
+    constexpr int PD = NBS - 1;
     constexpr int P_BYTES = PPX * 128, B_BYTES = BN * 128;
     constexpr int EP_ROWS = WTM;                      // epilogue staging: one wave row (64 pixels) per pass
     static_assert(NR <= TAPS, "one patch piece per tap must cover the patch");
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
 // enough work items to fill the chip: >= S2E_CONV_PATCH (default 224) output tiles, or fewer tiles with a long K that is
 // split over channel chunks (>= 2 chunks per split) until >= 192 workgroups exist.  Everything else: conv_igemm.hip.
 static double patch_rectangle(const s2e_conv_desc* d, int ks, int* tw_out, int* th_out) {
-    const int cap = ks == 3 ? 400 : 472;             // PPX of the kernel
+    const int cap = 400;                             // PPX of the kernel
     double best_fill = 0.0;
     for (int tw = 64; tw >= 8; --tw) {
         int th = 256 / tw;
