@@ -245,6 +245,19 @@ int s2e_loss_grad(int dtype, int mode, const void* a, const void* b, long n, flo
  * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float* hyper, void* stream);
 
+/* ------------------------------------------------------------------ OpenEDS validation metric
+ * What the reference's Tester and its --lambda_openeds loss compute on the host (util/tester.py:44-47,93-97;
+ * data/postprocessor.py:58-73,92-107; models/networks/loss.py:102-155), as device passes:
+ *   to255(x) = (int)(((x + 1) * 255) / 2)   -- fp32, truncation toward zero ([-1,1] -> 0..255)
+ *   s2e_openeds_error   : err[n] = sqrt(sum_pixels (to255(fake) - to255(target))^2) / (H*W)   (calculate_mse_for_tensors)
+ *   s2e_openeds_error_u8: the same on images that already are 0..255                         (calculate_mse_for_images)
+ *   s2e_resize_to255    : bilinear resize (half-pixel centres, edge clamp: cv2.INTER_LINEAR on float images) of (N,H,W)
+ *                         single-channel images to (N,Ho,Wo), then to255 -> uint8             (to_255resized_imagebatch)
+ * The squared-difference sums are exact 64-bit integers; err: fp32 [N]. */
+int s2e_openeds_error(int dtype, const void* fake, const void* target, int N, int H, int W, float* err, void* stream);
+int s2e_openeds_error_u8(const uint8_t* produced, const uint8_t* target, int N, int H, int W, float* err, void* stream);
+int s2e_resize_to255(int dtype, const void* x, int N, int H, int W, uint8_t* out, int Ho, int Wo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

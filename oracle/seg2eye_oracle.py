@@ -307,6 +307,52 @@ def feature_matching_loss(pred_fake, pred_real, lambda_feat=10.0):
 
 # ----------------------------------------------------------------------------- model-level
 
+# ---------------------------------------------------------------------------------------------- OpenEDS metric
+def to_255(image):
+    """data/postprocessor.py:58-73 (`ImageProcessor.unnormalize`, the branch taken for images in [-1, 1]):
+    add 1, multiply by 255, divide by 2 (fp32, in this order), then `.int()` -- truncation toward zero."""
+    return torch.div(torch.mul(torch.add(image.float(), 1), 255), 2).int()
+
+
+def openeds_accuracy(produced, target):
+    """models/networks/loss.py:102-111: sqrt(sum((p - t)^2)) / (h * w) of ONE image (any leading dims are summed too)."""
+    diff = produced.float() - target.float()
+    h, w = diff.shape[-2:]
+    return torch.sqrt(torch.sum(diff * diff).float()) / (h * w)
+
+
+def mse_for_images(produced, target):
+    """loss.py:116-133 (`MSECalculator.calculate_mse_for_images`): per-image error of 0..255 images (N,C,H,W) -> (N,)."""
+    return torch.stack([openeds_accuracy(produced[i], target[i]) for i in range(produced.shape[0])])
+
+
+def mse_for_tensors(produced, target):
+    """loss.py:135-155 (`calculate_mse_for_tensors`, = criterionOpenEDS, pix2pix_model.py:36): both in [-1, 1], mapped to
+    0..255 ints first; the result carries no gradient (`.int()`)."""
+    return mse_for_images(to_255(produced), to_255(target))
+
+
+def error_statistics(all_errors, mode, dataset_key):
+    """loss.py:157-171: {'mse/<key>/<mode>/relative': sum(errors) / len(errors) * 1471}."""
+    import numpy as np
+    all_errors = np.asarray(all_errors, dtype=np.float64)
+    return {'mse/%s/%s/relative' % (dataset_key, mode): float(np.sum(all_errors) / len(all_errors) * 1471)}
+
+
+def resize_bilinear(image, w=400, h=640):
+    """data/postprocessor.py:99-105 (`ImageProcessor.resize`): cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR) per
+    image.  THIRD-PARTY, ABSENT HERE: opencv-python (requirements.txt, unpinned) is not in this image, so this one function
+    is PARITY-UNPINNED: it restates INTER_LINEAR's published rule for float images -- source coordinate
+    (dst + 0.5) * scale - 0.5, clamped at both edges, two-tap linear weights, no antialiasing when shrinking -- through
+    torch's `F.interpolate(mode='bilinear', align_corners=False)`, which implements the same rule."""
+    return F.interpolate(image.float(), size=(h, w), mode='bilinear', align_corners=False)
+
+
+def to_255_resized(image, w=400, h=640):
+    """postprocessor.py:92-97 (`to_255resized_imagebatch`): resize, then unnormalize."""
+    return to_255(resize_bilinear(image, w, h))
+
+
 class OracleModel:
     """Functional counterpart of Pix2PixModel + Pix2PixTrainer
     (models/pix2pix_model.py, trainers/pix2pix_trainer.py) over three state
@@ -361,6 +407,8 @@ class OracleModel:
             losses['L2/weighted'] = F.mse_loss(fake, data['target']) * opt.lambda_l2
         if getattr(opt, 'lambda_l1', 0):                                   # :201-205
             losses['L1/weighted'] = F.l1_loss(fake, data['target']) * opt.lambda_l1
+        if getattr(opt, 'lambda_openeds', 0):                              # :206-210 (per image; carries no gradient)
+            losses['openeds/weighted'] = mse_for_tensors(fake.detach(), data['target']) * opt.lambda_openeds
         if style_terms:                                                    # :212-229: second encode, u/v keep iterating
             E2 = {**E, **updE} if training else E
             w_fake, feats_fake = encode_w(E2, fake.unsqueeze(1), opt.style_aggr_method, training, updE, True)

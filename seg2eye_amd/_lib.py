@@ -73,6 +73,9 @@ SIGNATURES = {
     's2e_colsum': [_i, _vp, _l, _i, _vp, _vp],
     's2e_label_conv3x3': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     's2e_onehot_nhwc': [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    's2e_openeds_error': [_i, _vp, _vp, _i, _i, _i, _vp, _vp],
+    's2e_openeds_error_u8': [_vp, _vp, _i, _i, _i, _vp, _vp],
+    's2e_resize_to255': [_i, _vp, _i, _i, _i, _vp, _i, _i, _vp],
     's2e_upsample2x_fwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
     's2e_upsample2x_bwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
     's2e_avgpool3x3s2_fwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -22,15 +22,21 @@ class SyntheticEyes:
         self.opt, self.rank, self.world, self.seed = opt, rank, world, seed
         self.h, self.w = image_hw(opt)
         self.n_batches = max(1, int(getattr(opt, 'synthetic_size', 64)) // (opt.batchSize * world))
+        self.N = self.n_batches * opt.batchSize
 
     def __len__(self):
         return self.n_batches
 
     def batch(self, i):
         b = syn.make_batch(self.opt.batchSize, self.h, self.w, self.opt.input_ns, seed=self.seed + 7919 * (i * self.world + self.rank))
-        return {'label': torch.from_numpy(b['label']), 'style_image': torch.from_numpy(b['style_image']),
-                'target': torch.from_numpy(b['target']), 'filename': b['filename'],
-                'user': ['synthetic'] * self.opt.batchSize}
+        out = {'label': torch.from_numpy(b['label']), 'style_image': torch.from_numpy(b['style_image']),
+               'target': torch.from_numpy(b['target']), 'filename': b['filename'],
+               'user': ['synthetic'] * self.opt.batchSize}
+        if not getattr(self.opt, 'isTrain', True):
+            # the Tester scores against the ORIGINAL 640 x 400 image as 0..255 (openeds_dataset.py:103-118 `target_original`)
+            orig = syn.smooth_images('target_original', (self.opt.batchSize, 1, 640, 400), self.seed + 7919 * (i * self.world + self.rank))
+            out['target_original'] = torch.from_numpy(((orig + 1.0) * 255.0 / 2.0).astype('int32').astype('uint8'))
+        return out
 
     def __iter__(self):
         for i in range(self.n_batches):

@@ -74,3 +74,41 @@ def gram_matrix(x):
     a, b, c, d = x.size()
     f = x.reshape(a * b, c * d)
     return torch.mm(f, f.t()).div(a * b * c * d)
+
+
+def openEDSaccuracy(produced, target):
+    """models/networks/loss.py:102-111 for ONE image pair already in 0..255 (any numeric dtype, on the GPU):
+    sqrt(sum (p - t)^2) / (h * w)."""
+    from .. import ops
+    p8 = produced.reshape(1, *produced.shape[-2:]).to(torch.uint8)
+    t8 = target.reshape(1, *target.shape[-2:]).to(torch.uint8)
+    return ops.openeds_error_u8(p8, t8)[0]
+
+
+class MSECalculator:
+    """The reference's OpenEDS metric (models/networks/loss.py:114-171), computed on the device by `s2e_openeds_error*`
+    instead of a Python loop over CPU images.  Same method names, argument meaning and checks."""
+
+    @classmethod
+    def calculate_mse_for_images(cls, produced, target):
+        assert produced.shape == target.shape
+        assert produced.shape[-2:] == (640, 400), 'Invalid shape: %s' % (tuple(produced.shape),)
+        assert len(produced.shape) == 4, 'Please feed 4D tensors'
+        if produced.dtype != torch.uint8:
+            assert float(produced.min()) >= 0 and float(produced.max()) <= 255
+            assert float(target.min()) >= 0 and float(target.max()) <= 255
+        from .. import ops
+        return ops.openeds_error_u8(produced.to(torch.uint8), target.to(torch.uint8))
+
+    @classmethod
+    def calculate_mse_for_tensors(cls, produced, target):
+        assert produced.shape == target.shape
+        assert len(produced.shape) == 4, 'Please feed 4D tensors'
+        from .. import ops
+        return ops.openeds_error(produced, target)
+
+    @classmethod
+    def calculate_error_statistics(cls, all_errors, mode, dataset_key):
+        import numpy as np
+        all_errors = np.asarray(all_errors, dtype=np.float64)
+        return {'mse/%s/%s/relative' % (dataset_key, mode): float(np.sum(all_errors) / len(all_errors) * 1471)}

@@ -824,3 +824,49 @@ def adam_flat_step(p, g, m, v, hyper):
     hyper: 6-float DEVICE tensor {lr, beta1, beta2, eps, completed steps, grad_scale}."""
     _need(p, g, m, v, hyper)
     L.check(L.lib().s2e_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _stream()), 's2e_adam_flat')
+
+
+# ------------------------------------------------------------------------------ OpenEDS validation metric (SURVEY 8 f3)
+def _single_channel(x):
+    """(N,1,H,W) / (N,H,W,1) / (N,H,W) -> contiguous (N,H,W) view of the same dtype."""
+    if x.dim() == 4 and x.shape[1] == 1:
+        x = x[:, 0]
+    elif x.dim() == 4 and x.shape[-1] == 1:
+        x = x[..., 0]
+    if x.dim() != 3:
+        raise ValueError('single-channel image batch expected, got shape %s' % (tuple(x.shape),))
+    return x.contiguous()
+
+
+def openeds_error(produced, target):
+    """Per-image OpenEDS error of two batches in [-1, 1] (models/networks/loss.py:135-155 `calculate_mse_for_tensors`):
+    both mapped to 0..255 with the reference's int truncation, then sqrt(sum d^2) / (H*W).  -> fp32 (N,), no gradient."""
+    a, b = _single_channel(produced.detach()), _single_channel(target.detach().to(produced.dtype))
+    _need(a, b)
+    n, h, w = a.shape
+    err = torch.empty(n, dtype=torch.float32, device=a.device)
+    L.check(L.lib().s2e_openeds_error(_dt(a), _p(a), _p(b), n, h, w, _p(err), _stream()), 's2e_openeds_error')
+    return err
+
+
+def openeds_error_u8(produced, target):
+    """The same on uint8 images that already are 0..255 (loss.py:116-133 `calculate_mse_for_images`)."""
+    a, b = _single_channel(produced), _single_channel(target)
+    if a.dtype != torch.uint8 or b.dtype != torch.uint8:
+        raise ValueError('uint8 images expected')
+    _need(a, b)
+    n, h, w = a.shape
+    err = torch.empty(n, dtype=torch.float32, device=a.device)
+    L.check(L.lib().s2e_openeds_error_u8(_p(a), _p(b), n, h, w, _p(err), _stream()), 's2e_openeds_error_u8')
+    return err
+
+
+def resize_to255(x, w=400, h=640):
+    """Bilinear resize (cv2.INTER_LINEAR rule) of single-channel [-1, 1] images to (h, w), then 0..255 with int truncation
+    (data/postprocessor.py:92-107 `to_255resized_imagebatch`).  -> uint8 (N,1,h,w)."""
+    a = _single_channel(x.detach())
+    _need(a)
+    n, hi, wi = a.shape
+    out = torch.empty(n, 1, h, w, dtype=torch.uint8, device=a.device)
+    L.check(L.lib().s2e_resize_to255(_dt(a), _p(a), n, hi, wi, _p(out), h, w, _stream()), 's2e_resize_to255')
+    return out

@@ -38,9 +38,6 @@ class Pix2PixModel(nn.Module):
             if not opt.no_vgg_loss:
                 raise NotImplementedError('VGGLoss does not exist in the reference either (SURVEY F1); '
                                           'keep --no_vgg_loss')
-            if getattr(opt, 'lambda_openeds', 0):
-                raise NotImplementedError('lambda_openeds != 0 needs the OpenEDS metric (SURVEY 8 f3: Tester/MSECalculator), '
-                                          'outside the hot path built so far')
             self.reset_loss_log()
 
     # ------------------------------------------------------------------ loss log (pix2pix_model.py:49-59)
@@ -162,6 +159,13 @@ class Pix2PixModel(nn.Module):
             l1 = ops.loss_sum(a, b, LOSS_L1, 1.0 / a.numel()).view(1)
             G_losses['L1/weighted'] = l1 * self.opt.lambda_l1
             self.add_to_loss_log('L1/raw', l1.detach())
+        if getattr(self.opt, 'lambda_openeds', 0):
+            # pix2pix_model.py:206-210: the OpenEDS metric of the batch (per image; no gradient -- the reference's
+            # `.int()` cuts the graph too), weighted into the logged loss
+            from .networks.loss import MSECalculator
+            oe = MSECalculator.calculate_mse_for_tensors(fake_image, target_image)
+            G_losses['openeds/weighted'] = oe * self.opt.lambda_openeds
+            self.add_to_loss_log('openeds/raw', oe.detach())
         if style_terms:
             # Style consistency (pix2pix_model.py:162-184, 212-229): the generated image is encoded again and compared with
             # the encoding of the style images -- latent code (MSE), per-layer feature maps (MSE), Gram matrices (MSE,

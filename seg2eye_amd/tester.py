@@ -1,0 +1,116 @@
+"""Validation / inference harness with the reference Tester's interface (util/tester.py:15-233), metric on the device.
+
+    tester = Tester(opt, dataset_key='validation')
+    tester.run(model, mode='full')            # per-image OpenEDS error over the dataset + 'mse/<key>/<mode>/relative'
+    tester.run_test(model)                    # uint8 .npy predictions of shape (1, 640, 400) + pred_npy_list.txt
+
+What differs from the reference: the generated batch never leaves the GPU before it is scored (resize to 400 x 640,
+0..255 truncation and sqrt(sum d^2)/(H W) are `s2e_resize_to255` + `s2e_openeds_error_u8`); the H5 error log and the
+visdom / TF visualisations are not built (out of scope); the dataset is whatever `data.create_dataloader`
+yields -- batches must carry `target_original` (N, 640, 400) uint8 for validation."""
+import os
+import re
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from . import data as data_mod
+from .networks.loss import MSECalculator
+from .postprocessor import ImageProcessor
+
+
+class Tester:
+    def __init__(self, opt, dataset_key='test', visualizer=None):
+        self.opt = deepcopy(opt)
+        self.opt.serial_batches = True
+        self.opt.no_flip = True
+        self.opt.isTrain = False
+        self.opt.dataset_key = dataset_key
+        if not hasattr(self.opt, 'results_dir'):
+            self.opt.results_dir = 'results/'
+        self.dataloader = data_mod.create_dataloader(self.opt)
+        self.is_validation = self.opt.dataset_key in ['validation', 'train']
+        self.N = getattr(self.dataloader, 'N', len(self.dataloader) * self.opt.batchSize)
+        self.results_dir = os.path.join(opt.checkpoints_dir, self.opt.name, self.opt.results_dir, self.opt.dataset_key)
+        os.makedirs(self.results_dir, exist_ok=True)
+
+    def forward(self, model, data_i):
+        """tester.py:44-47: (fake in [-1,1], fake resized to 640 x 400 as 0..255); both stay on the device."""
+        with torch.no_grad():
+            fake = model.forward(data_i, mode='inference').detach()
+        return fake, ImageProcessor.to_255resized_imagebatch(fake)
+
+    def get_iterator(self, dataloader, indices=None):
+        if indices is None:
+            for data_i in dataloader:
+                yield data_i
+        else:
+            for i_val in indices:
+                yield dataloader.batch(i_val)
+
+    def run_batch(self, data_i, model):
+        """tester.py:93-97."""
+        fake, fake_resized = self.forward(model, data_i)
+        target = ImageProcessor.as_batch(data_i['target_original']).to(fake_resized.device)
+        errors = MSECalculator.calculate_mse_for_images(fake_resized, target).cpu().numpy()
+        return errors, fake, fake_resized, target
+
+    def run_validation(self, model, generator, limit=-1, write_error_log=False):
+        """tester.py:99-121 (no H5 error log)."""
+        assert self.is_validation, 'Must be in validation mode'
+        if write_error_log:
+            raise NotImplementedError('the H5 error log (tester.py:67-91) needs h5py and the visualiser: not built')
+        all_errors, counter = [], 0
+        for i, data_i in enumerate(generator):
+            counter += data_i['label'].shape[0]
+            if counter > limit:
+                break
+            if i % 10 == 9:
+                print('Processing batch %d' % i)
+                print('Error so far: %s' % (np.sum(all_errors) / len(all_errors) * 1471))
+            errors, _, _, _ = self.run_batch(data_i, model)
+            all_errors += list(errors)
+        return all_errors
+
+    def print_results(self, all_errors, errors_dict, epoch='n.a.', n_steps='n.a.'):
+        print('Validation Results')
+        print('------------------')
+        print('Error calculated on %d / %d samples' % (len(all_errors), self.N))
+        for k in sorted(errors_dict):
+            print('  %s, %.2f' % (k, errors_dict[k]))
+        print('  dataset_key: %s, model: %s, epoch: %s, n_steps: %s' % (self.opt.dataset_key, self.opt.name, epoch, n_steps))
+
+    def run(self, model, mode, epoch=None, n_steps=None, limit=-1, write_error_log=False, log=False):
+        """tester.py:165-176 ('full' walks the whole dataset; 'fix*' / 'rand*' subsets need the H5 dataset's index lists)."""
+        if 'full' not in mode:
+            raise NotImplementedError("validation mode '%s' needs the OpenEDS dataset's index lists (SURVEY 8 f4)" % mode)
+        print("Running validation for mode '%s'..." % mode)
+        limit = limit if limit > 0 else self.N
+        all_errors = self.run_validation(model, self.get_iterator(self.dataloader), limit=limit, write_error_log=write_error_log)
+        errors_dict = MSECalculator.calculate_error_statistics(all_errors, mode=mode, dataset_key=self.opt.dataset_key)
+        self.print_results(all_errors, errors_dict, epoch, n_steps)
+        return all_errors, errors_dict
+
+    def run_test(self, model, limit=-1):
+        """tester.py:193-219: one uint8 .npy of shape (1, 640, 400) per sample + the list of written paths."""
+        filepaths = []
+        for i, data_i in enumerate(self.dataloader):
+            if limit > 0 and i * self.opt.batchSize >= limit:
+                break
+            if i % 10 == 0:
+                print('Processing batch %d (processed %d images)' % (i, self.opt.batchSize * i))
+            names = [re.sub(r'\\.', '', f) for f in data_i['filename']]        # test file names carry a dot to remove
+            _, fake_resized = self.forward(model, data_i)
+            imgs = fake_resized.cpu().numpy()
+            for b, name in enumerate(names):
+                path = os.path.join(self.results_dir, name + '.npy')
+                np.save(path, imgs[b].astype(np.uint8))
+                filepaths.append(path)
+        list_path = os.path.join(self.results_dir, 'pred_npy_list.txt')
+        with open(list_path, 'w') as f:
+            for line in filepaths:
+                f.write(line)
+                f.write(os.linesep)
+        print('Written %d files. Filepath: %s' % (len(filepaths), list_path))
+        return filepaths

@@ -1,39 +1,30 @@
 #!/usr/bin/env python3
-"""Inference entry point, flag-compatible with the reference's test.py (test.py:13-28): loads
-`<checkpoints_dir>/<name>/<which_epoch>_net_{G,E}.pth`, generates one image per sample from its label map and style
-images (`Pix2PixModel(data, mode='inference')`) and, with `--produce_npy`, writes them as uint8 `.npy` files of shape
-(1, H, W) under `<results_dir>/<name>/` ([-1,1] -> 0..255 with the reference's int truncation, data/postprocessor.py:72).
-Data: `--dataset_mode synthetic` (the OpenEDS pipeline and the Tester's resize-to-400x640 metric are SURVEY 8 f3/f4)."""
-import os
+"""Inference / validation entry point, flag-compatible with the reference's test.py (test.py:13-28): loads
+`<checkpoints_dir>/<name>/<which_epoch>_net_{G,E}.pth` and hands the model to the Tester --
+  * `--dataset_key validation|train` without `--produce_npy`: walks the dataset, scores every generated image with the
+    OpenEDS metric (resize to 400 x 640, 0..255, sqrt(sum d^2)/(H W); all on the device) and prints
+    `mse/<key>/full/relative`;
+  * otherwise: writes one uint8 `.npy` of shape (1, 640, 400) per sample under
+    `<checkpoints_dir>/<name>/<results_dir>/<dataset_key>/` plus `pred_npy_list.txt` (util/tester.py:193-219).
+Data: `--dataset_mode synthetic` (the OpenEDS H5 pipeline is SURVEY 8 f4)."""
 import sys
 
-import numpy as np
-import torch
-
-from seg2eye_amd.data import create_dataloader
 from seg2eye_amd.options import parse
 from seg2eye_amd.pix2pix_model import Pix2PixModel
+from seg2eye_amd.tester import Tester
 
 
 def main(argv=None):
     opt = parse(argv, is_train=False)
+    tester = Tester(opt, dataset_key=opt.dataset_key)
     model = Pix2PixModel(opt)
     model.eval()
-    out_dir = os.path.join(opt.results_dir, opt.name)
-    done = 0
-    for data_i in create_dataloader(opt):
-        if done >= opt.how_many:
-            break
-        with torch.no_grad():
-            fake = model(data_i, mode='inference')
-        if opt.produce_npy:
-            os.makedirs(out_dir, exist_ok=True)
-            img = ((fake.float().cpu() + 1.0) / 2.0 * 255.0).clamp(0, 255).to(torch.int32).numpy().astype(np.uint8)
-            for b, fn in enumerate(data_i['filename']):
-                np.save(os.path.join(out_dir, os.path.splitext(os.path.basename(fn))[0] + '.npy'), img[b])
-        done += fake.shape[0]
-    print('generated %d images%s' % (done, (' -> ' + out_dir) if opt.produce_npy else ''))
-    return done
+    limit = opt.how_many if opt.how_many != float('inf') else -1
+    if opt.dataset_key in ['validation', 'train'] and not opt.produce_npy:
+        all_errors, errors_dict = tester.run(model, mode='full', limit=int(limit), write_error_log=opt.write_error_log)
+        return all_errors, errors_dict
+    print('Running inference')
+    return tester.run_test(model, limit=int(limit))
 
 
 if __name__ == '__main__':

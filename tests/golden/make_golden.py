@@ -145,6 +145,34 @@ def bn_generator_fixture(args, syn, onehot, SPADESTYLEGenerator):
     print('bn generator ok', float(y.std()), [k for k in rec if 'running_mean' in k][:1])
 
 
+def openeds_fixture(args, syn):
+    """openeds_metric.npz: the reference's OpenEDS error metric (models/networks/loss.py:102-171 `openEDSaccuracy`,
+    `MSECalculator`; data/postprocessor.py:58-97 `ImageProcessor.unnormalize / to_255imagebatch`) on synthetic images.
+    (`ImageProcessor.resize` needs cv2, which this image lacks: not part of the fixture.)"""
+    from models.networks.loss import MSECalculator, openEDSaccuracy
+    from data.postprocessor import ImageProcessor
+    a = torch.from_numpy(syn.make_batch(3, 96, 80, seed=501)['target'])            # (3,1,96,80) in [-1,1]
+    b = torch.from_numpy(syn.make_batch(3, 96, 80, seed=502)['target'])
+    # 0..255 images at the metric's mandatory 640 x 400: synthetic targets through the reference's own unnormalize
+    ia = ImageProcessor.to_255imagebatch(torch.from_numpy(syn.make_batch(2, 640, 400, seed=503)['target']))
+    ib = ImageProcessor.to_255imagebatch(torch.from_numpy(syn.make_batch(2, 640, 400, seed=504)['target']))
+    out = {                                         # inputs are regenerated from the seeds by the tests (seg2eye_amd.synthetic)
+        'seeds': np.array([501, 502, 503, 504]),
+        'to255_a': ImageProcessor.to_255imagebatch(a).numpy().astype(np.uint8),
+        'ia_checksum': np.array([int(ia.long().sum()), int((ia.long() * ia.long()).sum())]),
+        'mse_tensors': MSECalculator.calculate_mse_for_tensors(a, b).numpy(),
+        'mse_images': MSECalculator.calculate_mse_for_images(ia, ib).numpy(),
+        'acc_single': openEDSaccuracy(ia[0], ib[0]).numpy(),
+    }
+    errs = [0.0123, 0.0456, 0.0101, 0.0320]
+    st = MSECalculator.calculate_error_statistics(np.array(errs), mode='full', dataset_key='validation')
+    out['stat_errors'] = np.array(errs)
+    out['stat_key'] = np.array(list(st.keys())[0])
+    out['stat_value'] = np.array(list(st.values())[0])
+    np.savez_compressed(os.path.join(args.out, 'openeds_metric.npz'), **out)
+    print('openeds_metric.npz', out['mse_tensors'], out['mse_images'], st)
+
+
 def options_fixture(args):
     """reference_option_defaults.json: every flag of the reference's TrainOptions / TestOptions parsers
     (options/base_options.py, train_options.py, test_options.py) with its default, type, action and choices."""
@@ -166,7 +194,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=HERE)
     ap.add_argument('--full', action='store_true', help='also the ngf=64 256x256 N=8 pin (slow)')
-    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture); 'options': only reference_option_defaults.json; 'bn': only g_bn_ngf8_64.npz")
+    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture); 'options': only reference_option_defaults.json; 'bn': only g_bn_ngf8_64.npz; 'openeds': only openeds_metric.npz")
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -190,6 +218,9 @@ def main():
         return
     if args.only == 'options':
         options_fixture(args)
+        return
+    if args.only == 'openeds':
+        openeds_fixture(args, syn)
         return
     if args.only == 'bn':
         bn_generator_fixture(args, syn, onehot, SPADESTYLEGenerator)

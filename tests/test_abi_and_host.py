@@ -142,8 +142,7 @@ def test_options_and_shapes():
     assert len(bn.netG.state_dict()) == 270 and 'head_0.norm_0.spade.param_free_norm.running_mean' in bn.netG.state_dict()
     with pytest.raises(ValueError):
         Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], norm_G='spectralspadesyncbatch3x3'))
-    with pytest.raises(NotImplementedError):
-        Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], lambda_openeds=1.0))
+    Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], lambda_openeds=1.0))          # built since SURVEY 8 f3 (s2e_openeds_error)
     with pytest.raises(NotImplementedError):
         Pix2PixModel(default_opt(ngf=8, ndf=8, gpu_ids=[], no_vgg_loss=False))
 

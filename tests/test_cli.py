@@ -97,10 +97,16 @@ def test_train_resume_test_end_to_end(tmp_path):
     assert torch.equal(sd['fc.weight'], w_end)
     tr2 = train_mod.main(common + ['--niter', '2', '--niter_decay', '1', '--continue_train'])    # resumes at epoch 3
     assert not torch.equal(tr2.pix2pix_model.netG.fc.weight.detach().cpu(), w_end)
-    n = test_mod.main(['--name', 'e2e', '--checkpoints_dir', str(tmp_path / 'ck'), '--results_dir', str(tmp_path / 'res'), '--ngf', '8',
-                       '--batchSize', '2', '--aspect_ratio', '1.0', '--synthetic_size', '4', '--compute_dtype', 'fp32', '--produce_npy'])
-    assert n == 4
-    outs = sorted(os.listdir(tmp_path / 'res' / 'e2e'))
-    assert len(outs) == 4
-    img = np.load(tmp_path / 'res' / 'e2e' / outs[0])
-    assert img.shape == (1, 256, 256) and img.dtype == np.uint8
+    targs = ['--name', 'e2e', '--checkpoints_dir', str(tmp_path / 'ck'), '--results_dir', 'res', '--ngf', '8',
+             '--batchSize', '2', '--aspect_ratio', '1.0', '--synthetic_size', '4', '--compute_dtype', 'fp32']
+    # inference: one (1, 640, 400) uint8 .npy per sample + the list file (util/tester.py:193-219)
+    paths = test_mod.main(targs + ['--produce_npy'])
+    assert len(paths) == 4
+    rdir = tmp_path / 'ck' / 'e2e' / 'res' / 'train'
+    assert sorted(os.listdir(rdir)) == sorted([os.path.basename(p) for p in paths] + ['pred_npy_list.txt'])
+    img = np.load(paths[0])
+    assert img.shape == (1, 640, 400) and img.dtype == np.uint8
+    # validation: per-image OpenEDS errors + the x1471 statistic (util/tester.py:99-121,165-176)
+    errs, stats = test_mod.main(targs + ['--dataset_key', 'validation'])
+    assert len(errs) == 4 and all(0.0 < e < 1.0 for e in errs)
+    assert abs(stats['mse/validation/full/relative'] - float(np.mean(errs)) * 1471) < 1e-3

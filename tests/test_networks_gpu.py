@@ -339,6 +339,37 @@ def test_trainer_two_iterations_fp32_match_reference():
                 assert_checksum_close(v, z['it%d_ck_%s.%s' % (it, tag, k)], 2e-3, 'it%d %s.%s' % (it, tag, k), flip=flip)
 
 
+@pytest.mark.parametrize('graphs', [False, True])
+def test_trainer_openeds_loss_matches_oracle(graphs):
+    """--lambda_openeds (pix2pix_model.py:206-210): the per-image OpenEDS error of the generated batch enters
+    the logged G loss (no gradient); one G + D step on the HIP path vs the CPU oracle, eager and as hipGraph replays."""
+    from oracle import seg2eye_oracle as O
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    z = load_golden('trainer_ngf8_256')
+    opt = _opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='fp32', hip_graphs=graphs, lambda_openeds=3.0)
+    tr = Pix2PixTrainer(opt)
+    m = tr.pix2pix_model
+    sds = {}
+    for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+        sds[tag] = filled_state(z, tag)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(sds[tag][k])
+    batch = _batch(2, 256, 256, 21)
+    data = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    tr.run_generator_one_step(dict(data))
+    tr.run_discriminator_one_step(dict(data))
+    got = tr.get_latest_losses()
+    om = O.OracleModel(sds['G'], sds['D'], sds['E'], opt, 8, 8)
+    gl, fake = om.run_generator_one_step({**batch, 'label': batch['label'].long()})
+    assert 'openeds/weighted' in got and got['openeds/weighted'].shape == (2,)
+    # a generated pixel within 1e-5 of an integer boundary may truncate either way: 1 grey level on a few pixels
+    np.testing.assert_allclose(got['openeds/weighted'].detach().cpu().numpy(), gl['openeds/weighted'].numpy(), rtol=2e-3)
+    np.testing.assert_allclose(float(got['GAN'].mean()), float(gl['GAN'].mean()), rtol=2e-3, atol=2e-4)
+    log = m.get_loss_log()
+    np.testing.assert_allclose(float(log['openeds/raw']) * 3.0, float(gl['openeds/weighted'].mean()), rtol=2e-3)
+
+
 STYLE_LAMBDAS = dict(lambda_l2=15.0, lambda_l1=2.0, lambda_style_w=0.5, lambda_style_feat=0.001, lambda_gram=10000.0)
 
 

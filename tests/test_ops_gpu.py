@@ -3,6 +3,7 @@ PyTorch fp64 CPU references of the same op.  fp32 kernels: tight tolerance; bf16
 both sides start from the same bf16-rounded inputs, tolerance = bf16 output rounding."""
 import numpy as np
 import pytest
+from conftest import load_golden
 import torch
 import torch.nn.functional as F
 
@@ -391,3 +392,35 @@ def test_conv2d_random_shapes(forced):
     out = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'done, mismatches: 0' in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_openeds_metric_kernels(dtype):
+    """SURVEY 8 f3 on the device vs the oracle: 0..255 truncation and per-image error (integer work: bit-exact sums, the
+    fp32 sqrt / division to 1e-6), and the bilinear resize + truncation (cv2.INTER_LINEAR rule; the oracle restates it with
+    torch -- a pixel whose interpolated value lands within fp32 rounding of an integer may truncate either way)."""
+    from oracle import seg2eye_oracle as O
+    from seg2eye_amd import ops, synthetic as syn
+    from seg2eye_amd.networks.loss import MSECalculator, openEDSaccuracy
+    from seg2eye_amd.postprocessor import ImageProcessor
+    dev = _dev()
+    a = torch.from_numpy(syn.make_batch(3, 96, 80, seed=501)['target']).to(dtype)
+    b = torch.from_numpy(syn.make_batch(3, 96, 80, seed=502)['target']).to(dtype)
+    ref = O.mse_for_tensors(a.float(), b.float())
+    got = MSECalculator.calculate_mse_for_tensors(a.to(dev), b.to(dev)).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-6)
+    if dtype == torch.float32:                                   # and against the REAL reference's numbers
+        np.testing.assert_allclose(got.numpy(), load_golden('openeds_metric')['mse_tensors'], rtol=1e-6)
+    # resize to 640 x 400 + truncation
+    r_ref = O.to_255_resized(a.float())
+    r_got = ImageProcessor.to_255resized_imagebatch(a.to(dev)).cpu()
+    assert r_got.shape == (3, 1, 640, 400) and r_got.dtype == torch.uint8
+    d = (r_got.int() - r_ref.int()).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, (int(d.max()), float((d > 0).float().mean()))
+    # images already in 0..255
+    ia, ib = r_ref.to(torch.uint8), O.to_255_resized(b.float()).to(torch.uint8)
+    np.testing.assert_allclose(MSECalculator.calculate_mse_for_images(ia.to(dev), ib.to(dev)).cpu().numpy(),
+                               O.mse_for_images(ia, ib).numpy(), rtol=1e-6)
+    np.testing.assert_allclose(float(openEDSaccuracy(ia[0].to(dev), ib[0].to(dev))), float(O.openeds_accuracy(ia[0], ib[0])), rtol=1e-6)
+    assert ImageProcessor.to_255imagebatch(a.float()).equal(O.to_255(a.float()))
+

@@ -197,3 +197,27 @@ def test_generator_batchnorm_spade():
     with torch.no_grad():
         ye = O.generator_forward({**sd, **{k: v.detach() for k, v in upd.items()}}, seg, w, 2, 2, training=False)
     np.testing.assert_allclose(ye.numpy(), z['y_eval_after'], atol=TOL, rtol=0)
+
+
+def test_openeds_metric():
+    """the oracle's restatement of the OpenEDS error (loss.py:102-171, postprocessor.py:58-97) against the
+    REAL reference's outputs on synthetic images regenerated from the fixture's seeds (tests/golden/openeds_metric.npz)."""
+    z = load_golden('openeds_metric')
+    sa, sb, sia, sib = (int(x) for x in z['seeds'])
+    a = torch.from_numpy(syn.make_batch(3, 96, 80, seed=sa)['target'])
+    b = torch.from_numpy(syn.make_batch(3, 96, 80, seed=sb)['target'])
+    assert np.array_equal(O.to_255(a).numpy().astype(np.uint8), z['to255_a'])                  # integer work: bit-exact
+    np.testing.assert_allclose(O.mse_for_tensors(a, b).numpy(), z['mse_tensors'], rtol=1e-6)
+    ia = O.to_255(torch.from_numpy(syn.make_batch(2, 640, 400, seed=sia)['target']))
+    ib = O.to_255(torch.from_numpy(syn.make_batch(2, 640, 400, seed=sib)['target']))
+    assert [int(ia.long().sum()), int((ia.long() * ia.long()).sum())] == z['ia_checksum'].tolist()
+    np.testing.assert_allclose(O.mse_for_images(ia, ib).numpy(), z['mse_images'], rtol=1e-6)
+    np.testing.assert_allclose(float(O.openeds_accuracy(ia[0], ib[0])), float(z['acc_single']), rtol=1e-6)
+    st = O.error_statistics(z['stat_errors'], 'full', 'validation')
+    assert list(st.keys()) == [str(z['stat_key'])]
+    np.testing.assert_allclose(list(st.values())[0], float(z['stat_value']), rtol=1e-12)
+    # the resize restatement (cv2 absent: parity-unpinned, see the oracle): shape, range and exactness on constants
+    r = O.to_255_resized(a)
+    assert r.shape == (3, 1, 640, 400) and int(r.min()) >= 0 and int(r.max()) <= 255
+    assert int(O.to_255_resized(torch.full((1, 1, 8, 8), 0.5)).unique().item()) == int((0.5 + 1) * 255 / 2)
+
