@@ -16,9 +16,8 @@ class SyntheticEyes:
 
     def __init__(self, opt, rank=0, world=1, seed=1234):
         if opt.dataset_mode != 'synthetic':
-            raise NotImplementedError("dataset_mode '%s': only 'synthetic' is built (the OpenEDS H5 pipeline is SURVEY 8 f4); "
-                                      "feed Pix2PixTrainer your own batches with the keys documented in seg2eye_amd/data.py"
-                                      % opt.dataset_mode)
+            raise NotImplementedError("dataset_mode '%s': 'synthetic' and 'openeds' are built; feed Pix2PixTrainer your own "
+                                      "batches with the keys documented in seg2eye_amd/data.py" % opt.dataset_mode)
         self.opt, self.rank, self.world, self.seed = opt, rank, world, seed
         self.h, self.w = image_hw(opt)
         self.n_batches = max(1, int(getattr(opt, 'synthetic_size', 64)) // (opt.batchSize * world))
@@ -43,5 +42,10 @@ class SyntheticEyes:
             yield self.batch(i)
 
 
-def create_dataloader(opt, rank=0, world=1):
+def create_dataloader(opt, rank=0, world=1, store=None, style_refs=None):
+    """data/__init__.py:43-59.  `--dataset_mode synthetic`: the seeded generator above; `--dataset_mode openeds`: the
+    OpenEDS H5 dataset (seg2eye_amd/openeds_dataset.py; `store` = an in-memory H5-like mapping instead of opt.dataroot)."""
+    if opt.dataset_mode == 'openeds':
+        from .openeds_dataset import create_dataloader as _create
+        return _create(opt, store=store, style_refs=style_refs)
     return SyntheticEyes(opt, rank, world)

@@ -7,7 +7,7 @@
 What differs from the reference: the generated batch never leaves the GPU before it is scored (resize to 400 x 640,
 0..255 truncation and sqrt(sum d^2)/(H W) are `s2e_resize_to255` + `s2e_openeds_error_u8`); the H5 error log and the
 visdom / TF visualisations are not built (out of scope); the dataset is whatever `data.create_dataloader`
-yields -- batches must carry `target_original` (N, 640, 400) uint8 for validation."""
+yields (synthetic, or the OpenEDS H5 dataset) -- batches must carry `target_original` (N, 1, 640, 400) for validation."""
 import os
 import re
 from copy import deepcopy
@@ -42,17 +42,32 @@ class Tester:
         return fake, ImageProcessor.to_255resized_imagebatch(fake)
 
     def get_iterator(self, dataloader, indices=None):
+        """tester.py:49-65: the whole dataset, or the listed samples one by one (`dataset.get_particular`)."""
         if indices is None:
             for data_i in dataloader:
                 yield data_i
         else:
+            ds = getattr(dataloader, 'dataset', None)
             for i_val in indices:
-                yield dataloader.batch(i_val)
+                yield ds.get_particular(int(i_val)) if ds is not None else dataloader.batch(int(i_val))
+
+    def _get_validation_indices(self, mode, limit):
+        """tester.py:152-163: 'rand*' -> random samples, 'fix*' -> first/last sample of every person, 'full' -> all."""
+        ds = getattr(self.dataloader, 'dataset', None)
+        if 'full' in mode:
+            return None
+        if ds is None or not hasattr(ds, 'get_validation_indices'):
+            raise NotImplementedError("validation mode '%s' needs a dataset with index lists (--dataset_mode openeds)" % mode)
+        if 'rand' in mode:
+            return ds.get_random_indices(limit)
+        if 'fix' in mode:
+            return ds.get_validation_indices()[:limit]
+        raise ValueError('Invalid mode: %s' % mode)
 
     def run_batch(self, data_i, model):
         """tester.py:93-97."""
         fake, fake_resized = self.forward(model, data_i)
-        target = ImageProcessor.as_batch(data_i['target_original']).to(fake_resized.device)
+        target = ImageProcessor.as_batch(data_i['target_original']).to(fake_resized.device).to(torch.uint8)
         errors = MSECalculator.calculate_mse_for_images(fake_resized, target).cpu().numpy()
         return errors, fake, fake_resized, target
 
@@ -82,12 +97,11 @@ class Tester:
         print('  dataset_key: %s, model: %s, epoch: %s, n_steps: %s' % (self.opt.dataset_key, self.opt.name, epoch, n_steps))
 
     def run(self, model, mode, epoch=None, n_steps=None, limit=-1, write_error_log=False, log=False):
-        """tester.py:165-176 ('full' walks the whole dataset; 'fix*' / 'rand*' subsets need the H5 dataset's index lists)."""
-        if 'full' not in mode:
-            raise NotImplementedError("validation mode '%s' needs the OpenEDS dataset's index lists (SURVEY 8 f4)" % mode)
+        """tester.py:165-176."""
         print("Running validation for mode '%s'..." % mode)
         limit = limit if limit > 0 else self.N
-        all_errors = self.run_validation(model, self.get_iterator(self.dataloader), limit=limit, write_error_log=write_error_log)
+        generator = self.get_iterator(self.dataloader, indices=self._get_validation_indices(mode, limit))
+        all_errors = self.run_validation(model, generator, limit=limit, write_error_log=write_error_log)
         errors_dict = MSECalculator.calculate_error_statistics(all_errors, mode=mode, dataset_key=self.opt.dataset_key)
         self.print_results(all_errors, errors_dict, epoch, n_steps)
         return all_errors, errors_dict
@@ -100,7 +114,7 @@ class Tester:
                 break
             if i % 10 == 0:
                 print('Processing batch %d (processed %d images)' % (i, self.opt.batchSize * i))
-            names = [re.sub(r'\\.', '', f) for f in data_i['filename']]        # test file names carry a dot to remove
+            names = [re.sub(r'\.', '', f) for f in data_i['filename']]        # test file names carry a dot to remove
             _, fake_resized = self.forward(model, data_i)
             imgs = fake_resized.cpu().numpy()
             for b, name in enumerate(names):

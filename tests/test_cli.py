@@ -78,7 +78,7 @@ def test_synthetic_data_contract():
     other = next(iter(create_dataloader(o, rank=0, world=2)))
     assert not torch.equal(other['label'], b['label'])                      # ranks see different shards
     with pytest.raises(NotImplementedError):
-        create_dataloader(parse(['--dataset_mode', 'openeds']))
+        create_dataloader(parse(['--dataset_mode', 'cityscapes']))
 
 
 @pytest.mark.gpu
@@ -110,3 +110,118 @@ def test_train_resume_test_end_to_end(tmp_path):
     errs, stats = test_mod.main(targs + ['--dataset_key', 'validation'])
     assert len(errs) == 4 and all(0.0 < e < 1.0 for e in errs)
     assert abs(stats['mse/validation/full/relative'] - float(np.mean(errs)) * 1471) < 1e-3
+
+
+
+def _fake_openeds_store(seed=0, users=('U001', 'U002', 'U003'), n_ss=(3, 2, 4), n_gen=5):
+    """An in-memory stand-in for the OpenEDS H5 file (data/prepare_openeds.py:77-138): /<key>/<user>/{images_ss, labels_ss,
+    images_gen, images_seq, labels_gen} uint8 (n, 640, 400) + *_filenames (S13)."""
+    rng = np.random.RandomState(seed)
+    store = {}
+    for key in ('train', 'validation', 'test'):
+        store[key] = {}
+        for u, n in zip(users, n_ss):
+            g = {'images_ss': rng.randint(0, 256, (n, 640, 400)).astype(np.uint8),
+                 'labels_ss': rng.randint(0, 4, (n, 640, 400)).astype(np.uint8),
+                 'images_gen': rng.randint(0, 256, (n_gen, 640, 400)).astype(np.uint8),
+                 'images_seq': rng.randint(0, 256, (2, 640, 400)).astype(np.uint8),
+                 'labels_gen': rng.randint(0, 4, (n, 640, 400)).astype(np.uint8),
+                 'images_ss_filenames': np.array([('%s.%03d_ss' % (u, i)).encode() for i in range(n)], dtype='S13'),
+                 'labels_gen_filenames': np.array([('%s_%03d_gen' % (u, i)).encode() for i in range(n)], dtype='S13')}
+            store[key][u] = g
+    return store
+
+
+def test_openeds_dataset_semantics():
+    """the reference's dataset behaviour (data/openeds_dataset.py:40-209, base_dataset.py:51-146) on an
+    in-memory H5-like store: flat index -> (user, index), key sets of train/validation vs test, 'fixed' preprocessing
+    (nearest for masks, PIL bicubic for images, [-1, 1]), flip augmentation, style sampling modes, the batch contract."""
+    from seg2eye_amd.data import create_dataloader
+    from seg2eye_amd.openeds_dataset import OpenEDSDataset, resize_nearest
+    from seg2eye_amd.options import parse
+    from PIL import Image
+    store = _fake_openeds_store()
+    o = parse(['--dataset_mode', 'openeds', '--dataset_key', 'validation', '--crop_size', '64', '--aspect_ratio', '0.8',
+               '--style_sample_method', 'first', '--no_flip', '--batchSize', '2', '--serial_batches'])
+    ds = OpenEDSDataset(o, store=store)
+    assert len(ds) == 9 and ds.N_start == [0, 3, 5]
+    assert ds._get_tuple_identifier_from_index(4) == ('U002', 1) and ds._get_tuple_identifier_from_index(8) == ('U003', 3)
+    assert sorted(ds.get_validation_indices()) == [0, 2, 3, 4, 5, 8]                      # first and last sample of every person
+    it = ds[4]
+    assert it['user'] == 'U002' and it['filename'] == 'U002001_ss'                        # the dot is removed
+    assert it['label'].shape == (80, 64) and it['label'].dtype == torch.uint8              # h = round(64 / 0.8)
+    assert torch.equal(it['label'], torch.from_numpy(resize_nearest(store['validation']['U002']['labels_ss'][1], 64, 80)))
+    assert it['style_image'].shape == (4, 1, 80, 64) and it['target'].shape == (1, 80, 64)
+    assert float(it['target'].min()) >= -1 and float(it['target'].max()) <= 1
+    ref = np.asarray(Image.fromarray(store['validation']['U002']['images_ss'][1], mode='L').resize((64, 80), Image.BICUBIC), dtype=np.float32)
+    assert torch.allclose(it['target'][0], torch.from_numpy(ref / 255.0 - 0.5) / 0.5, atol=1e-6)
+    assert it['target_original'].shape == (1, 640, 400) and it['target_original'].dtype == torch.int32
+    first = np.asarray(Image.fromarray(store['validation']['U002']['images_gen'][0], mode='L').resize((64, 80), Image.BICUBIC), dtype=np.float32)
+    assert torch.allclose(it['style_image'][0, 0], torch.from_numpy(first / 255.0 - 0.5) / 0.5, atol=1e-6)     # 'first': images_gen[0..3]
+    # test split: other keys, no target
+    ot = parse(['--dataset_mode', 'openeds', '--dataset_key', 'test', '--crop_size', '64', '--aspect_ratio', '0.8', '--no_flip'], is_train=False)
+    t = OpenEDSDataset(ot, store=store)[0]
+    assert 'target' not in t and t['filename'] == 'U001_000_gen' and t['style_image'].shape == (4, 1, 80, 64)
+    # flip augmentation flips mask, images and the ORIGINAL consistently (train mode, flip drawn True)
+    class _Always:                       # rng stub: random() -> 0.9 (> 0.5: flip), choice -> first n
+        def random(self): return 0.9
+        def choice(self, seq, n): return list(seq)[:n]
+    otr = parse(['--dataset_mode', 'openeds', '--dataset_key', 'train', '--crop_size', '64', '--aspect_ratio', '0.8', '--style_sample_method', 'random'])
+    f = OpenEDSDataset(otr, store=store, rng=_Always())[0]
+    g = OpenEDSDataset(parse(['--dataset_mode', 'openeds', '--dataset_key', 'train', '--crop_size', '64', '--aspect_ratio', '0.8',
+                              '--style_sample_method', 'random', '--no_flip']), store=store, rng=_Always())[0]
+    assert torch.equal(f['label'], g['label'].flip(-1)) and torch.allclose(f['target'], g['target'].flip(-1))
+    assert torch.equal(f['target_original'], g['target_original'].flip(-1)) and torch.allclose(f['style_image'], g['style_image'].flip(-1))
+    # ref sampling: a similarity ranking per (user, filename), optionally pointing into the sequence images
+    refs = {'train': {'U001': {'U001000_ss': {'index': np.array([4, 6, 0, 2, 1]), 'subset': np.array([b'g', b's', b'g', b'g', b'g'])}}}}
+    orf = parse(['--dataset_mode', 'openeds', '--dataset_key', 'train', '--crop_size', '64', '--aspect_ratio', '0.8',
+                 '--style_sample_method', 'ref_first', '--no_flip'])
+    r = OpenEDSDataset(orf, store=store, style_refs=refs)
+    st, idx, sub = r.get_style_images('U001', 4, lambda im: torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()), 'U001000_ss')
+    assert idx == [4, 1, 0, 2] and [bytes(x) for x in sub] == [b'g', b's', b'g', b'g']      # 6 - n_images(5) = 1 into images_seq
+    assert torch.equal(st[1], torch.from_numpy(store['train']['U001']['images_seq'][1]))
+    # the DataLoader contract
+    dl = create_dataloader(o, store=store)
+    b = next(iter(dl))
+    assert dl.N == 9 and b['label'].shape == (2, 80, 64) and b['style_image'].shape == (2, 4, 1, 80, 64)
+    assert b['target_original'].shape == (2, 1, 640, 400) and len(b['filename']) == 2
+
+
+@pytest.mark.gpu
+def test_tester_on_openeds_store(tmp_path):
+    """SURVEY 8 f3 + f4 together: the Tester walks an OpenEDS-layout store (in memory), generates with the HIP generator,
+    resizes / truncates / scores on the device; 'fix' mode uses the dataset's per-person index list, 'full' all samples;
+    errors agree with the CPU oracle applied to the same generated images."""
+    from oracle import seg2eye_oracle as O
+    from seg2eye_amd.options import parse
+    from seg2eye_amd.pix2pix_model import Pix2PixModel
+    from seg2eye_amd.tester import Tester
+    import seg2eye_amd.data as data_mod
+    store = _fake_openeds_store(seed=3)
+    argv = ['--name', 'oe', '--checkpoints_dir', str(tmp_path), '--dataset_mode', 'openeds', '--dataset_key', 'validation', '--ngf', '8',
+            '--crop_size', '256', '--aspect_ratio', '0.8', '--batchSize', '2', '--style_sample_method', 'first', '--compute_dtype', 'fp32']
+    opt = parse(argv, is_train=False)
+    orig = data_mod.create_dataloader
+    data_mod.create_dataloader = lambda o, *a, **k: orig(o, store=store)
+    try:
+        tester = Tester(opt, dataset_key='validation')
+    finally:
+        data_mod.create_dataloader = orig
+    assert tester.N == 9
+    torch.manual_seed(0)
+    Pix2PixModel(parse(argv)).save('latest')                 # a (randomly initialised) checkpoint for test mode to load
+    model = Pix2PixModel(opt)
+    model.eval()
+    errs, stats = tester.run(model, mode='full')
+    assert len(errs) == 9 and abs(stats['mse/validation/full/relative'] - float(np.mean(errs)) * 1471) < 1e-3
+    errs_fix, _ = tester.run(model, mode='fix', limit=6)
+    assert len(errs_fix) == 6
+    # one batch against the oracle: same generated image -> resize + truncation + error on the CPU
+    b = next(iter(tester.dataloader))
+    e, fake, fake_resized, target = tester.run_batch(b, model)
+    ref_resized = O.to_255_resized(fake.float().cpu())
+    d = (fake_resized.cpu().int() - ref_resized).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3
+    ref_err = O.mse_for_images(fake_resized.cpu().int(), b['target_original'].int())
+    np.testing.assert_allclose(e, ref_err.numpy(), rtol=1e-6)
+
