@@ -7,21 +7,27 @@
 // 66-73 GB/s per CU), with the loads removed it runs at 1.2-1.5 PFLOP/s.  Deeper pipelines, more resident waves and a
 // 256-pixel tile at the same per-tap gather all measured flat, because none of them changes bytes per FLOP enough.
 //
-// Here a workgroup owns a RECTANGLE of up to 256 output pixels (4 x 64, 8 x 32, 16 x 16, 7 x 34 ...: any width <= 64) and, per 64-channel chunk of Cin, brings
-// the input patch with its halo ((TH+2) x (TW+2) pixels x 128 B, <= 400 pixels = 50 KB) into LDS ONCE; the nine taps
-// are nine shifted views of that patch.  Per chunk and 256 pixels the vector-memory path carries 50 KB of activations
-// + 9 x 16 KB of weights = 194 KB instead of 9 x (32 + 16) = 432 KB at the same tile (576 KB as two 128-pixel tiles).
+// Here a workgroup owns a RECTANGLE of up to 256 output pixels (4 x 64, 8 x 32, 16 x 16, 7 x 34 ...: any width <= 64,
+// chosen per shape by the host) and, per 64-channel chunk of Cin, brings the input patch with its halo
+// ((TH+KS-1) x (TW+KS-1) pixels x 128 B, <= 400 pixels = 50 KB) into LDS ONCE; the KS x KS taps are shifted views of that
+// patch.  Per chunk and 256 pixels (3x3) the vector-memory path carries 50 KB of activations + 9 x 16 KB of weights =
+// 194 KB instead of 9 x (32 + 16) = 432 KB at the same tile (576 KB as two 128-pixel tiles).
 //
-//   LDS        : 2 patch buffers (chunk c is read while c+1 lands, one 1-KiB piece per thread per tap) + 2 weight
-//                K-step buffers = 2 x 51,200 + 2 x 16,384 B = 135 KB -> one 512-thread workgroup per CU.
+//   LDS        : 2 patch buffers (chunk c is read while c+1 lands, one 1-KiB piece per thread per tap) + 3 weight K-step
+//                stages (K-step kt+2 in flight while kt is multiplied) = 2 x 51,200 + 3 x 16,384 B = 151.5 KB -> one
+//                512-thread workgroup per CU, PERSISTENT over tiles (tile i+1's first loads are issued before tile i is
+//                written out).
 //   patch image: pixel pp = py * PW + px at byte pp * 128, 16-B chunk index XORed with (pp >> 1) & 7 (source-side
-//                swizzle of the LDS-DMA, as in conv_igemm.hip).  An A fragment is 32 consecutive tx of one tile row =
-//                32 consecutive pp at ANY tap shift, so every ds_read_b128 stays conflict-free.
-//   waves      : 8 = 4 (pixels) x 2 (channels), wave tile 64 x BN/2, v_mfma_f32_32x32x16_bf16 (32x32x2 f32 for fp32).
+//                swizzle of the LDS-DMA, as in conv_igemm.hip).  With a width that is a multiple of 32 an A fragment is
+//                32 consecutive tx of one tile row = 32 consecutive pp at ANY tap shift, so every ds_read_b128 stays
+//                conflict-free; other widths let a fragment span two rows (a 2-way conflict on a few lanes).
+//   waves      : 8 = 4 (pixels) x 2 (channels), wave tile 64 x BN/2, v_mfma_f32_32x32x16_bf16 (32x32x2 f32 for fp32);
+//                fragment reads hand-pipelined (two register sets, counted lgkmcnt waits, bare s_barrier).
 //   K order    : chunk-major, tap-minor; the packed weight matrix (row co, k = tap * Cin + ci) is used as it is.
-//   data-gradient (stride 1): the same kernel with the patch origin moved to o + pad - 2 and the taps mirrored.
-//   epilogue   : fp32 accumulators -> LDS in two 128-row halves -> 16-B row stores with bias / residual / activation /
-//                mask fused (same contract as conv_igemm.hip).
+//   data-gradient (stride 1): the same kernel with the patch origin moved to o + pad - (KS-1) and the taps mirrored.
+//   split      : long-K layers with few tiles are split over channel chunks (fp32 slabs + conv_igemm's finish kernel).
+//   epilogue   : fp32 accumulators -> LDS one 64-row wave row at a time (staged in the idle patch buffer) -> 16-B row
+//                stores with bias / residual / activation / mask fused (same contract as conv_igemm.hip).
 #include "conv_patch.h"
 #include <stdlib.h>
 
