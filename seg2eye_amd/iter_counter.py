@@ -56,3 +56,9 @@ class IterationCounter:
 
     def needs_printing(self):
         return (self.total_steps_so_far % self.opt.print_freq) < self.opt.batchSize
+
+    def needs_displaying(self):                                  # util/iter_counter.py:76-77
+        return (self.total_steps_so_far % self.opt.display_freq) < self.opt.batchSize
+
+    def needs_full_validation(self):                             # util/iter_counter.py:79-80
+        return (self.total_steps_so_far % self.opt.full_val_freq) < self.opt.batchSize

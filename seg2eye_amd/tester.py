@@ -106,6 +106,14 @@ class Tester:
         self.print_results(all_errors, errors_dict, epoch, n_steps)
         return all_errors, errors_dict
 
+    def run_partial_modes(self, model, epoch, n_steps, log=False, visualize_images=False, limit=-1):
+        """tester.py:221-233: a quick validation on `limit` random samples ('rand'); a dataset without index lists (the
+        synthetic one) is walked from the start for `limit` samples instead.  (No image visualisation: not built.)"""
+        try:
+            return self.run(model=model, mode='rand', epoch=epoch, n_steps=n_steps, log=log, limit=limit)
+        except NotImplementedError:
+            return self.run(model=model, mode='full', epoch=epoch, n_steps=n_steps, log=log, limit=limit)
+
     def run_test(self, model, limit=-1):
         """tester.py:193-219: one uint8 .npy of shape (1, 640, 400) per sample + the list of written paths."""
         filepaths = []

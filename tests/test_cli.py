@@ -87,7 +87,8 @@ def test_train_resume_test_end_to_end(tmp_path):
     import test as test_mod
     common = ['--name', 'e2e', '--checkpoints_dir', str(tmp_path / 'ck'), '--ngf', '8', '--ndf', '8', '--batchSize', '2',
               '--aspect_ratio', '1.0', '--synthetic_size', '4', '--compute_dtype', 'fp32']
-    tr = train_mod.main(common + ['--niter', '1', '--niter_decay', '1', '--print_freq', '2', '--lambda_l2', '15'])
+    tr = train_mod.main(common + ['--niter', '1', '--niter_decay', '1', '--print_freq', '2', '--lambda_l2', '15', '--lambda_openeds', '1',
+                                  '--display_freq', '4', '--full_val_freq', '4', '--validation_limit', '2'])   # with the periodic validation passes
     ck = tmp_path / 'ck' / 'e2e'
     for f in ('latest_net_G.pth', 'latest_net_D.pth', 'latest_net_E.pth', '1_net_G.pth', '2_net_G.pth', 'iter.txt'):
         assert (ck / f).exists(), f

@@ -2,8 +2,10 @@
 """Training entry point, flag-compatible with the reference's train.py (train.py:23-116): same option names and defaults
 (seg2eye_amd/options.py), same loop -- G step when `i % D_steps_per_G == 0`, then the D step -- same LR schedule,
 same checkpoint files (`<checkpoints_dir>/<name>/<epoch>_net_{G,D,E}.pth`, reference state-dict keys) and `iter.txt`
-resume record.  Not carried over (out of scope or later rows): the visualizer / TF logging, the Tester
-validation passes and the OpenEDS H5 dataset; data comes from `--dataset_mode synthetic`.
+resume record, same validation passes -- every `--display_freq` samples a quick one (`--validation_limit` samples), every
+`--full_val_freq` samples a full one, on the train and validation splits, scored with the OpenEDS metric on the device
+(seg2eye_amd/tester.py).  Not carried over (out of scope): the visualizer / TF logging, source-tree copy.
+Data: `--dataset_mode synthetic` (default) or `openeds` (an H5 file at `--dataroot`; needs h5py).
 
     python train.py --name run1 --batchSize 8 --aspect_ratio 1.0 --niter 1 --niter_decay 0
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 train.py ...
@@ -18,6 +20,7 @@ from seg2eye_amd.data import create_dataloader
 from seg2eye_amd.iter_counter import IterationCounter
 from seg2eye_amd.options import parse
 from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+from seg2eye_amd.tester import Tester
 
 
 def main(argv=None):
@@ -29,6 +32,7 @@ def main(argv=None):
     dataloader = create_dataloader(opt, rank, world)
     trainer = Pix2PixTrainer(opt)
     iter_counter = IterationCounter(opt, len(dataloader) * opt.batchSize)
+    testers = [Tester(opt, dataset_key=k) for k in ('train', 'validation')] if rank == 0 else []
     try:
         for epoch in iter_counter.training_epochs():
             if iter_counter.current_epoch != epoch:
@@ -42,6 +46,16 @@ def main(argv=None):
                     losses = trainer.get_latest_losses(include_log_losses=True)
                     msg = '(epoch: %d, iters: %d, time: %.3f) ' % (epoch, iter_counter.total_steps_so_far, iter_counter.time_per_iter)
                     print(msg + ' '.join('%s: %.3f' % (k, float(v.float().mean())) for k, v in losses.items()), flush=True)
+                if iter_counter.needs_displaying():
+                    with torch.no_grad():                        # (the reference validates the model as it is: train mode)
+                        for t in testers:
+                            t.run_partial_modes(model=trainer.pix2pix_model, epoch=epoch, n_steps=iter_counter.total_steps_so_far,
+                                                log=True, visualize_images=False, limit=opt.validation_limit)
+                if iter_counter.needs_full_validation():
+                    with torch.no_grad():
+                        for t in testers:
+                            t.run(trainer.pix2pix_model, mode='full', epoch=epoch, n_steps=iter_counter.total_steps_so_far,
+                                  log=True, write_error_log=opt.write_error_log)
                 if iter_counter.needs_saving() and rank == 0:
                     print('saving the latest model (epoch %d, total_steps %d)' % (epoch, iter_counter.total_steps_so_far))
                     trainer.save('latest')
