@@ -27,19 +27,38 @@ __global__ __launch_bounds__(256) void sn_gemvT_kernel(const s2e_sn_layer* __res
     atomicAdd(L.t + col, acc);
 }
 
-// ---- one block per layer: v = t / max(|t|, eps)   (train only)
-__global__ __launch_bounds__(256) void sn_norm_v_kernel(const s2e_sn_layer* __restrict__ layers, float eps) {
-    __shared__ float red[4];
-    const s2e_sn_layer L = layers[blockIdx.x];
-    float q = 0.f;
-    for (int j = threadIdx.x; j < L.cols; j += 256) { const float t = L.t[j]; q += t * t; }
+// ---- one block per layer: v = t / max(|t|, eps)   (train only).  1024 threads and every load of a thread in flight
+// at once: a latency chain (cols <= 9216 -> 9 loads per thread), 20 times per train step.
+static constexpr int SN_NT = 1024, SN_MAXL = 12;
+__device__ __forceinline__ float sn_block_sum(float q, float* red) {
     q = wave_sum(q);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
     __syncthreads();
-    const float inv = 1.f / fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), eps);
-    for (int j = threadIdx.x; j < L.cols; j += 256) L.v[j] = L.t[j] * inv;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < SN_NT / 64; ++w) tot += red[w];
+    return tot;
+}
+__global__ __launch_bounds__(SN_NT) void sn_norm_v_kernel(const s2e_sn_layer* __restrict__ layers, float eps) {
+    __shared__ float red[SN_NT / 64];
+    const s2e_sn_layer L = layers[blockIdx.x];
+    float q = 0.f;
+    if (L.cols <= SN_NT * SN_MAXL) {
+        float t[SN_MAXL];
+#pragma unroll
+        for (int k = 0; k < SN_MAXL; ++k) { const int j = threadIdx.x + k * SN_NT; t[k] = j < L.cols ? L.t[j] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < SN_MAXL; ++k) q += t[k] * t[k];
+        const float inv = 1.f / fmaxf(sqrtf(sn_block_sum(q, red)), eps);
+#pragma unroll
+        for (int k = 0; k < SN_MAXL; ++k) { const int j = threadIdx.x + k * SN_NT; if (j < L.cols) L.v[j] = t[k] * inv; }
+    } else {
+        for (int j = threadIdx.x; j < L.cols; j += SN_NT) { const float t = L.t[j]; q += t * t; }
+        const float inv = 1.f / fmaxf(sqrtf(sn_block_sum(q, red)), eps);
+        for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.v[j] = L.t[j] * inv;
+    }
     // s is accumulated (atomics) by the next launch: clear it here instead of a separate zero-fill launch per iteration
-    for (int i = threadIdx.x; i < L.rows; i += 256) L.s[i] = 0.f;
+    for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.s[i] = 0.f;
 }
 
 // ---- s += W v over a [SN_BR x SN_BC] block
@@ -66,31 +85,28 @@ __global__ __launch_bounds__(256) void sn_gemv_kernel(const s2e_sn_layer* __rest
 }
 
 // ---- one block per layer: train: u = s / max(|s|, eps); both: sigma = u . s
-__global__ __launch_bounds__(256) void sn_finalize_kernel(const s2e_sn_layer* __restrict__ layers, float* __restrict__ sigma, int train, float eps) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(SN_NT) void sn_finalize_kernel(const s2e_sn_layer* __restrict__ layers, float* __restrict__ sigma, int train, float eps) {
+    __shared__ float red[SN_NT / 64];
     const s2e_sn_layer L = layers[blockIdx.x];
     float q = 0.f;
     if (train) {
-        for (int i = threadIdx.x; i < L.rows; i += 256) { const float s = L.s[i]; q += s * s; }
+        for (int i = threadIdx.x; i < L.rows; i += SN_NT) { const float s = L.s[i]; q += s * s; }
     } else {
-        for (int i = threadIdx.x; i < L.rows; i += 256) q += L.u[i] * L.s[i];
+        for (int i = threadIdx.x; i < L.rows; i += SN_NT) q += L.u[i] * L.s[i];
     }
-    q = wave_sum(q);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
-    __syncthreads();
-    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float tot = sn_block_sum(q, red);
     if (train) {
         const float inv = 1.f / fmaxf(sqrtf(tot), eps);
-        for (int i = threadIdx.x; i < L.rows; i += 256) L.u[i] = L.s[i] * inv;
+        for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.u[i] = L.s[i] * inv;
         if (threadIdx.x == 0) sigma[blockIdx.x] = tot * inv;            // u . s = |s|^2 / max(|s|, eps)
     } else if (threadIdx.x == 0) {
         sigma[blockIdx.x] = tot;
     }
     // leave both accumulators cleared for the next iteration / forward (each thread clears what it alone read): the
     // scratch is zero at creation and stays zero between calls, so no zero-fill launch is needed per iteration
-    for (int i = threadIdx.x; i < L.rows; i += 256) L.s[i] = 0.f;
+    for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.s[i] = 0.f;
     if (train)
-        for (int j = threadIdx.x; j < L.cols; j += 256) L.t[j] = 0.f;
+        for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.t[j] = 0.f;
 }
 
 extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map, int n_blocks,
@@ -104,10 +120,10 @@ extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, 
     for (int it = 0; it < iters; ++it) {
         if (train) {
             sn_gemvT_kernel<<<n_blocks, 256, 0, st>>>(layers, block_map);
-            sn_norm_v_kernel<<<n_layers, 256, 0, st>>>(layers, eps);
+            sn_norm_v_kernel<<<n_layers, SN_NT, 0, st>>>(layers, eps);
         }
         sn_gemv_kernel<<<n_blocks, 256, 0, st>>>(layers, block_map);
-        sn_finalize_kernel<<<n_layers, 256, 0, st>>>(layers, sigma, train, eps);
+        sn_finalize_kernel<<<n_layers, SN_NT, 0, st>>>(layers, sigma, train, eps);
     }
     S2E_CHECK_LAUNCH("sn power-iteration kernels");
     return S2E_OK;
