@@ -32,10 +32,16 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
         if self.learned_shortcut:
             self.norm_s = SPADE_STYLE_Block(fin, opt)
 
-    def forward(self, x, seg, latent_style):
+    def input_stats(self, x, replication=1):
+        """Statistics for norm_0 / norm_s of this block from x BEFORE the generator's nearest 2x upsampling
+        (replication=4): the same numbers from a quarter of the bytes.  Pass the result to forward(stats=...)."""
+        return spade_stats(x, [self.norm_0.spade] + ([self.norm_s.spade] if self.learned_shortcut else []), replication)
+
+    def forward(self, x, seg, latent_style, stats=None):
         seg = SegMap.of(seg)
         sn_begin(self)                  # no-op inside a generator (its forward already stepped the bank)
-        stats = spade_stats(x, [self.norm_0.spade] + ([self.norm_s.spade] if self.learned_shortcut else []))
+        if stats is None:
+            stats = self.input_stats(x)
         if self.learned_shortcut:
             x_s = ops.conv2d_m(self.norm_s(x, seg, latent_style, stats, lrelu=False), self.conv_s)
         else:

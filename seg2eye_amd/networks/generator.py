@@ -53,15 +53,21 @@ class SPADESTYLEGenerator(BaseNetwork):
         with packing.network_scope(self, bank), stylebank.scope(self, w):   # all weight packs: one launch; all style FCs: one GEMM
             # F.interpolate(seg, (sh, sw)) + fc conv, generator.py:72-73
             x = ops.label_conv3x3(seg.label, self.fc.weight, self.fc.bias, self.sh, self.sw, False, self.cdtype)
+            # a block that follows an upsampling takes its input statistics from the tensor BEFORE it (nearest 2x
+            # replication changes neither mean nor variance): a quarter of the bytes for the same numbers
             x = self.head_0(x, seg, w)
+            st = self.G_middle_0.input_stats(x, 4)
             x = ops.upsample2x(x)
-            x = self.G_middle_0(x, seg, w)
+            x = self.G_middle_0(x, seg, w, st)
+            st = None
             if self.opt.num_upsampling_layers == 'more':
+                st = self.G_middle_1.input_stats(x, 4)
                 x = ops.upsample2x(x)
-            x = self.G_middle_1(x, seg, w)
+            x = self.G_middle_1(x, seg, w, st)
             for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
+                st = blk.input_stats(x, 4)
                 x = ops.upsample2x(x)
-                x = blk(x, seg, w)
+                x = blk(x, seg, w, st)
             # conv_img(leaky_relu(x)) + tanh, generator.py:99-100: one launch
             y = ops.conv2d(x, self.conv_img.weight, self.conv_img.bias, None, 1, 1, ACT_LRELU, ACT_TANH)
             return y.permute(0, 3, 1, 2)

@@ -73,8 +73,11 @@ class SPADE(nn.Module):
                 self.mlp_gamma.bias, self.mlp_beta.bias]
 
 
-def spade_stats(x, spades):
+def spade_stats(x, spades, replication=1):
     """{mean, rstd} (N,C,2) fp32 of x for the SPADE modules that normalise it (norm_0 and norm_s of a block share x).
+    replication: the modules will see every pixel of x `replication` times (x is about to go through the nearest 2x
+    upsampling: 4) -- mean and biased variance are those of x itself, so the pass runs over a quarter of the data; only
+    BatchNorm's unbiased running variance needs the real count.
     instance: per-sample statistics (one pass over x).  batch, train mode: statistics of the whole batch, combined from
     the same pass's per-sample fp64 sums; every module's running buffers are updated like nn.BatchNorm2d does (momentum
     0.1, unbiased running variance).  batch, eval mode: a module's own running statistics -- they differ between
@@ -90,8 +93,8 @@ def spade_stats(x, spades):
         st = torch.stack([bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)], -1)
         return st.unsqueeze(0).expand(n, c, 2).contiguous()
     _, sums = ops.in_stats(x.detach(), return_sums=True)
-    cnt = float(n * h * w)
-    tot = sums.sum(0)                                             # (C,2) fp64
+    cnt = float(n * h * w * replication)
+    tot = sums.sum(0) * float(replication)                        # (C,2) fp64
     mean = tot[:, 0] / cnt
     var = (tot[:, 1] / cnt - mean * mean).clamp_min(0.0)
     with torch.no_grad():
