@@ -80,6 +80,8 @@ class NLayerDiscriminator(BaseNetwork):
             h = tap(h)
         last = getattr(self, 'model%d' % (self.n_groups - 1))[0]
         h = ops.conv2d(h, last.weight, last.bias, None, 1, self.padw)
+        if ops.LivePrefix.n is not None:
+            h = ops.live_prefix_gate(h, ops.LivePrefix.n)          # the prediction for the real half: no gradient either
         feats.append(h)
         return feats
 
@@ -122,11 +124,13 @@ class MultiscaleDiscriminator(BaseNetwork):
             keep_all = not self.opt.no_ganFeat_loss
             terms = [] if feat_lambda is not None else None
             num_D = len(list(self.named_children()))
-            for name, D in self.named_children():
-                raw = D.forward_nhwc(x, terms, (feat_lambda or 0.0) / num_D)
-                feats = [f.permute(0, 3, 1, 2) for f in raw]
-                result.append(feats if keep_all else [feats[-1]])
-                x = ops.avgpool3x3s2(x)                    # F.avg_pool2d(3, 2, 1, count_include_pad=False)
+            # G step ([fake | real], real = detached feature-matching target): gradients exist for the fake half only
+            with ops.LivePrefix.of(x.shape[0] // 2 if terms is not None else None):
+                for name, D in self.named_children():
+                    raw = D.forward_nhwc(x, terms, (feat_lambda or 0.0) / num_D)
+                    feats = [f.permute(0, 3, 1, 2) for f in raw]
+                    result.append(feats if keep_all else [feats[-1]])
+                    x = ops.avgpool3x3s2(x)                    # F.avg_pool2d(3, 2, 1, count_include_pad=False)
             if terms is None:
                 return result
             return result, torch.stack(terms).sum().view(1)

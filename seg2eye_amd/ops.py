@@ -8,6 +8,7 @@ NHWC-contiguous 4-D tensors (N, H, W, C) in the compute dtype (bf16 or fp32).
 There is no CPU path: calling an op with a non-CUDA tensor raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -266,11 +267,13 @@ _WGRAD_FAMILY = ('conv_wgrad', 'conv_wgrad_small', 'conv_wgrad_patch')
 
 
 def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transposed=False,
-               in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE):
+               in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE, out=None):
     _need(x, wp, bias, residual, aux)
     n, hi, wi, cin = x.shape
     ho, wo, cout = out_hw_c
-    y = torch.empty(n, ho, wo, cout, dtype=x.dtype, device=x.device)
+    y = torch.empty(n, ho, wo, cout, dtype=x.dtype, device=x.device) if out is None else out
+    if out is not None and (tuple(out.shape) != (n, ho, wo, cout) or out.dtype != x.dtype or not out.is_contiguous()):
+        raise ValueError('conv2d_raw: out must be a contiguous %s tensor with the shape of the result' % (x.dtype,))
     d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, int(transposed), in_act, out_act, aux_mode)
     # algorithmic FLOPs = those of the forward conv this launch computes or differentiates (a stride-2
     # data-gradient executes 4x that on structural zeros; not counted)
@@ -407,6 +410,43 @@ def _unpack_dw(dw, cout, cin, kh, kw, cin_pad):
 
 # ------------------------------------------------------------------------------ conv2d
 
+class LivePrefix:
+    """Batches of which only the first `n` samples carry a gradient.  In the G step netD runs on [fake | real] and the
+    real half only serves as the (detached) target of the feature-matching loss: its gradient is exactly zero all the way
+    down.  A conv recorded inside `with LivePrefix.of(n)` computes its DATA gradient for the first n samples only and
+    zero-fills the rest -- the same numbers for half the MFMA work.  netD gates its outputs (live_prefix_gate) so that the
+    premise holds whatever the caller does with them."""
+    n = None
+
+    class of:
+        def __init__(self, n):
+            self.n = n
+
+        def __enter__(self):
+            self.prev, LivePrefix.n = LivePrefix.n, self.n
+
+        def __exit__(self, *exc):
+            LivePrefix.n = self.prev
+
+
+class _LivePrefixGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, n):
+        ctx.n = n
+        return h.view_as(h)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        g[ctx.n:].zero_()
+        return g, None
+
+
+def live_prefix_gate(h, n):
+    """Identity whose backward zeroes the gradient of samples n.. (see LivePrefix)."""
+    return _LivePrefixGate.apply(h, n)
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = out_act(conv(in_act(x), W) + b + residual) on NHWC tensors.  x may carry more channels
     than W has input channels (structural zero padding).  With (u, v, sigma) given, W = weight/sigma
@@ -427,6 +467,7 @@ class Conv2dFn(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act)
         ctx.cfg = (stride, pad, in_act, out_act, bias is not None, residual is not None)
+        ctx.live = LivePrefix.n
         ctx.wdst = _grad_dst(weight)                       # direct accumulation targets (or None)
         ctx.bdst = _grad_dst(bias) if bias is not None else None
         ctx.save_for_backward(x, weight, y if out_act != ACT_NONE else None, u, v, sigma)
@@ -439,6 +480,22 @@ class Conv2dFn(torch.autograd.Function):
         n, hi, wi, cx = x.shape
         cout, cin, kh, kw = weight.shape
         g = gy.contiguous()
+        live = ctx.live
+        if (live is not None and 0 < live < n and ctx.needs_input_grad[0] and not ctx.needs_input_grad[1]
+                and not (has_bias and ctx.needs_input_grad[2]) and not (has_res and ctx.needs_input_grad[3])
+                and out_act in (ACT_NONE, ACT_LRELU)):
+            # only the first `live` samples carry a gradient (LivePrefix): data gradient of that prefix, zeros behind it
+            gl = g[:live]
+            if out_act == ACT_LRELU:
+                g2 = torch.empty_like(gl)
+                L.check(L.lib().s2e_lrelu_bwd(_dt(gl), _p(gl), _p(y), _p(g2), gl.numel(), _stream()), 's2e_lrelu_bwd')
+                gl = g2
+            gx = torch.empty_like(x)
+            wpt = packed_weight(weight, x.dtype, cx, True, sigma, ctx.plan, ctx.plan_gen)
+            conv2d_raw(gl, wpt, None, None, x[:live] if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
+                       True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE, out=gx[:live])
+            gx[live:].zero_()
+            return gx, None, None, None, None, None, None, None, None, None, None
         if out_act == ACT_TANH:
             g2 = torch.empty_like(g)
             L.check(L.lib().s2e_tanh_bwd(_dt(g), _p(g), _p(y), _p(g2), g.numel(), _stream()), 's2e_tanh_bwd')
