@@ -44,7 +44,8 @@ class Pix2PixTrainer:
         """trainers/pix2pix_trainer.py:26-35.  With opt.hip_graphs the body is one graph replay."""
         self.pix2pix_model.train()
         if self.use_graphs:
-            self._stage_inputs(data)
+            self._stage_inputs(data)                         # captures on first use; turns graphs off if that fails
+        if self.use_graphs:
             self.graph_G.replay()
         else:
             self._g_body(data)
@@ -55,6 +56,7 @@ class Pix2PixTrainer:
         self.pix2pix_model.train()
         if self.use_graphs:
             self._stage_inputs(data)
+        if self.use_graphs:
             self.graph_D.replay()
         else:
             self._d_body(data)
@@ -69,7 +71,20 @@ class Pix2PixTrainer:
         """Copy the batch into the static input buffers the graphs read (capturing on first use).
         Shapes are fixed for the lifetime of the graphs."""
         if self._static is None:
-            self._capture(data)
+            try:
+                self._capture(data)
+            except Exception as e:                           # noqa: BLE001 -- any capture failure: run eager instead
+                # Eager runs the same kernels at the same rate (the GPU is busy throughout, DESIGN 5); a failed capture
+                # must not take a multi-GPU job down.  The step that triggered the capture has not run yet.
+                import sys
+                import torch
+                print('seg2eye_amd: hipGraph capture failed (%s: %s) -- continuing without graphs' % (type(e).__name__, e),
+                      file=sys.stderr)
+                torch.cuda.synchronize()
+                self.opt.hip_graphs = False
+                self._static, self.graph_G, self.graph_D = None, None, None
+                ZeroPool.frozen = False
+                return
         for k, buf in self._static.items():
             src = data[k]
             if src.data_ptr() != buf.data_ptr():
@@ -97,15 +112,22 @@ class Pix2PixTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ZeroPool.freeze()                                    # the graphs hold raw pointers into the pool
-        self.graph_G = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_G):
-            self._g_body(self._static)
-        self.graph_D = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_D, pool=self.graph_G.pool()):
-            self._d_body(self._static)
-        with torch.no_grad():
-            for b, s0 in zip(banks, snap):
-                b.uv_arena.copy_(s0)
+        # With a process group up, RCCL's watchdog thread polls events while we capture: only calls made by the
+        # capturing threads may invalidate the capture (the collectives themselves stay outside the graphs).
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized()
+        mode = {'capture_error_mode': 'thread_local'} if multi else {}
+        try:
+            graph_G = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_G, **mode):
+                self._g_body(self._static)
+            graph_D = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_D, pool=graph_G.pool(), **mode):
+                self._d_body(self._static)
+            self.graph_G, self.graph_D = graph_G, graph_D
+        finally:
+            with torch.no_grad():
+                for b, s0 in zip(banks, snap):
+                    b.uv_arena.copy_(s0)
 
     def get_latest_losses(self, include_log_losses=False):
         losses = {**self.g_losses, **self.d_losses}

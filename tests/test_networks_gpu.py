@@ -555,6 +555,24 @@ def test_resblk_matches_oracle_tight(fin, fout, name, hw):
         assert rel(p.grad, leaf['p.' + k].grad) < 2e-5, k
 
 
+def test_hip_graph_capture_failure_falls_back_to_eager(monkeypatch, capsys):
+    """A capture that fails (e.g. a runtime thread interfering in a multi-process job) must not take the job down:
+    the trainer reports it once and runs the same step bodies eagerly."""
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    tr = Pix2PixTrainer(_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='bf16', hip_graphs=True))
+
+    def boom(data):
+        raise RuntimeError('capture refused')
+    monkeypatch.setattr(tr, '_capture', boom)
+    data = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in _batch(2, 256, 256, 5).items()}
+    for _ in range(2):
+        tr.run_generator_one_step(dict(data))
+        tr.run_discriminator_one_step(dict(data))
+    assert tr.use_graphs is False and tr.graph_G is None
+    assert 'continuing without graphs' in capsys.readouterr().err
+    assert all(bool(torch.isfinite(v.float()).all()) for v in tr.get_latest_losses().values())
+
+
 def test_hip_graph_steps_match_eager():
     """opt.hip_graphs: replaying the captured step bodies must follow the eager trajectory (same losses
     over 3 iterations within float-atomics noise, capture itself leaves weights AND u, v untouched)."""
