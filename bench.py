@@ -93,11 +93,12 @@ def main():
     rank, world, local_rank = sdist.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)     # (== local_rank on a full node; lets a 2-rank gloo
+    torch.cuda.set_device(dev_index)                               #  dry run share the single GPU of a test box)
+    dev = torch.device('cuda', dev_index)
 
     opt_kwargs = dict(ngf=args.ngf, ndf=args.ngf, crop_size=args.size, aspect_ratio=1.0, batchSize=args.batch,
-                      compute_dtype=args.dtype, gpu_ids=[local_rank], hip_graphs=not args.no_graphs)
+                      compute_dtype=args.dtype, gpu_ids=[dev_index], hip_graphs=not args.no_graphs)
     opt = default_opt(**opt_kwargs)
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -128,13 +129,15 @@ def main():
     # Per-launch HIP events for the roofline.  A graph replay cannot carry per-launch events, so the
     # same step (same kernels, shapes, data) is re-run eagerly right after the timed region with an
     # event pair around every MFMA-kernel launch, on the launch stream.
+    # Every rank runs these extra steps (a step contains the gradient all-reduce: rank 0 alone would wait for ever);
+    # only rank 0 records events.
     prof_steps = 0
-    if rank == 0 and not args.no_kernel_events:
+    if not args.no_kernel_events:
         trainer.opt.hip_graphs = False
         step()
         torch.cuda.synchronize()
         ops.LaunchProfiler.reset()
-        ops.LaunchProfiler.enabled = True
+        ops.LaunchProfiler.enabled = rank == 0
         prof_steps = 2
         for _ in range(prof_steps):
             step()

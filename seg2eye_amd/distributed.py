@@ -24,7 +24,9 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # S2E_DIST_BACKEND=gloo: the multi-rank control flow on a box with fewer GPUs than ranks (tests); RCCL
+            # itself refuses two ranks on one device
+            backend = os.environ.get('S2E_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

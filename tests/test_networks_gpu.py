@@ -656,3 +656,25 @@ def test_full_size_train_step_matches_oracle():
         assert abs(res['bf16'][0][k] - r) <= 0.05 * max(1.0, abs(r)), (k, res['bf16'][0][k], r)
     d = (res['bf16'][1] - res['fp32'][1]).abs()
     assert float(d.mean()) < 3e-2 and float(d.max()) < 0.5, (float(d.mean()), float(d.max()))
+
+
+def test_bench_two_ranks_dry_run():
+    """bench.py's multi-rank control flow (barriers, max-over-ranks timing, the eager event pass on EVERY rank -- a step
+    contains the gradient all-reduce, so rank 0 alone would wait for ever -- and the final barrier) with two ranks sharing
+    this box's GPU over gloo.  RCCL refuses two ranks on one device; the collective calls are the same."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, S2E_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+                          '--gpus', '2', '--steps', '2', '--warmup', '1', '--ngf', '16', '--batch', '2'],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
+    assert d['value'] > 0 and 'roofline' in d and 'cpu_baseline' not in d
