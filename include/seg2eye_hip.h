@@ -38,7 +38,9 @@ enum { S2E_F32 = 0, S2E_BF16 = 1 };
 enum { S2E_ACT_NONE = 0, S2E_ACT_LRELU = 1, S2E_ACT_TANH = 2 };          /* LeakyReLU slope 0.2 */
 enum { S2E_AUX_NONE = 0, S2E_AUX_RELU_MASK = 1, S2E_AUX_LRELU_GRAD = 2 }; /* y *= (aux>0 ? 1 : 0 | 0.2) */
 enum { S2E_NORM_SPADE_STYLE = 0, S2E_NORM_PLAIN_IN = 1,
-       S2E_NORM_SPADE_STYLE_BATCH = 2 };   /* s2e_modulate_bwd only: stats are BATCH statistics (BatchNorm SPADE) */
+       S2E_NORM_SPADE_STYLE_BATCH = 2,     /* s2e_modulate_bwd only: stats are BATCH statistics (BatchNorm SPADE) */
+       S2E_NORM_ACCUMULATE_DX = 0x100 };   /* s2e_modulate_bwd only, OR-ed into mode: dx += instead of dx = (dx holds the
+                                              gradient another consumer of the same x has already written) */
 enum { S2E_LOSS_NEG_MEAN = 0, S2E_LOSS_HINGE_REAL = 1, S2E_LOSS_HINGE_FAKE = 2, S2E_LOSS_L1 = 3 };
 
 int s2e_version(void);

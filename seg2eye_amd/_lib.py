@@ -16,6 +16,7 @@ S2E_F32, S2E_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD = 0, 1, 2
 NORM_SPADE_STYLE, NORM_PLAIN_IN, NORM_SPADE_STYLE_BATCH = 0, 1, 2
+NORM_ACCUMULATE_DX = 0x100
 LOSS_NEG_MEAN, LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_L1 = 0, 1, 2, 3
 
 

@@ -434,7 +434,7 @@ __global__ void modulate_bwd_coef_kernel(const double* __restrict__ ws, f32x4_t*
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __restrict__ gin, const T* __restrict__ x,
         const T* __restrict__ gb, const T* __restrict__ dgb, const f32x4_t* __restrict__ coef, T* __restrict__ dx,
-        int vps, int HW, int C, int cg, int cg_shift, int lrelu) {
+        int vps, int HW, int C, int cg, int cg_shift, int lrelu, int acc) {
     constexpr int VEC = Vec<T>::N;
     const int n = blockIdx.y;                              // one sample per grid row: 32-bit indices, no 64-bit division
     // The channel group of a thread does not change over the grid-stride loop when the stride is a multiple of cg
@@ -476,6 +476,12 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
                 o[j] = K[j][1] * go - K[j][2] - f[j] * K[j][3];
             }
         }
+        if (acc) {                                         // dx already holds another consumer's gradient of the same x
+            float prev[VEC];
+            unpack16<T>(*(const u32x4_t*)(dx + row * C + c0), prev);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] += prev[j];
+        }
         *(u32x4_t*)(dx + row * C + c0) = pack16<T>(o);
     }
 }
@@ -484,6 +490,8 @@ extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* 
                                 const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                                 int N, int HW, int C, int lrelu, int style_ld, void* stream) {
     const int sld = style_ld > 0 ? style_ld : 2 * C;
+    const int acc = (mode & S2E_NORM_ACCUMULATE_DX) != 0;
+    mode &= ~S2E_NORM_ACCUMULATE_DX;
     const int batch = mode == S2E_NORM_SPADE_STYLE_BATCH;
     if (batch) mode = S2E_NORM_SPADE_STYLE;                // same passes; only the coefficient kernel sums over the batch
     if (!g || !x || !stats || !dx || !ws || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: bad argument");
@@ -509,7 +517,7 @@ extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* 
 #define S2E_LAUNCH_BWD(TT, MM) do { \
     modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters); \
     modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, coef, stats, style, dstyle, N, C, HW, sld, batch); \
-    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu); } while (0)
+    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc); } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_BWD

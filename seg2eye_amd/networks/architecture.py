@@ -1,4 +1,5 @@
 """SPADE+Style residual block (reference models/networks/architecture.py:13-62)."""
+import torch
 import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
@@ -42,10 +43,17 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
         sn_begin(self)                  # no-op inside a generator (its forward already stepped the bank)
         if stats is None:
             stats = self.input_stats(x)
+        # x has two consumers (norm_0 and norm_s, or norm_0 and the residual).  With gradients on, the second one hangs off
+        # an alias of x that norm_0 hands out, so its gradient reaches norm_0's backward and is accumulated there in place
+        # instead of autograd adding two full-size tensors.
+        if torch.is_grad_enabled() and x.requires_grad:
+            h0, x = self.norm_0(x, seg, latent_style, stats, lrelu=True, relay=True)
+        else:
+            h0 = self.norm_0(x, seg, latent_style, stats, lrelu=True)
         if self.learned_shortcut:
             x_s = ops.conv2d_m(self.norm_s(x, seg, latent_style, stats, lrelu=False), self.conv_s)
         else:
             x_s = x
-        dx = ops.conv2d_m(self.norm_0(x, seg, latent_style, stats, lrelu=True), self.conv_0, None, 1, 1)
+        dx = ops.conv2d_m(h0, self.conv_0, None, 1, 1)
         dx = ops.conv2d_m(self.norm_1(dx, seg, latent_style, None, lrelu=True), self.conv_1, x_s, 1, 1)
         return dx

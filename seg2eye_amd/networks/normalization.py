@@ -152,7 +152,9 @@ class SPADE_STYLE_Block(nn.Module):
         self.spade = SPADE(opt.norm_G.replace('spectral', ''), fin, opt.semantic_nc)
         self.adain = ApplyStyle(opt.w_dim, channels=fin, use_wscale=False)
 
-    def forward(self, x, segmap, latent_style, stats=None, lrelu=False):
+    def forward(self, x, segmap, latent_style, stats=None, lrelu=False, relay=False):
+        """relay (not in the reference): also return an alias x' of x for the other consumers of x, see
+        ops.spade_style_modulate."""
         seg = SegMap.of(segmap)
         n, h, w, c = x.shape
         gb = self.spade.gamma_beta(seg, h, w, x.dtype)
@@ -162,9 +164,10 @@ class SPADE_STYLE_Block(nn.Module):
         from . import stylebank
         sb = stylebank.current()                                    # inside a generator: all style FCs were one GEMM
         if sb is not None and id(self.adain.linear) in sb[0]:
-            return ops.spade_style_modulate(x, gb, sb[1], stats, lrelu, off=sb[0][id(self.adain.linear)], dbig=sb[2], batch=batch)
+            return ops.spade_style_modulate(x, gb, sb[1], stats, lrelu, off=sb[0][id(self.adain.linear)], dbig=sb[2], batch=batch,
+                                            relay=relay)
         style = self.adain.linear(latent_style)                     # (N, 2C) fp32
-        return ops.spade_style_modulate(x, gb, style, stats, lrelu, batch=batch)
+        return ops.spade_style_modulate(x, gb, style, stats, lrelu, batch=batch, relay=relay)
 
 
 def get_nonspade_norm_layer(opt, norm_type='instance'):

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 from . import packing
-from ._lib import (NORM_SPADE_STYLE_BATCH, ConvDesc, ACT_NONE, ACT_LRELU, ACT_TANH, AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD,
+from ._lib import (NORM_SPADE_STYLE_BATCH, NORM_ACCUMULATE_DX, ConvDesc, ACT_NONE, ACT_LRELU, ACT_TANH, AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD,
                    NORM_SPADE_STYLE, NORM_PLAIN_IN, LOSS_NEG_MEAN, LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_L1)
 
 IN_EPS = 1e-5      # nn.InstanceNorm2d default (models/networks/normalization.py:41,73)
@@ -660,7 +660,7 @@ class ModulateFn(torch.autograd.Function):
     accumulator) and hands autograd nothing for `style`: the bank's own backward picks dbig up."""
 
     @staticmethod
-    def forward(ctx, x, gb, style, stats, lrelu, off=None, dbig=None, batch=False):
+    def forward(ctx, x, gb, style, stats, lrelu, off=None, dbig=None, batch=False, relay=False):
         _need(x, gb, style, stats)
         n, h, w, c = x.shape
         out = torch.empty_like(x)
@@ -668,16 +668,24 @@ class ModulateFn(torch.autograd.Function):
         sp = style.data_ptr() + 4 * (off or 0)
         L.check(L.lib().s2e_modulate_fwd(_dt(x), NORM_SPADE_STYLE, _p(x), _p(gb), _p(stats), sp, _p(out),
                                          n, h * w, c, int(lrelu), ld, _stream()), 's2e_modulate_fwd')
-        ctx.lrelu, ctx.off, ctx.dbig, ctx.batch = lrelu, off, dbig, bool(batch)
+        ctx.lrelu, ctx.off, ctx.dbig, ctx.batch, ctx.relay = lrelu, off, dbig, bool(batch), bool(relay)
         ctx.save_for_backward(x, gb, style, stats)
+        if relay:
+            ctx.set_materialize_grads(False)
+            return out, x.view_as(x)
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_relay=None):
         x, gb, style, stats = ctx.saved_tensors
         n, h, w, c = x.shape
+        if g is None:                                       # (relay mode: this layer's own output went unused)
+            return g_relay, None, None, None, None, None, None, None, None
         g = g.contiguous()
-        dx = torch.empty_like(x)
+        # relay: the OTHER consumers of x hang off this node's second output, so their gradient arrives here first and
+        # the element-wise pass adds this layer's dx to it in place -- instead of autograd summing two full tensors
+        acc = g_relay is not None and g_relay.is_contiguous() and g_relay.dtype == x.dtype
+        dx = g_relay if acc else torch.empty_like(x)
         dgb = torch.empty_like(gb)
         if ctx.off is None:
             dstyle = ZeroPool.take(style.numel(), torch.float32, x.device).view(style.shape)
@@ -688,17 +696,22 @@ class ModulateFn(torch.autograd.Function):
             dstyle, dsp, ld = None, ctx.dbig.data_ptr() + 4 * ctx.off, style.shape[1]
         sp = style.data_ptr() + 4 * (ctx.off or 0)
         ws = ZeroPool.take(n * c * 6, torch.float64, x.device)      # fp64 sums + float4 coefficients
-        L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_SPADE_STYLE_BATCH if ctx.batch else NORM_SPADE_STYLE, _p(g), _p(x), _p(gb), _p(stats), sp, _p(dx),
+        mode = (NORM_SPADE_STYLE_BATCH if ctx.batch else NORM_SPADE_STYLE) | (NORM_ACCUMULATE_DX if acc else 0)
+        L.check(L.lib().s2e_modulate_bwd(_dt(x), mode, _p(g), _p(x), _p(gb), _p(stats), sp, _p(dx),
                                          _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()),
                 's2e_modulate_bwd')
-        return dx, dgb, dstyle, None, None, None, None, None
+        if g_relay is not None and not acc:
+            dx = dx + g_relay
+        return dx, dgb, dstyle, None, None, None, None, None, None
 
 
-def spade_style_modulate(x, gb, style, stats, lrelu, off=None, dbig=None, batch=False):
-    """batch: `stats` are batch statistics (BatchNorm SPADE) -- the same row for every sample."""
+def spade_style_modulate(x, gb, style, stats, lrelu, off=None, dbig=None, batch=False, relay=False):
+    """batch: `stats` are batch statistics (BatchNorm SPADE) -- the same row for every sample.
+    relay: returns (out, x') with x' an alias of x; feed x' to the OTHER consumers of x (the block's second SPADE, the
+    residual) and their gradient reaches this layer's backward, which adds its own dx into it in place."""
     if off is None:
         style = style.float().contiguous()
-    return ModulateFn.apply(x, gb, style, stats, lrelu, off, dbig, batch)
+    return ModulateFn.apply(x, gb, style, stats, lrelu, off, dbig, batch, relay)
 
 
 class InstanceNormFn(torch.autograd.Function):
