@@ -48,7 +48,10 @@ def get_transform(opt, params, mask=False):
     """base_dataset.py:51-80 for preprocess_mode 'fixed'.  mask=True: the label-map variant (nearest, no normalisation,
     numpy in / numpy out); else PIL in -> float tensor (1, H, W) in [-1, 1]."""
     if opt.preprocess_mode != 'fixed':
-        raise NotImplementedError("preprocess_mode '%s': only 'fixed' (the reference's training recipe) is built" % opt.preprocess_mode)
+        # the reference's dataset hands its mask transform numpy arrays (openeds_dataset.py:89-90): the resize / scale / crop
+        # branches of base_dataset.get_transform need PIL images and fail there, and 'none' transposes a non-square label map
+        raise NotImplementedError("preprocess_mode '%s': only 'fixed' works with the reference's OpenEDS dataset, and only it is built"
+                                  % opt.preprocess_mode)
     w = opt.crop_size
     h = round(opt.crop_size / opt.aspect_ratio)
     do_flip = bool(opt.isTrain and not opt.no_flip and params['flip'])
