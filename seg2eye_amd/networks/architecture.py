@@ -17,21 +17,20 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
 
     def __init__(self, fin, fout, opt):
         super().__init__()
-        self.learned_shortcut = (fin != fout)
-        fmiddle = min(fin, fout)
-        self.conv_0 = nn.Conv2d(fin, fmiddle, kernel_size=3, padding=1)
-        self.conv_1 = nn.Conv2d(fmiddle, fout, kernel_size=3, padding=1)
+        fmid = min(fin, fout)
+        self.learned_shortcut = fin != fout
+        wrap = spectral_norm if 'spectral' in opt.norm_G else (lambda conv: conv)
+        # (name, in, out, kernel, bias) / (name, channels); registered in the order of the reference's state_dict:
+        # conv_0, conv_1, [conv_s], norm_0, norm_1, [norm_s]
+        convs = [('conv_0', fin, fmid, 3, True), ('conv_1', fmid, fout, 3, True)]
+        norms = [('norm_0', fin), ('norm_1', fmid)]
         if self.learned_shortcut:
-            self.conv_s = nn.Conv2d(fin, fout, kernel_size=1, bias=False)
-        if 'spectral' in opt.norm_G:
-            self.conv_0 = spectral_norm(self.conv_0)
-            self.conv_1 = spectral_norm(self.conv_1)
-            if self.learned_shortcut:
-                self.conv_s = spectral_norm(self.conv_s)
-        self.norm_0 = SPADE_STYLE_Block(fin, opt)
-        self.norm_1 = SPADE_STYLE_Block(fmiddle, opt)
-        if self.learned_shortcut:
-            self.norm_s = SPADE_STYLE_Block(fin, opt)
+            convs.append(('conv_s', fin, fout, 1, False))
+            norms.append(('norm_s', fin))
+        for name, cin, cout, k, bias in convs:
+            setattr(self, name, wrap(nn.Conv2d(cin, cout, kernel_size=k, padding=k // 2, bias=bias)))
+        for name, c in norms:
+            setattr(self, name, SPADE_STYLE_Block(c, opt))
 
     def input_stats(self, x, replication=1):
         """Statistics for norm_0 / norm_s of this block from x BEFORE the generator's nearest 2x upsampling

@@ -23,59 +23,95 @@ from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
 from seg2eye_amd.tester import Tester
 
 
+class TrainingRun:
+    """The objects of one run and what is due around every iteration.  `fit()` walks the epochs; the per-iteration
+    duties (progress line, quick / full validation, `latest` checkpoint) are a table of (is it due?, do it) pairs
+    checked in the reference's order."""
+
+    def __init__(self, opt, rank=0, world=1):
+        self.opt, self.rank = opt, rank
+        self.dataloader = create_dataloader(opt, rank, world)
+        self.trainer = Pix2PixTrainer(opt)
+        self.counter = IterationCounter(opt, len(self.dataloader) * opt.batchSize)
+        # validation runs on rank 0 only (it has no collectives); the reference keeps one tester per split
+        self.testers = [Tester(opt, dataset_key=split) for split in ('train', 'validation')] if rank == 0 else []
+        c = self.counter
+        self.duties = ((c.needs_printing, self.report), (c.needs_displaying, self.quick_validation),
+                       (c.needs_saving, self.save_latest), (c.needs_full_validation, self.full_validation))
+        self.epoch = c.current_epoch
+
+    # ---- duties
+    def report(self):
+        if self.rank:
+            return
+        c = self.counter
+        losses = self.trainer.get_latest_losses(include_log_losses=True)
+        head = '(epoch: %d, iters: %d, time: %.3f) ' % (self.epoch, c.total_steps_so_far, c.time_per_iter)
+        print(head + ' '.join('%s: %.3f' % (name, float(v.float().mean())) for name, v in losses.items()), flush=True)
+
+    def quick_validation(self):
+        with torch.no_grad():                                    # (the reference validates the model as it is: train mode)
+            for t in self.testers:
+                t.run_partial_modes(model=self.trainer.pix2pix_model, epoch=self.epoch, n_steps=self.counter.total_steps_so_far,
+                                    log=True, visualize_images=False, limit=self.opt.validation_limit)
+
+    def full_validation(self):
+        with torch.no_grad():
+            for t in self.testers:
+                t.run(self.trainer.pix2pix_model, mode='full', epoch=self.epoch, n_steps=self.counter.total_steps_so_far,
+                      log=True, write_error_log=self.opt.write_error_log)
+
+    def save_latest(self):
+        if self.rank:
+            return
+        print('saving the latest model (epoch %d, total_steps %d)' % (self.epoch, self.counter.total_steps_so_far))
+        self.trainer.save('latest')
+        self.counter.record_current_iter()
+
+    # ---- the loop
+    def one_epoch(self, epoch):
+        c, trainer = self.counter, self.trainer
+        self.epoch = epoch
+        if c.current_epoch != epoch:                             # equal only at the very start and right after a resume
+            c.record_epoch_start(epoch)
+        for i, batch in enumerate(self.dataloader, start=c.epoch_iter):
+            c.record_one_iteration()
+            if i % self.opt.D_steps_per_G == 0:
+                trainer.run_generator_one_step(batch)
+            trainer.run_discriminator_one_step(batch)
+            for due, act in self.duties:
+                if due():
+                    act()
+        trainer.update_learning_rate(epoch)
+        c.record_epoch_end()
+        if self.rank == 0 and (epoch % self.opt.save_epoch_freq == 0 or epoch == c.total_epochs):
+            print('saving the model at the end of epoch %d, iters %d' % (epoch, c.total_steps_so_far))
+            trainer.save('latest')
+            trainer.save(epoch)
+
+    def fit(self):
+        try:
+            for epoch in self.counter.training_epochs():
+                self.one_epoch(epoch)
+            print('Training was successfully finished.')
+        except (KeyboardInterrupt, SystemExit):
+            print('KeyboardInterrupt. Shutting down.')
+            print(traceback.format_exc())
+        finally:
+            if self.rank == 0:
+                print('saving the model before quitting')
+                self.trainer.save('latest')
+                self.counter.record_current_iter()
+        return self.trainer
+
+
 def main(argv=None):
     opt = parse(argv, is_train=True)
     rank, world, local = dist.init_from_env()
     if torch.cuda.is_available():
         opt.gpu_ids = [local]
         torch.cuda.set_device(local)
-    dataloader = create_dataloader(opt, rank, world)
-    trainer = Pix2PixTrainer(opt)
-    iter_counter = IterationCounter(opt, len(dataloader) * opt.batchSize)
-    testers = [Tester(opt, dataset_key=k) for k in ('train', 'validation')] if rank == 0 else []
-    try:
-        for epoch in iter_counter.training_epochs():
-            if iter_counter.current_epoch != epoch:
-                iter_counter.record_epoch_start(epoch)
-            for i, data_i in enumerate(dataloader, start=iter_counter.epoch_iter):
-                iter_counter.record_one_iteration()
-                if i % opt.D_steps_per_G == 0:
-                    trainer.run_generator_one_step(data_i)
-                trainer.run_discriminator_one_step(data_i)
-                if iter_counter.needs_printing() and rank == 0:
-                    losses = trainer.get_latest_losses(include_log_losses=True)
-                    msg = '(epoch: %d, iters: %d, time: %.3f) ' % (epoch, iter_counter.total_steps_so_far, iter_counter.time_per_iter)
-                    print(msg + ' '.join('%s: %.3f' % (k, float(v.float().mean())) for k, v in losses.items()), flush=True)
-                if iter_counter.needs_displaying():
-                    with torch.no_grad():                        # (the reference validates the model as it is: train mode)
-                        for t in testers:
-                            t.run_partial_modes(model=trainer.pix2pix_model, epoch=epoch, n_steps=iter_counter.total_steps_so_far,
-                                                log=True, visualize_images=False, limit=opt.validation_limit)
-                if iter_counter.needs_full_validation():
-                    with torch.no_grad():
-                        for t in testers:
-                            t.run(trainer.pix2pix_model, mode='full', epoch=epoch, n_steps=iter_counter.total_steps_so_far,
-                                  log=True, write_error_log=opt.write_error_log)
-                if iter_counter.needs_saving() and rank == 0:
-                    print('saving the latest model (epoch %d, total_steps %d)' % (epoch, iter_counter.total_steps_so_far))
-                    trainer.save('latest')
-                    iter_counter.record_current_iter()
-            trainer.update_learning_rate(epoch)
-            iter_counter.record_epoch_end()
-            if rank == 0 and (epoch % opt.save_epoch_freq == 0 or epoch == iter_counter.total_epochs):
-                print('saving the model at the end of epoch %d, iters %d' % (epoch, iter_counter.total_steps_so_far))
-                trainer.save('latest')
-                trainer.save(epoch)
-        print('Training was successfully finished.')
-    except (KeyboardInterrupt, SystemExit):
-        print('KeyboardInterrupt. Shutting down.')
-        print(traceback.format_exc())
-    finally:
-        if rank == 0:
-            print('saving the model before quitting')
-            trainer.save('latest')
-            iter_counter.record_current_iter()
-    return trainer
+    return TrainingRun(opt, rank, world).fit()
 
 
 if __name__ == '__main__':
