@@ -21,26 +21,30 @@ def modify_commandline_options(parser, is_train):
 
 
 def create_network(cls, opt):
-    """construct -> print -> move to the GPU -> init_weights (models/networks/__init__.py:39-48).
-    One process drives one GPU, so there is no nn.DataParallel wrap; multi-GPU is
-    seg2eye_amd.distributed (RCCL gradient all-reduce)."""
+    """The reference's construction sequence (models/networks/__init__.py:39-48): build, print the parameter count, move to
+    the GPU named by opt.gpu_ids, initialise the weights.  One process drives one GPU, so there is no nn.DataParallel
+    wrap; multi-GPU is seg2eye_amd.distributed (RCCL gradient all-reduce)."""
+    on_gpu = len(opt.gpu_ids) > 0
+    if on_gpu and not torch.cuda.is_available():
+        raise RuntimeError('opt.gpu_ids=%s but no GPU is visible' % (opt.gpu_ids,))
     net = cls(opt)
     net.print_network()
-    if len(opt.gpu_ids) > 0:
-        if not torch.cuda.is_available():
-            raise RuntimeError('opt.gpu_ids=%s but no GPU is visible' % (opt.gpu_ids,))
+    if on_gpu:
         net.cuda()
     net.init_weights(opt.init_type, opt.init_variance)
     return net
 
 
-def define_G(opt):
-    return create_network(SPADESTYLEGenerator, opt)
+# the three factories the reference's Pix2PixModel calls (models/networks/__init__.py:51-60)
+NETWORK_FAMILIES = {'G': SPADESTYLEGenerator, 'D': MultiscaleDiscriminator, 'E': ConvEncoder}
 
 
-def define_D(opt):
-    return create_network(MultiscaleDiscriminator, opt)
+def _factory(kind):
+    def define(opt):
+        return create_network(NETWORK_FAMILIES[kind], opt)
+    define.__name__ = define.__qualname__ = 'define_' + kind
+    define.__doc__ = 'opt -> %s on the HIP kernels' % NETWORK_FAMILIES[kind].__name__
+    return define
 
 
-def define_E(opt):
-    return create_network(ConvEncoder, opt)
+define_G, define_D, define_E = _factory('G'), _factory('D'), _factory('E')
