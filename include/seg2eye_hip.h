@@ -184,6 +184,21 @@ int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, doub
  * lrelu != 0 applies LeakyReLU(0.2) to out. */
 int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* gb, const float* stats, const float* style,
                      void* out, int N, int HW, int C, int lrelu, int style_ld, void* stream);
+/* The [gamma | beta] conv of a SPADE and the SPADE+Style modulation in ONE kernel (SPADE.forward normalization.py:97-105 +
+ * ApplyStyle.forward :163-169 + SPADE_STYLE_Block.forward :184-192 [+ LeakyReLU architecture.py:61]):
+ *     [gamma | beta] = conv3x3(actv; nh -> 2C, pad 1) + bias          (w_packed: s2e_pack_conv_weight of [W_gamma; W_beta],
+ *                                                                     rows 0..C-1 gamma, C..2C-1 beta; bias fp32 [2C] or NULL)
+ *     out = 0.5*( (x-mean)*rstd*(1+gamma) + beta + x*(1+s0) + s1 )    [LeakyReLU(0.2) if lrelu]
+ * gamma and beta go from the fp32 accumulators straight into the result: they are never written to memory (SURVEY 8(d):
+ * "need never exist in HBM").  gamma_out: NULL (no-grad forward), or (N,H,W,C): gamma is stored for s2e_modulate_bwd's
+ * S2E_NORM_GAMMA_ONLY mode.  actv (N,H,W,nh), x / out (N,H,W,C) NHWC; stats (N,C,2); style / style_ld as s2e_modulate_fwd.
+ * Taken shapes (s2e_spade_conv_modulate_supported != 0): C % 64 == 0, nh a multiple of the 128-byte K row, enough
+ * 256-pixel x 64-channel tiles to fill the chip (flags & 1: any tile count -- tests).  Other shapes return
+ * S2E_ERR_UNSUPPORTED: run s2e_conv2d + s2e_modulate_fwd. */
+int s2e_spade_conv_modulate_supported(int dtype, int N, int H, int W, int C, int nh, int flags);
+int s2e_spade_conv_modulate(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
+                            const float* stats, const float* style, int style_ld, void* out, void* gamma_out,
+                            int N, int H, int W, int C, int nh, int lrelu, int flags, void* stream);
 /* Backward of the above given g = dL/dout.  Writes dx (N,HW,C), dgb (N,HW,2C) and ACCUMULATES
  * dstyle (N,2C) fp32 (SPADE_STYLE mode only; dgb/dstyle may be NULL in PLAIN_IN mode).
  * style_ld (both calls): floats between consecutive samples' rows of style AND dstyle; 0 = dense (2C).  A
@@ -195,6 +210,12 @@ int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* gb, const f
 int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
                      const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                      int N, int HW, int C, int lrelu, int style_ld, void* stream);
+/* The same backward for a forward that went through s2e_spade_conv_modulate: `gamma` is (N,HW,C) (what that call stored in
+ * gamma_out; beta was never written) and the LeakyReLU mask is taken from the sign of the forward's output `out` (N,HW,C).
+ * dgb is still (N,HW,2C) = [dgamma | dbeta], the operand of the conv's weight / data gradients.  SPADE_STYLE modes only. */
+int s2e_modulate_bwd_gamma(int dtype, int mode, const void* g, const void* x, const void* gamma, const void* out,
+                           const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
+                           int N, int HW, int C, int lrelu, int style_ld, void* stream);
 /* out[c] += sum_m g[m][c]  (conv bias gradient).  g (M, C); out fp32 (C). */
 int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream);
 

@@ -71,6 +71,9 @@ SIGNATURES = {
     's2e_in_stats': [_i, _vp, _i, _i, _i, _f, _vp, _vp, _vp],
     's2e_modulate_fwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     's2e_modulate_bwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    's2e_modulate_bwd_gamma': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    's2e_spade_conv_modulate_supported': [_i, _i, _i, _i, _i, _i, _i],
+    's2e_spade_conv_modulate': [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     's2e_colsum': [_i, _vp, _l, _i, _vp, _vp],
     's2e_label_conv3x3': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     's2e_onehot_nhwc': [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -45,6 +45,12 @@ struct PatchParams {
     int tiles_x, tiles_y, tiles_n, tiles;
     int splits, cps, tiles_out, M;    // split-K over channel chunks: split s owns chunks [s * cps, (s+1) * cps); tiles = tiles_out * splits
     float* partial;                   // splits > 1: fp32 slabs [splits][M][Cout], combined by conv_finish_kernel (conv_igemm.hip)
+    // FUSE (SPADE+Style modulation in the epilogue of the [gamma | beta] conv; Cout = 2 * mC, bias = [b_gamma | b_beta]):
+    const void* mx;                   // the tensor being modulated, (N, Ho, Wo, mC)
+    const float* mstats;              // (N, mC, 2) {mean, rstd}
+    const float* mstyle; int msld;    // style codes {s0 | s1}: row n at mstyle + n * msld, 2 * mC floats
+    void* mgamma;                     // NULL, or (N, Ho, Wo, mC): gamma (with its bias) is stored for the backward pass
+    int mC, mlrelu;
 };
 
 template <typename T> struct PMfma;
@@ -63,8 +69,15 @@ template <> struct PMfma<float> {           // same k permutation on both operan
     }
 };
 
-template <typename T, int BN, int KS>
+// FUSE: the launch is the [gamma | beta] conv of a SPADE (Cout = 2C, BN = 128).  A Cout tile then pairs 64 gamma rows of
+// the packed weight with the 64 beta rows of the SAME channels, and the epilogue -- instead of writing 2C channels of
+// gamma, beta for a second kernel to read back -- reads x once and writes
+//     out = [lrelu] 0.5 * ((x - mean) * rstd * (1 + gamma) + beta + x * (1 + s0) + s1)         (C channels)
+// (normalization.py:91-105,163-169,184-192 of the reference in one pass); gamma itself is stored only when the backward
+// pass will need it.  gamma and beta stay fp32 from the accumulators to the result.
+template <typename T, int BN, int KS, bool FUSE = false>
 __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p) {
+    static_assert(!FUSE || (BN == 128 && KS == 3), "fused modulation: 3x3, 64 gamma + 64 beta columns per tile");
     constexpr int BM = 256, NW = 8, NT = 512;
     constexpr int VEC = Vec<T>::N, BK = 8 * VEC;      // one 128-byte row of K per pixel / weight row
     constexpr int TAPS = KS * KS;
@@ -139,7 +152,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
             const bool ok = py < PH && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             aoff[r] = ok ? ((long)(q.n * p.Hi + iy) * p.Wi + ix) * p.Cin + cbase + pcol[r] : -1L;
         });
-        wrow = wgt + (size_t)(q.tn * BN + brow) * p.Kpad + q.split * p.cps * BK + ((lane & 7) ^ ((brow >> 1) & 7)) * VEC;
+        // FUSE: tile rows 0..63 = gamma rows 64 tn .. 64 tn + 63 of the packed [gamma | beta] matrix, rows 64..127 = the beta
+        // rows of the same channels (mC rows further down): piece j = 1 of dma_w is mC rows away instead of 64
+        wrow = wgt + (size_t)(q.tn * (FUSE ? 64 : BN) + brow) * p.Kpad + q.split * p.cps * BK + ((lane & 7) ^ ((brow >> 1) & 7)) * VEC;
     };
     auto dma_patch = [&](auto R, int chunk, int buf) __attribute__((always_inline)) -> int {
         constexpr int r = decltype(R)::value;
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         const T* src = wrow + (p.flip ? TAPS - 1 - tp : tp) * p.Cin + chunk * BK;
         static_for<0, NBJ>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            __builtin_amdgcn_global_load_lds((gptr_t)(const void*)(src + (size_t)(64 * j) * p.Kpad),
+            __builtin_amdgcn_global_load_lds((gptr_t)(const void*)(src + (size_t)((FUSE ? p.mC : 64) * j) * p.Kpad),
                                              (lptr_t)(smem + 2 * P_BYTES + stage * B_BYTES + (8 * wave + 64 * j) * 128), 16, 0, 0);
         });
     };
@@ -322,6 +337,92 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         }
     };
 
+    // ---- FUSE epilogue.  A thread owns 16 bytes of x / out = VEC channels of one pixel: the gamma accumulators of those
+    // channels sit in columns cw.. of the staged tile, the beta ones 64 columns further.  Per-channel constants (the two
+    // biases, mean, rstd, 1 + s0, s1 + b_beta) are fetched once per tile like the bias above.
+    constexpr int FTPR = 64 / VEC, FRPP = NT / FTPR;
+    const int fcw = (tid % FTPR) * VEC;
+    float k_bg[VEC], k_mu[VEC], k_rs[VEC], k_sa[VEC], k_sb[VEC];
+    auto load_mod_consts = [&](const Tile& q) __attribute__((always_inline)) {
+        // 16-byte loads (c, msld and mC are multiples of 4 floats; the host checks the base pointers): one-dword loads
+        // were 48 vector-memory instructions per thread per tile and cost the tile ~7 % (measured against the plain conv)
+        const int c = q.tn * 64 + fcw;
+        const f32x4_t* stp = (const f32x4_t*)(p.mstats + ((size_t)q.n * p.mC + c) * 2);
+        const f32x4_t* s0p = (const f32x4_t*)(p.mstyle + (size_t)q.n * p.msld + c);
+        const f32x4_t* s1p = (const f32x4_t*)(p.mstyle + (size_t)q.n * p.msld + p.mC + c);
+        const f32x4_t* bgp = (const f32x4_t*)(p.bias + c);
+        const f32x4_t* bbp = (const f32x4_t*)(p.bias + p.mC + c);
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+            const f32x4_t st0 = stp[j / 2], st1 = stp[j / 2 + 1], s0 = s0p[j / 4], s1 = s1p[j / 4];
+            f32x4_t bg = {0.f, 0.f, 0.f, 0.f}, bb = bg;
+            if (p.bias) { bg = bgp[j / 4]; bb = bbp[j / 4]; }
+            k_mu[j] = st0[0]; k_rs[j] = st0[1]; k_mu[j + 1] = st0[2]; k_rs[j + 1] = st0[3];
+            k_mu[j + 2] = st1[0]; k_rs[j + 2] = st1[1]; k_mu[j + 3] = st1[2]; k_rs[j + 3] = st1[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { k_bg[j + i] = bg[i]; k_sa[j + i] = 1.f + s0[i]; k_sb[j + i] = s1[i] + bb[i]; }
+        }
+    };
+    auto epilogue_fused = [&](const Tile& q, int sbuf) __attribute__((always_inline)) {
+        float* Cs = (float*)(smem + sbuf * P_BYTES);
+        const T* __restrict__ mx = (const T*)p.mx;
+        T* __restrict__ gout = (T*)p.mgamma;
+        const int c = q.tn * 64 + fcw;
+        constexpr int SWEEPS = EP_ROWS / FRPP > 0 ? EP_ROWS / FRPP : 1;
+        static_assert(EP_ROWS % FRPP == 0 || FRPP % EP_ROWS == 0, "whole sweeps");
+#pragma unroll
+        for (int ep = 0; ep < WM; ++ep) {
+            size_t o[SWEEPS]; bool live[SWEEPS];
+            u32x4_t xx[SWEEPS];
+#pragma unroll
+            for (int sw = 0; sw < SWEEPS; ++sw) {
+                const int lr = sw * FRPP + tid / FTPR;              // row inside this pass
+                const int tr = ep * EP_ROWS + lr;
+                const int ty = tr / TW;
+                const int oy = q.oy0 + ty, ox = q.ox0 + (tr - ty * TW);
+                live[sw] = lr < EP_ROWS && tr < TW * TH && oy < p.Ho && ox < p.Wo;
+                o[sw] = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.mC + c;
+                xx[sw] = u32x4_t{0u, 0u, 0u, 0u};
+                if (live[sw]) xx[sw] = *(const u32x4_t*)(mx + o[sw]);
+            }
+            if (ep > 0) __syncthreads();
+            if (wm == ep) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            Cs[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wn * WTN + ni * 32 + l31] = acc[mi][ni][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int sw = 0; sw < SWEEPS; ++sw) {
+                if (!live[sw]) continue;
+                const int row = sw * FRPP + tid / FTPR;
+                float f[VEC], ga[VEC], v[VEC];
+                unpack16<T>(xx[sw], f);
+#pragma unroll
+                for (int j = 0; j < VEC; j += 4) {
+                    const f32x4_t g4 = *(const f32x4_t*)(Cs + row * BN + fcw + j);
+                    const f32x4_t b4 = *(const f32x4_t*)(Cs + row * BN + 64 + fcw + j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ga[j + i] = g4[i] + k_bg[j + i];
+                        const float xh = (f[j + i] - k_mu[j + i]) * k_rs[j + i];
+                        v[j + i] = 0.5f * (xh * (1.f + ga[j + i]) + (b4[i] + k_sb[j + i]) + f[j + i] * k_sa[j + i]);
+                    }
+                }
+                if (p.mlrelu) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j] = lrelu02(v[j]);
+                }
+                *(u32x4_t*)(yg + o[sw]) = pack16<T>(v);
+                if (gout) *(u32x4_t*)(gout + o[sw]) = pack16<T>(ga);
+            }
+        }
+    };
+
     Tile cur = decode(tile_id);
     aim(cur);
     int pb = 0;                                       // patch buffer of the current tile's chunk 0
@@ -370,9 +471,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         const int next_id = tile_id + G;
         const bool has_next = next_id < p.tiles;
         Tile nxt = cur;
-        load_bias(cur);
+        if constexpr (FUSE) load_mod_consts(cur); else load_bias(cur);
         if (has_next) { nxt = decode(next_id); aim(nxt); prologue(pbn); }
-        epilogue(cur, pbn ^ 1);
+        if constexpr (FUSE) epilogue_fused(cur, pbn ^ 1); else epilogue(cur, pbn ^ 1);
         if (!has_next) break;
         cur = nxt; tile_id = next_id; pb = pbn;
     }
@@ -473,4 +574,61 @@ int s2e_conv_patch_launch(int dtype, const s2e_patch_plan* plan, const void* x, 
     if (dtype == S2E_BF16) return bn == 128 ? launch_patch<bf16_t, 128>(p, d->KH, st) : launch_patch<bf16_t, 64>(p, d->KH, st);
     if (dtype == S2E_F32) return bn == 128 ? launch_patch<float, 128>(p, d->KH, st) : launch_patch<float, 64>(p, d->KH, st);
     S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: bad dtype %d", dtype);
+}
+
+// ------------------------------------------------------------------------------------ fused [gamma | beta] conv + modulation
+// The shapes the fused launch takes: the 3x3 pad-1 conv nh -> 2C with C a multiple of 64 (a tile pairs 64 gamma with 64 beta
+// columns) and nh a multiple of the 128-byte K row; never split over channel chunks (the modulation needs the finished sums).
+// It takes smaller maps than s2e_conv_patch_plan does: measured at batch 8 (tools/bench_spade_fused.py), one launch of 128
+// workgroups beats conv + modulation as two launches even at 16x16 (33 -> 23 us) and at 8x8, where three quarters of a tile's
+// rows are idle (31 -> 22 us).  Below S2E_SPADE_FUSED_TILES (default 96) tiles the two-launch path runs; flags & 1 forces the
+// fused kernel at any tile count (tests).
+static int fused_plan(int dtype, int N, int H, int W, int C, int nh, int flags, s2e_conv_desc* d, s2e_patch_plan* plan) {
+    static const int min_tiles = [] { const char* e = getenv("S2E_SPADE_FUSED_TILES"); return e ? atoi(e) : 96; }();
+    if (min_tiles <= 0 && !(flags & 1)) return 0;
+    if (C <= 0 || C % 64 != 0 || N <= 0 || H <= 0 || W <= 0) return 0;
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (nh % (8 * vec) != 0) return 0;
+    *d = s2e_conv_desc{N, H, W, nh, H, W, 2 * C, 3, 3, 1, 1, 0, S2E_ACT_NONE, S2E_ACT_NONE, S2E_AUX_NONE};
+    plan->splits = 1; plan->tw = plan->th = 0;
+    if (patch_rectangle(d, 3, &plan->tw, &plan->th) < ((flags & 1) ? 0.01 : 0.2)) return 0;
+    const long tiles = (long)N * ceil_div(H, plan->th) * ceil_div(W, plan->tw) * (C / 64);
+    return (flags & 1) || tiles >= min_tiles;
+}
+
+extern "C" int s2e_spade_conv_modulate_supported(int dtype, int N, int H, int W, int C, int nh, int flags) {
+    s2e_conv_desc d; s2e_patch_plan plan;
+    if (dtype != S2E_BF16 && dtype != S2E_F32) return 0;
+    return fused_plan(dtype, N, H, W, C, nh, flags, &d, &plan);
+}
+
+extern "C" int s2e_spade_conv_modulate(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
+                                       const float* stats, const float* style, int style_ld, void* out, void* gamma_out,
+                                       int N, int H, int W, int C, int nh, int lrelu, int flags, void* stream) {
+    if (!actv || !w_packed || !x || !stats || !style || !out) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: null pointer");
+    if (((uintptr_t)stats | (uintptr_t)style | (uintptr_t)bias) & 15 || (style_ld & 3))
+        S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: stats, style and bias must be 16-byte aligned (style_ld a multiple of 4)");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: bad dtype %d", dtype);
+    s2e_conv_desc d; s2e_patch_plan plan;
+    if (!fused_plan(dtype, N, H, W, C, nh, flags, &d, &plan))
+        S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_spade_conv_modulate: shape N=%d %dx%d C=%d nh=%d is not taken by the fused kernel "
+                 "(s2e_spade_conv_modulate_supported); run s2e_conv2d + s2e_modulate_fwd", N, H, W, C, nh);
+    PatchParams p{};
+    p.x = actv; p.w = w_packed; p.bias = bias; p.y = out;
+    p.N = N; p.Hi = H; p.Wi = W; p.Cin = nh; p.Ho = H; p.Wo = W; p.Cout = 2 * C;
+    p.Kpad = ceil_div(9 * nh, dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
+    p.org = -1; p.flip = 0; p.out_act = S2E_ACT_NONE; p.aux_mode = S2E_AUX_NONE;
+    p.tw = plan.tw; p.th = plan.th;
+    p.tiles_x = ceil_div(W, p.tw); p.tiles_y = ceil_div(H, p.th); p.tiles_n = C / 64;
+    p.tiles_out = N * p.tiles_y * p.tiles_x * p.tiles_n;
+    p.splits = 1; p.cps = nh / (dtype == S2E_BF16 ? 64 : 32); p.tiles = p.tiles_out;
+    p.M = N * H * W; p.partial = nullptr;
+    p.mx = x; p.mstats = stats; p.mstyle = style; p.msld = style_ld > 0 ? style_ld : 2 * C; p.mgamma = gamma_out;
+    p.mC = C; p.mlrelu = lrelu;
+    const int grid = p.tiles < cu_count() ? p.tiles : cu_count();
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) conv_patch_kernel<bf16_t, 128, 3, true><<<grid, 512, 0, st>>>(p);
+    else conv_patch_kernel<float, 128, 3, true><<<grid, 512, 0, st>>>(p);
+    S2E_CHECK_LAUNCH("conv_patch_kernel (fused modulation)");
+    return S2E_OK;
 }

@@ -292,9 +292,13 @@ extern "C" int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __restrict__ gin, const T* __restrict__ x,
         const T* __restrict__ gb, const float* __restrict__ stats, const float* __restrict__ style,
-        T* __restrict__ dgb, double* __restrict__ ws, int HW, int C, int cg, int cgb, int rpp, int lrelu, int sld, int iters) {
+        T* __restrict__ dgb, double* __restrict__ ws, int HW, int C, int cg, int cgb, int rpp, int lrelu, int sld, int iters,
+        const T* __restrict__ fout) {
+    // fout != NULL (S2E_NORM_GAMMA_ONLY): gb holds gamma alone, (N,HW,C); the LeakyReLU mask comes from the sign of the
+    // forward's OUTPUT fout (LeakyReLU keeps the sign of its argument) instead of recomputing it from gamma and beta
     constexpr int VEC = Vec<T>::N;
     constexpr int NS = (MODE == S2E_NORM_SPADE_STYLE) ? 4 : 2;
+    const int gst = fout ? C : 2 * C;                      // pixels of gb are this many elements apart
     __shared__ float red[256 * VEC * NS];
     const int tid = threadIdx.x;
     const int tx = tid % cgb, ty = tid / cgb;
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
                     const float G = 1.f + ga[j];
                     float go = gg[j];
                     if (lrelu) {
-                        const float pre = 0.5f * (xh * G + be[j] + f[j] * a[j] + b[j]);
+                        const float pre = fout ? be[j] : 0.5f * (xh * G + be[j] + f[j] * a[j] + b[j]);
                         go *= (pre > 0.f ? 1.f : 0.2f);
                     }
                     dga[j] = 0.5f * go * xh;
@@ -363,8 +367,9 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
             const u32x4_t g0 = *(const u32x4_t*)(gin + r0 * C + c0), g1 = *(const u32x4_t*)(gin + r1 * C + c0);
             u32x4_t a0 = zero4, b0 = zero4, a1 = zero4, b1 = zero4;
             if (MODE == S2E_NORM_SPADE_STYLE) {
-                a0 = *(const u32x4_t*)(gb + r0 * 2 * C + c0); b0 = *(const u32x4_t*)(gb + r0 * 2 * C + C + c0);
-                a1 = *(const u32x4_t*)(gb + r1 * 2 * C + c0); b1 = *(const u32x4_t*)(gb + r1 * 2 * C + C + c0);
+                a0 = *(const u32x4_t*)(gb + r0 * gst + c0); a1 = *(const u32x4_t*)(gb + r1 * gst + c0);
+                if (fout) { if (lrelu) { b0 = *(const u32x4_t*)(fout + r0 * C + c0); b1 = *(const u32x4_t*)(fout + r1 * C + c0); } }
+                else { b0 = *(const u32x4_t*)(gb + r0 * gst + C + c0); b1 = *(const u32x4_t*)(gb + r1 * gst + C + c0); }
             }
             consume(r0, x0, g0, a0, b0);
             consume(r1, x1, g1, a1, b1);
@@ -372,7 +377,11 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
         if (pr < pend) {
             const size_t r0 = (size_t)n * HW + pr;
             u32x4_t a0 = zero4, b0 = zero4;
-            if (MODE == S2E_NORM_SPADE_STYLE) { a0 = *(const u32x4_t*)(gb + r0 * 2 * C + c0); b0 = *(const u32x4_t*)(gb + r0 * 2 * C + C + c0); }
+            if (MODE == S2E_NORM_SPADE_STYLE) {
+                a0 = *(const u32x4_t*)(gb + r0 * gst + c0);
+                if (fout) { if (lrelu) b0 = *(const u32x4_t*)(fout + r0 * C + c0); }
+                else b0 = *(const u32x4_t*)(gb + r0 * gst + C + c0);
+            }
             consume(r0, *(const u32x4_t*)(x + r0 * C + c0), *(const u32x4_t*)(gin + r0 * C + c0), a0, b0);
         }
     }
@@ -434,7 +443,7 @@ __global__ void modulate_bwd_coef_kernel(const double* __restrict__ ws, f32x4_t*
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __restrict__ gin, const T* __restrict__ x,
         const T* __restrict__ gb, const T* __restrict__ dgb, const f32x4_t* __restrict__ coef, T* __restrict__ dx,
-        int vps, int HW, int C, int cg, int cg_shift, int lrelu, int acc) {
+        int vps, int HW, int C, int cg, int cg_shift, int lrelu, int acc, int gst) {
     constexpr int VEC = Vec<T>::N;
     const int n = blockIdx.y;                              // one sample per grid row: 32-bit indices, no 64-bit division
     // The channel group of a thread does not change over the grid-stride loop when the stride is a multiple of cg
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
         }
         if (MODE == S2E_NORM_SPADE_STYLE) {
             float ga[VEC], dbe[VEC];
-            unpack16<T>(*(const u32x4_t*)(gb + row * 2 * C + c0), ga);
+            unpack16<T>(*(const u32x4_t*)(gb + row * gst + c0), ga);
             unpack16<T>(*(const u32x4_t*)(dgb + row * 2 * C + C + c0), dbe);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] = dbe[j] * (K[j][0] + K[j][1] * ga[j]) - K[j][2] - f[j] * K[j][3];
@@ -486,10 +495,11 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
     }
 }
 
-extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
-                                const float* style, void* dx, void* dgb, float* dstyle, double* ws,
-                                int N, int HW, int C, int lrelu, int style_ld, void* stream) {
+static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, const void* gb, const void* fout, const float* stats,
+                             const float* style, void* dx, void* dgb, float* dstyle, double* ws,
+                             int N, int HW, int C, int lrelu, int style_ld, void* stream) {
     const int sld = style_ld > 0 ? style_ld : 2 * C;
+    const int gst = fout ? C : 2 * C;
     const int acc = (mode & S2E_NORM_ACCUMULATE_DX) != 0;
     mode &= ~S2E_NORM_ACCUMULATE_DX;
     const int batch = mode == S2E_NORM_SPADE_STYLE_BATCH;
@@ -515,12 +525,27 @@ extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* 
     const int gridc = ceil_div((long)N * C, 256);
     f32x4_t* coef = (f32x4_t*)(ws + (size_t)N * C * 4);
 #define S2E_LAUNCH_BWD(TT, MM) do { \
-    modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters); \
+    modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters, (const TT*)fout); \
     modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, coef, stats, style, dstyle, N, C, HW, sld, batch); \
-    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc); } while (0)
+    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst); } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_BWD
     S2E_CHECK_LAUNCH("modulate_bwd kernels");
     return S2E_OK;
+}
+
+extern "C" int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
+                                const float* style, void* dx, void* dgb, float* dstyle, double* ws,
+                                int N, int HW, int C, int lrelu, int style_ld, void* stream) {
+    return modulate_bwd_impl(dtype, mode, g, x, gb, nullptr, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream);
+}
+
+extern "C" int s2e_modulate_bwd_gamma(int dtype, int mode, const void* g, const void* x, const void* gamma, const void* out,
+                                      const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
+                                      int N, int HW, int C, int lrelu, int style_ld, void* stream) {
+    const int m = mode & ~S2E_NORM_ACCUMULATE_DX;
+    if (m != S2E_NORM_SPADE_STYLE && m != S2E_NORM_SPADE_STYLE_BATCH) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_gamma: SPADE_STYLE modes only");
+    if (!gamma || !out) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_gamma: gamma and out are required");
+    return modulate_bwd_impl(dtype, mode, g, x, gamma, out, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream);
 }

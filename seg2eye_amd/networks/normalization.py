@@ -157,17 +157,24 @@ class SPADE_STYLE_Block(nn.Module):
         ops.spade_style_modulate."""
         seg = SegMap.of(segmap)
         n, h, w, c = x.shape
-        gb = self.spade.gamma_beta(seg, h, w, x.dtype)
+        sp = self.spade
         if stats is None:
-            stats = spade_stats(x, [self.spade])
-        batch = self.spade.kind == 'batch'
+            stats = spade_stats(x, [sp])
+        batch = sp.kind == 'batch'
         from . import stylebank
         sb = stylebank.current()                                    # inside a generator: all style FCs were one GEMM
-        if sb is not None and id(self.adain.linear) in sb[0]:
-            return ops.spade_style_modulate(x, gb, sb[1], stats, lrelu, off=sb[0][id(self.adain.linear)], dbig=sb[2], batch=batch,
-                                            relay=relay)
-        style = self.adain.linear(latent_style)                     # (N, 2C) fp32
-        return ops.spade_style_modulate(x, gb, style, stats, lrelu, batch=batch, relay=relay)
+        banked = sb is not None and id(self.adain.linear) in sb[0]
+        if banked:
+            style, kw = sb[1], dict(off=sb[0][id(self.adain.linear)], dbig=sb[2])
+        else:
+            style, kw = self.adain.linear(latent_style), {}         # (N, 2C) fp32
+        if ops.spade_fused_supported(x, sp.mlp_shared[0].out_channels):
+            # the big layers: [gamma | beta] conv and modulation in ONE launch, gamma / beta never written (ops.SpadeFusedFn)
+            return ops.spade_style_fused(x, seg.label, sp.mlp_shared[0].weight, sp.mlp_shared[0].bias, sp.mlp_gamma.weight,
+                                         sp.mlp_gamma.bias, sp.mlp_beta.weight, sp.mlp_beta.bias, style, stats, lrelu,
+                                         batch=batch, relay=relay, **kw)
+        gb = sp.gamma_beta(seg, h, w, x.dtype)
+        return ops.spade_style_modulate(x, gb, style, stats, lrelu, batch=batch, relay=relay, **kw)
 
 
 def get_nonspade_norm_layer(opt, norm_type='instance'):

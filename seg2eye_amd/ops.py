@@ -595,53 +595,71 @@ class SpadeParamFn(torch.autograd.Function):
     def forward(ctx, label, w_sh, b_sh, w_g, b_g, w_b, b_b, h, w, dtype):
         n, H, W = label.shape
         nh, C = w_sh.shape[0], w_g.shape[0]
-        fused = _adjacent(w_g, w_b) and _adjacent(b_g, b_b)
-        if fused:
-            w_gb, b_gb = _span2(w_g, (2 * C, nh, 3, 3)), _span2(b_g, (2 * C,))
-        else:
-            w_gb = torch.cat([w_g.detach(), w_b.detach()], 0)
-            b_gb = torch.cat([b_g.detach(), b_b.detach()], 0)
+        fused, w_gb, b_gb = _gb_operands(w_g, b_g, w_b, b_b, nh)
         actv = label_conv3x3_raw(label, _table_of(w_sh), b_sh.detach().float().contiguous(), n, H, W, h, w, nh, True, dtype)
         plan = packing.current()
         wp = packed_weight(w_gb, dtype, nh, False, None, plan, stable=fused)
         ctx.plan, ctx.plan_gen, ctx.fused = plan, (plan.generation if plan is not None else None), fused
         gb = conv2d_raw(actv, wp, b_gb.float().contiguous(), None, None, (h, w, 2 * C), 3, 3, 1, 1)
         ctx.cfg = (h, w, C)
-        gwg, gwb, gbg, gbb = _grad_dst(w_g), _grad_dst(w_b), _grad_dst(b_g), _grad_dst(b_b)
-        ctx.gb_dst = (_span2(gwg, (2 * C, nh, 3, 3)), _span2(gbg, (2 * C,))) \
-            if (fused and _adjacent(gwg, gwb) and _adjacent(gbg, gbb)) else None
-        ctx.sh_dst = (_grad_dst(w_sh), _grad_dst(b_sh))
+        _gb_grad_targets(ctx, fused, w_sh, b_sh, w_g, b_g, w_b, b_b, nh)
         ctx.save_for_backward(label, w_sh, w_gb, actv)
         return gb
 
     @staticmethod
     def backward(ctx, ggb):
         label, w_sh, w_gb, actv = ctx.saved_tensors
-        h, w, C = ctx.cfg
-        g = ggb.contiguous()
-        c2, nh = w_gb.shape[0], w_gb.shape[1]
-        ncls = w_sh.shape[1]
-        gw_g = gb_g = gw_b = gb_b = gw_sh = gb_sh = None
-        if ctx.gb_dst is not None:
-            dwp, _ = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1])
-            unpack_weight_grad_into(dwp, ctx.gb_dst[0], c2, nh, 3, 3, nh)
-        else:
-            dwp, gb_gb = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True)
-            gw_gb = _unpack_dw(dwp, c2, nh, 3, 3, nh)
-            gw_g, gw_b, gb_g, gb_b = gw_gb[:C], gw_gb[C:], gb_gb[:C], gb_gb[C:]
-        wpt = packed_weight(w_gb, g.dtype, nh, True, None, ctx.plan, ctx.plan_gen, stable=ctx.fused)
-        dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
-        # (a streaming class-bucket kernel for this gradient was tried twice -- LDS float atomics, then per-wave
-        # queues of boundary pixels -- and lost to the MFMA wgrad against the 8-channel one-hot map: 1.7 vs 0.75 ms
-        # per step; see DESIGN.md "tried and dropped")
-        oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
-        wdst, bdst = ctx.sh_dst
-        dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True, bdst)
-        if wdst is not None:
-            unpack_weight_grad_into(dwp, wdst, nh, ncls, 3, 3, 8)
-        else:
-            gw_sh = _unpack_dw(dwp, nh, ncls, 3, 3, 8)
-        return None, gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b, None, None, None
+        return (None,) + _spade_param_grads(ctx, ggb.contiguous(), label, w_sh, w_gb, actv) + (None, None, None)
+
+
+def _gb_operands(w_g, b_g, w_b, b_b, nh):
+    """[W_gamma; W_beta] and [b_gamma; b_beta] as single tensors: zero-copy views when the four parameters sit back to
+    back in the optimizer arena (Pix2PixModel orders them so), concatenated copies otherwise.  -> (fused, w_gb, b_gb)"""
+    C = w_g.shape[0]
+    fused = _adjacent(w_g, w_b) and _adjacent(b_g, b_b)
+    if fused:
+        return True, _span2(w_g, (2 * C, nh, 3, 3)), _span2(b_g, (2 * C,))
+    return False, torch.cat([w_g.detach(), w_b.detach()], 0), torch.cat([b_g.detach(), b_b.detach()], 0)
+
+
+def _gb_grad_targets(ctx, fused, w_sh, b_sh, w_g, b_g, w_b, b_b, nh):
+    """Where the backward may accumulate the SPADE branch's parameter gradients directly (see _grad_dst)."""
+    C = w_g.shape[0]
+    gwg, gwb, gbg, gbb = _grad_dst(w_g), _grad_dst(w_b), _grad_dst(b_g), _grad_dst(b_b)
+    ctx.gb_dst = (_span2(gwg, (2 * C, nh, 3, 3)), _span2(gbg, (2 * C,))) \
+        if (fused and _adjacent(gwg, gwb) and _adjacent(gbg, gbb)) else None
+    ctx.sh_dst = (_grad_dst(w_sh), _grad_dst(b_sh))
+
+
+def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
+    """Backward of gb = conv3x3(ReLU(conv3x3(one_hot(label)))) given g = d/d[gamma | beta] (N,h,w,2C):
+    -> (gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b), None where the gradient went straight into the arena.
+    The ReLU mask is fused into the data-gradient epilogue; the mlp_shared weight gradient is an MFMA wgrad against the
+    (tiny) 8-channel one-hot map; bias gradients come out of the wgrad kernels."""
+    h, w, C = ctx.cfg
+    c2, nh = w_gb.shape[0], w_gb.shape[1]
+    ncls = w_sh.shape[1]
+    gw_g = gb_g = gw_b = gb_b = gw_sh = gb_sh = None
+    if ctx.gb_dst is not None:
+        dwp, _ = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1])
+        unpack_weight_grad_into(dwp, ctx.gb_dst[0], c2, nh, 3, 3, nh)
+    else:
+        dwp, gb_gb = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True)
+        gw_gb = _unpack_dw(dwp, c2, nh, 3, 3, nh)
+        gw_g, gw_b, gb_g, gb_b = gw_gb[:C], gw_gb[C:], gb_gb[:C], gb_gb[C:]
+    wpt = packed_weight(w_gb, g.dtype, nh, True, None, ctx.plan, ctx.plan_gen, stable=ctx.fused)
+    dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
+    # (a streaming class-bucket kernel for this gradient was tried twice -- LDS float atomics, then per-wave
+    # queues of boundary pixels -- and lost to the MFMA wgrad against the 8-channel one-hot map: 1.7 vs 0.75 ms
+    # per step; see DESIGN.md "tried and dropped")
+    oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
+    wdst, bdst = ctx.sh_dst
+    dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True, bdst)
+    if wdst is not None:
+        unpack_weight_grad_into(dwp, wdst, nh, ncls, 3, 3, 8)
+    else:
+        gw_sh = _unpack_dw(dwp, nh, ncls, 3, 3, 8)
+    return gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b
 
 
 def spade_params(label, w_sh, b_sh, w_g, b_g, w_b, b_b, h, w, dtype):
@@ -678,31 +696,116 @@ class ModulateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, g_relay=None):
         x, gb, style, stats = ctx.saved_tensors
-        n, h, w, c = x.shape
         if g is None:                                       # (relay mode: this layer's own output went unused)
             return g_relay, None, None, None, None, None, None, None, None
-        g = g.contiguous()
-        # relay: the OTHER consumers of x hang off this node's second output, so their gradient arrives here first and
-        # the element-wise pass adds this layer's dx to it in place -- instead of autograd summing two full tensors
-        acc = g_relay is not None and g_relay.is_contiguous() and g_relay.dtype == x.dtype
-        dx = g_relay if acc else torch.empty_like(x)
-        dgb = torch.empty_like(gb)
-        if ctx.off is None:
-            dstyle = ZeroPool.take(style.numel(), torch.float32, x.device).view(style.shape)
-            dsp, ld = dstyle.data_ptr(), 0
-        else:
-            if ctx.dbig is None:
-                raise RuntimeError('ModulateFn: banked style without a gradient accumulator')
-            dstyle, dsp, ld = None, ctx.dbig.data_ptr() + 4 * ctx.off, style.shape[1]
-        sp = style.data_ptr() + 4 * (ctx.off or 0)
-        ws = ZeroPool.take(n * c * 6, torch.float64, x.device)      # fp64 sums + float4 coefficients
-        mode = (NORM_SPADE_STYLE_BATCH if ctx.batch else NORM_SPADE_STYLE) | (NORM_ACCUMULATE_DX if acc else 0)
+        dx, dgb, dstyle = _modulate_grads(ctx, g, g_relay, x, gb, None, style, stats)
+        return dx, dgb, dstyle, None, None, None, None, None, None
+
+
+def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
+    """Backward of the SPADE+Style modulation -> (dx, dgb (N,h,w,2C), dstyle or None).  fout None: gb = [gamma | beta];
+    else gb = gamma alone and fout = the forward's output (s2e_modulate_bwd_gamma).
+    relay: the OTHER consumers of x hang off the node's second output, so their gradient arrives here first and the
+    element-wise pass adds this layer's dx to it in place -- instead of autograd summing two full tensors."""
+    n, h, w, c = x.shape
+    g = g.contiguous()
+    acc = g_relay is not None and g_relay.is_contiguous() and g_relay.dtype == x.dtype
+    dx = g_relay if acc else torch.empty_like(x)
+    dgb = torch.empty(n, h, w, 2 * c, dtype=x.dtype, device=x.device)
+    if ctx.off is None:
+        dstyle = ZeroPool.take(style.numel(), torch.float32, x.device).view(style.shape)
+        dsp, ld = dstyle.data_ptr(), 0
+    else:
+        if ctx.dbig is None:
+            raise RuntimeError('ModulateFn: banked style without a gradient accumulator')
+        dstyle, dsp, ld = None, ctx.dbig.data_ptr() + 4 * ctx.off, style.shape[1]
+    sp = style.data_ptr() + 4 * (ctx.off or 0)
+    ws = ZeroPool.take(n * c * 6, torch.float64, x.device)      # fp64 sums + float4 coefficients
+    mode = (NORM_SPADE_STYLE_BATCH if ctx.batch else NORM_SPADE_STYLE) | (NORM_ACCUMULATE_DX if acc else 0)
+    if fout is None:
         L.check(L.lib().s2e_modulate_bwd(_dt(x), mode, _p(g), _p(x), _p(gb), _p(stats), sp, _p(dx),
                                          _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()),
                 's2e_modulate_bwd')
-        if g_relay is not None and not acc:
-            dx = dx + g_relay
-        return dx, dgb, dstyle, None, None, None, None, None, None
+    else:
+        L.check(L.lib().s2e_modulate_bwd_gamma(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx),
+                                               _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()),
+                's2e_modulate_bwd_gamma')
+    if g_relay is not None and not acc:
+        dx = dx + g_relay
+    return dx, dgb, dstyle
+
+
+class SpadeFusedFn(torch.autograd.Function):
+    """SpadeParamFn + ModulateFn as ONE forward launch for the layers s2e_spade_conv_modulate takes: the [gamma | beta]
+    conv's epilogue applies the SPADE+Style modulation, so gamma and beta never reach HBM (normalization.py:91-105,
+    163-169, 184-192 in one kernel).  With gradients on, gamma (C channels) is stored for the backward, which takes the
+    LeakyReLU mask from the sign of the saved output; the backward itself is the two-stage one (modulation gradients ->
+    [dgamma | dbeta] -> the conv's weight / data gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags):
+        _need(x, style, stats)
+        n, h, w, c = x.shape
+        _, H, W = label.shape
+        nh = w_sh.shape[0]
+        dtype = x.dtype
+        fused, w_gb, b_gb = _gb_operands(w_g, b_g, w_b, b_b, nh)
+        actv = label_conv3x3_raw(label, _table_of(w_sh), b_sh.detach().float().contiguous(), n, H, W, h, w, nh, True, dtype)
+        plan = packing.current()
+        wp = packed_weight(w_gb, dtype, nh, False, None, plan, stable=fused)
+        ctx.plan, ctx.plan_gen, ctx.fused = plan, (plan.generation if plan is not None else None), fused
+        train = any(ctx.needs_input_grad)
+        out = torch.empty_like(x)
+        gamma = torch.empty_like(x) if train else None
+        ld = 0 if off is None else style.shape[1]
+        sp = style.data_ptr() + 4 * (off or 0)
+        flops = 2.0 * n * h * w * nh * 2 * c * 9
+        LaunchProfiler.run('conv_patch', flops, lambda: L.check(
+            L.lib().s2e_spade_conv_modulate(_dt(x), _p(actv), _p(wp), _p(b_gb.float().contiguous()), _p(x), _p(stats), sp, ld,
+                                            _p(out), _p(gamma), n, h, w, c, nh, int(lrelu), int(flags), _stream()),
+            's2e_spade_conv_modulate'),
+            tag='F n%d %dx%d c%d->%d k3 s1 +mod%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
+            # algorithmic bytes: actv, packed w, x in; out (and gamma when it is kept) out
+            nbytes=float((actv.numel() + wp.numel() + x.numel() * (3 if train else 2)) * x.element_size()))
+        ctx.cfg = (h, w, c)
+        ctx.lrelu, ctx.off, ctx.dbig, ctx.batch, ctx.relay = lrelu, off, dbig, bool(batch), bool(relay)
+        if train:
+            _gb_grad_targets(ctx, fused, w_sh, b_sh, w_g, b_g, w_b, b_b, nh)
+            ctx.save_for_backward(x, label, w_sh, w_gb, actv, gamma, out, style, stats)
+        if relay:
+            ctx.set_materialize_grads(False)
+            return out, x.view_as(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g, g_relay=None):
+        x, label, w_sh, w_gb, actv, gamma, out, style, stats = ctx.saved_tensors
+        nn_ = (None,) * 8
+        if g is None:
+            return (g_relay,) + (None,) * 15
+        dx, dgb, dstyle = _modulate_grads(ctx, g, g_relay, x, gamma, out, style, stats)
+        gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b = _spade_param_grads(ctx, dgb, label, w_sh, w_gb, actv)
+        return (dx, None, gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b, dstyle) + (None,) * 7
+
+
+def spade_fused_supported(x, nh, flags=0):
+    """Does s2e_spade_conv_modulate take this layer (x: (N,h,w,C) NHWC, nh = mlp_shared's width)?"""
+    n, h, w, c = x.shape
+    if _FUSED_OFF:
+        return False
+    return bool(L.lib().s2e_spade_conv_modulate_supported(_dt(x), n, h, w, c, nh, int(flags)))
+
+
+_FUSED_OFF = os.environ.get('S2E_SPADE_FUSED', '1') == '0'      # A/B switch: the two-launch path everywhere
+
+
+def spade_style_fused(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off=None, dbig=None, batch=False,
+                      relay=False, flags=0):
+    """SPADE+Style block forward in one conv launch (see SpadeFusedFn); same arguments as spade_params +
+    spade_style_modulate."""
+    if off is None:
+        style = style.float().contiguous()
+    return SpadeFusedFn.apply(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags)
 
 
 def spade_style_modulate(x, gb, style, stats, lrelu, off=None, dbig=None, batch=False, relay=False):

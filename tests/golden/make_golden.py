@@ -77,7 +77,8 @@ def manifest_arrays(prefix, manifest):
 
 def checksum(t):
     t = t.detach().double().flatten()
-    idx = torch.linspace(0, t.numel() - 1, 16).long()
+    # (fp32 linspace as the first fixtures were written with; past 2^24 elements its end point rounds out of range)
+    idx = torch.linspace(0, t.numel() - 1, 16, dtype=torch.float32 if t.numel() <= (1 << 24) else torch.float64).long()
     return np.concatenate([[t.sum().item(), t.abs().sum().item()], t[idx].numpy()])
 
 
@@ -173,6 +174,114 @@ def openeds_fixture(args, syn):
     print('openeds_metric.npz', out['mse_tensors'], out['mse_images'], st)
 
 
+def full_train_fixture(args, syn):
+    """T3 (config 3 AS BENCHED): one G step + one D step of the reference `Pix2PixTrainer`
+    (trainers/pix2pix_trainer.py:26-45) at ngf=ndf=64, 256x256, N=8 -- the batch bench.py times (seed 1234).
+    Stores the losses, a strided subsample of the generated image, a checksum of every ResBlk output of the G step's
+    generator forward, and checksums of every parameter / buffer after the iteration.  A few minutes of CPU."""
+    class FloatAdam(torch.optim.Adam):           # SURVEY F6
+        def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), **kw):
+            super().__init__(params, lr=lr, betas=(float(betas[0]), float(betas[1])), **kw)
+    torch.optim.Adam = FloatAdam
+    from trainers.pix2pix_trainer import Pix2PixTrainer
+    import time
+    opt = ref_opt(ngf=64, ndf=64, crop_size=256, aspect_ratio=1.0, batchSize=8, init_type='normal')
+    opt.checkpoints_dir = '/tmp/s2e_golden_ckpt'
+    trainer = Pix2PixTrainer(opt)
+    model = trainer.pix2pix_model
+    mG, mD, mE = load_filled(model.netG), load_filled(model.netD), load_filled(model.netE)
+    batch = syn.make_batch(8, 256, 256, seed=1234)
+
+    def tdata():
+        return {'label': torch.from_numpy(batch['label'].astype(np.int64)),
+                'style_image': torch.from_numpy(batch['style_image']),
+                'target': torch.from_numpy(batch['target']), 'filename': batch['filename']}
+    rec, hooks = {}, []
+    for name in ('head_0', 'G_middle_0', 'G_middle_1', 'up_0', 'up_1', 'up_2', 'up_3'):
+        def hook(mod, inp, out, name=name):
+            rec.setdefault('it0_act_' + name, checksum(out))           # first call = the G step's forward
+        hooks.append(getattr(model.netG, name).register_forward_hook(hook))
+    t0 = time.time()
+    trainer.run_generator_one_step(tdata())
+    for h in hooks:
+        h.remove()
+    for k, v in trainer.g_losses.items():
+        rec['it0_%s' % k.replace('/', '_')] = v.detach().numpy().reshape(-1)
+    rec['it0_fake_sub'] = trainer.generated.detach()[:, :, ::8, ::8].numpy()
+    for tag, net in (('G', model.netG), ('E', model.netE)):
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                rec['it0_grad_%s.%s' % (tag, k)] = checksum(p.grad)
+    t1 = time.time()
+    trainer.run_discriminator_one_step(tdata())
+    for k, v in trainer.d_losses.items():
+        rec['it0_%s' % k.replace('/', '_')] = v.detach().numpy().reshape(-1)
+    for k, p in model.netD.named_parameters():
+        if p.grad is not None:
+            rec['it0_grad_D.%s' % k] = checksum(p.grad)
+    for tag, net in (('G', model.netG), ('D', model.netD), ('E', model.netE)):
+        for k, v in net.state_dict().items():
+            rec['it0_ck_%s.%s' % (tag, k)] = checksum(v)
+    rec['seconds'] = np.array([t1 - t0, time.time() - t1, torch.get_num_threads()])
+    np.savez_compressed(os.path.join(args.out, 'trainer_ngf64_256_n8.npz'), **rec,
+                        **manifest_arrays('G', mG), **manifest_arrays('D', mD), **manifest_arrays('E', mE))
+    print('full train ok (G step %.0f s, D step %.0f s)' % (t1 - t0, time.time() - t1),
+          {k: float(v.reshape(-1)[0]) for k, v in rec.items() if k.startswith('it0_') and v.size == 1})
+
+
+def cfg5_fixture(args, syn, onehot, SPADESTYLEGenerator, MultiscaleDiscriminator):
+    """C5 (config 5 geometry at full width): the reference netG eval-mode forward at ngf=64, 640x384
+    (--crop_size 384 --aspect_ratio 0.6; generator.py:52-67), N=4, and netD's forward lists (ndf=64) on
+    [cat(seg, fake); cat(seg, real)] (pix2pix_model.py:328-342)."""
+    opt = ref_opt(ngf=64, ndf=64, crop_size=384, aspect_ratio=0.6)
+    netG = SPADESTYLEGenerator(opt)
+    manG = load_filled(netG)
+    H, W = netG.sh * 32, netG.sw * 32
+    assert (H, W) == (640, 384), (H, W)
+    batch = syn.make_batch(4, H, W, seed=55)
+    label = batch['label']
+    w = syn.hash_normal('latent_w', (4, 16), seed=55)
+    seg = onehot(label)
+    netG.eval()
+    with torch.no_grad():
+        y = netG(seg, torch.from_numpy(w))
+    netD = MultiscaleDiscriminator(opt)
+    manD = load_filled(netD)
+    netD.eval()
+    real = torch.from_numpy(batch['target'])
+    with torch.no_grad():
+        pred = netD(torch.cat([torch.cat([seg, y], 1), torch.cat([seg, real], 1)], 0))
+    rec = {'w': w, 'y_sub': y[:, :, ::8, ::8].numpy().astype(np.float32),
+           'stats': np.array([y.mean().item(), y.std().item(), y.norm().item()])}
+    for i in range(2):
+        for j in range(5):
+            rec['pred_%d_%d' % (i, j)] = pred[i][j].numpy() if j == 4 else checksum(pred[i][j])
+            rec['pred_shape_%d_%d' % (i, j)] = np.array(pred[i][j].shape)
+    np.savez_compressed(os.path.join(args.out, 'cfg5_ngf64_640x384_n4.npz'), **rec,
+                        **manifest_arrays('G', manG), **manifest_arrays('D', manD))
+    print('cfg5 ok: y mean/std', y.mean().item(), y.std().item())
+
+
+def more_fixture(args, syn, onehot, SPADESTYLEGenerator):
+    """--num_upsampling_layers more (generator.py:52-67,80-82: six upsamplings, crop/64 start): eval forward + grads."""
+    opt = ref_opt(ngf=8, crop_size=128, aspect_ratio=1.0, num_upsampling_layers='more')
+    netG = SPADESTYLEGenerator(opt)
+    man = load_filled(netG)
+    H, W = netG.sh * 64, netG.sw * 64
+    label = syn.ellipse_labels(2, H, W, seed=41)
+    w = syn.hash_normal('latent_w', (2, 16), seed=41)
+    netG.eval()
+    wt = torch.from_numpy(w).clone().requires_grad_(True)
+    y = netG(onehot(label), wt)
+    proj = torch.from_numpy(syn.hash_uniform('g_proj', tuple(y.shape), seed=41))
+    (y * proj).sum().backward()
+    rec = {'label': label, 'w': w, 'y_eval': y.detach().numpy(), 'grad_w': wt.grad.numpy(), 'hw': np.array([H, W, netG.sh, netG.sw])}
+    for k, p in netG.named_parameters():
+        rec['grad_' + k] = checksum(p.grad)
+    np.savez_compressed(os.path.join(args.out, 'g_more_ngf8_128.npz'), **rec, **manifest_arrays('G', man))
+    print('more ok', (H, W), float(y.std()))
+
+
 def options_fixture(args):
     """reference_option_defaults.json: every flag of the reference's TrainOptions / TestOptions parsers
     (options/base_options.py, train_options.py, test_options.py) with its default, type, action and choices."""
@@ -194,7 +303,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=HERE)
     ap.add_argument('--full', action='store_true', help='also the ngf=64 256x256 N=8 pin (slow)')
-    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture); 'options': only reference_option_defaults.json; 'bn': only g_bn_ngf8_64.npz; 'openeds': only openeds_metric.npz")
+    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture); 'options': only reference_option_defaults.json; 'bn': only g_bn_ngf8_64.npz; 'openeds': only openeds_metric.npz; 'full-train': only trainer_ngf64_256_n8.npz (config 3 as benched, minutes); 'cfg5': only cfg5_ngf64_640x384_n4.npz; 'more': only g_more_ngf8_128.npz")
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -224,6 +333,15 @@ def main():
         return
     if args.only == 'bn':
         bn_generator_fixture(args, syn, onehot, SPADESTYLEGenerator)
+        return
+    if args.only == 'full-train':
+        full_train_fixture(args, syn)
+        return
+    if args.only == 'cfg5':
+        cfg5_fixture(args, syn, onehot, SPADESTYLEGenerator, MultiscaleDiscriminator)
+        return
+    if args.only == 'more':
+        more_fixture(args, syn, onehot, SPADESTYLEGenerator)
         return
 
     # ---- G1/G2: generator, ngf=8 (64x64) and ngf=16 (128x128 portrait-ish 128x64) -------

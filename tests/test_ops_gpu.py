@@ -251,6 +251,64 @@ def test_spade_params_and_label_conv(cfg, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(2, 64, 64, 32, 32, 64, True, True), (1, 48, 80, 24, 40, 128, False, True), (2, 32, 32, 16, 16, 192, True, False),
+                                 (3, 64, 64, 64, 64, 64, True, True)])
+def test_spade_conv_modulate_fused(cfg, dtype):
+    """s2e_spade_conv_modulate (the [gamma | beta] conv with the modulation in its epilogue; flags=1 forces the fused kernel at
+    any tile count) against the fp64 reference of SPADE_STYLE_Block.forward (normalization.py:184-192) and against the two-launch
+    path, forward (no-grad: gamma never stored; with grad) and every gradient (s2e_modulate_bwd_gamma)."""
+    from seg2eye_amd import ops
+    N, H, W, h, w, C, lrelu, relay = cfg
+    dev = _dev()
+    lab = _labels(N, H, W, 5)
+    onehot = torch.zeros(N, 4, H, W).scatter_(1, lab.long().unsqueeze(1), 1.0)
+    seg_h = F.interpolate(onehot, size=(h, w), mode='nearest').double()
+    x = _rnd((N, C, h, w), 41, dtype) * 1.3 + 0.2
+    style = _rnd((N, 2 * C), 42, torch.float32, 0.5)
+    gy = _rnd((N, C, h, w), 43, dtype)
+    w_sh = _rnd((128, 4, 3, 3), 44, torch.float32, 0.3)
+    b_sh = _rnd((128,), 45, torch.float32, 0.1)
+    w_gb = _rnd((2 * C, 128, 3, 3), 46, torch.float32, 0.03)
+    b_gb = _rnd((2 * C,), 47, torch.float32, 0.1)
+    refs = [t.double().requires_grad_(True) for t in (w_sh, b_sh, w_gb.to(dtype), b_gb)]
+    xr, sr = x.double().requires_grad_(True), style.double().requires_grad_(True)
+    actv = F.relu(F.conv2d(seg_h, refs[0], refs[1], padding=1))
+    if dtype == torch.bfloat16:
+        actv = actv + (actv.detach().to(dtype).double() - actv.detach())      # the kernel stores actv in bf16
+    gbr = F.conv2d(actv, refs[2], refs[3], padding=1)
+    gamma, beta = gbr[:, :C], gbr[:, C:]
+    s0, s1 = sr[:, :C, None, None], sr[:, C:, None, None]
+    yr = 0.5 * (F.instance_norm(xr, eps=1e-5) * (1 + gamma) + beta + xr * (1 + s0) + s1)
+    if lrelu:
+        yr = F.leaky_relu(yr, 0.2)
+    yr.backward(gy.double())
+    assert ops.spade_fused_supported(nhwc(x).to(dev), 128, flags=1)
+    prm = [t.to(dev).requires_grad_(True) for t in (w_sh, b_sh, w_gb[:C].clone(), b_gb[:C].clone(), w_gb[C:].clone(), b_gb[C:].clone())]
+    xg = nhwc(x).to(dev).requires_grad_(True)
+    sg = style.to(dev).requires_grad_(True)
+    st = ops.in_stats(xg.detach())
+    with torch.no_grad():
+        y0 = ops.spade_style_fused(xg, lab.to(dev), *prm, sg, st, lrelu, flags=1)
+    _close(nchw(y0), yr, dtype, what='fused out (no grad)')
+    y = ops.spade_style_fused(xg, lab.to(dev), *prm, sg, st, lrelu, relay=relay, flags=1)
+    if relay:
+        y, xalias = y
+        assert xalias.data_ptr() == xg.data_ptr()
+    assert torch.equal(y, y0)
+    y.backward(nhwc(gy).to(dev))
+    _close(nchw(xg.grad), xr.grad, dtype, what='fused dx')
+    _close(sg.grad, sr.grad, dtype, scale=float(sr.grad.abs().max()), what='fused dstyle')
+    _close(prm[0].grad, refs[0].grad, dtype, what='fused dw_sh')
+    _close(prm[1].grad, refs[1].grad, dtype, what='fused db_sh')
+    _close(torch.cat([prm[2].grad, prm[4].grad]), refs[2].grad, dtype, what='fused dw_gb')
+    _close(torch.cat([prm[3].grad, prm[5].grad]), refs[3].grad, dtype, what='fused db_gb')
+    # the two-launch path on the same inputs: same result up to the bf16 rounding of gamma / beta it stores in between
+    gb2 = ops.spade_params(lab.to(dev), *[t.detach() for t in prm], h, w, dtype)
+    y2 = ops.spade_style_modulate(xg.detach(), gb2, sg.detach(), st, lrelu)
+    _close(y, y2, dtype, what='fused vs two-launch')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_resampling_and_concat(dtype):
     from seg2eye_amd import ops
     dev = _dev()
