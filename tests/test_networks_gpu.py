@@ -678,3 +678,265 @@ def test_bench_two_ranks_dry_run():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and 'roofline' in d and 'cpu_baseline' not in d
+
+
+# ------------------------------------------------------------------------------------------ config 3 AS BENCHED
+_BLOCKS = ('head_0', 'G_middle_0', 'G_middle_1', 'up_0', 'up_1', 'up_2', 'up_3')
+
+
+def _bench_shape_kernels(dt):
+    """The kernels the library picks for the layers of the benchmarked configuration (N = 8, 256x256, ngf = ndf = 64):
+    name -> kind, via the same planner calls the launches use."""
+    import ctypes as C
+    from seg2eye_amd import _lib as L
+    lib = L.lib()
+    d = L.S2E_BF16 if dt == 'bf16' else L.S2E_F32
+
+    def conv(n, h, cin, cout, k, s, p, tr=0):
+        ho = h if s == 1 and 2 * p == k - 1 else ((h + 2 * p - k) // s + 1)
+        desc = L.ConvDesc(n, h, h, cin, ho, ho, cout, k, k, s, p, tr, 0, 0, 0) if not tr else \
+            L.ConvDesc(n, ho, ho, cout, h, h, cin, k, k, s, p, 1, 0, 0, 0)
+        return lib.s2e_conv2d_kernel_kind(d, C.byref(desc)), lib.s2e_conv2d_workspace_bytes(d, C.byref(desc))
+
+    def wgrad(n, h, cin, cout, k):
+        desc = L.ConvDesc(n, h, h, cin, h, h, cout, k, k, 1, k // 2, 0, 0, 0, 0)
+        return lib.s2e_conv2d_wgrad_kernel_kind(d, C.byref(desc))
+    return {
+        'up_3 conv_0 fwd': conv(8, 256, 128, 64, 3, 1, 1), 'up_2 conv_0 fwd': conv(8, 128, 256, 128, 3, 1, 1),
+        'mid conv split fwd': conv(8, 16, 1024, 1024, 3, 1, 1), 'gb dgrad 32^2': conv(8, 32, 128, 2048, 3, 1, 1, 1),
+        'D m3 4x4 s1': conv(16, 33, 256, 512, 4, 1, 2),
+        'gb wgrad 256^2': wgrad(8, 256, 128, 256, 3), 'up_1 wgrad': wgrad(8, 64, 512, 256, 3),
+        'fused 256^2 C=128': lib.s2e_spade_conv_modulate_supported(d, 8, 256, 256, 128, 128, 0),
+        'fused 16^2 C=1024': lib.s2e_spade_conv_modulate_supported(d, 8, 16, 16, 1024, 128, 0),
+    }
+
+
+def _cfg3_run(dt, graphs, z, steps=1, hooks=True):
+    """One (or more) G+D iterations of Pix2PixTrainer at the benchmarked configuration on the fixture's weights and batch.
+    -> dict(losses, fake, acts {block: NCHW fp32 cpu}, grads {name: fp32 gpu clone}, trainer)"""
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    opt = _opt(ngf=64, ndf=64, crop_size=256, aspect_ratio=1.0, batchSize=8, compute_dtype=dt, hip_graphs=graphs)
+    tr = Pix2PixTrainer(opt)
+    m = tr.pix2pix_model
+    for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+        sd = filled_state(z, tag)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(sd[k])
+    data = _batch(8, 256, 256, 1234)
+    acts, hs = {}, []
+    if hooks:
+        for name in _BLOCKS:
+            def hook(mod, inp, out, name=name):
+                acts.setdefault(name, out.detach().permute(0, 3, 1, 2).float().contiguous().cpu())   # first call = the G step's forward
+            hs.append(getattr(m.netG, name).register_forward_hook(hook))
+    out = {'acts': acts, 'tr': tr}
+    for it in range(steps):
+        tr.run_generator_one_step(dict(data))
+        if it == 0:
+            for h in hs:
+                h.remove()
+            torch.cuda.synchronize()
+            out['grads_G'] = {('G.' + k): p.grad.detach().clone() for k, p in m.netG.named_parameters() if p.grad is not None}
+            out['grads_G'].update({('E.' + k): p.grad.detach().clone() for k, p in m.netE.named_parameters() if p.grad is not None})
+            out['fake'] = tr.get_latest_generated().detach().float().cpu()
+        tr.run_discriminator_one_step(dict(data))
+        if it == 0:
+            torch.cuda.synchronize()
+            out['grads_D'] = {('D.' + k): p.grad.detach().clone() for k, p in m.netD.named_parameters() if p.grad is not None}
+            out['losses'] = {k: float(v.detach().float().mean()) for k, v in tr.get_latest_losses().items()}
+    return out
+
+
+def _relrms(a, b):
+    a, b = a.double(), b.double()
+    return float(((a - b) ** 2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
+
+
+def test_cfg3_as_benched_matches_reference():
+    """BASELINE.json configs[2] exactly as bench.py runs it -- ngf = ndf = 64, 256x256, batch 8, the bench's seed-1234 batch --
+    against ONE G step + ONE D step of the real reference's Pix2PixTrainer (trainers/pix2pix_trainer.py:26-45; fixture
+    trainer_ngf64_256_n8.npz, `make_golden.py --only full-train`):
+      (a) fp32 eager: losses 2e-3, generated image < 1e-3, every ResBlk output, every G / E / D parameter gradient and every
+          parameter / buffer after the iteration, by checksum;
+      (b) bf16 eager against the fp32 run: every ResBlk output, losses, the weight gradients of the five largest layers;
+      (c) bf16 with hipGraphs ON (what the bench times): the replayed step against (b) and against the reference's losses.
+    The shapes take the patch-resident / split / fused kernels at batch 8 (they take the generic one at batch 1): asserted."""
+    z = load_golden('trainer_ngf64_256_n8')
+    from seg2eye_amd import _lib as L
+    for dt in ('fp32', 'bf16'):
+        kinds = _bench_shape_kernels(dt)
+        for name in ('up_3 conv_0 fwd', 'up_2 conv_0 fwd', 'mid conv split fwd', 'gb dgrad 32^2', 'D m3 4x4 s1'):
+            assert kinds[name][0] == 2, (dt, name, kinds[name])                       # S2E_KERNEL_PATCH
+        assert kinds['mid conv split fwd'][1] > 0, kinds['mid conv split fwd']          # ... split over channel chunks
+        assert kinds['fused 256^2 C=128'] == 1 and kinds['fused 16^2 C=1024'] == 1, kinds
+        if dt == 'bf16':
+            assert kinds['gb wgrad 256^2'] == 2 and kinds['up_1 wgrad'] == 2, kinds     # patch-resident weight gradient
+    # ---- (a) fp32 eager vs the reference
+    a = _cfg3_run('fp32', False, z)
+    errs = []
+    for k, v in a['losses'].items():
+        ref = float(z['it0_%s' % k.replace('/', '_')].reshape(-1)[0])
+        errs.append(('loss ' + k, abs(v - ref), 2e-3 * max(1.0, abs(ref))))
+    errs.append(('fake', float(np.abs(a['fake'][:, :, ::8, ::8].numpy() - z['it0_fake_sub']).max()), G_TOL))
+    from conftest import checksum
+    for name in _BLOCKS:
+        ref, got = z['it0_act_' + name], checksum(a['acts'][name])
+        scale = ref[1] / a['acts'][name].numel()                                       # mean |activation|
+        errs.append(('act ' + name + ' sums', abs(got[0] - ref[0]) + abs(got[1] - ref[1]), 1e-4 * ref[1]))
+        errs.append(('act ' + name + ' samples', float(np.abs(got[2:] - ref[2:]).max()), 2e-3 * scale))
+    ngrad = 0
+    # D's gradients belong to the D step, i.e. they sit behind netG's Adam update: with beta1 = 0 the first update is
+    # -lr * sign(g), so gradients within summation noise of zero move their weight by +lr here and -lr there and the
+    # regenerated image -- D's input -- differs by ~1e-4: their sums wobble at the 2e-3 level run to run (measured)
+    for grads, rt in ((a['grads_G'], 2e-3), (a['grads_D'], 6e-3)):
+        for k, g in grads.items():
+            key = 'it0_grad_' + k
+            if key not in z.files:
+                continue
+            ref, got = z[key], checksum(g)
+            ngrad += 1
+            # (a one-element gradient -- conv_img's bias -- is a signed sum over N*H*W pixels that cancels to ~1e-3: its error is
+            # fp32 summation noise relative to the L1 mass of the summands, not to the sum; measured 3e-5)
+            errs.append(('grad ' + k + ' sums', abs(got[0] - ref[0]) + abs(got[1] - ref[1]), rt * ref[1] + (1e-4 if g.numel() == 1 else 1e-9)))
+            # 16 sampled elements: each is a signed sum over all pixels (the one-hot input channels of D's first layer cancel
+            # to a few % of the mean magnitude): bound relative to the mean |g| of the tensor; worst measured 0.053
+            errs.append(('grad ' + k + ' samples', float(np.abs(got[2:] - ref[2:]).max()), 0.1 * ref[1] / g.numel() + 1e-9))
+    assert ngrad >= 200, ngrad
+    bad = [e for e in errs if not e[1] <= e[2]]
+    assert not bad, '\n'.join('%s err %.3e > %.3e' % e for e in bad)
+    m = a['tr'].pix2pix_model
+    for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+        lr = 2e-4 * 2 if tag == 'D' else 2e-4 / 2
+        for k, v in net.state_dict().items():
+            flip = 2 * lr if v.dtype.is_floating_point and not k.endswith(('_u', '_v')) else 0.0
+            assert_checksum_close(v, z['it0_ck_%s.%s' % (tag, k)], 2e-3, 'after it0 %s.%s' % (tag, k), flip=flip)
+    fp32 = {k: a[k] for k in ('losses', 'fake', 'acts', 'grads_G', 'grads_D')}
+    del a, m
+    torch.cuda.empty_cache()
+    # ---- (b) bf16 eager vs fp32
+    b = _cfg3_run('bf16', False, z)
+    rep = {name: _relrms(b['acts'][name], fp32['acts'][name]) for name in _BLOCKS}
+    big = sorted(fp32['grads_G'], key=lambda k: -fp32['grads_G'][k].numel())[:5]
+    grep = {k: _relrms(b['grads_G'][k], fp32['grads_G'][k]) for k in big}
+    drep = {k: _relrms(b['grads_D'][k], fp32['grads_D'][k]) for k in sorted(fp32['grads_D'], key=lambda k: -fp32['grads_D'][k].numel())[:3]}
+    print('cfg3 bf16 vs fp32: ResBlk rel-RMS', {k: round(v, 4) for k, v in rep.items()})
+    print('cfg3 bf16 vs fp32: wgrad rel-RMS', {k: round(v, 4) for k, v in {**grep, **drep}.items()})
+    print('cfg3 losses fp32 %s | bf16 %s' % (fp32['losses'], b['losses']))
+    assert max(rep.values()) < 2e-2, rep
+    assert max(grep.values()) < 6e-2 and max(drep.values()) < 6e-2, (grep, drep)
+    for k, v in b['losses'].items():
+        assert abs(v - fp32['losses'][k]) <= 2e-2 * max(1.0, abs(fp32['losses'][k])), (k, v, fp32['losses'][k])
+    dimg = (b['fake'] - fp32['fake']).abs()
+    print('cfg3 bf16 image vs fp32: mean %.4f max %.4f rel-RMS %.4f' % (float(dimg.mean()), float(dimg.max()), _relrms(b['fake'], fp32['fake'])))
+    assert _relrms(b['fake'], fp32['fake']) < 3e-2 and float(dimg.mean()) < 1e-2
+    bf = {k: b[k] for k in ('losses', 'fake', 'grads_G')}
+    del b
+    torch.cuda.empty_cache()
+    # ---- (c) bf16 + hipGraphs: the replayed step (what bench.py times)
+    c = _cfg3_run('bf16', True, z, steps=1, hooks=False)
+    assert c['tr'].use_graphs and c['tr'].graph_G is not None, 'the step did not run as a hipGraph replay'
+    for k, v in c['losses'].items():
+        ref = float(z['it0_%s' % k.replace('/', '_')].reshape(-1)[0])
+        assert abs(v - bf['losses'][k]) <= 1e-2 * max(1.0, abs(bf['losses'][k])), ('graph vs eager', k, v, bf['losses'][k])
+        assert abs(v - ref) <= 2e-2 * max(1.0, abs(ref)), ('graph vs reference', k, v, ref)
+    assert _relrms(c['fake'], fp32['fake']) < 3e-2
+    g5 = {k: _relrms(c['grads_G'][k], fp32['grads_G'][k]) for k in big}
+    print('cfg3 bf16 hipGraph vs fp32: wgrad rel-RMS', {k: round(v, 4) for k, v in g5.items()})
+    assert max(g5.values()) < 6e-2, g5
+
+
+def test_cfg5_full_width_matches_reference():
+    """BASELINE.json configs[4] geometry at full width: ngf = ndf = 64, 640x384 (--crop_size 384 --aspect_ratio 0.6),
+    batch 4 -- fp32 eval-mode netG and netD's feature lists against the real reference (fixture cfg5_ngf64_640x384_n4.npz:
+    generator.py:69-101, discriminator.py:53-63), then one bf16 G+D trainer iteration of the same shape against the fp32 one."""
+    from seg2eye_amd import networks, synthetic as syn, ops
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    from conftest import checksum
+    z = load_golden('cfg5_ngf64_640x384_n4')
+    opt = _opt(ngf=64, ndf=64, crop_size=384, aspect_ratio=0.6, compute_dtype='fp32')
+    H, W = 640, 384
+    b = syn.make_batch(4, H, W, seed=55)
+    label = torch.from_numpy(b['label']).to(DEV)
+    G = networks.define_G(opt)
+    G.load_state_dict(filled_state(z, 'G'))
+    G.eval()
+    with torch.no_grad():
+        y = G(label, torch.from_numpy(z['w']).to(DEV))
+    yc = y.float().cpu()
+    err = float((yc[:, :, ::8, ::8] - torch.from_numpy(z['y_sub'])).abs().max())
+    assert err < G_TOL, 'cfg5 fp32 G differs from the reference by %.3e' % err
+    np.testing.assert_allclose([float(yc.mean()), float(yc.std())], z['stats'][:2], atol=1e-4)
+    D = networks.define_D(opt)
+    D.load_state_dict(filled_state(z, 'D'))
+    D.eval()
+    imgs = torch.cat([y[:, 0].float(), torch.from_numpy(b['target'])[:, 0].to(DEV)], 0).contiguous()
+    x = ops.seg_image_concat(torch.cat([label[:, 0], label[:, 0]], 0).contiguous(), imgs, 4, networks.discriminator.D_CPAD)
+    with torch.no_grad():
+        pred = D(x)
+    for i in range(2):
+        for j in range(5):
+            t = pred[i][j].float()
+            assert tuple(t.shape) == tuple(int(v) for v in z['pred_shape_%d_%d' % (i, j)]), (i, j, t.shape)
+            ref = z['pred_%d_%d' % (i, j)]
+            if j == 4:
+                assert float((t.cpu() - torch.from_numpy(ref)).abs().max()) < 2e-3 * max(1.0, float(np.abs(ref).max())), (i, j)
+            else:
+                assert_checksum_close(t, ref, 1e-3, 'cfg5 D feature %d/%d' % (i, j))
+    del G, D, pred, x, y
+    torch.cuda.empty_cache()
+    # one trainer iteration at this shape: bf16 against fp32 (same weights, same batch)
+    data = {'label': torch.from_numpy(b['label']), 'style_image': torch.from_numpy(b['style_image']), 'target': torch.from_numpy(b['target'])}
+    res = {}
+    for dt in ('fp32', 'bf16'):
+        o = _opt(ngf=64, ndf=64, crop_size=384, aspect_ratio=0.6, batchSize=4, compute_dtype=dt)
+        tr = Pix2PixTrainer(o)
+        m = tr.pix2pix_model
+        for tag, net in (('G', m.netG), ('D', m.netD)):
+            sd = filled_state(z, tag)
+            with torch.no_grad():
+                for k, v in net.state_dict().items():
+                    v.copy_(sd[k])
+        sdE = syn.fill_state_dict([(k, tuple(v.shape)) for k, v in m.netE.state_dict().items()])
+        with torch.no_grad():
+            for k, v in m.netE.state_dict().items():
+                v.copy_(torch.from_numpy(sdE[k]))
+        tr.run_generator_one_step(dict(data))
+        torch.cuda.synchronize()
+        big = sorted(((k, p) for k, p in m.netG.named_parameters()), key=lambda kp: -kp[1].numel())[:5]
+        grads = {k: p.grad.detach().clone() for k, p in big}
+        tr.run_discriminator_one_step(dict(data))
+        res[dt] = ({k: float(v.detach().float().mean()) for k, v in tr.get_latest_losses().items()},
+                   tr.get_latest_generated().float().cpu(), grads)
+        assert tuple(res[dt][1].shape) == (4, 1, H, W)
+        del tr, m
+        torch.cuda.empty_cache()
+    for k, v in res['bf16'][0].items():
+        assert np.isfinite(v) and abs(v - res['fp32'][0][k]) <= 2e-2 * max(1.0, abs(res['fp32'][0][k])), (k, v, res['fp32'][0][k])
+    assert _relrms(res['bf16'][1], res['fp32'][1]) < 3e-2
+    g5 = {k: _relrms(res['bf16'][2][k], res['fp32'][2][k]) for k in res['fp32'][2]}
+    print('cfg5 bf16 vs fp32: image rel-RMS %.4f, wgrad rel-RMS %s' % (_relrms(res['bf16'][1], res['fp32'][1]), {k: round(v, 4) for k, v in g5.items()}))
+    assert max(g5.values()) < 6e-2, g5
+
+
+def test_generator_more_upsampling_matches_reference():
+    """--num_upsampling_layers more (generator.py:52-67,80-82: a sixth upsampling between the two middle blocks, start map
+    crop/64): eval forward, d/dw and every parameter gradient against the real reference (g_more_ngf8_128.npz)."""
+    from seg2eye_amd import networks, synthetic as syn
+    from conftest import checksum
+    z = load_golden('g_more_ngf8_128')
+    opt = _opt(ngf=8, crop_size=128, aspect_ratio=1.0, num_upsampling_layers='more', compute_dtype='fp32')
+    G = _load(networks.define_G(opt), z, 'G')
+    G.eval()
+    w = torch.from_numpy(z['w']).to(DEV).requires_grad_(True)
+    y = G(_label(z), w)
+    assert tuple(y.shape) == tuple(z['y_eval'].shape) == (2, 1, 128, 128)
+    err = float((y.detach().float().cpu() - torch.from_numpy(z['y_eval'])).abs().max())
+    assert err < G_TOL, "'more' generator differs from the reference by %.3e" % err
+    proj = torch.from_numpy(syn.hash_uniform('g_proj', tuple(z['y_eval'].shape), seed=41)).to(DEV)
+    (y.float() * proj).sum().backward()
+    gw = z['grad_w']
+    assert float((w.grad.cpu() - torch.from_numpy(gw)).abs().max()) <= KINK_TOL * float(np.abs(gw).max())
+    for k, p in G.named_parameters():
+        ref, got = z['grad_' + k], checksum(p.grad)
+        assert abs(got[0] - ref[0]) + abs(got[1] - ref[1]) <= KINK_TOL * ref[1] + 1e-9, (k, got[:2], ref[:2])
