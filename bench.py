@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_BF16 = 2500.0     # TFLOP/s dense (MI355X_MICROARCH.md)
 MFMA_PEAK_F32 = 157.3
+HBM_PEAK_GBS = 8000.0        # HBM3E (MI355X_MICROARCH.md)
 
 
 def make_data(n, hw, seed, dev):
@@ -177,25 +178,35 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    # Per-launch HIP events for the roofline.  A graph replay cannot carry per-launch events, so the
-    # same step (same kernels, shapes, data) is re-run eagerly right after the timed region with an
-    # event pair around every MFMA-kernel launch, on the launch stream.
-    # Every rank runs these extra steps (a step contains the gradient all-reduce: rank 0 alone would wait for ever);
-    # only rank 0 records events.
     # did the timed steps really run as hipGraph replays? (a failed capture falls back to eager launches and clears the option)
     graphs_ran = bool(trainer.use_graphs and trainer.graph_G is not None and trainer.graph_D is not None)
+    # SURVEY 8(d) quotes the steady-state MEDIAN: a second, per-step-synchronised pass over the same number of steps gives
+    # the distribution (the contract's `value` stays the whole-region mean above; the per-step syncs cost a launch gap each)
+    per_step = []
+    for _ in range(args.steps):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        per_step.append((time.perf_counter() - t1) * 1e3)
+    # Per-launch HIP events for the roofline.  A graph replay cannot carry per-launch events, so the
+    # same step (same kernels, shapes, data) is re-run eagerly right after the timed region with an
+    # event pair around every C-ABI call, on the launch stream.
+    # Every rank runs these extra steps (a step contains the gradient all-reduce: rank 0 alone would wait for ever);
+    # only rank 0 records events.
     prof_steps = 0
+    prof = ops.LaunchProfiler()
     if not args.no_kernel_events:
         trainer.opt.hip_graphs = False
         step()
         torch.cuda.synchronize()
-        ops.LaunchProfiler.reset()
-        ops.LaunchProfiler.enabled = rank == 0
+        if rank == 0:
+            ops.LaunchProfiler.install(prof)
         prof_steps = 2
         for _ in range(prof_steps):
             step()
         torch.cuda.synchronize()
-        ops.LaunchProfiler.enabled = False
+        ops.LaunchProfiler.install(None)
     losses = {k: float(v.detach().float().mean()) for k, v in trainer.get_latest_losses().items()}
     if not all(np.isfinite(list(losses.values()))):
         raise SystemExit('non-finite losses: %s' % losses)
@@ -214,19 +225,24 @@ def main():
                        'global_batch': global_batch, 'parallelism': 'dp%d' % world},
             'losses': losses,
         }
-        prof = ops.LaunchProfiler.summary()
+        out['ms_per_step_median'] = float(np.median(per_step))
+        prof = prof.summary()
         if prof:
             peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
-            fam = max(prof, key=lambda k: prof[k]['ms'])
-            d = prof[fam]
+            pmc_rel = os.path.join('profiles', 'r02', 'pmc', 'hbm_traffic.json')
+            pmc = {}
+            if os.path.exists(os.path.join(ROOT, pmc_rel)):   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+                pmc = json.load(open(os.path.join(ROOT, pmc_rel)))
+
+            def traffic_of(fam):
+                k = pmc.get('kernels', {}).get(fam)
+                return (k['hbm_bytes_per_launch'], '%s @ %s' % (pmc_rel, pmc.get('git_head', '?'))) if k else (None, None)
+            mfma = {k: v for k, v in prof.items() if v['flops'] > 0}
+            hbm = {k: v for k, v in prof.items() if v['flops'] == 0}
+            fam = max(mfma, key=lambda k: mfma[k]['ms'])
+            d = mfma[fam]
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
-            args_steps = prof_steps
-            traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r01', 'pmc', 'hbm_traffic.json')
-            if os.path.exists(pmc):                       # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-                k = json.load(open(pmc)).get('kernels', {}).get(fam)
-                if k:
-                    traffic, traffic_src = k['hbm_bytes_per_launch'], 'profiles/r01/pmc/hbm_traffic.json'
+            traffic, traffic_src = traffic_of(fam)
             out['roofline'] = {'kernel': fam, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': ach / peak, 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC, separate passes)',
                                'traffic_source': traffic_src,
@@ -235,8 +251,22 @@ def main():
                                'launches_per_step': d['launches'] / prof_steps, 'ms_per_step': d['ms'] / prof_steps,
                                'gflop_per_step': d['flops'] / prof_steps / 1e9,
                                'measured': 'HIP events around every launch, eager re-run of the timed step'}
-            out['kernels'] = {k: {'launches_per_step': v['launches'] / prof_steps, 'ms_per_step': v['ms'] / prof_steps,
-                                  'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} for k, v in prof.items()}
+            if hbm:
+                # the HBM-bound class (north_star: "HBM GB/s against the roofline"): its dominant family by time, algorithmic
+                # bytes per SURVEY 8(d) / DESIGN 3.5 over the same HIP-event durations, against 8 TB/s
+                hf = max(hbm, key=lambda k: hbm[k]['ms'])
+                h = hbm[hf]
+                gbs = h['bytes'] / (h['ms'] * 1e-3) / 1e9
+                tr_h, tr_src = traffic_of(hf)
+                out['roofline_hbm'] = {'kernel': hf, 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                       'frac': gbs / HBM_PEAK_GBS, 'traffic': tr_h, 'traffic_unit': 'HBM bytes per launch (PMC, separate passes)',
+                                       'traffic_source': tr_src, 'algorithmic_bytes_per_launch': h['bytes'] / h['launches'],
+                                       'launches_per_step': h['launches'] / prof_steps, 'ms_per_step': h['ms'] / prof_steps,
+                                       'measured': 'HIP events around every C-ABI call (all kernels of the call), eager re-run of the timed step'}
+            out['kernels'] = {k: dict({'launches_per_step': v['launches'] / prof_steps, 'ms_per_step': v['ms'] / prof_steps},
+                                      **({'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} if v['flops'] > 0 else
+                                         {'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9}))
+                              for k, v in prof.items()}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(opt_kwargs, args.size, args.batch)
         print(json.dumps(out), flush=True)

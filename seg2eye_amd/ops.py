@@ -48,28 +48,40 @@ def _need(*ts):
 
 # ------------------------------------------------------------------------------ per-launch timing
 class LaunchProfiler:
-    """Optional HIP-event timing of the MFMA kernels, per launch, on the stream they are launched on
-    (torch's current stream).  bench.py turns it on to measure the dominant kernel's achieved rate
-    live; off by default (zero overhead)."""
-    enabled = False
-    records = []          # (family, algorithmic_flops, start_event, end_event, tag, algorithmic_bytes)
+    """Optional HIP-event timing of the kernels, per C-ABI call, on the stream they are launched on (torch's current
+    stream).  bench.py / tools create one, install it with `LaunchProfiler.install(p)` and read `p.summary()`; with none
+    installed (the default) `run` is a plain call.  Families: the MFMA kernels by `s2e_conv2d_kernel_kind` (conv_patch /
+    conv_igemm / conv_small and the weight-gradient ones), the HBM-bound ones by entry point (in_stats, modulate_fwd,
+    modulate_bwd, label_conv, adam, ...), each with its ALGORITHMIC FLOPs / bytes."""
+    current = None        # the installed profiler (one per process at a time: it times whatever runs on this thread)
+
+    def __init__(self):
+        self.records = []     # (family, algorithmic_flops, start_event, end_event, tag, algorithmic_bytes)
+
+    @classmethod
+    def install(cls, prof):
+        cls.current = prof
+
+    @classmethod
+    def active(cls):
+        return cls.current is not None
 
     @classmethod
     def run(cls, family, flops, fn, tag='', nbytes=0.0):
-        if not cls.enabled:
+        prof = cls.current
+        if prof is None:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         r = fn()
         e.record()
-        cls.records.append((family, flops, s, e, tag, nbytes))
+        prof.records.append((family() if callable(family) else family, flops, s, e, tag, nbytes))
         return r
 
-    @classmethod
-    def summary(cls):
-        """family -> dict(launches, flops, ms); call after a device synchronize."""
+    def summary(self):
+        """family -> dict(launches, flops, ms, bytes); call after a device synchronize."""
         out = {}
-        for fam, fl, s, e, _, nb in cls.records:
+        for fam, fl, s, e, _, nb in self.records:
             d = out.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
             d['launches'] += 1
             d['flops'] += fl
@@ -77,98 +89,114 @@ class LaunchProfiler:
             d['ms'] += s.elapsed_time(e)
         return out
 
-    @classmethod
-    def reset(cls):
-        cls.records = []
+    def reset(self):
+        self.records = []
 
 
 # ------------------------------------------------------------------------------ zero-filled scratch
 class ZeroPool:
-    """Zero-initialised scratch for ONE trainer step, filled by ONE launch.
+    """Zero-initialised scratch for the steps of ONE trainer, filled by ONE launch per step.
 
-    A G or D step needs ~200 small zero-filled buffers (packed weight-gradient accumulators, fp64
-    reduction scratch of the statistics / modulation kernels, the spectral-norm dot products).  Zeroing
-    each with its own 4-5 us launch cost ~1 ms of a 35 ms step.  Inside `with ZeroPool.scope(key)` they are
-    bump-allocated from one device buffer whose used prefix (the high-water mark of earlier scopes with
-    the same key) is cleared by a single fill at scope entry; a take beyond the cleared prefix clears its
-    own slice.  Outside a scope `take` is plain torch.zeros, so stand-alone ops and tests behave as
-    before.  Everything taken inside a scope must be dead when the next scope starts: true for the
-    scratch listed above, NOT for tensors handed to the caller (losses, parameter gradients) -- those
-    never come from the pool.  After `freeze()` (a hipGraph holds raw pointers into the buffer) the
-    buffer is never re-allocated; overflow falls back to torch.zeros."""
+    A G or D step needs ~200 small zero-filled buffers (packed weight-gradient accumulators, fp64 reduction scratch of
+    the statistics / modulation kernels, the spectral-norm dot products).  Zeroing each with its own 4-5 us launch cost
+    ~1 ms of a 35 ms step.  Inside `with pool.scope(key)` they are bump-allocated from the pool's device buffer, whose
+    used prefix (the high-water mark of earlier scopes with the same key) is cleared by a single fill at scope entry; a
+    take beyond the cleared prefix clears its own slice.  The ops ask `ZeroPool.take(...)`, which serves from the pool
+    whose scope is open on this process (scopes do not nest) and is plain torch.zeros when none is -- stand-alone ops,
+    inference models and tests behave as before.  Everything taken inside a scope must be dead when the pool's next
+    scope starts: true for the scratch listed above, NOT for tensors handed to the caller (losses, parameter
+    gradients) -- those never come from a pool.  After `freeze()` (a hipGraph holds raw pointers into the buffer) the
+    buffer is never re-allocated; overflow falls back to torch.zeros.
+
+    Each Pix2PixTrainer owns its pool (and with it the queue of deferred weight-gradient re-layouts, GradSink): two
+    trainers -- or a trainer and an inference model -- in one process share nothing."""
     ALIGN = 256
-    buf = None
-    cap = 0            # bytes allocated
-    bump = 0           # bytes handed out in the current scope
-    clean = 0          # [bump, clean) is known to be zero
-    need = 0           # largest total any scope asked for (drives growth)
-    high = {}          # key -> high-water mark
-    key = None
-    frozen = False
-    serial = 0         # scopes begun so far (lets per-scope state elsewhere notice a new step)
-    step_cache = {}    # per-scope memo of derived read-only tensors (cleared at scope entry and exit)
+    _active = None     # the pool whose scope is open
+    serial = 0         # scopes begun so far, over all pools (lets per-scope state elsewhere notice a new step)
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.buf = None
+        self.cap = 0            # bytes allocated
+        self.bump = 0           # bytes handed out in the current scope
+        self.clean = 0          # [bump, clean) is known to be zero
+        self.need = 0           # largest total any scope asked for (drives growth)
+        self.high = {}          # key -> high-water mark
+        self.key = None
+        self.frozen = False
+        self.step_cache = {}    # per-scope memo of derived read-only tensors (cleared at scope entry and exit)
+        self.sink = GradSink()
+
+    def scope(self, key):
+        return _ZeroScope(self, key)
+
+    def freeze(self):
+        self.frozen = True
+
+    def unfreeze(self):
+        self.frozen = False
 
     @classmethod
-    def scope(cls, key, device):
-        return _ZeroScope(key, device)
+    def active(cls):
+        """The pool whose scope is open, or None."""
+        return cls._active
 
-    @classmethod
-    def freeze(cls):
-        cls.frozen = True
-
-    @classmethod
-    def _begin(cls, key, device):
-        if cls.key is not None:
+    def _begin(self, key):
+        if ZeroPool._active is not None:
             raise RuntimeError('ZeroPool scopes do not nest')
-        if not cls.frozen and cls.need > cls.cap:
-            cls.cap = (int(cls.need * 1.25) + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
-            cls.buf = torch.zeros(cls.cap, dtype=torch.uint8, device=device)
-            cls.clean = cls.cap
+        if not self.frozen and self.need > self.cap:
+            self.cap = (int(self.need * 1.25) + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.buf = torch.zeros(self.cap, dtype=torch.uint8, device=self.device)
+            self.clean = self.cap
         else:
-            hw = min(cls.high.get(key, 0), cls.cap)
+            hw = min(self.high.get(key, 0), self.cap)
             if hw:
-                cls.buf[:hw].zero_()
-            cls.clean = hw
-        cls.key, cls.bump = key, 0
-        cls.step_cache = {}
-        cls.serial += 1
+                self.buf[:hw].zero_()
+            self.clean = hw
+        self.key, self.bump = key, 0
+        self.step_cache = {}
+        ZeroPool._active = self
+        ZeroPool.serial += 1
 
-    @classmethod
-    def _end(cls):
-        cls.high[cls.key] = max(cls.high.get(cls.key, 0), cls.bump)
-        cls.need = max(cls.need, cls.bump)
-        cls.key = None
-        cls.step_cache = {}
+    def _end(self):
+        self.high[self.key] = max(self.high.get(self.key, 0), self.bump)
+        self.need = max(self.need, self.bump)
+        self.key = None
+        self.step_cache = {}
+        ZeroPool._active = None
 
     @classmethod
     def take(cls, numel, dtype, device):
-        if cls.key is None:
+        pool = cls._active
+        if pool is None:
             return torch.zeros(numel, dtype=dtype, device=device)
         nbytes = numel * torch.empty((), dtype=dtype).element_size()
-        off = cls.bump
+        off = pool.bump
         end = off + (nbytes + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
-        cls.bump = end                                   # counts overflow too: that is how the pool learns its size
-        if end > cls.cap or cls.buf.device != device:
+        pool.bump = end                                  # counts overflow too: that is how the pool learns its size
+        if end > pool.cap or pool.buf.device != torch.device(device):
             return torch.zeros(numel, dtype=dtype, device=device)
-        if end > cls.clean:
-            cls.buf[max(off, cls.clean):end].zero_()
-            cls.clean = end
-        return cls.buf[off:off + nbytes].view(dtype)
+        if end > pool.clean:
+            pool.buf[max(off, pool.clean):end].zero_()
+            pool.clean = end
+        return pool.buf[off:off + nbytes].view(dtype)
 
 
 class _ZeroScope:
-    def __init__(self, key, device):
-        self.key, self.device = key, device
+    def __init__(self, pool, key):
+        self.pool, self.key = pool, key
 
     def __enter__(self):
-        ZeroPool._begin(self.key, self.device)
+        self.pool._begin(self.key)
 
     def __exit__(self, *exc):
-        if exc[0] is None:
-            GradSink.flush()                                 # all queued weight-gradient re-layouts: two launches
-        else:
-            GradSink.jobs = []
-        ZeroPool._end()
+        try:
+            if exc[0] is None:
+                self.pool.sink.flush()                       # all queued weight-gradient re-layouts: two launches
+            else:
+                self.pool.sink.jobs = []
+        finally:
+            self.pool._end()
         return False
 
 
@@ -178,26 +206,30 @@ class GradSink:
     re-layout, or the spectral-norm chain rule dW_orig = (dW - <dW, W_sn> u v^T)/sigma -- are not launched one by one
     (~95 launches of a few microseconds of work each, 1.2 ms per step) but queued and done by TWO launches at scope
     exit (`s2e_weight_grads_batched`).  The packed buffers are ZeroPool slices, alive until the next scope.  The
-    device job table is cached by content: in steady state (and always under a hipGraph) every pointer repeats."""
-    jobs = []
-    tables = {}
+    device job table is cached by content: in steady state (and always under a hipGraph) every pointer repeats.
+    One sink per pool (= per trainer)."""
 
-    @classmethod
-    def push(cls, dwp, dst, cout, cin, taps, cin_pad, w_orig=None, u=None, v=None, sigma=None):
+    def __init__(self):
+        self.jobs = []
+        self.tables = {}
+        self.keepalive = None
+
+    @staticmethod
+    def push(dwp, dst, cout, cin, taps, cin_pad, w_orig=None, u=None, v=None, sigma=None):
         """True if queued (caller must not touch dst until flush); False: no scope active, do it now."""
-        if ZeroPool.key is None:
+        pool = ZeroPool.active()
+        if pool is None:
             return False
-        cls.jobs.append((dwp, dst, w_orig, u, v, sigma, int(cout), int(cin), int(taps), int(cin_pad)))
+        pool.sink.jobs.append((dwp, dst, w_orig, u, v, sigma, int(cout), int(cin), int(taps), int(cin_pad)))
         return True
 
-    @classmethod
-    def flush(cls):
-        if not cls.jobs:
+    def flush(self):
+        if not self.jobs:
             return
-        jobs, cls.jobs = cls.jobs, []
+        jobs, self.jobs = self.jobs, []
         key = tuple((j[0].data_ptr(), j[1].data_ptr()) + tuple(0 if t is None else t.data_ptr() for t in j[2:6]) + j[6:] for j in jobs)
         dev = jobs[0][0].device
-        ent = cls.tables.get(key)
+        ent = self.tables.get(key)
         if ent is None:
             arr = (L.GradJob * len(jobs))()
             nsn = 0
@@ -217,14 +249,16 @@ class GradSink:
             jobs_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
             map_dev = torch.from_numpy(bm).to(dev)
             ent = (jobs_dev, map_dev, int(nb), max(j[8] for j in jobs), nsn)
-            if len(cls.tables) > 8:
-                cls.tables.clear()
-            cls.tables[key] = ent
+            if len(self.tables) > 8:
+                self.tables.clear()
+            self.tables[key] = ent
         jobs_dev, map_dev, nb, max_taps, nsn = ent
         dots = ZeroPool.take(max(nsn, 1), torch.float32, dev)
-        L.check(L.lib().s2e_weight_grads_batched(jobs_dev.data_ptr(), map_dev.data_ptr(), nb, max_taps, int(nsn > 0),
-                                                 dots.data_ptr(), _stream()), 's2e_weight_grads_batched')
-        cls.keepalive = jobs                                 # the tensors of this flush stay referenced until the next one
+        nbytes = float(sum(j[0].numel() * 4 * (3 if j[2] is not None else 2) + (j[0].numel() * 4 if j[2] is not None else 0) for j in jobs))
+        LaunchProfiler.run('weight_grad_relayout', 0.0, lambda: L.check(
+            L.lib().s2e_weight_grads_batched(jobs_dev.data_ptr(), map_dev.data_ptr(), nb, max_taps, int(nsn > 0),
+                                             dots.data_ptr(), _stream()), 's2e_weight_grads_batched'), nbytes=nbytes)
+        self.keepalive = jobs                                # the tensors of this flush stay referenced until the next one
 
 
 # ------------------------------------------------------------------------------ raw launchers
@@ -281,7 +315,7 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     flops = 2.0 * n * pix * cin * cout * kh * kw
     wsb = L.lib().s2e_conv2d_workspace_bytes(_dt(x), C.byref(d))          # > 0 only for split-K shapes
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
-    LaunchProfiler.run(_CONV_FAMILY[L.lib().s2e_conv2d_kernel_kind(_dt(x), C.byref(d))] if LaunchProfiler.enabled else 'conv_igemm', flops, lambda: L.check(
+    LaunchProfiler.run(lambda: _CONV_FAMILY[L.lib().s2e_conv2d_kernel_kind(_dt(x), C.byref(d))], flops, lambda: L.check(
         L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _p(ws), wsb,
                            _stream()), 's2e_conv2d'),
         tag='%s n%d %dx%d c%d->%d k%d s%d' % ('D' if transposed else 'F', n, hi, wi, cin, cout, kh, stride),
@@ -309,7 +343,7 @@ def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=Fals
     d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
     wsb = L.lib().s2e_conv2d_wgrad_workspace_bytes(_dt(x), C.byref(d))    # > 0 only for the 1-channel shapes
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
-    LaunchProfiler.run(_WGRAD_FAMILY[L.lib().s2e_conv2d_wgrad_kernel_kind(_dt(x), C.byref(d))] if LaunchProfiler.enabled else 'conv_wgrad',
+    LaunchProfiler.run(lambda: _WGRAD_FAMILY[L.lib().s2e_conv2d_wgrad_kernel_kind(_dt(x), C.byref(d))],
                        2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
         L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), _p(dbp), C.byref(d), _p(ws), wsb, _stream()),
         's2e_conv2d_wgrad'),
@@ -367,7 +401,9 @@ def in_stats(x, return_sums=False):
     n, h, w, c = x.shape
     ws = ZeroPool.take(n * c * 2, torch.float64, x.device)
     stats = torch.empty(n, c, 2, dtype=torch.float32, device=x.device)
-    L.check(L.lib().s2e_in_stats(_dt(x), _p(x), n, h * w, c, IN_EPS, _p(ws), _p(stats), _stream()), 's2e_in_stats')
+    LaunchProfiler.run('in_stats', 0.0, lambda: L.check(
+        L.lib().s2e_in_stats(_dt(x), _p(x), n, h * w, c, IN_EPS, _p(ws), _p(stats), _stream()), 's2e_in_stats'),
+        nbytes=float(x.numel() * x.element_size()))                   # algorithmic: x read once
     return (stats, ws.view(n, c, 2)) if return_sums else stats
 
 
@@ -376,8 +412,10 @@ def label_conv3x3_raw(label, weight, bias, n, H, W, h, w, cout, relu, dtype):
     _need(label, weight, bias)
     out = torch.empty(n, h, w, cout, dtype=dtype, device=label.device)
     ncls = weight.shape[1]
-    L.check(L.lib().s2e_label_conv3x3(_dt(out), _p(label), _p(weight), _p(bias), _p(out), n, H, W, h, w, ncls, cout,
-                                      int(relu), _stream()), 's2e_label_conv3x3')
+    LaunchProfiler.run('label_conv', 0.0, lambda: L.check(
+        L.lib().s2e_label_conv3x3(_dt(out), _p(label), _p(weight), _p(bias), _p(out), n, H, W, h, w, ncls, cout,
+                                  int(relu), _stream()), 's2e_label_conv3x3'),
+        nbytes=float(out.numel() * out.element_size() + n * h * w))     # algorithmic: the output written once (+ the label bytes)
     return out
 
 
@@ -386,14 +424,15 @@ def onehot_nhwc_raw(label, img, h, w, ncls, cpad, dtype):
     n, H, W = label.shape
     # inside a trainer step the three SPADEs of a block (and both blocks of a resolution) ask for the same
     # one-hot map in their backward: build it once per (label, resolution) per step
-    key = (label.data_ptr(), label._version, n, H, W, h, w, ncls, cpad, dtype) if (img is None and ZeroPool.key is not None) else None
-    if key is not None and key in ZeroPool.step_cache:
-        return ZeroPool.step_cache[key]
+    pool = ZeroPool.active()
+    key = (label.data_ptr(), label._version, n, H, W, h, w, ncls, cpad, dtype) if (img is None and pool is not None) else None
+    if key is not None and key in pool.step_cache:
+        return pool.step_cache[key]
     out = torch.empty(n, h, w, cpad, dtype=dtype, device=label.device)
     L.check(L.lib().s2e_onehot_nhwc(_dt(out), _p(label), _p(img), _p(out), n, H, W, h, w, ncls, cpad, _stream()),
             's2e_onehot_nhwc')
     if key is not None:
-        ZeroPool.step_cache[key] = out
+        pool.step_cache[key] = out
     return out
 
 
@@ -684,8 +723,10 @@ class ModulateFn(torch.autograd.Function):
         out = torch.empty_like(x)
         ld = 0 if off is None else style.shape[1]
         sp = style.data_ptr() + 4 * (off or 0)
-        L.check(L.lib().s2e_modulate_fwd(_dt(x), NORM_SPADE_STYLE, _p(x), _p(gb), _p(stats), sp, _p(out),
-                                         n, h * w, c, int(lrelu), ld, _stream()), 's2e_modulate_fwd')
+        LaunchProfiler.run('modulate_fwd', 0.0, lambda: L.check(
+            L.lib().s2e_modulate_fwd(_dt(x), NORM_SPADE_STYLE, _p(x), _p(gb), _p(stats), sp, _p(out),
+                                     n, h * w, c, int(lrelu), ld, _stream()), 's2e_modulate_fwd'),
+            nbytes=float(2 * x.numel() * x.element_size()))           # algorithmic: x read, out written (gamma/beta are not)
         ctx.lrelu, ctx.off, ctx.dbig, ctx.batch, ctx.relay = lrelu, off, dbig, bool(batch), bool(relay)
         ctx.save_for_backward(x, gb, style, stats)
         if relay:
@@ -722,14 +763,18 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     sp = style.data_ptr() + 4 * (ctx.off or 0)
     ws = ZeroPool.take(n * c * 6, torch.float64, x.device)      # fp64 sums + float4 coefficients
     mode = (NORM_SPADE_STYLE_BATCH if ctx.batch else NORM_SPADE_STYLE) | (NORM_ACCUMULATE_DX if acc else 0)
+    # algorithmic bytes: the two-pass structure is forced by the per-(n,c) sums, so g, x, gamma are read by
+    # both passes; dgamma, dbeta and dx are written once: 9 accesses per element of x
+    nb = float(9 * x.numel() * x.element_size())
     if fout is None:
-        L.check(L.lib().s2e_modulate_bwd(_dt(x), mode, _p(g), _p(x), _p(gb), _p(stats), sp, _p(dx),
-                                         _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()),
-                's2e_modulate_bwd')
+        LaunchProfiler.run('modulate_bwd', 0.0, lambda: L.check(
+            L.lib().s2e_modulate_bwd(_dt(x), mode, _p(g), _p(x), _p(gb), _p(stats), sp, _p(dx),
+                                     _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()), 's2e_modulate_bwd'), nbytes=nb)
     else:
-        L.check(L.lib().s2e_modulate_bwd_gamma(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx),
-                                               _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()),
-                's2e_modulate_bwd_gamma')
+        LaunchProfiler.run('modulate_bwd', 0.0, lambda: L.check(
+            L.lib().s2e_modulate_bwd_gamma(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx),
+                                           _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()),
+            's2e_modulate_bwd_gamma'), nbytes=nb)
     if g_relay is not None and not acc:
         dx = dx + g_relay
     return dx, dgb, dstyle
@@ -826,8 +871,10 @@ class InstanceNormFn(torch.autograd.Function):
         n, h, w, c = x.shape
         stats = in_stats(x)
         out = torch.empty_like(x)
-        L.check(L.lib().s2e_modulate_fwd(_dt(x), NORM_PLAIN_IN, _p(x), None, _p(stats), None, _p(out),
-                                         n, h * w, c, int(lrelu), 0, _stream()), 's2e_modulate_fwd')
+        LaunchProfiler.run('modulate_fwd', 0.0, lambda: L.check(
+            L.lib().s2e_modulate_fwd(_dt(x), NORM_PLAIN_IN, _p(x), None, _p(stats), None, _p(out),
+                                     n, h * w, c, int(lrelu), 0, _stream()), 's2e_modulate_fwd'),
+            nbytes=float(2 * x.numel() * x.element_size()))
         ctx.lrelu = lrelu
         ctx.save_for_backward(x, stats)
         return out
@@ -839,8 +886,10 @@ class InstanceNormFn(torch.autograd.Function):
         g = g.contiguous()
         dx = torch.empty_like(x)
         ws = ZeroPool.take(n * c * 6, torch.float64, x.device)      # fp64 sums + float4 coefficients
-        L.check(L.lib().s2e_modulate_bwd(_dt(x), NORM_PLAIN_IN, _p(g), _p(x), None, _p(stats), None, _p(dx), None, None,
-                                         _p(ws), n, h * w, c, int(ctx.lrelu), 0, _stream()), 's2e_modulate_bwd')
+        LaunchProfiler.run('modulate_bwd', 0.0, lambda: L.check(
+            L.lib().s2e_modulate_bwd(_dt(x), NORM_PLAIN_IN, _p(g), _p(x), None, _p(stats), None, _p(dx), None, None,
+                                     _p(ws), n, h * w, c, int(ctx.lrelu), 0, _stream()), 's2e_modulate_bwd'),
+            nbytes=float(5 * x.numel() * x.element_size()))           # algorithmic: g, x read twice (sums, then dx), dx written
         return dx, None
 
 
@@ -856,7 +905,9 @@ class Upsample2xFn(torch.autograd.Function):
         _need(x)
         n, h, w, c = x.shape
         y = torch.empty(n, 2 * h, 2 * w, c, dtype=x.dtype, device=x.device)
-        L.check(L.lib().s2e_upsample2x_fwd(_dt(x), _p(x), _p(y), n, h, w, c, _stream()), 's2e_upsample2x_fwd')
+        LaunchProfiler.run('resample', 0.0, lambda: L.check(
+            L.lib().s2e_upsample2x_fwd(_dt(x), _p(x), _p(y), n, h, w, c, _stream()), 's2e_upsample2x_fwd'),
+            nbytes=float(5 * x.numel() * x.element_size()))
         return y
 
     @staticmethod
@@ -996,7 +1047,9 @@ def adam_flat_step(p, g, m, v, hyper):
     """One torch.optim.Adam step over flat fp32 arenas (pix2pix_model.py:92-110 semantics).
     hyper: 6-float DEVICE tensor {lr, beta1, beta2, eps, completed steps, grad_scale}."""
     _need(p, g, m, v, hyper)
-    L.check(L.lib().s2e_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _stream()), 's2e_adam_flat')
+    LaunchProfiler.run('adam', 0.0, lambda: L.check(
+        L.lib().s2e_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _stream()), 's2e_adam_flat'),
+        nbytes=float(7 * 4 * p.numel()))                              # SURVEY 8(d): read p, g, m, v + write p, m, v
 
 
 # ------------------------------------------------------------------------------ OpenEDS validation metric (SURVEY 8 f3)

@@ -108,9 +108,13 @@ class PackPlan:
                 continue
             if any(j['sigma_index'] >= 0 for j in jobs) and sigma_base is None:
                 raise L.Seg2EyeHipError('PackPlan: spectral-normed weights but no sigma array')
-            L.check(L.lib().s2e_pack_conv_weights(dt, jobs_dev.data_ptr(), map_dev.data_ptr(), nb, max_taps,
-                                                  None if sigma_base is None else sigma_base.data_ptr(), st),
-                    's2e_pack_conv_weights')
+            from .ops import LaunchProfiler
+            esz = 2 if dt == L.S2E_BF16 else 4
+            nbytes = float(sum(j['w'].numel() * (4 + esz) for i, j in enumerate(jobs) if want_tr or i < n_fwd))
+            LaunchProfiler.run('weight_pack', 0.0, lambda: L.check(
+                L.lib().s2e_pack_conv_weights(dt, jobs_dev.data_ptr(), map_dev.data_ptr(), nb, max_taps,
+                                              None if sigma_base is None else sigma_base.data_ptr(), st),
+                's2e_pack_conv_weights'), nbytes=nbytes)                # fp32 master read, packed copy written
             for i, j in enumerate(jobs):
                 j['stale'] = not (want_tr or i < n_fwd)
 

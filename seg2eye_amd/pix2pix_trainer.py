@@ -14,6 +14,7 @@ class Pix2PixTrainer:
         self.generated = None
         self.g_losses, self.d_losses = {}, {}
         self._static, self.graph_G, self.graph_D = None, None, None
+        self.pool = ZeroPool(self.pix2pix_model.device())    # this trainer's zero-filled scratch + deferred gradient re-layouts
         if opt.isTrain:
             self.optimizer_G, self.optimizer_D = self.pix2pix_model_on_one_gpu.create_optimizers(opt)
             self.old_lr = opt.lr
@@ -25,7 +26,7 @@ class Pix2PixTrainer:
     # ---- step bodies: zero_grad + forward + backward (what a hipGraph captures) -------------------
     def _g_body(self, data):
         self.optimizer_G.zero_grad()
-        with ZeroPool.scope('G', self.pix2pix_model.device()):   # all zero-filled scratch of the step: one fill
+        with self.pool.scope('G'):                               # all zero-filled scratch of the step: one fill
             g_losses, generated = self.pix2pix_model(data, mode='generator')
             sum(g_losses.values()).mean().backward()
         # keep detached copies only: a live autograd graph would pin last iteration's AccumulateGrad nodes
@@ -35,7 +36,7 @@ class Pix2PixTrainer:
 
     def _d_body(self, data):
         self.optimizer_D.zero_grad()
-        with ZeroPool.scope('D', self.pix2pix_model.device()):
+        with self.pool.scope('D'):
             d_losses = self.pix2pix_model(data, mode='discriminator')
             sum(d_losses.values()).mean().backward()
         self.d_losses = {k: v.detach() for k, v in d_losses.items()}
@@ -83,7 +84,7 @@ class Pix2PixTrainer:
                 torch.cuda.synchronize()
                 self.opt.hip_graphs = False
                 self._static, self.graph_G, self.graph_D = None, None, None
-                ZeroPool.frozen = False
+                self.pool.unfreeze()
                 return
         for k, buf in self._static.items():
             src = data[k]
@@ -111,7 +112,7 @@ class Pix2PixTrainer:
                 self._d_body(self._static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ZeroPool.freeze()                                    # the graphs hold raw pointers into the pool
+        self.pool.freeze()                                   # the graphs hold raw pointers into the pool
         # With a process group up, RCCL's watchdog thread polls events while we capture: only calls made by the
         # capturing threads may invalidate the capture (the collectives themselves stay outside the graphs).
         multi = torch.distributed.is_available() and torch.distributed.is_initialized()

@@ -100,7 +100,7 @@ class SpectralBank:
         # forward.  Anywhere else every forward gets its own sigma / snapshot, so an older forward can still be
         # differentiated after a newer one.
         from .ops import ZeroPool
-        persistent = ZeroPool.key is not None
+        persistent = ZeroPool.active() is not None
         if persistent:
             # a network may run more than once per step (netE encodes the real styles and, with the style-consistency
             # losses on, the generated image): the i-th forward of a step gets the i-th persistent buffer pair
@@ -117,10 +117,13 @@ class SpectralBank:
             self.sigma = self._sigma_bufs[i]
         else:
             self.sigma = torch.empty(self.n, dtype=torch.float32, device=w.device)
-        L.check(L.lib().s2e_sn_power_iteration(
+        from .ops import LaunchProfiler
+        wbytes = 4.0 * sum(r * c for r, c in zip(self.rows, self.cols))
+        LaunchProfiler.run('spectral_norm', 0.0, lambda: L.check(L.lib().s2e_sn_power_iteration(
             self.table_dev.data_ptr(), self.n, self.block_map.data_ptr(), self.block_map.shape[0],
             self.scratch.data_ptr(), self.scratch.numel() * 4, self.sigma.data_ptr(), int(bool(training)),
-            int(iterations), SN_EPS, torch.cuda.current_stream().cuda_stream), 's2e_sn_power_iteration')
+            int(iterations), SN_EPS, torch.cuda.current_stream().cuda_stream), 's2e_sn_power_iteration'),
+            nbytes=wbytes * (2 * int(iterations) if training else 1))     # algorithmic: W^T u and W v each read W once per iteration
         # the backward of this forward needs u, v as they are NOW (later forwards update them in place)
         if not torch.is_grad_enabled():
             self.uv_snap = self.uv_arena

@@ -942,3 +942,51 @@ def test_generator_more_upsampling_matches_reference():
     for k, p in G.named_parameters():
         ref, got = z['grad_' + k], checksum(p.grad)
         assert abs(got[0] - ref[0]) + abs(got[1] - ref[1]) <= KINK_TOL * ref[1] + 1e-9, (k, got[:2], ref[:2])
+
+
+def test_two_graph_trainers_and_inference_share_nothing():
+    """Two Pix2PixTrainers with hipGraphs on plus inference forwards (what Tester.forward calls, util/tester.py:44-47) in ONE
+    process: every trainer owns its ZeroPool / gradient sink, so interleaving their steps -- and running no-grad inference
+    between a trainer's G and D step -- gives each trainer exactly the parameters it reaches when it runs alone."""
+    from seg2eye_amd import synthetic as syn
+    from seg2eye_amd.ops import ZeroPool
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+
+    def make(seed):
+        opt = _opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='fp32', hip_graphs=True)
+        tr = Pix2PixTrainer(opt)
+        m = tr.pix2pix_model
+        for net, s in ((m.netG, seed), (m.netD, seed + 1), (m.netE, seed + 2)):
+            sd = syn.fill_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], s)
+            with torch.no_grad():
+                for k, v in net.state_dict().items():
+                    v.copy_(torch.from_numpy(sd[k]))
+        return tr
+    d1, d2 = _batch(2, 256, 256, 61), _batch(2, 256, 256, 62)
+
+    def alone(seed, data):
+        tr = make(seed)
+        for _ in range(3):
+            tr.run_generator_one_step(dict(data))
+            tr.run_discriminator_one_step(dict(data))
+        torch.cuda.synchronize()
+        return tr.optimizer_G.flat_p.clone(), tr.optimizer_D.flat_p.clone()
+    ref1, ref2 = alone(101, d1), alone(202, d2)
+    a, b = make(101), make(202)
+    assert a.pool is not b.pool and a.pool.sink is not b.pool.sink
+    for _ in range(3):
+        a.run_generator_one_step(dict(d1))
+        b.run_generator_one_step(dict(d2))
+        with torch.no_grad():                                      # inference between the steps: no pool scope is open
+            assert ZeroPool.active() is None
+            b.pix2pix_model.eval()                                 # (train mode would advance b's spectral-norm u, v: a different trajectory)
+            img = b.pix2pix_model(dict(d1), mode='inference')
+            assert tuple(img.shape) == (2, 1, 256, 256) and bool(torch.isfinite(img.float()).all())
+        b.run_discriminator_one_step(dict(d2))
+        a.run_discriminator_one_step(dict(d1))
+    torch.cuda.synchronize()
+    assert a.use_graphs and b.use_graphs and a.graph_G is not None and b.graph_G is not None
+    # fp32 weight-gradient atomics are not bit-reproducible: bound by a few Adam sign flips (see the trainer tests)
+    bound = 2 * 4e-4 * sum(((1 - 0.9 ** t) / (1 - 0.9)) ** 0.5 for t in (1, 2, 3)) + 1e-5
+    for got, ref in ((a.optimizer_G.flat_p, ref1[0]), (a.optimizer_D.flat_p, ref1[1]), (b.optimizer_G.flat_p, ref2[0]), (b.optimizer_D.flat_p, ref2[1])):
+        assert float((got - ref).abs().max()) <= bound, float((got - ref).abs().max())

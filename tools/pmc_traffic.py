@@ -1,20 +1,21 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch of the conv kernel families from two rocprofv3 PMC passes.
+"""HBM bytes per launch of every kernel family of the G+D step from two rocprofv3 PMC passes.
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
-    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r01/pmc
+    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r02/pmc [steps-profiled]
 
 Counters are in KB; FETCH_SIZE is doubled (gfx950 counts a 128-B request as 64 B: MI355X_MICROARCH.md, HBM section).
-Families follow seg2eye_amd.ops.LaunchProfiler (= s2e_conv2d_kernel_kind / s2e_conv2d_wgrad_kernel_kind): `conv_patch`,
-`conv_igemm` (generic), `conv_small`, and the same three for the weight gradient; the per-family figure is total bytes /
-number of C-ABI calls (= launches of the family's MAIN kernel; helper kernels -- split-K finish, partial-tile reduction --
-add bytes, not launches)."""
+Families are seg2eye_amd.ops.LaunchProfiler's -- one per C-ABI entry point (the conv entry points split by
+s2e_conv2d_kernel_kind / s2e_conv2d_wgrad_kernel_kind) -- so the per-launch figure divides the bytes of EVERY kernel a call
+launches (split-K finish, partial-tile reductions, the three kernels of s2e_modulate_bwd ...) by the number of calls (= the
+dispatches of the family's MAIN kernel).  The output is stamped with the commit it was measured at."""
 import csv
 import glob
 import json
 import os
+import subprocess
 import sys
 from collections import defaultdict
 
@@ -29,6 +30,21 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'conv_wgrad_kernel': ('conv_wgrad', True), 'conv_wgrad_glds_kernel': ('conv_wgrad', True),
     'wgrad_cout1_kernel': ('conv_wgrad_small', True), 'wgrad_cin1_kernel': ('conv_wgrad_small', True),
     'small_wgrad_reduce_kernel': ('conv_wgrad_small', False),
+    # HBM-bound families
+    'in_stats_partial_kernel': ('in_stats', True), 'in_stats_finalize_kernel': ('in_stats', False),
+    'modulate_fwd_kernel': ('modulate_fwd', True),
+    'modulate_bwd_reduce_kernel': ('modulate_bwd', True), 'modulate_bwd_coef_kernel': ('modulate_bwd', False),
+    'modulate_bwd_apply_kernel': ('modulate_bwd', False),
+    'label_conv3x3_kernel': ('label_conv', True),
+    'adam_flat_kernel': ('adam', True),
+    'pack_batch_kernel': ('weight_pack', True),
+    'grad_unpack_batch_kernel': ('weight_grad_relayout', True), 'grad_dot_batch_kernel': ('weight_grad_relayout', False),
+    'sn_gemvT_kernel': ('spectral_norm', True), 'sn_gemv_kernel': ('spectral_norm', False),     # launches = power ITERATIONS
+    'sn_norm_v_kernel': ('spectral_norm', False), 'sn_finalize_kernel': ('spectral_norm', False),
+    'upsample2x_fwd_kernel': ('resample', True), 'upsample2x_bwd_kernel': ('resample', True),
+    'avgpool_fwd_kernel': ('resample', True), 'avgpool_bwd_kernel': ('resample', True),
+    'loss_reduce_kernel': ('loss', True), 'loss_grad_kernel': ('loss', True),
+    'onehot_nhwc_kernel': ('onehot', True),
 }
 
 
@@ -56,8 +72,19 @@ def read(dirname, counter):
     return per_kernel
 
 
+def git_head():
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        head = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(['git', '-C', root, 'status', '--porcelain', '--', 'seg2eye_amd', 'bench.py'], capture_output=True, text=True).stdout.strip()
+        return (head or os.environ.get('S2E_GIT_HEAD', 'unknown')) + ('+dirty' if dirty else '')
+    except OSError:
+        return os.environ.get('S2E_GIT_HEAD', 'unknown')
+
+
 def main():
     fdir, wdir, outdir = sys.argv[1:4]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3          # bench.py --steps 2 --warmup 1 runs 3 (+2 per-step-timed) steps
     fetch, write = read(fdir, 'FETCH_SIZE'), read(wdir, 'WRITE_SIZE')
     fams = defaultdict(lambda: {'launches': 0, 'fetch': 0.0, 'write': 0.0})
     rows = []
@@ -71,12 +98,15 @@ def main():
         fams[fam]['write'] += wb
         if counts:
             fams[fam]['launches'] += n
-    out = {'_how': __doc__.split('\n\n')[1].strip() + ' | counters KB -> bytes, FETCH_SIZE doubled (gfx950); per-family: '
+    # the head is passed in by the caller when the tool runs on the GPU box (no .git there)
+    out = {'git_head': os.environ.get('S2E_GIT_HEAD') or git_head(), 'steps_profiled': steps,
+           '_how': __doc__.split('\n\n')[1].strip() + ' | counters KB -> bytes, FETCH_SIZE doubled (gfx950); per-family: '
            'total bytes of every kernel launched inside the C-ABI call / number of calls', 'kernels': {}}
     for fam, v in fams.items():
         n = max(v['launches'], 1)
         out['kernels'][fam] = {'launches': v['launches'], 'fetch_bytes_per_launch': v['fetch'] / n,
-                               'write_bytes_per_launch': v['write'] / n, 'hbm_bytes_per_launch': (v['fetch'] + v['write']) / n}
+                               'write_bytes_per_launch': v['write'] / n, 'hbm_bytes_per_launch': (v['fetch'] + v['write']) / n,
+                               'hbm_bytes_per_step': (v['fetch'] + v['write']) / steps}
     os.makedirs(outdir, exist_ok=True)
     json.dump(out, open(os.path.join(outdir, 'hbm_traffic.json'), 'w'), indent=1)
     with open(os.path.join(outdir, 'hbm_traffic_per_kernel.csv'), 'w') as f:

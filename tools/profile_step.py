@@ -14,12 +14,12 @@ data = bench.make_data(8, 256, 1234, torch.device('cuda:0'))
 def step():
     tr.run_generator_one_step(dict(data)); tr.run_discriminator_one_step(dict(data))
 for _ in range(2): step()
-torch.cuda.synchronize(); ops.LaunchProfiler.reset(); ops.LaunchProfiler.enabled = True
+torch.cuda.synchronize(); prof = ops.LaunchProfiler(); ops.LaunchProfiler.install(prof)
 N = 3
 for _ in range(N): step()
-torch.cuda.synchronize(); ops.LaunchProfiler.enabled = False
+torch.cuda.synchronize(); ops.LaunchProfiler.install(None)
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-for fam, fl, s, e, tag, _nb in ops.LaunchProfiler.records:
+for fam, fl, s, e, tag, _nb in prof.records:
     a = agg[(fam, tag)]; a[0] += 1; a[1] += s.elapsed_time(e); a[2] += fl
 for fam in ('conv_patch', 'conv_igemm', 'conv_small', 'conv_wgrad_patch', 'conv_wgrad', 'conv_wgrad_small'):
     items = sorted(((k, v) for k, v in agg.items() if k[0] == fam), key=lambda kv: -kv[1][1])
@@ -27,3 +27,7 @@ for fam in ('conv_patch', 'conv_igemm', 'conv_small', 'conv_wgrad_patch', 'conv_
     print('== %s total %.2f ms/step' % (fam, tot))
     for (f, tag), v in items[:40]:
         print('  %-34s x%4.1f  %6.3f ms/step  %7.1f TF' % (tag, v[0] / N, v[1] / N, v[2] / (v[1] * 1e-3) / 1e12))
+print('== HBM-bound families (algorithmic bytes / HIP-event time)')
+for fam, v in sorted(prof.summary().items(), key=lambda kv: -kv[1]['ms']):
+    if v['flops'] == 0:
+        print('  %-22s x%5.1f  %6.3f ms/step  %7.0f GB/s' % (fam, v['launches'] / N, v['ms'] / N, v['bytes'] / (v['ms'] * 1e-3) / 1e9))
