@@ -130,11 +130,13 @@ int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float*
  *   train != 0 (per iteration): v = normalize(W^T u); u = normalize(W v); sigma = u . (W v)   (u, v updated in place)
  *   train == 0:                 sigma = u . (W v)                                              (u, v untouched)
  * layers: DEVICE array of n_layers descriptors.  block_map: DEVICE int32 [n_blocks][3] = {layer, row0, col0}
- * covering every layer with 16-row x 256-column blocks.  t (cols floats) and s (rows floats) of all layers
- * live in `scratch`, which must be ZERO on the first call (the kernels leave it zero again: no fill per iteration).
+ * covering every layer with 16-row x 256-column blocks.  t (cols) and s (rows) of all layers are 64-bit fixed-point
+ * accumulators (the blocks' partial sums are combined with INTEGER atomics, so u, v, sigma are bit-reproducible: identical
+ * run to run and on every data-parallel replica); they live in `scratch`, which must be ZERO on the first call (the
+ * kernels leave it zero again: no fill per iteration).
  * sigma: fp32 [n_layers] out. */
 typedef struct {
-    const float* w; float* u; float* v; float* t; float* s;
+    const float* w; float* u; float* v; long long* t; long long* s;
     int rows, cols;
 } s2e_sn_layer;
 int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map, int n_blocks,
@@ -216,6 +218,16 @@ int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const vo
 int s2e_modulate_bwd_gamma(int dtype, int mode, const void* g, const void* x, const void* gamma, const void* out,
                            const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                            int N, int HW, int C, int lrelu, int style_ld, void* stream);
+/* s2e_modulate_bwd / s2e_modulate_bwd_gamma (out == NULL: gb = [gamma | beta]; else gb = gamma, out = the forward's output) in
+ * two stages, for BatchNorm SPADE under data parallelism (the per-channel sums of the normalisation's backward must be summed
+ * over ALL replicas' samples, as torch SyncBatchNorm does -- the 2C-float exchange of SURVEY 8 f4):
+ *   stage 1: the row-walking pass only: dgb written, the per-(n,c) fp64 sums left in ws as (N,C,4) {S0, S1, S2, S3};
+ *   (caller: all-reduce sum over samples of S0, S1 across the replicas and fold the difference into ws[0,:,0:2])
+ *   stage 2: coefficients + dx, with the normalisation count batch_count (= world * N * HW; 0 = N * HW) in BATCH mode.
+ * stage 0 = both (the plain calls). */
+int s2e_modulate_bwd_staged(int dtype, int mode, const void* g, const void* x, const void* gb, const void* out,
+                            const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
+                            int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, void* stream);
 /* out[c] += sum_m g[m][c]  (conv bias gradient).  g (M, C); out fp32 (C). */
 int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream);
 

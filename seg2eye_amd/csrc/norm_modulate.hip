@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
 // batch != 0 (BatchNorm SPADE: statistics over the whole batch): S0, S1 are summed over the samples and HW -> N*HW.
 template <int MODE>
 __global__ void modulate_bwd_coef_kernel(const double* __restrict__ ws, f32x4_t* __restrict__ coef, const float* __restrict__ stats,
-                                         const float* __restrict__ style, float* __restrict__ dstyle, int N, int C, int HW, int sld, int batch) {
+                                         const float* __restrict__ style, float* __restrict__ dstyle, int N, int C, int HW, int sld, int batch,
+                                         double batch_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
@@ -421,7 +422,7 @@ __global__ void modulate_bwd_coef_kernel(const double* __restrict__ ws, f32x4_t*
     if (batch) {
         s0d = 0.0; s1d = 0.0;
         for (int m = 0; m < N; ++m) { s0d += ws[((size_t)m * C + c) * 4]; s1d += ws[((size_t)m * C + c) * 4 + 1]; }
-        inv_hw = 1.f / ((float)HW * (float)N);
+        inv_hw = (float)(1.0 / (batch_count > 0.0 ? batch_count : (double)HW * (double)N));
     }
     const float mean = stats[2 * i], rs = stats[2 * i + 1];
     const float m0 = (float)s0d * inv_hw, m1 = (float)s1d * inv_hw;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
 
 static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, const void* gb, const void* fout, const float* stats,
                              const float* style, void* dx, void* dgb, float* dstyle, double* ws,
-                             int N, int HW, int C, int lrelu, int style_ld, void* stream) {
+                             int N, int HW, int C, int lrelu, int style_ld, void* stream, int stage = 0, double batch_count = 0.0) {
     const int sld = style_ld > 0 ? style_ld : 2 * C;
     const int gst = fout ? C : 2 * C;
     const int acc = (mode & S2E_NORM_ACCUMULATE_DX) != 0;
@@ -525,9 +526,9 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
     const int gridc = ceil_div((long)N * C, 256);
     f32x4_t* coef = (f32x4_t*)(ws + (size_t)N * C * 4);
 #define S2E_LAUNCH_BWD(TT, MM) do { \
-    modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters, (const TT*)fout); \
-    modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, coef, stats, style, dstyle, N, C, HW, sld, batch); \
-    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst); } while (0)
+    if (stage != 2) modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters, (const TT*)fout); \
+    if (stage != 1) { modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, coef, stats, style, dstyle, N, C, HW, sld, batch, batch_count); \
+    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst); } } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_BWD
@@ -548,4 +549,11 @@ extern "C" int s2e_modulate_bwd_gamma(int dtype, int mode, const void* g, const 
     if (m != S2E_NORM_SPADE_STYLE && m != S2E_NORM_SPADE_STYLE_BATCH) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_gamma: SPADE_STYLE modes only");
     if (!gamma || !out) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_gamma: gamma and out are required");
     return modulate_bwd_impl(dtype, mode, g, x, gamma, out, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream);
+}
+
+extern "C" int s2e_modulate_bwd_staged(int dtype, int mode, const void* g, const void* x, const void* gb, const void* out,
+                                       const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
+                                       int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, void* stream) {
+    if (stage < 0 || stage > 2) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_staged: stage %d", stage);
+    return modulate_bwd_impl(dtype, mode, g, x, gb, out, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream, stage, batch_count);
 }

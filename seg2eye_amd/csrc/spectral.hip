@@ -10,6 +10,19 @@
 // W / sigma never exists in memory: the packers divide on the fly while converting to the MFMA layout.
 #include "common.h"
 
+// The partial dot products of the blocks are combined with 64-bit INTEGER atomics on fixed-point values (2^-40 units):
+// integer addition is associative, so t, s -- and with them u, v, sigma -- come out bit-identical whatever order the
+// blocks finish in: run to run, and on every data-parallel replica (the fp32 atomics used before made sigma differ by
+// ~1e-7 between runs, which bf16 weight rounding and the InstanceNorm chain amplified to ~0.05 on the generated image).
+// |partial| < 2^22 fits with room to spare (spectral norms here are O(1..100)); the quantisation (9e-13) is far below
+// fp32 resolution of the values being summed.
+static constexpr float SN_FIX = 1099511627776.0f;          // 2^40
+static constexpr float SN_UNFIX = 1.0f / 1099511627776.0f;
+__device__ __forceinline__ void sn_fix_add(long long* dst, float v) {
+    atomicAdd((unsigned long long*)dst, (unsigned long long)__double2ll_rn((double)v * (double)SN_FIX));
+}
+__device__ __forceinline__ float sn_unfix(long long q) { return (float)((double)q * (double)SN_UNFIX); }
+
 static constexpr int SN_BR = 16;       // rows per block: all of a block's row loads are in flight together
 static constexpr int SN_BC = 256;      // columns per block (one per thread)
 
@@ -24,7 +37,7 @@ __global__ __launch_bounds__(256) void sn_gemvT_kernel(const s2e_sn_layer* __res
     const float* wp = L.w + (size_t)row0 * L.cols + col;
 #pragma unroll 16
     for (int r = row0; r < rend; ++r, wp += L.cols) acc += *wp * L.u[r];
-    atomicAdd(L.t + col, acc);
+    sn_fix_add(L.t + col, acc);
 }
 
 // ---- one block per layer: v = t / max(|t|, eps)   (train only).  1024 threads and every load of a thread in flight
@@ -46,19 +59,19 @@ __global__ __launch_bounds__(SN_NT) void sn_norm_v_kernel(const s2e_sn_layer* __
     if (L.cols <= SN_NT * SN_MAXL) {
         float t[SN_MAXL];
 #pragma unroll
-        for (int k = 0; k < SN_MAXL; ++k) { const int j = threadIdx.x + k * SN_NT; t[k] = j < L.cols ? L.t[j] : 0.f; }
+        for (int k = 0; k < SN_MAXL; ++k) { const int j = threadIdx.x + k * SN_NT; t[k] = j < L.cols ? sn_unfix(L.t[j]) : 0.f; }
 #pragma unroll
         for (int k = 0; k < SN_MAXL; ++k) q += t[k] * t[k];
         const float inv = 1.f / fmaxf(sqrtf(sn_block_sum(q, red)), eps);
 #pragma unroll
         for (int k = 0; k < SN_MAXL; ++k) { const int j = threadIdx.x + k * SN_NT; if (j < L.cols) L.v[j] = t[k] * inv; }
     } else {
-        for (int j = threadIdx.x; j < L.cols; j += SN_NT) { const float t = L.t[j]; q += t * t; }
+        for (int j = threadIdx.x; j < L.cols; j += SN_NT) { const float t = sn_unfix(L.t[j]); q += t * t; }
         const float inv = 1.f / fmaxf(sqrtf(sn_block_sum(q, red)), eps);
-        for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.v[j] = L.t[j] * inv;
+        for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.v[j] = sn_unfix(L.t[j]) * inv;
     }
     // s is accumulated (atomics) by the next launch: clear it here instead of a separate zero-fill launch per iteration
-    for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.s[i] = 0.f;
+    for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.s[i] = 0;
 }
 
 // ---- s += W v over a [SN_BR x SN_BC] block
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(256) void sn_gemv_kernel(const s2e_sn_layer* __rest
         if (lane == 0) red[k][wave] = q;
     }
     __syncthreads();
-    if (threadIdx.x < nr) atomicAdd(L.s + row0 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < nr) sn_fix_add(L.s + row0 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
 // ---- one block per layer: train: u = s / max(|s|, eps); both: sigma = u . s
@@ -90,23 +103,23 @@ __global__ __launch_bounds__(SN_NT) void sn_finalize_kernel(const s2e_sn_layer* 
     const s2e_sn_layer L = layers[blockIdx.x];
     float q = 0.f;
     if (train) {
-        for (int i = threadIdx.x; i < L.rows; i += SN_NT) { const float s = L.s[i]; q += s * s; }
+        for (int i = threadIdx.x; i < L.rows; i += SN_NT) { const float s = sn_unfix(L.s[i]); q += s * s; }
     } else {
-        for (int i = threadIdx.x; i < L.rows; i += SN_NT) q += L.u[i] * L.s[i];
+        for (int i = threadIdx.x; i < L.rows; i += SN_NT) q += L.u[i] * sn_unfix(L.s[i]);
     }
     const float tot = sn_block_sum(q, red);
     if (train) {
         const float inv = 1.f / fmaxf(sqrtf(tot), eps);
-        for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.u[i] = L.s[i] * inv;
+        for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.u[i] = sn_unfix(L.s[i]) * inv;
         if (threadIdx.x == 0) sigma[blockIdx.x] = tot * inv;            // u . s = |s|^2 / max(|s|, eps)
     } else if (threadIdx.x == 0) {
         sigma[blockIdx.x] = tot;
     }
     // leave both accumulators cleared for the next iteration / forward (each thread clears what it alone read): the
     // scratch is zero at creation and stays zero between calls, so no zero-fill launch is needed per iteration
-    for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.s[i] = 0.f;
+    for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.s[i] = 0;
     if (train)
-        for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.t[j] = 0.f;
+        for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.t[j] = 0;
 }
 
 extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map, int n_blocks,

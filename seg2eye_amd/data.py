@@ -47,5 +47,5 @@ def create_dataloader(opt, rank=0, world=1, store=None, style_refs=None):
     OpenEDS H5 dataset (seg2eye_amd/openeds_dataset.py; `store` = an in-memory H5-like mapping instead of opt.dataroot)."""
     if opt.dataset_mode == 'openeds':
         from .openeds_dataset import create_dataloader as _create
-        return _create(opt, store=store, style_refs=style_refs)
+        return _create(opt, store=store, style_refs=style_refs, rank=rank, world=world)
     return SyntheticEyes(opt, rank, world)

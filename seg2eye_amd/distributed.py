@@ -29,7 +29,10 @@ def init_from_env(backend=None):
             backend = os.environ.get('S2E_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # generous timeout: rank 0 alone runs the periodic validation passes (train.py) while the others wait in the next
+        # collective; a full validation over the OpenEDS set takes longer than the default 10 minutes
+        import datetime
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(hours=3))
     return rank, world, local_rank
 
 
@@ -65,6 +68,41 @@ class FlatGradSync:
 def broadcast_flat(flat, src=0):
     if world_size() > 1:
         dist.broadcast(flat, src=src)
+
+
+def all_reduce_sum_(t, group=None):
+    """In-place sum over the replicas (no-op on one process); returns t."""
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def replica_buffers(nets):
+    """The per-network state that is NOT in the optimizer arenas and must be the same on every replica: each spectral-norm
+    bank's u|v arena (the power iteration is deterministic -- integer atomics -- so equal weights keep them equal, but they
+    are drawn randomly at construction) and BatchNorm SPADE's running_mean / running_var / num_batches_tracked."""
+    from .spectral import ensure_bank
+    out = []
+    for net in nets:
+        if net is None:
+            continue
+        bank = ensure_bank(net)
+        if bank is not None and bank.n:
+            bank.ensure_built()
+            out.append(bank.uv_arena)
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats:
+                out += [m.running_mean, m.running_var, m.num_batches_tracked]
+    return out
+
+
+def broadcast_buffers(nets, src=0):
+    """Make the replicas' non-parameter state rank `src`'s (at start-up, and after rank 0 alone ran a train-mode validation
+    pass, which advances its u, v and BatchNorm statistics like the reference's does, util/tester.py + SURVEY F7)."""
+    if world_size() == 1:
+        return
+    for t in replica_buffers(nets):
+        dist.broadcast(t, src=src)
 
 
 def shard_seed(base_seed):

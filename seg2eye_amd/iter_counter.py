@@ -70,10 +70,12 @@ class IterationCounter:
         self.epoch_iter += batch
         self.total_steps_so_far += batch
 
-    def record_epoch_end(self):
+    def record_epoch_end(self, write=True):
+        """write=False: a data-parallel rank other than 0 (one writer for iter.txt)."""
         self.time_per_epoch = time.time() - self.epoch_start_time
-        print('End of epoch %d / %d \t Time Taken: %d sec' % (self.current_epoch, self.total_epochs, self.time_per_epoch))
-        if self.current_epoch % self.opt.save_epoch_freq == 0:
+        if write:
+            print('End of epoch %d / %d \t Time Taken: %d sec' % (self.current_epoch, self.total_epochs, self.time_per_epoch))
+        if write and self.current_epoch % self.opt.save_epoch_freq == 0:
             self._record.store(self.current_epoch + 1, 0)       # a resume starts the next epoch from its beginning
 
     def record_current_iter(self):

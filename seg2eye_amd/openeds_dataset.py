@@ -195,11 +195,20 @@ class OpenEDSDataset(torch.utils.data.Dataset):
         return self.rng.choice(list(range(self.N)), n)
 
 
-def create_dataloader(opt, store=None, style_refs=None):
-    """data/__init__.py:43-59: batch_size, shuffle = not serial_batches, nThreads workers, drop_last = isTrain."""
+def create_dataloader(opt, store=None, style_refs=None, rank=0, world=1):
+    """data/__init__.py:43-59: batch_size, shuffle = not serial_batches, nThreads workers, drop_last = isTrain.
+    world > 1 (data parallel, new relative to the reference): every rank walks its own 1/world of each epoch's permutation
+    (torch DistributedSampler; call `loader.sampler.set_epoch(epoch)` per epoch -- train.py does), so an epoch is still ONE
+    pass over the dataset and the per-epoch LR decay / save_epoch_freq / iter.txt mean what they do on one GPU."""
     ds = OpenEDSDataset(opt, store=store, style_refs=style_refs)
     print('dataset [%s] of size %d was created' % (type(ds).__name__, len(ds)))
-    dl = torch.utils.data.DataLoader(ds, batch_size=opt.batchSize, shuffle=not opt.serial_batches,
-                                     num_workers=int(opt.nThreads) if store is None else 0, drop_last=opt.isTrain)
+    workers = int(opt.nThreads) if store is None else 0
+    if world > 1 and opt.isTrain:
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=not opt.serial_batches,
+                                                                  drop_last=True)
+        dl = torch.utils.data.DataLoader(ds, batch_size=opt.batchSize, sampler=sampler, num_workers=workers, drop_last=True)
+    else:
+        dl = torch.utils.data.DataLoader(ds, batch_size=opt.batchSize, shuffle=not opt.serial_batches, num_workers=workers,
+                                         drop_last=opt.isTrain)
     dl.N = ds.N
     return dl

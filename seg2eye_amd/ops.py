@@ -766,15 +766,24 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     # algorithmic bytes: the two-pass structure is forced by the per-(n,c) sums, so g, x, gamma are read by
     # both passes; dgamma, dbeta and dx are written once: 9 accesses per element of x
     nb = float(9 * x.numel() * x.element_size())
-    if fout is None:
-        LaunchProfiler.run('modulate_bwd', 0.0, lambda: L.check(
-            L.lib().s2e_modulate_bwd(_dt(x), mode, _p(g), _p(x), _p(gb), _p(stats), sp, _p(dx),
-                                     _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()), 's2e_modulate_bwd'), nbytes=nb)
+    from . import distributed as sdist
+    world = sdist.world_size() if ctx.batch else 1
+
+    def launch(stage, count):
+        return L.check(L.lib().s2e_modulate_bwd_staged(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx), _p(dgb), dsp,
+                                                       _p(ws), n, h * w, c, int(ctx.lrelu), ld, stage, float(count), _stream()),
+                       's2e_modulate_bwd_staged')
+    if world == 1:
+        LaunchProfiler.run('modulate_bwd', 0.0, lambda: launch(0, 0.0), nbytes=nb)
     else:
-        LaunchProfiler.run('modulate_bwd', 0.0, lambda: L.check(
-            L.lib().s2e_modulate_bwd_gamma(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx),
-                                           _p(dgb), dsp, _p(ws), n, h * w, c, int(ctx.lrelu), ld, _stream()),
-            's2e_modulate_bwd_gamma'), nbytes=nb)
+        # BatchNorm SPADE under data parallelism: the normalisation's backward sums (S0, S1 per channel) run over the samples of
+        # ALL replicas -- one 2*C-double all-reduce between the two passes (the backward half of SURVEY 8 f4's exchange)
+        launch(1, 0.0)
+        sums = ws[:n * c * 4].view(n, c, 4)
+        local = sums[:, :, :2].sum(0)
+        glob = sdist.all_reduce_sum_(local.clone())
+        sums[0, :, :2] += glob - local                       # the coefficient kernel sums over this replica's samples
+        launch(2, float(world) * n * h * w)
     if g_relay is not None and not acc:
         dx = dx + g_relay
     return dx, dgb, dstyle

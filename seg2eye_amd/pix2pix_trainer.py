@@ -1,7 +1,7 @@
 """Pix2PixTrainer (reference trainers/pix2pix_trainer.py:8-88): owns the model and the two optimizers,
 runs one G step / one D step, LR decay, save.  Multi-GPU: when torch.distributed is initialised the
 flat gradient arenas are sum-all-reduced (RCCL) between backward and the Adam launch."""
-from .distributed import FlatGradSync, broadcast_flat
+from .distributed import FlatGradSync, broadcast_buffers, broadcast_flat
 from .ops import ZeroPool
 from .pix2pix_model import Pix2PixModel
 
@@ -20,8 +20,16 @@ class Pix2PixTrainer:
             self.old_lr = opt.lr
             self.sync_G = FlatGradSync(self.optimizer_G.flat_g)
             self.sync_D = FlatGradSync(self.optimizer_D.flat_g)
-            broadcast_flat(self.optimizer_G.flat_p)          # identical replicas at step 0
+            broadcast_flat(self.optimizer_G.flat_p)          # identical replicas at step 0: parameters ...
             broadcast_flat(self.optimizer_D.flat_p)
+            self.sync_replica_buffers()                      # ... and spectral-norm u, v / BatchNorm running statistics
+
+    def sync_replica_buffers(self):
+        """Every replica takes rank 0's spectral-norm u, v and BatchNorm running buffers (no-op on one process).  Called at
+        construction and by train.py after rank 0 alone ran a validation pass: that pass runs in train mode (the reference never
+        calls eval()) and so advances rank 0's u, v and running statistics."""
+        m = self.pix2pix_model
+        broadcast_buffers([m.netG, m.netD, m.netE])
 
     # ---- step bodies: zero_grad + forward + backward (what a hipGraph captures) -------------------
     def _g_body(self, data):

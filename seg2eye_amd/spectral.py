@@ -61,7 +61,7 @@ class SpectralBank:
                 c._buffers['weight_v'] = vview
                 self.uv_off.append((ou, ov))
         self.uv_arena = arena
-        self.scratch = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)      # t | s, same offsets
+        self.scratch = torch.zeros(int(offs[-1]), dtype=torch.int64, device=dev)        # t | s (64-bit fixed point), same offsets
         table = (L.SnLayer * self.n)()
         bm = []
         for i, c in enumerate(self.convs):
@@ -69,8 +69,8 @@ class SpectralBank:
             table[i].w = c.weight_orig.data_ptr()
             table[i].u = arena.data_ptr() + 4 * ou
             table[i].v = arena.data_ptr() + 4 * ov
-            table[i].s = self.scratch.data_ptr() + 4 * ou
-            table[i].t = self.scratch.data_ptr() + 4 * ov
+            table[i].s = self.scratch.data_ptr() + 8 * ou
+            table[i].t = self.scratch.data_ptr() + 8 * ov
             table[i].rows, table[i].cols = rows[i], cols[i]
             for r0 in range(0, rows[i], _BR):
                 for c0 in range(0, cols[i], _BC):
@@ -80,6 +80,11 @@ class SpectralBank:
         self.block_map = torch.tensor(bm, dtype=torch.int32, device=dev)
         self.rows, self.cols = rows, cols
         self._ptrs = self._current_ptrs()
+
+    def ensure_built(self):
+        """Build (or rebuild after the parameters moved) the device tables now instead of at the next forward."""
+        if self.n and (self._ptrs is None or self._ptrs != self._current_ptrs()):
+            self._build()
 
     def _current_ptrs(self):
         return tuple((c.weight_orig.data_ptr(), c.weight_u.data_ptr(), c.weight_v.data_ptr()) for c in self.convs)
@@ -121,7 +126,7 @@ class SpectralBank:
         wbytes = 4.0 * sum(r * c for r, c in zip(self.rows, self.cols))
         LaunchProfiler.run('spectral_norm', 0.0, lambda: L.check(L.lib().s2e_sn_power_iteration(
             self.table_dev.data_ptr(), self.n, self.block_map.data_ptr(), self.block_map.shape[0],
-            self.scratch.data_ptr(), self.scratch.numel() * 4, self.sigma.data_ptr(), int(bool(training)),
+            self.scratch.data_ptr(), self.scratch.numel() * 8, self.sigma.data_ptr(), int(bool(training)),
             int(iterations), SN_EPS, torch.cuda.current_stream().cuda_stream), 's2e_sn_power_iteration'),
             nbytes=wbytes * (2 * int(iterations) if training else 1))     # algorithmic: W^T u and W v each read W once per iteration
         # the backward of this forward needs u, v as they are NOW (later forwards update them in place)

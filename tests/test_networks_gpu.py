@@ -990,3 +990,53 @@ def test_two_graph_trainers_and_inference_share_nothing():
     bound = 2 * 4e-4 * sum(((1 - 0.9 ** t) / (1 - 0.9)) ** 0.5 for t in (1, 2, 3)) + 1e-5
     for got, ref in ((a.optimizer_G.flat_p, ref1[0]), (a.optimizer_D.flat_p, ref1[1]), (b.optimizer_G.flat_p, ref2[0]), (b.optimizer_D.flat_p, ref2[1])):
         assert float((got - ref).abs().max()) <= bound, float((got - ref).abs().max())
+
+
+def _run_dp_check(nproc, *extra):
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, S2E_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    script = os.path.join(root, 'tools', 'dp_check.py')
+    if nproc == 1:
+        cmd = [sys.executable, script, *extra]
+        env.pop('WORLD_SIZE', None)
+    else:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), script, *extra]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_data_parallel_replicas_stay_bit_identical():
+    """two ranks (sharing this box's GPU over gloo -- RCCL refuses two ranks on one device; same collective calls),
+    each constructed from DIFFERENT weights and spectral-norm vectors, run 3 full G+D trainer iterations on their shards: after
+    the start-up broadcasts and the summed-gradient exchange the parameter arenas AND the spectral-norm u|v arenas are
+    bit-identical across ranks (the power iteration accumulates with integer atomics), and losses / parameters agree with ONE
+    process running the global batch (2 x 2 = 4 samples; InstanceNorm is per sample, losses are batch means)."""
+    two = _run_dp_check(2, '--mode', 'train', '--iters', '3', '--batch', '2')
+    assert two['world'] == 2 and two['identical_G'] and two['identical_D'] and two['identical_uv'], two
+    one = _run_dp_check(1, '--mode', 'train', '--iters', '3', '--batch', '4')
+    for i in range(3):
+        for k, v in one['losses'][i].items():
+            assert abs(two['losses'][i][k] - v) <= (2e-3 if i == 0 else 1e-2) * max(1.0, abs(v)), (i, k, two['losses'][i][k], v)
+    # parameters: equal up to Adam's sign flips of near-zero gradients (see the trainer tests); compared through the arena sums
+    assert abs(two['G_abs'] - one['G_abs']) <= 1e-4 * one['G_abs'] and abs(two['D_abs'] - one['D_abs']) <= 1e-4 * one['D_abs'], (two, one)
+
+
+def test_batchnorm_spade_statistics_are_synchronised_across_replicas():
+    """--norm_G spectralspadebatch3x3 under data parallelism normalises with the statistics of the GLOBAL batch (one
+    2*C all-reduce per layer forward, one in its backward): two ranks on halves of a batch reproduce one process on the whole
+    batch -- generated images, the summed parameter gradient, and running buffers identical on both ranks."""
+    two = _run_dp_check(2, '--mode', 'bn', '--batch', '2', '--norm_G', 'spectralspadebatch3x3')
+    one = _run_dp_check(1, '--mode', 'bn', '--batch', '4', '--norm_G', 'spectralspadebatch3x3')
+    assert two['identical_running'], two
+    assert abs(sum(two['y_sum']) - one['y_sum'][0]) <= 2e-4 * one['y_abs'][0], (two, one)
+    assert abs(sum(two['y_abs']) - one['y_abs'][0]) <= 2e-4 * one['y_abs'][0], (two, one)
+    assert abs(two['g_sum'] - one['g_sum']) <= 2e-3 * one['g_abs'] and abs(two['g_abs'] - one['g_abs']) <= 2e-3 * one['g_abs'], (two, one)
+    assert abs(two['rm_abs'] - one['rm_abs']) <= 1e-5 * max(one['rm_abs'], 1e-6) and abs(two['rv_sum'] - one['rv_sum']) <= 1e-5 * one['rv_sum'], (two, one)

@@ -32,7 +32,12 @@ class TrainingRun:
         self.opt, self.rank = opt, rank
         self.dataloader = create_dataloader(opt, rank, world)
         self.trainer = Pix2PixTrainer(opt)
+        # samples per epoch AS THIS RANK COUNTS THEM (each rank sees 1/world of an epoch and counts its own samples, so the
+        # cadences --print_freq / --save_latest_freq / ... are per-rank sample counts).  The reference passes len(dataloader) --
+        # BATCHES -- while its counter advances in samples (train.py:33, util/iter_counter.py:13-31): the same number at its
+        # batchSize 1; counting samples throughout keeps `iter.txt` resumes exact at any batch size.
         self.counter = IterationCounter(opt, len(self.dataloader) * opt.batchSize)
+        self.world = world
         # validation runs on rank 0 only (it has no collectives); the reference keeps one tester per split
         self.testers = [Tester(opt, dataset_key=split) for split in ('train', 'validation')] if rank == 0 else []
         c = self.counter
@@ -54,12 +59,14 @@ class TrainingRun:
             for t in self.testers:
                 t.run_partial_modes(model=self.trainer.pix2pix_model, epoch=self.epoch, n_steps=self.counter.total_steps_so_far,
                                     log=True, visualize_images=False, limit=self.opt.validation_limit)
+        self.trainer.sync_replica_buffers()                      # rank 0's train-mode pass advanced its u, v / BN statistics
 
     def full_validation(self):
         with torch.no_grad():
             for t in self.testers:
                 t.run(self.trainer.pix2pix_model, mode='full', epoch=self.epoch, n_steps=self.counter.total_steps_so_far,
                       log=True, write_error_log=self.opt.write_error_log)
+        self.trainer.sync_replica_buffers()
 
     def save_latest(self):
         if self.rank:
@@ -74,6 +81,9 @@ class TrainingRun:
         self.epoch = epoch
         if c.current_epoch != epoch:                             # equal only at the very start and right after a resume
             c.record_epoch_start(epoch)
+        sampler = getattr(self.dataloader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(epoch)                             # (DistributedSampler: a new permutation per epoch)
         for i, batch in enumerate(self.dataloader, start=c.epoch_iter):
             c.record_one_iteration()
             if i % self.opt.D_steps_per_G == 0:
@@ -83,7 +93,7 @@ class TrainingRun:
                 if due():
                     act()
         trainer.update_learning_rate(epoch)
-        c.record_epoch_end()
+        c.record_epoch_end(write=self.rank == 0)
         if self.rank == 0 and (epoch % self.opt.save_epoch_freq == 0 or epoch == c.total_epochs):
             print('saving the model at the end of epoch %d, iters %d' % (epoch, c.total_steps_so_far))
             trainer.save('latest')
