@@ -46,22 +46,47 @@ def get_rank():
 
 class FlatGradSync:
     """Sum-all-reduce a flat gradient arena in `bucket_bytes` slices.  The division by world_size is
-    folded into the Adam kernel (grad_scale), so the exchange is a pure sum."""
+    folded into the Adam kernel (grad_scale), so the exchange is a pure sum.
 
-    def __init__(self, flat_grad, bucket_bytes=64 << 20, group=None):
+    groups: optional list of (start, end) element ranges of the arena in the order their gradients become FINAL during the
+    backward pass (Pix2PixModel lays the generator's parameters out so: the late blocks' range first).  `launch(i)` starts
+    the all-reduces of group i right away -- asynchronously: the collective is ordered after the kernels already enqueued on
+    the current stream and runs on the backend's own stream while the rest of the backward keeps the compute stream busy --
+    and `all_reduce()` starts whatever was not launched yet and waits for everything (buckets launched as they
+    become ready).  Without groups, or on one process, `all_reduce()` is the whole exchange."""
+
+    def __init__(self, flat_grad, bucket_bytes=64 << 20, group=None, groups=None):
         self.flat = flat_grad
         self.group = group
-        per = max(1, bucket_bytes // flat_grad.element_size())
+        self.per = max(1, bucket_bytes // flat_grad.element_size())
         n = flat_grad.numel()
-        self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
+        self.groups = [(int(a), int(b)) for a, b in groups] if groups else [(0, n)]
+        covered = sorted(self.groups)
+        if covered[0][0] != 0 or covered[-1][1] != n or any(a[1] != b[0] for a, b in zip(covered[:-1], covered[1:])):
+            raise ValueError('FlatGradSync: groups must tile the arena exactly: %s vs %d elements' % (covered, n))
+        self.buckets = [(s, min(b, s + self.per)) for a, b in self.groups for s in range(a, b, self.per)]
+        self._launched, self._handles = set(), []
+
+    def _start(self, i):
+        a, b = self.groups[i]
+        for s in range(a, b, self.per):
+            self._handles.append(dist.all_reduce(self.flat[s:min(b, s + self.per)], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._launched.add(i)
+
+    def launch(self, i):
+        """Group i's gradients are final: start their exchange now (no-op on one process / when already started)."""
+        if world_size() > 1 and i not in self._launched:
+            self._start(i)
 
     def all_reduce(self):
         if world_size() == 1:
             return 1.0
-        handles = [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                   for a, b in self.buckets]
-        for h in handles:
+        for i in range(len(self.groups)):
+            if i not in self._launched:
+                self._start(i)
+        for h in self._handles:
             h.wait()
+        self._launched, self._handles = set(), []
         return 1.0 / world_size()
 
 

@@ -67,6 +67,12 @@ class SPADESTYLEGenerator(BaseNetwork):
             for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
                 st = blk.input_stats(x, 4)
                 x = ops.upsample2x(x)
+                # data parallel: when the gradient w.r.t. the input of up_2 (up_0) exists, every parameter gradient of
+                # conv_img / up_3 / up_2 (up_1 / up_0) is final -- tell the trainer, which starts that group's all-reduce
+                # while the rest of the backward runs (Pix2PixModel.create_optimizers lays the arena out in these groups)
+                cb = self.__dict__.get('grad_ready')
+                if cb is not None and torch.is_grad_enabled() and x.requires_grad and blk in (self.up_2, self.up_0):
+                    x.register_hook(lambda g, i=(0 if blk is self.up_2 else 1): cb(i))
                 x = blk(x, seg, w, st)
             # conv_img(leaky_relu(x)) + tanh, generator.py:99-100: one launch
             y = ops.conv2d(x, self.conv_img.weight, self.conv_img.bias, None, 1, 1, ACT_LRELU, ACT_TANH)

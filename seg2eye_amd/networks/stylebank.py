@@ -30,7 +30,7 @@ def current():
 
 class StyleBankFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, w, Wcat, bcat, holder, gW, gb, want_grad):
+    def forward(ctx, w, Wcat, bcat, holder, gW, gb, want_grad, anchor=None):
         big = F.leaky_relu(torch.addmm(bcat, w, Wcat.t()), 0.2)
         ctx.set_materialize_grads(False)
         ctx.dst = (gW, gb)
@@ -51,8 +51,8 @@ class StyleBankFn(torch.autograd.Function):
         if gW is not None:
             gW.addmm_(dpre.t(), w)
             gb.add_(dpre.sum(0))
-            return dw, None, None, None, None, None, None
-        return dw, dpre.t() @ w, dpre.sum(0), None, None, None, None
+            return dw, None, None, None, None, None, None, None
+        return dw, dpre.t() @ w, dpre.sum(0), None, None, None, None, None
 
 
 class StyleBank:
@@ -85,7 +85,12 @@ class StyleBank:
         else:
             Wcat, bcat = torch.cat(Ws, 0), torch.cat(bs, 0)
         holder = []
-        big = StyleBankFn.apply(w.float().contiguous(), Wcat, bcat, holder, gW, gb, torch.is_grad_enabled())
+        # In the arena path Wcat / bcat are detached views and dW / db are written by the backward itself, so autograd sees no
+        # input that needs a gradient when `w` does not (a style code passed in directly -- generate_fake_from_stylecode --, a
+        # frozen or detached netE): the node would be pruned and all 21 FC gradients silently dropped.  The first FC weight
+        # rides along as an `anchor` input (its gradient slot returns None) to keep the node in the graph.
+        anchor = Ws[0] if (gW is not None and torch.is_grad_enabled() and Ws[0].requires_grad) else None
+        big = StyleBankFn.apply(w.float().contiguous(), Wcat, bcat, holder, gW, gb, torch.is_grad_enabled(), anchor)
         return big, holder[0]
 
 

@@ -29,6 +29,7 @@ _DEFAULTS = dict(
     # build-only knobs (no reference counterpart)
     compute_dtype='bf16',      # 'bf16' | 'fp32': storage + MFMA input type of the HIP path
     hip_graphs=False,          # capture zero_grad+forward+backward of each step into a hipGraph (fixed shapes)
+    no_overlap_allreduce=False,  # data parallel: exchange all gradients after the backward instead of group by group during it
 )
 
 
@@ -99,7 +100,7 @@ _CLI = [  # (name, type or 'flag', default, choices)
     ('num_upsampling_layers', _S, 'normal', ['normal', 'more', 'most']), ('netD_subarch', _S, 'n_layer', None),
     ('num_D', _I, 2, None), ('n_layers_D', _I, 4, None),
     # build-only
-    ('compute_dtype', _S, 'bf16', ['bf16', 'fp32']), ('hip_graphs', 'flag', False, None),
+    ('compute_dtype', _S, 'bf16', ['bf16', 'fp32']), ('hip_graphs', 'flag', False, None), ('no_overlap_allreduce', 'flag', False, None),
     ('synthetic_size', _I, 64, None),        # samples per epoch of the synthetic dataset
 ]
 _CLI_TRAIN = [

@@ -72,28 +72,48 @@ class Pix2PixModel(nn.Module):
 
     def create_optimizers(self, opt):
         """TTUR: betas (0, 0.9), lr_G = lr/2 over netG+netE, lr_D = 2*lr (pix2pix_model.py:92-110)."""
-        # same parameter SET as the reference (netG + netE); the ORDER inside the flat arena puts each SPADE's
-        # gamma/beta conv weights (and biases) back to back so [gamma|beta] is one zero-copy matrix
-        from .networks.normalization import SPADE
-        G_params, seen = [], set()
-        for mod in self.netG.modules():
-            if isinstance(mod, SPADE):
-                for q in mod.arena_order():
-                    seen.add(id(q))
-                    G_params.append(q)
-        # ... and the style FCs of all SPADE+Style layers back to back (weights, then biases): one GEMM for all
-        # of them (networks/stylebank.py)
-        from .networks.normalization import SPADE_STYLE_Block
+        # same parameter SET as the reference (netG + netE).  The ORDER inside the flat arena serves three things:
+        #  * each SPADE's gamma / beta conv weights (and biases) back to back, so [gamma | beta] is one zero-copy matrix;
+        #  * the style FCs of all SPADE+Style layers back to back (weights, then biases): one GEMM for all (networks/stylebank.py);
+        #  * the blocks grouped by WHEN their gradients become final in the backward pass -- late blocks (conv_img, up_3, up_2)
+        #    first, then up_1 / up_0, then everything that completes at the very end (middle / head blocks, fc, the style FCs,
+        #    netE) -- so that a data-parallel run can all-reduce a group's contiguous slice while the backward is still running
+        #    (distributed.FlatGradSync.launch; self.grad_groups_G = the element ranges, in completion order).
+        from .networks.normalization import SPADE, SPADE_STYLE_Block
         fcs = [m.adain.linear for m in self.netG.modules() if isinstance(m, SPADE_STYLE_Block)]
-        for q in [f.weight for f in fcs] + [f.bias for f in fcs if f.bias is not None]:
-            seen.add(id(q))
-            G_params.append(q)
-        G_params += [q for q in self.netG.parameters() if id(q) not in seen] + list(self.netE.parameters())
+        fc_params = [f.weight for f in fcs] + [f.bias for f in fcs if f.bias is not None]
+        seen = {id(q) for q in fc_params}
+
+        def block_params(mods):
+            out = []
+            for top in mods:
+                for mod in top.modules():
+                    if isinstance(mod, SPADE):
+                        for q in mod.arena_order():
+                            if id(q) not in seen:
+                                seen.add(id(q))
+                                out.append(q)
+                for q in top.parameters():
+                    if id(q) not in seen:
+                        seen.add(id(q))
+                        out.append(q)
+            return out
+        G = self.netG
+        late = block_params([m for m in (getattr(G, n, None) for n in ('conv_img', 'up_3', 'up_2')) if m is not None])
+        mid = block_params([m for m in (getattr(G, n, None) for n in ('up_1', 'up_0')) if m is not None])
+        early = block_params([G]) + fc_params + [q for q in self.netE.parameters()]       # whatever is left of netG, the FCs, netE
+        G_params = late + mid + early
+        self._arena_groups_G = [len(late), len(mid), len(early)]
         if opt.no_TTUR:
             beta1, beta2, G_lr, D_lr = opt.beta1, opt.beta2, opt.lr, opt.lr
         else:
             beta1, beta2, G_lr, D_lr = 0.0, 0.9, opt.lr / 2, opt.lr * 2
         optimizer_G = FlatAdam(G_params, lr=G_lr, betas=(beta1, beta2), weight_decay=opt.weight_decay)
+        bounds, k = [0], 0
+        for cnt in self._arena_groups_G:
+            k += cnt
+            bounds.append(optimizer_G.offsets[k] if k < len(optimizer_G.offsets) else optimizer_G.numel)
+        self.grad_groups_G = [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
         optimizer_D = FlatAdam(list(self.netD.parameters()), lr=D_lr, betas=(beta1, beta2),
                                weight_decay=opt.weight_decay) if opt.isTrain else None
         return optimizer_G, optimizer_D

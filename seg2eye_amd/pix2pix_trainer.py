@@ -1,7 +1,7 @@
 """Pix2PixTrainer (reference trainers/pix2pix_trainer.py:8-88): owns the model and the two optimizers,
 runs one G step / one D step, LR decay, save.  Multi-GPU: when torch.distributed is initialised the
 flat gradient arenas are sum-all-reduced (RCCL) between backward and the Adam launch."""
-from .distributed import FlatGradSync, broadcast_buffers, broadcast_flat
+from .distributed import FlatGradSync, broadcast_buffers, broadcast_flat, world_size
 from .ops import ZeroPool
 from .pix2pix_model import Pix2PixModel
 
@@ -18,8 +18,16 @@ class Pix2PixTrainer:
         if opt.isTrain:
             self.optimizer_G, self.optimizer_D = self.pix2pix_model_on_one_gpu.create_optimizers(opt)
             self.old_lr = opt.lr
-            self.sync_G = FlatGradSync(self.optimizer_G.flat_g)
+            self.sync_G = FlatGradSync(self.optimizer_G.flat_g, groups=self.pix2pix_model.grad_groups_G)
             self.sync_D = FlatGradSync(self.optimizer_D.flat_g)
+            if world_size() > 1 and not getattr(opt, 'no_overlap_allreduce', False):
+                # Overlap the gradient exchange with the backward pass: the generator reports when a group of
+                # blocks has all its gradients (networks/generator.py), we flush that group's queued gradient re-layouts and
+                # start the all-reduce of its arena slice.  That needs the backward to run as individual launches, not as one
+                # graph replay -- which costs nothing: eager launches run at the graph's rate (the GPU is busy
+                # throughout; 336.6 vs 337.1 img/s on the same box).
+                self.opt.hip_graphs = False
+                self.pix2pix_model.netG.__dict__['grad_ready'] = self._group_ready
             broadcast_flat(self.optimizer_G.flat_p)          # identical replicas at step 0: parameters ...
             broadcast_flat(self.optimizer_D.flat_p)
             self.sync_replica_buffers()                      # ... and spectral-norm u, v / BatchNorm running statistics
@@ -30,6 +38,14 @@ class Pix2PixTrainer:
         calls eval()) and so advances rank 0's u, v and running statistics."""
         m = self.pix2pix_model
         broadcast_buffers([m.netG, m.netD, m.netE])
+
+    def _group_ready(self, i):
+        """Backward hook (data parallel, eager): parameter group i of the G arena is final.  Only during the G step's backward --
+        the D step's no-grad generator forward registers no hooks."""
+        pool = ZeroPool.active()
+        if pool is self.pool and pool.key == 'G':
+            pool.sink.flush()                                # the group's queued packed-dW -> arena conversions: now
+            self.sync_G.launch(i)
 
     # ---- step bodies: zero_grad + forward + backward (what a hipGraph captures) -------------------
     def _g_body(self, data):

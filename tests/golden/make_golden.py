@@ -57,6 +57,7 @@ def ref_opt(**kw):
     opt = default_opt(**kw)
     delattr(opt, 'compute_dtype')
     delattr(opt, 'hip_graphs')
+    delattr(opt, 'no_overlap_allreduce')
     return opt
 
 

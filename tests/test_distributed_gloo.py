@@ -35,7 +35,21 @@ def _worker(rank, world, port, out):
     local = opt.flat_g.clone()
     scale = sync.all_reduce()
     assert abs(scale - 1.0 / world) < 1e-12
-    out[rank] = (p0, local, opt.flat_g.clone())
+    # grouped exchange (the overlap path): groups in "completion order", launched early and out of arena order
+    n = opt.flat_g.numel()
+    cut = opt.offsets[2]
+    gsync = sdist.FlatGradSync(opt.flat_g, bucket_bytes=64, groups=[(cut, n), (0, cut)])
+    opt.flat_g.copy_(local)
+    gsync.launch(0)                                      # the second Linear's slice is final first
+    gsync.launch(0)                                      # (idempotent)
+    assert abs(gsync.all_reduce() - 1.0 / world) < 1e-12 and not gsync._handles and not gsync._launched
+    grouped = opt.flat_g.clone()
+    try:
+        sdist.FlatGradSync(opt.flat_g, groups=[(0, cut - 1), (cut, n)])
+        raise AssertionError('a gap in the groups must be refused')
+    except ValueError:
+        pass
+    out[rank] = (p0, local, grouped, opt.flat_g.clone())
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -45,7 +59,8 @@ def test_flat_grad_allreduce_world2():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    (p_a, l_a, s_a), (p_b, l_b, s_b) = out[0], out[1]
+    (p_a, l_a, g_a, s_a), (p_b, l_b, g_b, s_b) = out[0], out[1]
+    assert torch.equal(g_a, s_a) and torch.equal(g_b, s_b)          # grouped / early-launched exchange == plain exchange
     assert torch.equal(p_a, p_b)                                   # broadcast made replicas identical
     assert torch.allclose(s_a, l_a + l_b) and torch.equal(s_a, s_b)  # sum all-reduce, same on both ranks
     assert not torch.equal(l_a, l_b)
