@@ -286,8 +286,10 @@ int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float* h
  *   to255(x) = (int)(((x + 1) * 255) / 2)   -- fp32, truncation toward zero ([-1,1] -> 0..255)
  *   s2e_openeds_error   : err[n] = sqrt(sum_pixels (to255(fake) - to255(target))^2) / (H*W)   (calculate_mse_for_tensors)
  *   s2e_openeds_error_u8: the same on images that already are 0..255                         (calculate_mse_for_images)
- *   s2e_resize_to255    : bilinear resize (half-pixel centres, edge clamp: cv2.INTER_LINEAR on float images) of (N,H,W)
- *                         single-channel images to (N,Ho,Wo), then to255 -> uint8             (to_255resized_imagebatch)
+ *   s2e_resize_to255    : bilinear resize of (N,H,W) single-channel images to (N,Ho,Wo) by OpenCV's INTER_LINEAR rule for the
+ *                         float64 image the reference hands it (data/postprocessor.py:108-114: half-pixel centres, edge clamp,
+ *                         float32 tap weights, float64 horizontal-then-vertical sums), then ((v+1)*255)/2 in float64 and the
+ *                         truncation -> uint8                                                  (to_255resized_imagebatch)
  * The squared-difference sums are exact 64-bit integers; err: fp32 [N]. */
 int s2e_openeds_error(int dtype, const void* fake, const void* target, int N, int H, int W, float* err, void* stream);
 int s2e_openeds_error_u8(const uint8_t* produced, const uint8_t* target, int N, int H, int W, float* err, void* stream);

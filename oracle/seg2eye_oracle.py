@@ -339,18 +339,57 @@ def error_statistics(all_errors, mode, dataset_key):
     return {'mse/%s/%s/relative' % (dataset_key, mode): float(np.sum(all_errors) / len(all_errors) * 1471)}
 
 
+def _cv2_linear_taps(n_dst, n_src):
+    """The tap table of OpenCV's resize for INTER_LINEAR (modules/imgproc/src/resize.cpp, `cv::resize` -> the generic
+    `resizeGeneric_` path): for destination index d,
+        scale = 1 / (n_dst / n_src)                      (double)
+        f  = (float)((d + 0.5) * scale - 0.5);  s = floor(f);  f -= s              (float)
+        s < 0            -> f = 0, s = 0                                          (left / top edge clamp)
+        s >= n_src - 1   -> f = 0, s = n_src - 1                                  (right / bottom edge clamp)
+        weights (1 - f, f) as FLOAT (`AT = float` also for CV_64F images); the second tap is s + 1 clamped into the image
+    -> (s0, s1, w0, w1): int64 indices, float32 weights."""
+    import numpy as np
+    inv = float(n_dst) / float(n_src)
+    scale = 1.0 / inv
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    lo = s < 0
+    f[lo], s[lo] = 0.0, 0
+    hi = s >= n_src - 1
+    f[hi], s[hi] = 0.0, n_src - 1
+    s1 = np.minimum(s + 1, n_src - 1)
+    return s, s1, (np.float32(1.0) - f).astype(np.float32), f
+
+
 def resize_bilinear(image, w=400, h=640):
-    """data/postprocessor.py:99-105 (`ImageProcessor.resize`): cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR) per
-    image.  THIRD-PARTY, ABSENT HERE: opencv-python (requirements.txt, unpinned) is not in this image, so this one function
-    is PARITY-UNPINNED: it restates INTER_LINEAR's published rule for float images -- source coordinate
-    (dst + 0.5) * scale - 0.5, clamped at both edges, two-tap linear weights, no antialiasing when shrinking -- through
-    torch's `F.interpolate(mode='bilinear', align_corners=False)`, which implements the same rule."""
-    return F.interpolate(image.float(), size=(h, w), mode='bilinear', align_corners=False)
+    """data/postprocessor.py:108-114 (`ImageProcessor.resize`): per image, `cv2.resize(img.astype(np.float), (w, h),
+    interpolation=cv2.INTER_LINEAR)` -- a float64 image through OpenCV's bilinear resize.
+    THIRD-PARTY, ABSENT HERE: opencv-python (requirements.txt: `opencv-python`, unpinned) is not in this image and cannot be
+    installed, so this function cannot be checked against cv2 itself: it is PARITY-UNPINNED against the library and pinned
+    only against its published algorithm, restated explicitly below (no torch / scipy resampling call in between):
+    half-pixel centres, edge clamp, float32 tap weights (`_cv2_linear_taps`), a horizontal pass then a vertical pass, both
+    in float64 (`WT = double` for CV_64F), `S0 * w0 + S1 * w1` with the weights promoted to double.  No antialiasing when
+    shrinking.  -> float64 tensor (N, C, h, w)."""
+    import numpy as np
+    x = image.detach().cpu().double().numpy()
+    H, W = x.shape[-2:]
+    xs0, xs1, xa0, xa1 = _cv2_linear_taps(w, W)
+    ys0, ys1, yb0, yb1 = _cv2_linear_taps(h, H)
+    rows = x[..., :, xs0] * xa0.astype(np.float64) + x[..., :, xs1] * xa1.astype(np.float64)            # horizontal pass
+    out = rows[..., ys0, :] * yb0.astype(np.float64)[:, None] + rows[..., ys1, :] * yb1.astype(np.float64)[:, None]
+    return torch.from_numpy(out)
+
+
+def to_255_pre_truncation(image, w=400, h=640):
+    """The float64 value `unnormalize` truncates (postprocessor.py:58-73 on the resized float64 image): ((x + 1) * 255) / 2."""
+    return torch.div(torch.mul(torch.add(resize_bilinear(image, w, h), 1), 255), 2)
 
 
 def to_255_resized(image, w=400, h=640):
     """postprocessor.py:92-97 (`to_255resized_imagebatch`): resize, then unnormalize."""
-    return to_255(resize_bilinear(image, w, h))
+    return to_255_pre_truncation(image, w, h).int()
 
 
 class OracleModel:

@@ -3,8 +3,8 @@
 // (util/tester.py:44-47,93-97; data/postprocessor.py:58-73,92-107; models/networks/loss.py:102-155).
 //
 //   to255(x)        = (int)(((x + 1) * 255) / 2)         fp32 operations in exactly this order, truncation toward zero
-//   resize          : bilinear with half-pixel centres and edge clamping (cv2.INTER_LINEAR on float images and
-//                     torch's align_corners=False agree on this; no antialiasing when shrinking), fp32
+//   resize          : cv2.INTER_LINEAR on a float64 image (half-pixel centres, edge clamp, float tap weights, double sums; no
+//                     antialiasing when shrinking), then ((v + 1) * 255) / 2 in double and the truncation
 //   err[n]          = sqrtf((float)sum_pixels (a - b)^2) / (float)(H * W)      a, b integers 0..255; the sum is exact (u64)
 //
 // HBM-bound, tiny (one pass over two images): one workgroup per image, no workspace, no atomics, deterministic.
@@ -52,27 +52,39 @@ __global__ __launch_bounds__(1024) void openeds_error_u8_kernel(const uint8_t* _
     if (threadIdx.x == 0) err[blockIdx.x] = sqrtf((float)t) / (float)HW;
 }
 
-// out[n][oy][ox] = to255(bilinear(x[n], oy, ox)); one thread per output pixel
+// out[n][oy][ox] = trunc(((bilinear(x[n], oy, ox) + 1) * 255) / 2); one thread per output pixel.
+// Arithmetic = OpenCV's INTER_LINEAR on a float64 image followed by the reference's float64 unnormalize
+// (data/postprocessor.py:108-114,58-73), step by step: tap position f = (float)((d + 0.5) * scale - 0.5) with scale a double,
+// s = floor(f), f -= s, clamped to the image at both edges with weight 0; FLOAT weights (1 - f, f); a horizontal pass then a
+// vertical pass S0 * w0 + S1 * w1 in DOUBLE; ((v + 1) * 255) / 2 in double; truncation toward zero.  No fused multiply-adds
+// (cv2 and numpy round every product), so the value agrees with the oracle's fp64 restatement to the last bit.
+struct LinTap { int s0, s1; float w0, w1; };
+__device__ __forceinline__ LinTap lin_tap(int d, double scale, int n_src) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    LinTap t;
+    t.s0 = s; t.s1 = s + 1 < n_src ? s + 1 : n_src - 1;
+    t.w0 = 1.f - f; t.w1 = f;
+    return t;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void resize_to255_kernel(const T* __restrict__ x, uint8_t* __restrict__ out, int H, int W, int Ho, int Wo,
-                                                           float sy, float sx) {
+                                                           double sy, double sx) {
+#pragma clang fp contract(off)
     const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y, n = blockIdx.z;
     if (ox >= Wo) return;
-    // source coordinate of the pixel centre, clamped at the edges (cv2: fx < 0 -> 0, sx >= W - 1 -> last pixel, weight 0)
-    float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
-    fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
-    int y0 = (int)fy, x0 = (int)fx;
-    float wy = fy - (float)y0, wx = fx - (float)x0;
-    if (y0 >= H - 1) { y0 = H - 1; wy = 0.f; }
-    if (x0 >= W - 1) { x0 = W - 1; wx = 0.f; }
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const LinTap tx = lin_tap(ox, sx, W), ty = lin_tap(oy, sy, H);
     const T* p = x + (size_t)n * H * W;
-    const float v00 = load1<T>(p + (size_t)y0 * W + x0), v01 = load1<T>(p + (size_t)y0 * W + x1);
-    const float v10 = load1<T>(p + (size_t)y1 * W + x0), v11 = load1<T>(p + (size_t)y1 * W + x1);
-    // horizontal first, then vertical (the order of torch's upsample_bilinear2d and of cv2's two-pass resize)
-    const float top = v00 + wx * (v01 - v00), bot = v10 + wx * (v11 - v10);
-    float v = top + wy * (bot - top);
-    int q = to255(v);
+    const double v00 = (double)load1<T>(p + (size_t)ty.s0 * W + tx.s0), v01 = (double)load1<T>(p + (size_t)ty.s0 * W + tx.s1);
+    const double v10 = (double)load1<T>(p + (size_t)ty.s1 * W + tx.s0), v11 = (double)load1<T>(p + (size_t)ty.s1 * W + tx.s1);
+    const double top = __dadd_rn(__dmul_rn(v00, (double)tx.w0), __dmul_rn(v01, (double)tx.w1));
+    const double bot = __dadd_rn(__dmul_rn(v10, (double)tx.w0), __dmul_rn(v11, (double)tx.w1));
+    const double v = __dadd_rn(__dmul_rn(top, (double)ty.w0), __dmul_rn(bot, (double)ty.w1));
+    const double u = __ddiv_rn(__dmul_rn(__dadd_rn(v, 1.0), 255.0), 2.0);
+    int q = (int)u;                                          // truncation toward zero (`.int()`)
     q = q < 0 ? 0 : (q > 255 ? 255 : q);
     out[((size_t)n * Ho + oy) * Wo + ox] = (uint8_t)q;
 }
@@ -102,7 +114,8 @@ extern "C" int s2e_resize_to255(int dtype, const void* x, int N, int H, int W, u
     if (Ho > 65535 || N > 65535) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_resize_to255: grid too large");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ceil_div(Wo, 256), Ho, N);
-    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    // cv2: inv_scale = dst / (double)src; scale = 1. / inv_scale
+    const double sy = 1.0 / ((double)Ho / (double)H), sx = 1.0 / ((double)Wo / (double)W);
     if (dtype == S2E_BF16) resize_to255_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, out, H, W, Ho, Wo, sy, sx);
     else if (dtype == S2E_F32) resize_to255_kernel<float><<<grid, 256, 0, st>>>((const float*)x, out, H, W, Ho, Wo, sy, sx);
     else S2E_FAIL(S2E_ERR_ARG, "s2e_resize_to255: bad dtype %d", dtype);

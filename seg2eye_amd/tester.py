@@ -5,8 +5,9 @@
     tester.run_test(model)                    # uint8 .npy predictions of shape (1, 640, 400) + pred_npy_list.txt
 
 What differs from the reference: the generated batch never leaves the GPU before it is scored (resize to 400 x 640,
-0..255 truncation and sqrt(sum d^2)/(H W) are `s2e_resize_to255` + `s2e_openeds_error_u8`); the H5 error log and the
-visdom / TF visualisations are not built (out of scope); the dataset is whatever `data.create_dataloader`
+0..255 truncation and sqrt(sum d^2)/(H W) are `s2e_resize_to255` + `s2e_openeds_error_u8`); the error log carries error / user /
+filename (h5 with h5py, else npz) without the visualiser's side-by-side images; the visdom / TF visualisations are not built
+(out of scope); the dataset is whatever `data.create_dataloader`
 yields (synthetic, or the OpenEDS H5 dataset) -- batches must carry `target_original` (N, 1, 640, 400) for validation."""
 import os
 import re
@@ -71,11 +72,40 @@ class Tester:
         errors = MSECalculator.calculate_mse_for_images(fake_resized, target).cpu().numpy()
         return errors, fake, fake_resized, target
 
+    def _prepare_error_log(self):
+        """tester.py:67-74: `error_log_<dataset_key>.h5` with one row per sample -- datasets `error` (float64), `user` (S4),
+        `filename` (S13).  Written with h5py when it is installed; this image has none, so the same three arrays go to
+        `error_log_<dataset_key>.npz` instead (np.load gives the same names).  The reference's fourth dataset, `visualisation`
+        (side-by-side images rendered by util/visualizer.py with cv2), belongs to the visualiser: not built."""
+        return {'error': np.zeros((self.N,), dtype=np.float64), 'user': np.zeros((self.N,), dtype='S4'),
+                'filename': np.zeros((self.N,), dtype='S13')}
+
+    def _write_error_log_batch(self, error_log, data_i, i, errors):
+        """tester.py:76-91 without the visualisation."""
+        a = i * self.opt.batchSize
+        b = min(a + len(errors), self.N)
+        error_log['user'][a:b] = np.array(list(data_i['user']), dtype='S4')[:b - a]
+        error_log['filename'][a:b] = np.array(list(data_i['filename']), dtype='S13')[:b - a]
+        error_log['error'][a:b] = np.asarray(errors, dtype=np.float64)[:b - a]
+        return error_log
+
+    def _close_error_log(self, error_log):
+        base = os.path.join(self.results_dir, 'error_log_%s' % self.opt.dataset_key)
+        try:
+            import h5py
+        except ImportError:
+            np.savez(base + '.npz', **error_log)
+            return base + '.npz'
+        with h5py.File(base + '.h5', 'w') as f:
+            for k, v in error_log.items():
+                f.create_dataset(k, data=v)
+        return base + '.h5'
+
     def run_validation(self, model, generator, limit=-1, write_error_log=False):
-        """tester.py:99-121 (no H5 error log)."""
+        """tester.py:99-121."""
         assert self.is_validation, 'Must be in validation mode'
-        if write_error_log:
-            raise NotImplementedError('the H5 error log (tester.py:67-91) needs h5py and the visualiser: not built')
+        print('write error log: %s' % write_error_log)
+        error_log = self._prepare_error_log() if write_error_log else None
         all_errors, counter = [], 0
         for i, data_i in enumerate(generator):
             counter += data_i['label'].shape[0]
@@ -86,6 +116,10 @@ class Tester:
                 print('Error so far: %s' % (np.sum(all_errors) / len(all_errors) * 1471))
             errors, _, _, _ = self.run_batch(data_i, model)
             all_errors += list(errors)
+            if error_log is not None:
+                self._write_error_log_batch(error_log, data_i, i, errors)
+        if error_log is not None:
+            print('error log: %s' % self._close_error_log(error_log))
         return all_errors
 
     def print_results(self, all_errors, errors_dict, epoch='n.a.', n_steps='n.a.'):

@@ -283,6 +283,29 @@ def more_fixture(args, syn, onehot, SPADESTYLEGenerator):
     print('more ok', (H, W), float(y.std()))
 
 
+def resize_fixture(args, syn):
+    """resize_cv2_rule.npz: the oracle's explicit float64 restatement of cv2.INTER_LINEAR + the reference's unnormalize
+    (oracle.resize_bilinear / to_255_pre_truncation; cv2 itself is not installable here -- parity-unpinned against the
+    library) on two synthetic images: the float64 pre-truncation values of a strided subsample, the full uint8
+    results' checksums, and the reference's OWN `unnormalize` (.int() of a float64 tensor) applied to those values, which
+    pins the truncation step to the real reference code."""
+    sys.path.insert(0, REPO)
+    from oracle import seg2eye_oracle as O
+    from data.postprocessor import ImageProcessor
+    out = {'seeds': np.array([601, 602])}
+    for i, (seed, hw) in enumerate(((601, (256, 256)), (602, (640, 384)))):
+        img = torch.from_numpy(syn.make_batch(1, hw[0], hw[1], seed=seed)['target'])          # (1,1,H,W) in [-1,1]
+        pre = O.to_255_pre_truncation(img)                                                       # float64 (1,1,640,400)
+        q_ref = ImageProcessor.unnormalize(O.resize_bilinear(img), as_tensor=True)              # the reference's own truncation
+        assert torch.equal(q_ref, pre.int())
+        out['pre_sub_%d' % i] = pre[0, 0, ::7, ::5].numpy()
+        out['q_sub_%d' % i] = q_ref[0, 0, ::3, ::3].numpy().astype(np.uint8)
+        out['q_sums_%d' % i] = np.array([int(q_ref.long().sum()), int((q_ref.long() ** 2).sum())])
+        out['hw_%d' % i] = np.array(hw)
+    np.savez_compressed(os.path.join(args.out, 'resize_cv2_rule.npz'), **out)
+    print('resize ok', {k: v.shape for k, v in out.items()})
+
+
 def options_fixture(args):
     """reference_option_defaults.json: every flag of the reference's TrainOptions / TestOptions parsers
     (options/base_options.py, train_options.py, test_options.py) with its default, type, action and choices."""
@@ -340,6 +363,9 @@ def main():
         return
     if args.only == 'cfg5':
         cfg5_fixture(args, syn, onehot, SPADESTYLEGenerator, MultiscaleDiscriminator)
+        return
+    if args.only == 'resize':
+        resize_fixture(args, syn)
         return
     if args.only == 'more':
         more_fixture(args, syn, onehot, SPADESTYLEGenerator)

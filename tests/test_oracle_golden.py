@@ -221,3 +221,28 @@ def test_openeds_metric():
     assert r.shape == (3, 1, 640, 400) and int(r.min()) >= 0 and int(r.max()) <= 255
     assert int(O.to_255_resized(torch.full((1, 1, 8, 8), 0.5)).unique().item()) == int((0.5 + 1) * 255 / 2)
 
+
+
+def test_resize_rule_matches_fixture():
+    """f3: the oracle's explicit float64 cv2.INTER_LINEAR restatement + unnormalize against the committed vectors (generated by
+    `make_golden.py --only resize`, which also ran the REFERENCE's own `ImageProcessor.unnormalize` on the resized float64 image:
+    the truncation step is the reference's code, the resize rule is OpenCV's published algorithm -- cv2 is not installable here).
+    Also the rule's defining properties: identity at equal size, edge clamp, exact 2x upsampling taps."""
+    from seg2eye_amd import synthetic as syn
+    z = load_golden('resize_cv2_rule')
+    for i, seed in enumerate(z['seeds']):
+        H, W = (int(v) for v in z['hw_%d' % i])
+        img = torch.from_numpy(syn.make_batch(1, H, W, seed=int(seed))['target'])
+        pre = O.to_255_pre_truncation(img)
+        assert pre.dtype == torch.float64 and tuple(pre.shape) == (1, 1, 640, 400)
+        np.testing.assert_array_equal(pre[0, 0, ::7, ::5].numpy(), z['pre_sub_%d' % i])             # bit-exact float64
+        q = O.to_255_resized(img)
+        np.testing.assert_array_equal(q[0, 0, ::3, ::3].numpy().astype(np.uint8), z['q_sub_%d' % i])
+        assert [int(q.long().sum()), int((q.long() ** 2).sum())] == [int(v) for v in z['q_sums_%d' % i]]
+    x = torch.from_numpy(syn.make_batch(1, 12, 10, seed=3)['target'])
+    assert torch.equal(O.resize_bilinear(x, w=10, h=12), x.double())                                 # same size: identity
+    up = O.resize_bilinear(x, w=20, h=12)[0, 0]                                                      # 2x along x: taps (0.75, 0.25)
+    xd = x.double()[0, 0]
+    assert torch.equal(up[:, 0], xd[:, 0]) and torch.equal(up[:, -1], xd[:, -1])                     # edge clamp
+    np.testing.assert_allclose(up[:, 1].numpy(), (0.75 * xd[:, 0] + 0.25 * xd[:, 1]).numpy(), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(up[:, 2].numpy(), (0.25 * xd[:, 0] + 0.75 * xd[:, 1]).numpy(), rtol=0, atol=1e-15)
