@@ -8,7 +8,7 @@ from .._lib import ACT_NONE, ACT_LRELU
 from .. import packing
 from ..spectral import sn_begin
 from .base_network import BaseNetwork, compute_dtype_of
-from .normalization import get_nonspade_norm_layer
+from .normalization import apply_nonspade_norm, get_nonspade_norm_layer
 
 D_CPAD = 8          # the 5-channel input cat([one-hot seg, image]) is stored as 8 NHWC channels (16-B vectors)
 
@@ -74,7 +74,7 @@ class NLayerDiscriminator(BaseNetwork):
             if isinstance(blk, nn.Sequential):                     # SN conv (bias removed) -> InstanceNorm -> LeakyReLU
                 conv = blk[0]
                 h = ops.conv2d_m(h, conv, None, self.strides[n], self.padw)
-                h = ops.instance_norm(h, lrelu=True)
+                h = apply_nonspade_norm(h, blk[1], lrelu=True)
             else:                                                  # norm_D without a norm layer: conv -> LeakyReLU
                 h = ops.conv2d_m(h, blk, None, self.strides[n], self.padw, ACT_NONE, ACT_LRELU)
             h = tap(h)
@@ -125,7 +125,9 @@ class MultiscaleDiscriminator(BaseNetwork):
             terms = [] if feat_lambda is not None else None
             num_D = len(list(self.named_children()))
             # G step ([fake | real], real = detached feature-matching target): gradients exist for the fake half only
-            with ops.LivePrefix.of(x.shape[0] // 2 if terms is not None else None):
+            # (not with BatchNorm in D: batch statistics couple the samples, the real half's activations then DO carry gradient)
+            coupled = any(isinstance(m, nn.BatchNorm2d) for m in self.modules())
+            with ops.LivePrefix.of(x.shape[0] // 2 if (terms is not None and not coupled) else None):
                 for name, D in self.named_children():
                     raw = D.forward_nhwc(x, terms, (feat_lambda or 0.0) / num_D)
                     feats = [f.permute(0, 3, 1, 2) for f in raw]

@@ -9,7 +9,7 @@ from .. import ops
 from .. import packing
 from ..spectral import sn_begin
 from .base_network import BaseNetwork, compute_dtype_of
-from .normalization import get_nonspade_norm_layer
+from .normalization import apply_nonspade_norm, get_nonspade_norm_layer
 
 
 class ConvEncoder(BaseNetwork):
@@ -51,7 +51,7 @@ class ConvEncoder(BaseNetwork):
                 conv = blk[0] if isinstance(blk, nn.Sequential) else blk
                 h = ops.conv2d_m(h, conv, None, 2, 1)
                 if isinstance(blk, nn.Sequential):
-                    h = ops.instance_norm(h, lrelu=False)
+                    h = apply_nonspade_norm(h, blk[1], lrelu=False)
                 feats.append(h.permute(0, 3, 1, 2))
             out = F.leaky_relu(feats[-1].float(), 0.2).reshape(h.shape[0], -1)     # NCHW flatten order, encoder.py:68
             mu = self.fc_mu(out)

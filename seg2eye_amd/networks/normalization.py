@@ -185,8 +185,8 @@ class SPADE_STYLE_Block(nn.Module):
 
 
 def get_nonspade_norm_layer(opt, norm_type='instance'):
-    """normalization.py:15-47 for the variants the hot path uses: 'spectralinstance' (and
-    'spectralnone' / 'instance' / 'none').  Returns add_norm_layer(conv) -> nn.Sequential(conv[, IN])
+    """normalization.py:15-47: 'spectralinstance' (the hot path), 'spectralbatch', and the same without 'spectral' / with
+    'none'.  Returns add_norm_layer(conv) -> nn.Sequential(conv[, IN])
     with the conv's bias removed when a norm follows, so state_dict keys match (`model1.0.0.weight_orig`)."""
     def add_norm_layer(layer):
         sub = norm_type
@@ -200,5 +200,21 @@ def get_nonspade_norm_layer(opt, norm_type='instance'):
             layer.register_parameter('bias', None)
         if sub == 'instance':
             return nn.Sequential(layer, nn.InstanceNorm2d(layer.out_channels, affine=False))
-        raise ValueError('normalization layer %s is not supported by this build (instance only)' % sub)
+        if sub == 'batch':                                          # normalization.py:38-39
+            return nn.Sequential(layer, nn.BatchNorm2d(layer.out_channels, affine=True))
+        raise ValueError('normalization layer %s is not recognized' % sub)
     return add_norm_layer
+
+
+def apply_nonspade_norm(h, norm, lrelu):
+    """The norm layer get_nonspade_norm_layer put behind a conv (+ the LeakyReLU(0.2) that follows it in netD), on an NHWC
+    tensor.  InstanceNorm2d -- the hot path's `spectralinstance` -- is the fused HIP statistics + modulation pass;
+    BatchNorm2d (`--norm_D / --norm_E spectralbatch`, normalization.py:38-39, off the benchmarked path) runs on stock
+    PyTorch-ROCm: nn.BatchNorm2d on the channels-last view, fp32, with its affine parameters and running buffers (per-GPU
+    statistics under data parallelism, as nn.DataParallel would give)."""
+    if isinstance(norm, nn.BatchNorm2d):
+        y = norm(h.permute(0, 3, 1, 2).float())
+        if lrelu:
+            y = F.leaky_relu(y, 0.2)
+        return y.permute(0, 2, 3, 1).contiguous().to(h.dtype)
+    return ops.instance_norm(h, lrelu=lrelu)

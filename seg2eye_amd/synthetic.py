@@ -62,6 +62,8 @@ def fill_state_entry(name, shape, seed=0):
             if 'adain' in name:
                 return (hash_normal(name, shape, seed) * 0.25).astype(np.float32)
             return (hash_normal(name, shape, seed) / np.sqrt(shape[1])).astype(np.float32)
+        if len(shape) == 1:                       # BatchNorm2d(affine=True).weight (norm_D / norm_E spectralbatch): scale near 1
+            return hash_uniform(name, shape, seed, 0.7, 1.3)
     if leaf == 'running_mean':                        # BatchNorm SPADE buffers: plausible non-trivial running statistics
         return hash_uniform(name, shape, seed, -0.2, 0.2)
     if leaf == 'running_var':

@@ -306,6 +306,44 @@ def resize_fixture(args, syn):
     print('resize ok', {k: v.shape for k, v in out.items()})
 
 
+def batchnorm_de_fixture(args, syn, onehot, MultiscaleDiscriminator, ConvEncoder):
+    """de_spectralbatch.npz: --norm_D spectralbatch / --norm_E spectralbatch (normalization.py:38-39: BatchNorm2d(affine=True)
+    behind the spectral-normed convs): train-mode forward (batch statistics, running buffers updated), the gradient w.r.t. the
+    fake image / the style images and every parameter gradient."""
+    opt = ref_opt(ndf=8, ngf=8, crop_size=256, norm_D='spectralbatch', norm_E='spectralbatch')
+    netD = MultiscaleDiscriminator(opt)
+    manD = load_filled(netD)
+    label = syn.ellipse_labels(2, 64, 64, seed=71)
+    seg = onehot(label)
+    fake = torch.from_numpy(syn.smooth_images('d_fake', (2, 1, 64, 64), seed=71)).requires_grad_(True)
+    real = torch.from_numpy(syn.smooth_images('d_real', (2, 1, 64, 64), seed=71))
+    netD.train()
+    pred = netD(torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, real], 1)], 0))
+    loss = sum((p[-1] * torch.from_numpy(syn.hash_uniform('dproj%d' % i, tuple(p[-1].shape), seed=71))).sum() for i, p in enumerate(pred))
+    loss = loss + sum(f.abs().mean() for p in pred for f in p[:-1])
+    loss.backward()
+    rec = {'label': label, 'grad_fake': fake.grad.numpy(), 'loss': np.array([loss.item()])}
+    for i in range(2):
+        rec['pred_%d' % i] = pred[i][-1].detach().numpy()
+        rec['feat_%d_1' % i] = checksum(pred[i][1])
+    for k, p in netD.named_parameters():
+        rec['gradD_' + k] = checksum(p.grad)
+    for k, v in netD.state_dict().items():
+        if 'running' in k or k.endswith(('weight_u', 'weight_v')):
+            rec['bufD_' + k] = v.detach().numpy().copy()
+    netE = ConvEncoder(opt)
+    manE = load_filled(netE)
+    xs = torch.from_numpy(syn.smooth_images('e_style', (3, 1, 256, 256), seed=72)).requires_grad_(True)
+    netE.train()
+    mu, logvar, feats = netE(xs)
+    (mu.sum() + 0.5 * logvar.sum()).backward()
+    rec.update({'e_mu': mu.detach().numpy(), 'e_logvar': logvar.detach().numpy(), 'e_grad_x_ck': checksum(xs.grad)})
+    for k, p in netE.named_parameters():
+        rec['gradE_' + k] = checksum(p.grad)
+    np.savez_compressed(os.path.join(args.out, 'de_spectralbatch.npz'), **rec, **manifest_arrays('D', manD), **manifest_arrays('E', manE))
+    print('spectralbatch D/E ok', loss.item())
+
+
 def options_fixture(args):
     """reference_option_defaults.json: every flag of the reference's TrainOptions / TestOptions parsers
     (options/base_options.py, train_options.py, test_options.py) with its default, type, action and choices."""
@@ -363,6 +401,9 @@ def main():
         return
     if args.only == 'cfg5':
         cfg5_fixture(args, syn, onehot, SPADESTYLEGenerator, MultiscaleDiscriminator)
+        return
+    if args.only == 'dbatch':
+        batchnorm_de_fixture(args, syn, onehot, MultiscaleDiscriminator, ConvEncoder)
         return
     if args.only == 'resize':
         resize_fixture(args, syn)

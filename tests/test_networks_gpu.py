@@ -1040,3 +1040,46 @@ def test_batchnorm_spade_statistics_are_synchronised_across_replicas():
     assert abs(sum(two['y_abs']) - one['y_abs'][0]) <= 2e-4 * one['y_abs'][0], (two, one)
     assert abs(two['g_sum'] - one['g_sum']) <= 2e-3 * one['g_abs'] and abs(two['g_abs'] - one['g_abs']) <= 2e-3 * one['g_abs'], (two, one)
     assert abs(two['rm_abs'] - one['rm_abs']) <= 1e-5 * max(one['rm_abs'], 1e-6) and abs(two['rv_sum'] - one['rv_sum']) <= 1e-5 * one['rv_sum'], (two, one)
+
+
+def test_spectralbatch_norm_d_and_e_match_reference():
+    """--norm_D spectralbatch / --norm_E spectralbatch (normalization.py:38-39; BatchNorm2d(affine=True) behind the spectral convs):
+    train-mode forward, input gradient, every parameter gradient and the running buffers against the real reference
+    (de_spectralbatch.npz)."""
+    from seg2eye_amd import networks, synthetic as syn, ops
+    from conftest import checksum
+    z = load_golden('de_spectralbatch')
+    opt = _opt(ndf=8, ngf=8, crop_size=256, norm_D='spectralbatch', norm_E='spectralbatch', compute_dtype='fp32')
+    D = _load(networks.define_D(opt), z, 'D')
+    D.train()
+    label = torch.from_numpy(z['label']).to(DEV)
+    fake = torch.from_numpy(syn.smooth_images('d_fake', (2, 1, 64, 64), seed=71)).to(DEV).requires_grad_(True)
+    real = torch.from_numpy(syn.smooth_images('d_real', (2, 1, 64, 64), seed=71)).to(DEV)
+    imgs = torch.cat([fake[:, 0], real[:, 0]], 0).contiguous()
+    x = ops.seg_image_concat(torch.cat([label[:, 0], label[:, 0]], 0).contiguous(), imgs, 4, networks.discriminator.D_CPAD)
+    pred = D(x)
+    loss = sum((p[-1].float() * torch.from_numpy(syn.hash_uniform('dproj%d' % i, tuple(p[-1].shape), seed=71)).to(DEV)).sum() for i, p in enumerate(pred))
+    loss = loss + sum(f.float().abs().mean() for p in pred for f in p[:-1])
+    loss.backward()
+    assert abs(float(loss) - float(z['loss'][0])) <= 1e-3 * max(1.0, abs(float(z['loss'][0])))
+    for i in range(2):
+        np.testing.assert_allclose(pred[i][-1].detach().float().cpu().numpy(), z['pred_%d' % i], atol=2e-3, rtol=0)
+        assert_checksum_close(pred[i][1].detach().float(), z['feat_%d_1' % i], 1e-3, 'feat %d' % i)
+    gf = z['grad_fake']
+    assert float((fake.grad.cpu() - torch.from_numpy(gf)).abs().max()) <= KINK_TOL * float(np.abs(gf).max())
+    for k, p in D.named_parameters():
+        ref, got = z['gradD_' + k], checksum(p.grad)
+        assert abs(got[0] - ref[0]) + abs(got[1] - ref[1]) <= KINK_TOL * ref[1] + 1e-7, (k, got[:2], ref[:2])
+    for k, v in D.state_dict().items():
+        if 'running' in k:
+            np.testing.assert_allclose(v.float().cpu().numpy(), z['bufD_' + k], atol=1e-4, rtol=1e-4, err_msg=k)
+    E = _load(networks.define_E(opt), z, 'E')
+    E.train()
+    xs = torch.from_numpy(syn.smooth_images('e_style', (3, 1, 256, 256), seed=72)).to(DEV).requires_grad_(True)
+    mu, logvar, feats = E(xs)
+    (mu.sum() + 0.5 * logvar.sum()).backward()
+    np.testing.assert_allclose(mu.detach().cpu().numpy(), z['e_mu'], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(logvar.detach().cpu().numpy(), z['e_logvar'], atol=1e-3, rtol=0)
+    for k, p in E.named_parameters():
+        ref, got = z['gradE_' + k], checksum(p.grad)
+        assert abs(got[0] - ref[0]) + abs(got[1] - ref[1]) <= KINK_TOL * ref[1] + 1e-7, (k, got[:2], ref[:2])
