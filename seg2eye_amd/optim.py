@@ -10,9 +10,18 @@ _ALIGN = 4          # elements; keeps every parameter 16-byte aligned inside the
 
 
 class FlatAdam:
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, never_updated=()):
+        """never_updated: parameters that are in the optimizer but never receive a gradient (netE.fc_var: `logvar` enters no
+        loss, pix2pix_model.py:307-314).  torch.optim.Adam SKIPS a parameter whose .grad is None -- no moment update and, what
+        matters, no weight decay -- so they are laid out at the END of the arenas and the Adam launch stops before them."""
+        skip = {id(p) for p in never_updated}
         seen, plist = set(), []
-        for p in params:
+        for p in list(params) + [p for p in never_updated]:
+            if id(p) not in seen and id(p) not in skip:
+                seen.add(id(p))
+                plist.append(p)
+        n_active_params = len(plist)
+        for p in never_updated:
             if id(p) not in seen:
                 seen.add(id(p))
                 plist.append(p)
@@ -26,6 +35,7 @@ class FlatAdam:
             self.offsets.append(n)
             n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = n
+        self.numel_active = self.offsets[n_active_params] if n_active_params < len(plist) else n
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -71,7 +81,8 @@ class FlatAdam:
         self.rebind_grads()
         self.sync_hyper(grad_scale)
         self.step_count += 1
-        ops.adam_flat_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hyper)
+        k = self.numel_active
+        ops.adam_flat_step(self.flat_p[:k], self.flat_g[:k], self.flat_m[:k], self.flat_v[:k], self.hyper)
 
     def state_dict(self):
         return {'step': self.step_count, 'm': self.flat_m, 'v': self.flat_v, 'lr': self.param_groups[0]['lr']}

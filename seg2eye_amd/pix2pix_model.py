@@ -101,18 +101,22 @@ class Pix2PixModel(nn.Module):
         G = self.netG
         late = block_params([m for m in (getattr(G, n, None) for n in ('conv_img', 'up_3', 'up_2')) if m is not None])
         mid = block_params([m for m in (getattr(G, n, None) for n in ('up_1', 'up_0')) if m is not None])
-        early = block_params([G]) + fc_params + [q for q in self.netE.parameters()]       # whatever is left of netG, the FCs, netE
+        dead = list(self.netE.fc_var.parameters())          # logvar enters no loss: never a gradient (torch's Adam skips them)
+        dead_ids = {id(q) for q in dead}
+        early = block_params([G]) + fc_params + [q for q in self.netE.parameters() if id(q) not in dead_ids]   # rest of netG, FCs, netE
         G_params = late + mid + early
+        self._arena_groups_G_dead = dead
         self._arena_groups_G = [len(late), len(mid), len(early)]
         if opt.no_TTUR:
             beta1, beta2, G_lr, D_lr = opt.beta1, opt.beta2, opt.lr, opt.lr
         else:
             beta1, beta2, G_lr, D_lr = 0.0, 0.9, opt.lr / 2, opt.lr * 2
-        optimizer_G = FlatAdam(G_params, lr=G_lr, betas=(beta1, beta2), weight_decay=opt.weight_decay)
+        optimizer_G = FlatAdam(G_params, lr=G_lr, betas=(beta1, beta2), weight_decay=opt.weight_decay, never_updated=dead)
         bounds, k = [0], 0
         for cnt in self._arena_groups_G:
             k += cnt
             bounds.append(optimizer_G.offsets[k] if k < len(optimizer_G.offsets) else optimizer_G.numel)
+        bounds[-1] = optimizer_G.numel                              # (the never-updated tail rides with the last group)
         self.grad_groups_G = [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
         optimizer_D = FlatAdam(list(self.netD.parameters()), lr=D_lr, betas=(beta1, beta2),
                                weight_decay=opt.weight_decay) if opt.isTrain else None

@@ -72,6 +72,8 @@ class Pix2PixTrainer:
             self._stage_inputs(data)                         # captures on first use; turns graphs off if that fails
         if self.use_graphs:
             self.graph_G.replay()
+            for k, v in getattr(self, '_static_log', {}).items():   # the replay refreshed these in place: log this step's values
+                self.pix2pix_model.add_to_loss_log(k, v.clone())
         else:
             self._g_body(data)
         self.optimizer_G.step(grad_scale=self.sync_G.all_reduce())
@@ -128,6 +130,11 @@ class Pix2PixTrainer:
         from .spectral import ensure_bank
         banks = [b for b in (ensure_bank(net) for net in (m.netG, m.netD, m.netE)) if b is not None]
         snap = [b.uv_arena.clone() for b in banks]
+        # ... and so do BatchNorm's running statistics (--norm_G spectralspadebatch3x3, the reference's default)
+        bn_bufs = [t for net in (m.netG, m.netD, m.netE) for mod in net.modules()
+                   if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) and mod.track_running_stats
+                   for t in (mod.running_mean, mod.running_var, mod.num_batches_tracked)]
+        bn_snap = [t.clone() for t in bn_bufs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -153,6 +160,12 @@ class Pix2PixTrainer:
             with torch.no_grad():
                 for b, s0 in zip(banks, snap):
                     b.uv_arena.copy_(s0)
+                for t, s0 in zip(bn_bufs, bn_snap):
+                    t.copy_(s0)
+            # the '*/raw' log entries (pix2pix_model.add_to_loss_log) appended while capturing are the graph's static output
+            # tensors: remember them, a replay refreshes their values and run_generator_one_step re-registers them
+            self._static_log = {k: v[-1] for k, v in m.loss_log.items() if len(v)}
+            m.reset_loss_log()
 
     def get_latest_losses(self, include_log_losses=False):
         losses = {**self.g_losses, **self.d_losses}

@@ -399,9 +399,18 @@ def test_trainer_optional_losses_fp32_match_reference(graphs):
         np.testing.assert_allclose(v.detach().cpu().numpy().reshape(ref.shape), ref, rtol=2e-3, atol=2e-4, err_msg=k)
     sub = tr.get_latest_generated().detach()[:, :, ::8, ::8].float().cpu().numpy()
     assert np.abs(sub - z['it0_fake_sub']).max() < G_TOL
+    state0 = {tag: {k: v.detach().clone() for k, v in net.state_dict().items()} for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE))}
+    # the log-only '*/raw' entries (pix2pix_model.py:49-59, 196-229) survive get_latest_losses' reset under graph replay too:
+    # every step logs its own values (L2/raw * lambda == L2/weighted of the same step)
+    for _ in range(2):
+        log = tr.get_latest_losses(include_log_losses=True)
+        assert {'L2/raw', 'L1/raw', 'style_w/raw', 'style_feat/raw', 'gram/raw'} <= set(log), sorted(log)
+        np.testing.assert_allclose(float(log['L2/raw']) * 15.0, float(log['L2/weighted'].mean()), rtol=1e-4)
+        tr.run_generator_one_step(dict(data))
+        tr.run_discriminator_one_step(dict(data))
     if not graphs:           # (capture runs warm-up iterations on the weights' spectral-norm state restored afterwards;
         for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):      # parameters are compared on the eager run)
-            for k, v in net.state_dict().items():
+            for k, v in state0[tag].items():
                 lr = opt.lr * 2 if tag == 'D' else opt.lr / 2
                 flip = 2 * lr if v.dtype.is_floating_point and not k.endswith(('_u', '_v')) else 0.0
                 assert_checksum_close(v, z['it0_ck_%s.%s' % (tag, k)], 2e-3, '%s.%s' % (tag, k), flip=flip)
