@@ -10,7 +10,8 @@ import torch  # noqa: F401  -- MUST load before the library: both link libamdhip
 #                       end up with torch's HIP runtime, or launches from the .so see "no ROCm-capable device"
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libseg2eye_hip.so')
+# S2E_LIB_PATH: an alternative build of the SAME library (same-box A/B runs of experiment builds); never a fallback
+LIB_PATH = os.environ.get('S2E_LIB_PATH') or os.path.join(_HERE, 'lib', 'libseg2eye_hip.so')
 
 S2E_F32, S2E_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
