@@ -172,8 +172,11 @@ int s2e_weight_grads_batched(const s2e_grad_job* jobs, const int* block_map, int
 
 /* ------------------------------------------------------------------ InstanceNorm statistics
  * nn.InstanceNorm2d(affine=False) statistics, normalization.py:73 / :41 (biased variance, eps 1e-5).
- * x (N, HW, C) -> stats (N, C, 2) fp32 = {mean, rstd}.  ws: N*C*2 doubles of scratch, ZERO-FILLED by the caller
- * (one fill can serve all the scratch of a step: seg2eye_amd/ops.py::ZeroPool); dirty on return. */
+ * x (N, HW, C) -> stats (N, C, 2) fp32 = {mean, rstd}.  ws: s2e_in_stats_workspace_bytes(...) bytes of scratch, no
+ * initialisation needed: the row-walking blocks write per-block partial sums there (no atomics) and the finalising kernel
+ * adds them in a fixed order in fp64 -- the statistics are bit-reproducible.  On return the first N*C*2 doubles of ws hold
+ * {sum x, sum x^2} per (n, c) (BatchNorm SPADE combines them over the batch). */
+size_t s2e_in_stats_workspace_bytes(int dtype, int N, int HW, int C);
 int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, void* stream);
 
 /* ------------------------------------------------------------------ SPADE+Style modulation / IN+LeakyReLU
@@ -206,9 +209,10 @@ int s2e_spade_conv_modulate(int dtype, const void* actv, const void* w_packed, c
  * style_ld (both calls): floats between consecutive samples' rows of style AND dstyle; 0 = dense (2C).  A
  * generator keeps the style codes of all its SPADE+Style layers as column slices of ONE (N, sum 2C) matrix
  * (one GEMM for all style FCs, networks/stylebank.py), hence the leading dimension.
- * ws: N*C*6 doubles of scratch (N*C*4 fp64 sums, then N*C float4 coefficients), the sums ZERO-FILLED by the caller;
- * dirty on return.  mode S2E_NORM_SPADE_STYLE_BATCH: `stats` holds the same {mean, rstd} of the whole batch for every
+ * ws: s2e_modulate_bwd_workspace_bytes(...) bytes of scratch, no initialisation needed (N*C*4 fp64 sums, N*C float4
+ * coefficients, then the row-walking blocks' partial sums: plain stores, added up in a fixed order -- no atomics).  mode S2E_NORM_SPADE_STYLE_BATCH: `stats` holds the same {mean, rstd} of the whole batch for every
  * sample (param_free_norm = BatchNorm2d, normalization.py:74-75) and the normalisation's backward sums over N*HW. */
+size_t s2e_modulate_bwd_workspace_bytes(int dtype, int N, int HW, int C);
 int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
                      const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                      int N, int HW, int C, int lrelu, int style_ld, void* stream);

@@ -9,11 +9,14 @@
 #include "common.h"
 
 static constexpr int kSlabIters = 16;     // row passes per block in the row-walking kernels
-// Row passes per block of the row-walking reduction kernels.  Every block ends with one fp64 atomic per
-// (channel, sum) on addresses shared by all blocks of the sample, and contended atomics are what these kernels
-// were bound by (measured: in_stats of (8,256,256,128) 115 us with 2048 blocks, 30 us with 256): aim for
-// S2E_SLAB_BLOCKS (default 256: 330.5 / 328.7 / 327.3 / 325.2 img/s at 256 / 384 / 512 / 1024 on one box, 318.0 / 316.9 /
-// 313.5 at 256 / 192 / 128 on another) blocks in total, never fewer than 16 passes per block.
+// Row passes per block of the row-walking reduction kernels.  A block ends by writing its per-channel partial sums to
+// its own slot of the workspace (plain stores; a later tiny kernel adds the slots of a sample up in fp64, in a fixed order:
+// the statistics are bit-reproducible, run to run and across data-parallel replicas).  Round 1 ended every block with fp64
+// atomics on addresses shared by all blocks of the sample; the grid was then capped by their contention (in_stats of
+// (8,256,256,128): 115 us with 2048 blocks, 30 us with 256).  Without atomics the optimum stays where it was -- few, long
+// sequential row streams suit HBM better than many short ones: S2E_SLAB_BLOCKS blocks in total, same box, whole step:
+// 348.1 / 343.7 / 341.7 / 342.1 img/s at 256 / 1024 / 2048 / 4096 (modulate_bwd 2.41 / 2.61 / 2.73 / 2.71 ms per step; with the
+// atomics, at 256: 2.49) -- default 256, never fewer than 16 passes per block.
 static int slab_iters_for(int HW, int rpp, int N, int zblocks) {
     static const int target = [] { const char* e = getenv("S2E_SLAB_BLOCKS"); return e ? atoi(e) : 256; }();
     const int per_n = target / (N * zblocks) > 1 ? target / (N * zblocks) : 1;
@@ -39,7 +42,7 @@ static RowGeom row_geom(int C, int vec) {
 
 // ------------------------------------------------------------------------------------ in_stats
 template <typename T>
-__global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restrict__ x, double* __restrict__ ws,
+__global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restrict__ x, float* __restrict__ part,
                                                                int HW, int C, int cg, int cgb, int rpp, int iters) {
     constexpr int VEC = Vec<T>::N;
     __shared__ float red[256 * VEC * 2];
@@ -87,21 +90,36 @@ __global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restri
                 a += red[((r * cgb + tx) * VEC + j) * 2];
                 b += red[((r * cgb + tx) * VEC + j) * 2 + 1];
             }
-            double* w = ws + ((size_t)n * C + g * VEC + j) * 2;
-            atomicAdd(w, (double)a);
-            atomicAdd(w + 1, (double)b);
+            float* w = part + (((size_t)n * gridDim.x + blockIdx.x) * C + g * VEC + j) * 2;     // slot [n][block][c]
+            w[0] = a; w[1] = b;
         }
     }
 }
 
-__global__ void in_stats_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats, int total, int HW, float eps) {
+__global__ void in_stats_finalize_kernel(const float* __restrict__ part, double* __restrict__ ws, float* __restrict__ stats,
+                                         int total, int C, int P, int HW, float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const double mean = ws[2 * i] / HW;
-    double var = ws[2 * i + 1] / HW - mean * mean;
+    const int n = i / C, c = i - n * C;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < P; ++b) {                            // fixed order: the statistics are bit-reproducible
+        const float* w = part + (((size_t)n * P + b) * C + c) * 2;
+        s += (double)w[0]; q += (double)w[1];
+    }
+    ws[2 * i] = s; ws[2 * i + 1] = q;                        // {sum x, sum x^2}: BatchNorm SPADE combines them over the batch
+    const double mean = s / HW;
+    double var = q / HW - mean * mean;
     if (var < 0.0) var = 0.0;
     stats[2 * i] = (float)mean;
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" size_t s2e_in_stats_workspace_bytes(int dtype, int N, int HW, int C) {
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (N <= 0 || HW <= 0 || C <= 0 || C % vec) return 0;
+    const RowGeom g = row_geom(C, vec);
+    const int P = ceil_div(HW, g.rpp * slab_iters_for(HW, g.rpp, N, g.zblocks));
+    return (size_t)N * C * 2 * sizeof(double) + (size_t)N * P * C * 2 * sizeof(float);
 }
 
 extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, void* stream) {
@@ -112,11 +130,13 @@ extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, floa
     hipStream_t st = (hipStream_t)stream;
     const RowGeom g = row_geom(C, vec);
     const int iters = slab_iters_for(HW, g.rpp, N, g.zblocks);
-    dim3 grid(ceil_div(HW, g.rpp * iters), N, g.zblocks);
-    if (dtype == S2E_BF16) in_stats_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, ws, HW, C, g.cg, g.cgb, g.rpp, iters);
-    else in_stats_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)x, ws, HW, C, g.cg, g.cgb, g.rpp, iters);
+    const int P = ceil_div(HW, g.rpp * iters);
+    dim3 grid(P, N, g.zblocks);
+    float* part = (float*)(ws + (size_t)N * C * 2);          // [N][P][C][2] floats behind the N*C*2 doubles
+    if (dtype == S2E_BF16) in_stats_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, part, HW, C, g.cg, g.cgb, g.rpp, iters);
+    else in_stats_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)x, part, HW, C, g.cg, g.cgb, g.rpp, iters);
     S2E_CHECK_LAUNCH("in_stats_partial_kernel");
-    in_stats_finalize_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(ws, stats, N * C, HW, eps);
+    in_stats_finalize_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, ws, stats, N * C, C, P, HW, eps);
     S2E_CHECK_LAUNCH("in_stats_finalize_kernel");
     return S2E_OK;
 }
@@ -292,7 +312,7 @@ extern "C" int s2e_modulate_fwd(int dtype, int mode, const void* x, const void* 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __restrict__ gin, const T* __restrict__ x,
         const T* __restrict__ gb, const float* __restrict__ stats, const float* __restrict__ style,
-        T* __restrict__ dgb, double* __restrict__ ws, int HW, int C, int cg, int cgb, int rpp, int lrelu, int sld, int iters,
+        T* __restrict__ dgb, float* __restrict__ part, int HW, int C, int cg, int cgb, int rpp, int lrelu, int sld, int iters,
         const T* __restrict__ fout) {
     // fout != NULL (S2E_NORM_GAMMA_ONLY): gb holds gamma alone, (N,HW,C); the LeakyReLU mask comes from the sign of the
     // forward's OUTPUT fout (LeakyReLU keeps the sign of its argument) instead of recomputing it from gamma and beta
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
             for (int k = 0; k < NS; ++k) {
                 float acc = 0.f;
                 for (int r = 0; r < rpp; ++r) acc += red[((r * cgb + tx) * VEC + j) * NS + k];
-                atomicAdd(ws + ((size_t)n * C + g * VEC + j) * 4 + k, (double)acc);
+                part[(((size_t)n * gridDim.x + blockIdx.x) * C + g * VEC + j) * 4 + k] = acc;      // slot [n][block][c][k]
             }
     }
 }
@@ -410,13 +430,42 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
 // The element-wise pass then needs 16 B of constants per channel instead of 32 B of doubles + stats + style and no
 // fp64 conversions: it was VALU-issue-bound (22 loads and ~350 instructions per 16-byte vector), not HBM-bound.
 // batch != 0 (BatchNorm SPADE: statistics over the whole batch): S0, S1 are summed over the samples and HW -> N*HW.
+// ws: (N,C,4) fp64 sums.  part != NULL: they are first formed here from the blocks' partial slots ([N][P][C][4] floats, added in
+// a fixed order: bit-reproducible); part == NULL: ws already holds them (second stage of s2e_modulate_bwd_staged).
 template <int MODE>
-__global__ void modulate_bwd_coef_kernel(const double* __restrict__ ws, f32x4_t* __restrict__ coef, const float* __restrict__ stats,
-                                         const float* __restrict__ style, float* __restrict__ dstyle, int N, int C, int HW, int sld, int batch,
-                                         double batch_count) {
+__global__ void modulate_bwd_sums_kernel(const float* __restrict__ part, double* __restrict__ ws, int N, int C, int P) {
+    constexpr int NS = (MODE == S2E_NORM_SPADE_STYLE) ? 4 : 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < P; ++b) {
+        const float* w = part + (((size_t)n * P + b) * C + c) * 4;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] += (double)w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ws[(size_t)i * 4 + k] = s[k];
+}
+
+template <int MODE>
+__global__ void modulate_bwd_coef_kernel(double* __restrict__ ws, const float* __restrict__ part, int P, f32x4_t* __restrict__ coef, const float* __restrict__ stats,
+                                         const float* __restrict__ style, float* __restrict__ dstyle, int N, int C, int HW, int sld, int batch,
+                                         double batch_count) {
+    constexpr int NS = (MODE == S2E_NORM_SPADE_STYLE) ? 4 : 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    if (part && !batch) {                                    // per-sample statistics: this thread's own (n, c) sums
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < P; ++b) {
+            const float* w = part + (((size_t)n * P + b) * C + c) * 4;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s[k] += (double)w[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ws[(size_t)i * 4 + k] = s[k];
+    }
     double s0d = ws[(size_t)i * 4], s1d = ws[(size_t)i * 4 + 1];
     float inv_hw = 1.f / (float)HW;
     if (batch) {
@@ -525,9 +574,15 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
     for (int b = 0; b < 31; ++b) if ((1 << b) == rg.cg) cg_shift = b;
     const int gridc = ceil_div((long)N * C, 256);
     f32x4_t* coef = (f32x4_t*)(ws + (size_t)N * C * 4);
+    const int P = (int)grid1.x;                            // partial-sum slots per sample
+    float* part = (float*)(ws + (size_t)N * C * 6);        // [N][P][C][4] floats behind the sums and the coefficients
+    // the sums of ALL samples must be complete before the batch-statistics coefficients read them, and a staged call hands
+    // them to the caller between the stages: a separate (tiny) launch then; otherwise the coefficient kernel adds up its own
+    const bool sums_first = batch || stage == 1;
 #define S2E_LAUNCH_BWD(TT, MM) do { \
-    if (stage != 2) modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, ws, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters, (const TT*)fout); \
-    if (stage != 1) { modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, coef, stats, style, dstyle, N, C, HW, sld, batch, batch_count); \
+    if (stage != 2) { modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, part, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters, (const TT*)fout); \
+        if (sums_first) modulate_bwd_sums_kernel<MM><<<gridc, 256, 0, st>>>(part, ws, N, C, P); } \
+    if (stage != 1) { modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, (stage == 2 || sums_first) ? nullptr : part, P, coef, stats, style, dstyle, N, C, HW, sld, batch, batch_count); \
     modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst); } } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
@@ -556,4 +611,12 @@ extern "C" int s2e_modulate_bwd_staged(int dtype, int mode, const void* g, const
                                        int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, void* stream) {
     if (stage < 0 || stage > 2) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_staged: stage %d", stage);
     return modulate_bwd_impl(dtype, mode, g, x, gb, out, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream, stage, batch_count);
+}
+
+extern "C" size_t s2e_modulate_bwd_workspace_bytes(int dtype, int N, int HW, int C) {
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (N <= 0 || HW <= 0 || C <= 0 || C % vec) return 0;
+    const RowGeom rg = row_geom(C, vec);
+    const int P = ceil_div(HW, rg.rpp * slab_iters_for(HW, rg.rpp, N, rg.zblocks));
+    return (size_t)N * C * 6 * sizeof(double) + (size_t)N * P * C * 4 * sizeof(float);
 }

@@ -399,12 +399,12 @@ def in_stats(x, return_sums=False):
     return_sums: also the raw fp64 per-sample sums (N,C,2) {sum x, sum x^2} (BatchNorm SPADE combines them over the batch)."""
     _need(x)
     n, h, w, c = x.shape
-    ws = ZeroPool.take(n * c * 2, torch.float64, x.device)
+    ws = torch.empty(L.lib().s2e_in_stats_workspace_bytes(_dt(x), n, h * w, c) // 8, dtype=torch.float64, device=x.device)
     stats = torch.empty(n, c, 2, dtype=torch.float32, device=x.device)
     LaunchProfiler.run('in_stats', 0.0, lambda: L.check(
         L.lib().s2e_in_stats(_dt(x), _p(x), n, h * w, c, IN_EPS, _p(ws), _p(stats), _stream()), 's2e_in_stats'),
         nbytes=float(x.numel() * x.element_size()))                   # algorithmic: x read once
-    return (stats, ws.view(n, c, 2)) if return_sums else stats
+    return (stats, ws[:n * c * 2].view(n, c, 2)) if return_sums else stats
 
 
 def label_conv3x3_raw(label, weight, bias, n, H, W, h, w, cout, relu, dtype):
@@ -761,7 +761,7 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
             raise RuntimeError('ModulateFn: banked style without a gradient accumulator')
         dstyle, dsp, ld = None, ctx.dbig.data_ptr() + 4 * ctx.off, style.shape[1]
     sp = style.data_ptr() + 4 * (ctx.off or 0)
-    ws = ZeroPool.take(n * c * 6, torch.float64, x.device)      # fp64 sums + float4 coefficients
+    ws = torch.empty(L.lib().s2e_modulate_bwd_workspace_bytes(_dt(x), n, h * w, c) // 8, dtype=torch.float64, device=x.device)
     mode = (NORM_SPADE_STYLE_BATCH if ctx.batch else NORM_SPADE_STYLE) | (NORM_ACCUMULATE_DX if acc else 0)
     # algorithmic bytes: the two-pass structure is forced by the per-(n,c) sums, so g, x, gamma are read by
     # both passes; dgamma, dbeta and dx are written once: 9 accesses per element of x
@@ -894,7 +894,7 @@ class InstanceNormFn(torch.autograd.Function):
         n, h, w, c = x.shape
         g = g.contiguous()
         dx = torch.empty_like(x)
-        ws = ZeroPool.take(n * c * 6, torch.float64, x.device)      # fp64 sums + float4 coefficients
+        ws = torch.empty(L.lib().s2e_modulate_bwd_workspace_bytes(_dt(x), n, h * w, c) // 8, dtype=torch.float64, device=x.device)
         LaunchProfiler.run('modulate_bwd', 0.0, lambda: L.check(
             L.lib().s2e_modulate_bwd(_dt(x), NORM_PLAIN_IN, _p(g), _p(x), None, _p(stats), None, _p(dx), None, None,
                                      _p(ws), n, h * w, c, int(ctx.lrelu), 0, _stream()), 's2e_modulate_bwd'),
