@@ -257,6 +257,11 @@ int s2e_upsample2x_bwd(int dtype, const void* gy, void* gx, int N, int h, int w,
  * Ho = (H+1)/2, Wo = (W+1)/2 (floor((H+2-3)/2)+1). */
 int s2e_avgpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
 int s2e_avgpool3x3s2_bwd(int dtype, const void* gy, void* gx, int N, int H, int W, int C, void* stream);
+/* F.interpolate(x, size=(Ho, Wo), mode='bilinear') (align_corners=False) of single-channel images: the encoder's front end
+ * (encoder.py:54-55 resizes every style image to 256 x 256).  x: fp32 (N,H,W); y: (N,Ho,Wo) of dtype -- what the first conv
+ * consumes.  bwd: gx fp32 (N,H,W), ZERO-FILLED by the caller, is accumulated into (fp32 atomics). */
+int s2e_bilinear_resize_fwd(int dtype, const float* x, void* y, int N, int H, int W, int Ho, int Wo, void* stream);
+int s2e_bilinear_resize_bwd(int dtype, const void* gy, float* gx, int N, int H, int W, int Ho, int Wo, void* stream);
 /* gx = gy * (1 - y*y)   (backward of torch.tanh, generator.py:100). */
 int s2e_tanh_bwd(int dtype, const void* gy, const void* y, void* gx, long n, void* stream);
 /* gx = gy * (y > 0 ? 1 : 0.2): backward of LeakyReLU(0.2) (discriminator.py:85, nn.LeakyReLU) given its

@@ -84,6 +84,8 @@ SIGNATURES = {
     's2e_openeds_error': [_i, _vp, _vp, _i, _i, _i, _vp, _vp],
     's2e_openeds_error_u8': [_vp, _vp, _i, _i, _i, _vp, _vp],
     's2e_resize_to255': [_i, _vp, _i, _i, _i, _vp, _i, _i, _vp],
+    's2e_bilinear_resize_fwd': [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    's2e_bilinear_resize_bwd': [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     's2e_upsample2x_fwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
     's2e_upsample2x_bwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],
     's2e_avgpool3x3s2_fwd': [_i, _vp, _vp, _i, _i, _i, _i, _vp],

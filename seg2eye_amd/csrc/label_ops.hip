@@ -361,3 +361,69 @@ extern "C" int s2e_lrelu_bwd(int dtype, const void* gy, const void* y, void* gx,
     S2E_CHECK_LAUNCH("lrelu_bwd_kernel");
     return S2E_OK;
 }
+
+// ------------------------------------------------------------------------------------ bilinear resize (encoder front end)
+// F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=False) of single-channel images (encoder.py:55: every style
+// image is resized to 256 x 256 before the first conv): source coordinate (d + 0.5) * (in / out) - 0.5 clamped at 0, taps
+// i0 = floor, i1 = min(i0 + 1, in - 1), weights (1 - l, l) -- torch's area_pixel_compute_source_index rule, fp32 (opmath).
+// x: (N, H, W) fp32; y: (N, Ho, Wo) of T (the compute dtype the first conv consumes; (N,Ho,Wo,1) NHWC is the same memory).
+struct BilTap { int i0, i1; float l; };
+__device__ __forceinline__ BilTap bil_tap(int d, float scale, int n_in) {
+    float f = ((float)d + 0.5f) * scale - 0.5f;
+    f = f < 0.f ? 0.f : f;
+    BilTap t;
+    t.i0 = (int)f;
+    t.i1 = t.i0 + (t.i0 < n_in - 1 ? 1 : 0);
+    t.l = f - (float)t.i0;
+    return t;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, T* __restrict__ y, int H, int W, int Ho, int Wo,
+                                                           float sy, float sx) {
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y, n = blockIdx.z;
+    if (ox >= Wo) return;
+    const BilTap ty = bil_tap(oy, sy, H), tx = bil_tap(ox, sx, W);
+    const float* p = x + (size_t)n * H * W;
+    const float v = (1.f - ty.l) * ((1.f - tx.l) * p[(size_t)ty.i0 * W + tx.i0] + tx.l * p[(size_t)ty.i0 * W + tx.i1])
+                  + ty.l * ((1.f - tx.l) * p[(size_t)ty.i1 * W + tx.i0] + tx.l * p[(size_t)ty.i1 * W + tx.i1]);
+    store1<T>(y + ((size_t)n * Ho + oy) * Wo + ox, v);
+}
+// gx (N, H, W) fp32, ZERO-FILLED by the caller, += the four taps of every output pixel's gradient (fp32 atomics: the images
+// are tiny -- 65536 outputs each -- and a gather form would need the inverse tap table of a non-integer scale)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ gy, float* __restrict__ gx, int H, int W, int Ho, int Wo,
+                                                           float sy, float sx) {
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y, n = blockIdx.z;
+    if (ox >= Wo) return;
+    const BilTap ty = bil_tap(oy, sy, H), tx = bil_tap(ox, sx, W);
+    const float g = load1<T>(gy + ((size_t)n * Ho + oy) * Wo + ox);
+    float* p = gx + (size_t)n * H * W;
+    atomicAdd(p + (size_t)ty.i0 * W + tx.i0, g * (1.f - ty.l) * (1.f - tx.l));
+    atomicAdd(p + (size_t)ty.i0 * W + tx.i1, g * (1.f - ty.l) * tx.l);
+    atomicAdd(p + (size_t)ty.i1 * W + tx.i0, g * ty.l * (1.f - tx.l));
+    atomicAdd(p + (size_t)ty.i1 * W + tx.i1, g * ty.l * tx.l);
+}
+
+static int bilinear_launch(int dtype, const void* a, void* b, int N, int H, int W, int Ho, int Wo, void* stream, bool fwd, const char* name) {
+    if (!a || !b || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) S2E_FAIL(S2E_ERR_ARG, "%s: bad argument", name);
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "%s: bad dtype %d", name, dtype);
+    if (Ho > 65535 || N > 65535) S2E_FAIL(S2E_ERR_UNSUPPORTED, "%s: grid too large", name);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(ceil_div(Wo, 256), Ho, N);
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    if (fwd) {
+        if (dtype == S2E_BF16) bilinear_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const float*)a, (bf16_t*)b, H, W, Ho, Wo, sy, sx);
+        else bilinear_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)a, (float*)b, H, W, Ho, Wo, sy, sx);
+    } else {
+        if (dtype == S2E_BF16) bilinear_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)a, (float*)b, H, W, Ho, Wo, sy, sx);
+        else bilinear_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)a, (float*)b, H, W, Ho, Wo, sy, sx);
+    }
+    S2E_CHECK_LAUNCH(name);
+    return S2E_OK;
+}
+extern "C" int s2e_bilinear_resize_fwd(int dtype, const float* x, void* y, int N, int H, int W, int Ho, int Wo, void* stream) {
+    return bilinear_launch(dtype, x, y, N, H, W, Ho, Wo, stream, true, "s2e_bilinear_resize_fwd");
+}
+extern "C" int s2e_bilinear_resize_bwd(int dtype, const void* gy, float* gx, int N, int H, int W, int Ho, int Wo, void* stream) {
+    return bilinear_launch(dtype, gy, gx, N, H, W, Ho, Wo, stream, false, "s2e_bilinear_resize_bwd");
+}

@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .._lib import ACT_LRELU
 from .. import packing
 from ..spectral import sn_begin
 from .base_network import BaseNetwork, compute_dtype_of
@@ -43,8 +44,9 @@ class ConvEncoder(BaseNetwork):
         bank = sn_begin(self, power_iterations)
         with packing.network_scope(self, bank):    # all weight packs of this forward: one launch
             if x.size(2) != 256 or x.size(3) != 256:
-                x = F.interpolate(x.float(), size=(256, 256), mode='bilinear')
-            h = x.permute(0, 2, 3, 1).contiguous().to(self.cdtype)          # (M,256,256,1): same memory order as NCHW
+                h = ops.bilinear_resize(x, 256, 256, self.cdtype)                    # F.interpolate(..., 'bilinear'), encoder.py:54-55
+            else:
+                h = x.permute(0, 2, 3, 1).contiguous().to(self.cdtype)              # (M,256,256,1): same memory order as NCHW
             feats = []
             for i in range(self.len_sequence):
                 blk = getattr(self, 'layer%d' % i)
@@ -53,7 +55,12 @@ class ConvEncoder(BaseNetwork):
                 if isinstance(blk, nn.Sequential):
                     h = apply_nonspade_norm(h, blk[1], lrelu=False)
                 feats.append(h.permute(0, 3, 1, 2))
-            out = F.leaky_relu(feats[-1].float(), 0.2).reshape(h.shape[0], -1)     # NCHW flatten order, encoder.py:68
-            mu = self.fc_mu(out)
-            logvar = self.fc_var(out)
-            return mu, logvar, feats
+        # fc_mu / fc_var on leaky_relu(x).view(M, -1) (encoder.py:68-71) as ONE 4x4 valid convolution: flattening (M,C,4,4) in
+        # NCHW order and multiplying by a (16, C*16) matrix is a conv with that matrix viewed (16, C, 4, 4); both heads are its 32
+        # output channels, the LeakyReLU is the conv's fused input activation.  fp32 (the style code feeds every modulation:
+        # the few kFLOP are not worth bf16's three digits).  Outside the pack plan's scope: the concatenated weight is a
+        # temporary, packed on the spot.
+        wcat = torch.cat([self.fc_mu.weight, self.fc_var.weight], 0).view(2 * self.opt.w_dim, h.shape[-1], self.so, self.so)
+        bcat = torch.cat([self.fc_mu.bias, self.fc_var.bias], 0)
+        out = ops.conv2d(h.float(), wcat, bcat, None, 1, 0, ACT_LRELU).reshape(h.shape[0], 2 * self.opt.w_dim)
+        return out[:, :self.opt.w_dim], out[:, self.opt.w_dim:], feats

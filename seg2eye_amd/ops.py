@@ -356,6 +356,8 @@ def _grad_dst(p):
     """The tensor a backward kernel may accumulate this parameter's gradient into directly: its .grad when
     that already exists as a contiguous fp32 tensor (optim.FlatAdam keeps .grad as a view of the gradient
     arena and zeroes it at the start of every step).  None -> return the gradient to autograd instead."""
+    if p is None or not p.is_leaf:                       # (a non-leaf's .grad is never an arena view; asking for it warns)
+        return None
     g = getattr(p, 'grad', None)
     if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
         return None
@@ -930,6 +932,34 @@ class Upsample2xFn(torch.autograd.Function):
 
 def upsample2x(x):
     return Upsample2xFn.apply(x)
+
+
+class BilinearResizeFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear') of single-channel images (N,1,H,W) fp32 -> (N,h,w,1) NHWC in `dtype`
+    (encoder.py:54-55)."""
+
+    @staticmethod
+    def forward(ctx, x, h, w, dtype):
+        a = _single_channel(x.detach().float())
+        _need(a)
+        n, H, W = a.shape
+        y = torch.empty(n, h, w, 1, dtype=dtype, device=a.device)
+        L.check(L.lib().s2e_bilinear_resize_fwd(_dt(y), _p(a), _p(y), n, H, W, h, w, _stream()), 's2e_bilinear_resize_fwd')
+        ctx.shape = (tuple(x.shape), H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        shape, H, W = ctx.shape
+        gy = gy.contiguous()
+        n, h, w, _ = gy.shape
+        gx = torch.zeros(n, H, W, dtype=torch.float32, device=gy.device)
+        L.check(L.lib().s2e_bilinear_resize_bwd(_dt(gy), _p(gy), _p(gx), n, H, W, h, w, _stream()), 's2e_bilinear_resize_bwd')
+        return gx.view(shape), None, None, None
+
+
+def bilinear_resize(x, h, w, dtype):
+    return BilinearResizeFn.apply(x, h, w, dtype)
 
 
 class AvgPool3x3s2Fn(torch.autograd.Function):

@@ -486,3 +486,23 @@ def test_openeds_metric_kernels(dtype):
     np.testing.assert_allclose(float(openEDSaccuracy(ia[0].to(dev), ib[0].to(dev))), float(O.openeds_accuracy(ia[0], ib[0])), rtol=1e-6)
     assert ImageProcessor.to_255imagebatch(a.float()).equal(O.to_255(a.float()))
 
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('hw', [(64, 96), (640, 384), (300, 200)])
+def test_bilinear_resize_matches_torch(hw, dtype):
+    """s2e_bilinear_resize_fwd / _bwd (the encoder's front end, encoder.py:54-55) against F.interpolate(mode='bilinear',
+    align_corners=False) and its autograd, up- and down-scaling."""
+    from seg2eye_amd import ops
+    H, W = hw
+    x = _rnd((3, 1, H, W), 51, torch.float32)
+    gy = _rnd((3, 1, 256, 256), 52, dtype)
+    xr = x.double().requires_grad_(True)
+    yr = F.interpolate(xr, size=(256, 256), mode='bilinear', align_corners=False)
+    yr.backward(gy.double())
+    xg = x.to(_dev()).requires_grad_(True)
+    y = ops.bilinear_resize(xg, 256, 256, dtype)
+    assert tuple(y.shape) == (3, 256, 256, 1) and y.dtype == dtype
+    _close(y.permute(0, 3, 1, 2), yr, dtype, what='bilinear fwd')
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(_dev()))
+    _close(xg.grad, xr.grad, torch.float32 if dtype == torch.float32 else dtype, what='bilinear bwd')
