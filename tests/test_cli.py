@@ -235,3 +235,59 @@ def test_tester_on_openeds_store(tmp_path):
         np.testing.assert_allclose(zl['error'][:len(errs_log)], np.asarray(errs_log, dtype=np.float64))
         assert zl['user'].dtype == np.dtype('S4') and zl['filename'].dtype == np.dtype('S13') and zl['user'][0] != b''
 
+
+
+def test_prepare_openeds_builds_the_store_the_dataset_reads(tmp_path):
+    """SURVEY 8 f4 (data/prepare_openeds.py:16-138): a miniature OpenEDS folder tree -> the per-user store -> OpenEDSDataset."""
+    from PIL import Image
+    from seg2eye_amd.options import parse
+    from seg2eye_amd.openeds_dataset import OpenEDSDataset
+    from seg2eye_amd.prepare_openeds import OpenEDSPreparator, load_store
+    rng = np.random.RandomState(0)
+    base = str(tmp_path)
+    P = OpenEDSPreparator
+    users = {'train': ['U111', 'U112'], 'validation': ['U211'], 'test': ['U311']}
+    truth = {}
+    for subset, ids in users.items():
+        mapping = []
+        for u in ids:
+            names = {k: ['%s%s%03d.png' % (u, k[0], i) for i in range(n)] for k, n in (('semantic_segmenation_images', 3), ('generative_images', 4), ('sequence_images', 2))}
+            mapping.append({'id': u, **names})
+            for key, folder in (('semantic_segmenation_images', os.path.join(P.FOLDER_SEMANTIC_SEGMENTATION, subset, 'images')),
+                                ('generative_images', os.path.join(P.FOLDER_GENERATIVE, subset)),
+                                ('sequence_images', os.path.join(P.FOLDER_SEQUENTIAL, subset))):
+                if subset == 'test' and key == 'generative_images':
+                    continue                                            # the test split has no generative images, only their labels
+                os.makedirs(os.path.join(base, folder), exist_ok=True)
+                for name in names[key]:
+                    img = rng.randint(0, 256, size=(640, 400)).astype(np.uint8)
+                    truth[name] = img
+                    Image.fromarray(img, mode='L').save(os.path.join(base, folder, name))
+            lab_src = names['generative_images'] if subset == 'test' else names['semantic_segmenation_images']
+            lab_dir = os.path.join(base, P.FOLDER_GENERATIVE, subset, 'labels') if subset == 'test' else \
+                os.path.join(base, P.FOLDER_SEMANTIC_SEGMENTATION, subset, 'labels')
+            os.makedirs(lab_dir, exist_ok=True)
+            for name in lab_src:
+                lab = rng.randint(0, 4, size=(640, 400)).astype(np.uint8)
+                truth['label:' + name] = lab
+                np.save(os.path.join(lab_dir, name[:-3] + 'npy'), lab)
+        with open(os.path.join(base, 'OpenEDS_%s_userID_mapping_to_images.json' % subset), 'w') as f:
+            json.dump(mapping, f)
+    out = OpenEDSPreparator(base, n_jobs=1, out_filename='mini.h5').run()
+    store = load_store(out) if out.endswith('.npz') else None
+    if store is None:
+        import h5py
+        store = h5py.File(out, 'r')
+    g = store['train']['U112']
+    assert g['images_ss'].shape == (3, 640, 400) and g['labels_ss'].shape == (3, 640, 400) and g['images_gen'].shape == (4, 640, 400)
+    assert bytes(g['images_ss_filenames'][1]) == b'U112s001' and bytes(g['labels_ss_filenames'][1]) == b'U112s001.png'
+    np.testing.assert_array_equal(np.asarray(g['images_gen'][2]), truth['U112g002.png'])
+    np.testing.assert_array_equal(np.asarray(g['labels_ss'][0]), truth['label:U112s000.png'])
+    assert 'labels_gen' in store['test']['U311'] and 'images_gen' not in store['test']['U311']
+    # ... and the dataset walks it
+    opt = parse(['--name', 'p', '--checkpoints_dir', str(tmp_path), '--dataset_mode', 'openeds', '--dataset_key', 'train', '--crop_size', '64',
+                 '--aspect_ratio', '0.8', '--style_sample_method', 'first', '--no_flip'])
+    ds = OpenEDSDataset(opt, store=store)
+    assert len(ds) == 6
+    it = ds[4]                                                          # second user, second sample
+    assert it['user'] == 'U112' and it['label'].shape == (80, 64) and it['style_image'].shape == (4, 1, 80, 64)
