@@ -250,6 +250,11 @@ def main():
                                'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                                'launches_per_step': d['launches'] / prof_steps, 'ms_per_step': d['ms'] / prof_steps,
                                'gflop_per_step': d['flops'] / prof_steps / 1e9,
+                               # label-sparse SPADE launches compute only the rectangles that cross a label boundary:
+                               # `achieved` counts their ALGORITHMIC FLOPs (2*Cin*Cout*k^2*pixels), `executed_*` the
+                               # multiply-adds really issued to the matrix pipe
+                               'executed_tflops': d['executed_flops'] / (d['ms'] * 1e-3) / 1e12,
+                               'executed_frac': d['executed_flops'] / (d['ms'] * 1e-3) / 1e12 / peak,
                                'measured': 'HIP events around every launch, eager re-run of the timed step'}
             if hbm:
                 # the HBM-bound class (north_star: "HBM GB/s against the roofline"): its dominant family by time, algorithmic

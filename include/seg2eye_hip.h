@@ -216,6 +216,32 @@ size_t s2e_modulate_bwd_workspace_bytes(int dtype, int N, int HW, int C);
 int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
                      const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                      int N, int HW, int C, int lrelu, int style_ld, void* stream);
+/* Label-sparse form of the fused launch.  gamma / beta at a pixel depend only on the labels of its 5x5 neighbourhood, so a
+ * rectangle of the fused launch's tiling (s2e_spade_conv_modulate_rect: tw x th pixels) whose pixels and in-image 2-pixel halo
+ * all carry ONE class takes them from a per-class table instead of the convolution -- exact up to fp32 summation order, and
+ * the common case on eye-region maps (72 % of the rectangles at 256^2 on the bench's maps):
+ *   s2e_label_rect_classify     : cls[r] = class | 255 per rectangle r = (n*tiles_y + ty)*tiles_x + tx of the nearest-downsampled
+ *                                 (h x w) label map; compact lists of the dense and of the uniform rectangles, in rectangle
+ *                                 order; counts[2] = {dense, uniform} (written).  Once per label batch and resolution.
+ *   s2e_spade_conv_modulate_sparse: s2e_spade_conv_modulate over the rectangles dense_list[0 .. counts[0]) only.
+ *   s2e_spade_class_table       : table[class][cy][cx][2C] fp32 = the SPADE's [gamma | beta] branch (mlp_shared -> ReLU -> the packed
+ *                                 [gamma | beta] conv, with all biases) on a map that is ONE class everywhere, per position class
+ *                                 (cy, cx) in {0, 1, interior, H-2, H-1}^2: zero padding makes the two outermost pixel rings differ.
+ *                                 w_sh fp32 (nh, ncls, 3, 3), nh <= 128; w_packed as the conv launches take it.
+ *   s2e_spade_modulate_uniform  : the modulation of the rectangles uni_list[0 .. counts[1]) with gamma | beta from that table.
+ * Together the two launches write every pixel of out (and gamma_out) exactly once. */
+int s2e_spade_conv_modulate_rect(int dtype, int N, int H, int W, int C, int nh, int flags, int* tw, int* th);
+int s2e_label_rect_classify(const uint8_t* label, int N, int H, int W, int h, int w, int tw, int th,
+                            uint8_t* cls, int* dense_list, int* uni_list, int* counts, void* stream);
+int s2e_spade_conv_modulate_sparse(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
+                                   const float* stats, const float* style, int style_ld, void* out, void* gamma_out,
+                                   int N, int H, int W, int C, int nh, int lrelu, int flags, const int* dense_list,
+                                   const int* counts, void* stream);
+int s2e_spade_class_table(int dtype, const float* w_sh, const float* b_sh, const void* w_packed, const float* bias,
+                          float* table, int ncls, int nh, int C, void* stream);
+int s2e_spade_modulate_uniform(int dtype, const void* x, const float* stats, const float* style, int style_ld,
+                               const float* table, const uint8_t* cls, const int* uni_list, const int* counts,
+                               void* out, void* gamma_out, int N, int H, int W, int C, int tw, int th, int lrelu, void* stream);
 /* The same backward for a forward that went through s2e_spade_conv_modulate: `gamma` is (N,HW,C) (what that call stored in
  * gamma_out; beta was never written) and the LeakyReLU mask is taken from the sign of the forward's output `out` (N,HW,C).
  * dgb is still (N,HW,2C) = [dgamma | dbeta], the operand of the conv's weight / data gradients.  SPADE_STYLE modes only. */

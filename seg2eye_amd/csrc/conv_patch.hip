@@ -51,6 +51,9 @@ struct PatchParams {
     const float* mstyle; int msld;    // style codes {s0 | s1}: row n at mstyle + n * msld, 2 * mC floats
     void* mgamma;                     // NULL, or (N, Ho, Wo, mC): gamma (with its bias) is stored for the backward pass
     int mC, mlrelu;
+    // FUSE, label-sparse launches: only the rectangles listed in rect_list[0 .. *rect_count) are computed (the others are
+    // label-uniform and take gamma / beta from a per-class table: s2e_spade_modulate_uniform); NULL = every rectangle
+    const int* rect_list; const int* rect_count;
 };
 
 template <typename T> struct PMfma;
@@ -113,10 +116,12 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     // ---- tiles: the grid is persistent (one workgroup per CU); round k works tiles k*G .. k*G+G-1, handed out so that an
     // XCD's workgroups hold a contiguous range (Cout tiles of one rectangle, then x, then y neighbours share L2 lines)
     struct Tile { int tn, n, oy0, ox0, split; };
-    auto decode = [&](int id) __attribute__((always_inline)) -> Tile {
+    auto decode = [&](int id, int rect = -1) __attribute__((always_inline)) -> Tile {
         Tile q;
         q.split = id / p.tiles_out; id -= q.split * p.tiles_out;
         q.tn = id % p.tiles_n; id /= p.tiles_n;
+        // (n, y, x) rectangle index from the dense list; `rect` >= 0: the entry was fetched ahead (one tile earlier)
+        if constexpr (FUSE) { if (p.rect_list) id = rect >= 0 ? rect : p.rect_list[id]; }
         q.ox0 = (id % p.tiles_x) * TW; id /= p.tiles_x;
         q.oy0 = (id % p.tiles_y) * TH;
         q.n = id / p.tiles_y;
@@ -125,7 +130,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     const int G = gridDim.x;
     const int slot = xcd_remap(blockIdx.x, G);
     int tile_id = slot;
-    if (tile_id >= p.tiles) return;
+    int n_tiles = p.tiles;
+    if constexpr (FUSE) { if (p.rect_count) n_tiles = *p.rect_count * p.tiles_n; }   // dense rectangles x Cout tiles
+    if (tile_id >= n_tiles) return;
 
     // ---- loads of one tile.  Patch piece q = r * NW + wave covers patch pixels 8q .. 8q+7; this lane brings the 16 bytes
     // at physical chunk lane & 7 of pixel 8q + (lane >> 3), i.e. logical chunk (lane & 7) ^ swz(pixel).
@@ -430,6 +437,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     for (;;) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        int next_rect = -1;                               // label-sparse launch: the next tile's rectangle, requested a tile ahead
+        if constexpr (FUSE) { if (p.rect_list && tile_id + G < n_tiles) next_rect = p.rect_list[(tile_id + G) / p.tiles_n]; }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -469,10 +478,10 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         // this tile out underneath them
         const int pbn = (pb + nch) & 1;               // continues the alternation; the other one stages the epilogue
         const int next_id = tile_id + G;
-        const bool has_next = next_id < p.tiles;
+        const bool has_next = next_id < n_tiles;
         Tile nxt = cur;
         if constexpr (FUSE) load_mod_consts(cur); else load_bias(cur);
-        if (has_next) { nxt = decode(next_id); aim(nxt); prologue(pbn); }
+        if (has_next) { nxt = decode(next_id, next_rect); aim(nxt); prologue(pbn); }
         if constexpr (FUSE) epilogue_fused(cur, pbn ^ 1); else epilogue(cur, pbn ^ 1);
         if (!has_next) break;
         cur = nxt; tile_id = next_id; pb = pbn;
@@ -591,7 +600,18 @@ static int fused_plan(int dtype, int N, int H, int W, int C, int nh, int flags, 
     if (nh % (8 * vec) != 0) return 0;
     *d = s2e_conv_desc{N, H, W, nh, H, W, 2 * C, 3, 3, 1, 1, 0, S2E_ACT_NONE, S2E_ACT_NONE, S2E_AUX_NONE};
     plan->splits = 1; plan->tw = plan->th = 0;
-    if (patch_rectangle(d, 3, &plan->tw, &plan->th) < ((flags & 1) ? 0.01 : 0.2)) return 0;
+    const double fill = patch_rectangle(d, 3, &plan->tw, &plan->th);
+    if (fill < ((flags & 1) ? 0.01 : 0.2)) return 0;
+    // among the rectangles that fill as well, the SQUAREST one (16 x 16 before 8 x 32 before 4 x 64): the smallest patch with its
+    // halo (324 vs 340 vs 396 pixels of DMA per chunk) and -- what matters for the label-sparse launch -- the shape most
+    // likely to lie inside one label region (bench maps at 256^2: 72 % / 70 % / 58 % of the rectangles are label-uniform)
+    for (int tw = 16; tw < plan->tw; tw *= 2) {
+        int th = 256 / tw;
+        if (th > H) th = H;
+        if ((th + 2) * (tw + 2) > 400) continue;
+        const double f = (double)H * W / (256.0 * ceil_div(H, th) * ceil_div(W, tw));
+        if (f >= fill - 1e-9) { plan->tw = tw; plan->th = th; break; }
+    }
     const long tiles = (long)N * ceil_div(H, plan->th) * ceil_div(W, plan->tw) * (C / 64);
     return (flags & 1) || tiles >= min_tiles;
 }
@@ -602,10 +622,20 @@ extern "C" int s2e_spade_conv_modulate_supported(int dtype, int N, int H, int W,
     return fused_plan(dtype, N, H, W, C, nh, flags, &d, &plan);
 }
 
-extern "C" int s2e_spade_conv_modulate(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
-                                       const float* stats, const float* style, int style_ld, void* out, void* gamma_out,
-                                       int N, int H, int W, int C, int nh, int lrelu, int flags, void* stream) {
+extern "C" int s2e_spade_conv_modulate_rect(int dtype, int N, int H, int W, int C, int nh, int flags, int* tw, int* th) {
+    s2e_conv_desc d; s2e_patch_plan plan;
+    if ((dtype != S2E_BF16 && dtype != S2E_F32) || !fused_plan(dtype, N, H, W, C, nh, flags, &d, &plan)) return 0;
+    if (tw) *tw = plan.tw;
+    if (th) *th = plan.th;
+    return 1;
+}
+
+static int spade_conv_modulate_impl(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
+                                    const float* stats, const float* style, int style_ld, void* out, void* gamma_out,
+                                    int N, int H, int W, int C, int nh, int lrelu, int flags, const int* rect_list, const int* rect_count,
+                                    void* stream) {
     if (!actv || !w_packed || !x || !stats || !style || !out) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: null pointer");
+    if ((rect_list == nullptr) != (rect_count == nullptr)) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate_sparse: rect_list and rect_count go together");
     if (((uintptr_t)stats | (uintptr_t)style | (uintptr_t)bias) & 15 || (style_ld & 3))
         S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: stats, style and bias must be 16-byte aligned (style_ld a multiple of 4)");
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: bad dtype %d", dtype);
@@ -625,10 +655,27 @@ extern "C" int s2e_spade_conv_modulate(int dtype, const void* actv, const void* 
     p.M = N * H * W; p.partial = nullptr;
     p.mx = x; p.mstats = stats; p.mstyle = style; p.msld = style_ld > 0 ? style_ld : 2 * C; p.mgamma = gamma_out;
     p.mC = C; p.mlrelu = lrelu;
+    p.rect_list = rect_list; p.rect_count = rect_count;
     const int grid = p.tiles < cu_count() ? p.tiles : cu_count();
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16) conv_patch_kernel<bf16_t, 128, 3, true><<<grid, 512, 0, st>>>(p);
     else conv_patch_kernel<float, 128, 3, true><<<grid, 512, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_patch_kernel (fused modulation)");
     return S2E_OK;
+}
+
+extern "C" int s2e_spade_conv_modulate(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
+                                       const float* stats, const float* style, int style_ld, void* out, void* gamma_out,
+                                       int N, int H, int W, int C, int nh, int lrelu, int flags, void* stream) {
+    return spade_conv_modulate_impl(dtype, actv, w_packed, bias, x, stats, style, style_ld, out, gamma_out, N, H, W, C, nh, lrelu, flags,
+                                    nullptr, nullptr, stream);
+}
+
+extern "C" int s2e_spade_conv_modulate_sparse(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
+                                              const float* stats, const float* style, int style_ld, void* out, void* gamma_out,
+                                              int N, int H, int W, int C, int nh, int lrelu, int flags, const int* rect_list,
+                                              const int* rect_count, void* stream) {
+    if (!rect_list || !rect_count) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate_sparse: rect_list / rect_count missing");
+    return spade_conv_modulate_impl(dtype, actv, w_packed, bias, x, stats, style, style_ld, out, gamma_out, N, H, W, C, nh, lrelu, flags,
+                                    rect_list, rect_count, stream);
 }

@@ -427,3 +427,271 @@ extern "C" int s2e_bilinear_resize_fwd(int dtype, const float* x, void* y, int N
 extern "C" int s2e_bilinear_resize_bwd(int dtype, const void* gy, float* gx, int N, int H, int W, int Ho, int Wo, void* stream) {
     return bilinear_launch(dtype, gy, gx, N, H, W, Ho, Wo, stream, false, "s2e_bilinear_resize_bwd");
 }
+
+// ------------------------------------------------------------------------------------ label-uniform rectangles (SPADE sparsity)
+// gamma and beta at a pixel depend on the labels of its 5x5 neighbourhood only (one-hot -> conv3x3 -> ReLU -> conv3x3,
+// normalization.py:97-101).  A rectangle of th x tw pixels of the (nearest-downsampled) h x w label map whose pixels AND the
+// in-image pixels of its 2-pixel halo all carry one class c takes gamma / beta from a per-class table instead of the conv
+// (s2e_spade_modulate_uniform); the others are listed for the dense launch (s2e_spade_conv_modulate_sparse).
+// Two launches: (1) one WAVE per rectangle reads the rectangle's pixels and in-image 2-pixel halo (<= ~550 labels, a few
+// independent byte loads per lane; a thread-per-rectangle loop with an early exit serialised 400 global-load latencies per
+// launch) and reduces "all equal to the first"; (2) one block compacts the flags into the two lists in rectangle order
+// (rectangle r = (n * tiles_y + ty) * tiles_x + tx, the fused launch's order) -- deterministic, and neighbouring dense
+// rectangles stay neighbours.  cls[r] = class, or 255 for a dense rectangle; counts = {dense, uniform}.
+__global__ __launch_bounds__(256) void label_rect_classify_kernel(const uint8_t* __restrict__ label, int N, int H, int W, int h, int w, int tw, int th,
+        int tiles_x, int tiles_y, uint8_t* __restrict__ cls) {
+    const int per = tiles_x * tiles_y;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= N * per) return;
+    const int n = r / per, rr = r - n * per;
+    const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
+    const int sy = H / h, sx = W / w;
+    const uint8_t* lb = label + (size_t)n * H * W;
+    const int y0 = max(0, ty * th - 2), y1 = min(h, ty * th + th + 2), x0 = max(0, tx * tw - 2), x1 = min(w, tx * tw + tw + 2);
+    const int rw = x1 - x0, cnt = rw * (y1 - y0);
+    const int first = lb[(size_t)y0 * sy * W + (size_t)x0 * sx];
+    int diff = 0;
+    for (int i = lane; i < cnt; i += 64) {
+        const int yy = i / rw, xx = i - yy * rw;
+        diff |= (lb[(size_t)(y0 + yy) * sy * W + (size_t)(x0 + xx) * sx] != first);
+    }
+    const bool any = __ballot(diff != 0) != 0ull;
+    if (lane == 0) cls[r] = any ? (uint8_t)255 : (uint8_t)first;
+}
+
+__global__ __launch_bounds__(1024) void label_rect_compact_kernel(const uint8_t* __restrict__ cls, int total, int* __restrict__ dense_list,
+        int* __restrict__ uni_list, int* __restrict__ counts) {
+    __shared__ int wsum[2][16];
+    __shared__ int base[2];
+    if (threadIdx.x == 0) { base[0] = 0; base[1] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r0 = 0; r0 < total; r0 += 1024) {
+        const int r = r0 + threadIdx.x;
+        const bool in = r < total;
+        const bool isd = in && cls[r] == 255, isu = in && cls[r] != 255;
+        const unsigned long long bd = __ballot(isd), bu = __ballot(isu);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int pd = __popcll(bd & below), pu = __popcll(bu & below);
+        if (lane == 0) { wsum[0][wave] = __popcll(bd); wsum[1][wave] = __popcll(bu); }
+        __syncthreads();
+        int od = base[0], ou = base[1];
+        for (int k = 0; k < wave; ++k) { od += wsum[0][k]; ou += wsum[1][k]; }
+        if (isd) dense_list[od + pd] = r;
+        if (isu) uni_list[ou + pu] = r;
+        __syncthreads();
+        if (threadIdx.x == 0) { for (int k = 0; k < 16; ++k) { base[0] += wsum[0][k]; base[1] += wsum[1][k]; } }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { counts[0] = base[0]; counts[1] = base[1]; }
+}
+
+extern "C" int s2e_label_rect_classify(const uint8_t* label, int N, int H, int W, int h, int w, int tw, int th,
+                                       uint8_t* cls, int* dense_list, int* uni_list, int* counts, void* stream) {
+    if (!label || !cls || !dense_list || !uni_list || !counts || N <= 0 || h <= 0 || w <= 0 || tw <= 0 || th <= 0)
+        S2E_FAIL(S2E_ERR_ARG, "s2e_label_rect_classify: bad argument");
+    if (H % h || W % w) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_label_rect_classify: %dx%d is not an integer multiple of %dx%d", H, W, h, w);
+    const int tiles_x = ceil_div(w, tw), tiles_y = ceil_div(h, th);
+    const int total = N * tiles_x * tiles_y;
+    hipStream_t st = (hipStream_t)stream;
+    label_rect_classify_kernel<<<ceil_div(total, 4), 256, 0, st>>>(label, N, H, W, h, w, tw, th, tiles_x, tiles_y, cls);
+    label_rect_compact_kernel<<<1, 1024, 0, st>>>(cls, total, dense_list, uni_list, counts);
+    S2E_CHECK_LAUNCH("label_rect_classify kernels");
+    return S2E_OK;
+}
+
+// The per-class table of a SPADE: gamma | beta (with their bias) of a map that is ONE class c everywhere, for every position
+// class (cy, cx) in {0, 1, interior, H-2, H-1}^2 -- 4 x 25 vectors of 2C floats.  With A[m] = ReLU(b_sh + sum of the in-image taps
+// of w_sh[:, c]) the activation at a pixel whose 3x3 window is cut by the image border as m = (my, mx) in {low, none, high}^2
+// (rounded to the activation dtype, as the dense path stores it),
+//     T[c][cy][cx][co] = b[co] + sum_{taps (ty,tx) inside the image at (cy,cx)}  W[co][ty][tx][:] . A[m(cy,ty)][m(cx,tx)][:]
+// with W the PACKED weight the conv launches use (same bf16 values).  One block = 64 output rows x one class; fp32 out.
+template <typename T>
+__global__ __launch_bounds__(256) void spade_class_table_kernel(const float* __restrict__ w_sh, const float* __restrict__ b_sh,
+        const T* __restrict__ wq, const float* __restrict__ bias, float* __restrict__ table, int ncls, int nh, int C2, int kpad) {
+    __shared__ float A[9][128];
+    __shared__ float part[4][25][64];
+    const int c = blockIdx.y, co0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * nh; i += 256) {                // A[m][ci]
+        const int m = i / nh, ci = i - m * nh, my = m / 3, mx = m - my * 3;
+        float a = b_sh[ci];
+        const float* wr = w_sh + ((size_t)ci * ncls + c) * 9;
+        for (int ty = 0; ty < 3; ++ty)
+            for (int tx = 0; tx < 3; ++tx) {
+                const bool ok = !((my == 0 && ty == 0) || (my == 2 && ty == 2) || (mx == 0 && tx == 0) || (mx == 2 && tx == 2));
+                if (ok) a += wr[ty * 3 + tx];
+            }
+        a = fmaxf(a, 0.f);
+        A[m][ci] = (float)(T)a;                              // the activation as the dense path stores it
+    }
+    __syncthreads();
+    const int col = tid & 63, pt = tid >> 6;                 // output row co0 + col; taps pt, pt + 4, pt + 8
+    float t25[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) t25[k] = 0.f;
+    const T* wrow = wq + (size_t)(co0 + col) * kpad;
+    for (int tap = pt; tap < 9; tap += 4) {
+        float v[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) v[m] = 0.f;
+        if (co0 + col < C2)
+            for (int ci = 0; ci < nh; ++ci) {
+                const float wv = load1<T>(wrow + tap * nh + ci);
+#pragma unroll
+                for (int m = 0; m < 9; ++m) v[m] += wv * A[m][ci];
+            }
+        const int ty = tap / 3, tx = tap - ty * 3;           // tap offset (ty - 1, tx - 1)
+#pragma unroll
+        for (int cy = 0; cy < 5; ++cy) {
+            if ((cy == 0 && ty == 0) || (cy == 4 && ty == 2)) continue;                       // neighbour row outside the image
+            const int my = ((cy == 0 && ty == 1) || (cy == 1 && ty == 0)) ? 0 : (((cy == 4 && ty == 1) || (cy == 3 && ty == 2)) ? 2 : 1);
+#pragma unroll
+            for (int cx = 0; cx < 5; ++cx) {
+                if ((cx == 0 && tx == 0) || (cx == 4 && tx == 2)) continue;
+                const int mx = ((cx == 0 && tx == 1) || (cx == 1 && tx == 0)) ? 0 : (((cx == 4 && tx == 1) || (cx == 3 && tx == 2)) ? 2 : 1);
+                t25[cy * 5 + cx] += v[my * 3 + mx];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 25; ++k) part[pt][k][col] = t25[k];
+    __syncthreads();
+    for (int i = tid; i < 25 * 64; i += 256) {
+        const int k = i >> 6, cc = i & 63;
+        if (co0 + cc >= C2) continue;
+        const float tv = part[0][k][cc] + part[1][k][cc] + part[2][k][cc] + part[3][k][cc] + (bias ? bias[co0 + cc] : 0.f);
+        table[((size_t)c * 25 + k) * C2 + co0 + cc] = tv;
+    }
+}
+
+extern "C" int s2e_spade_class_table(int dtype, const float* w_sh, const float* b_sh, const void* w_packed, const float* bias,
+                                     float* table, int ncls, int nh, int C, void* stream) {
+    if (!w_sh || !b_sh || !w_packed || !table || ncls <= 0 || ncls > 8 || nh <= 0 || nh > 128 || C <= 0)
+        S2E_FAIL(S2E_ERR_ARG, "s2e_spade_class_table: bad argument (nh <= 128)");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_class_table: bad dtype %d", dtype);
+    const int bk = dtype == S2E_BF16 ? 64 : 32;
+    const int kpad = ceil_div(9 * nh, bk) * bk;
+    const dim3 grid(ceil_div(2 * C, 64), ncls);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) spade_class_table_kernel<bf16_t><<<grid, 256, 0, st>>>(w_sh, b_sh, (const bf16_t*)w_packed, bias, table, ncls, nh, 2 * C, kpad);
+    else spade_class_table_kernel<float><<<grid, 256, 0, st>>>(w_sh, b_sh, (const float*)w_packed, bias, table, ncls, nh, 2 * C, kpad);
+    S2E_CHECK_LAUNCH("spade_class_table_kernel");
+    return S2E_OK;
+}
+
+// SPADE+Style modulation of the label-uniform rectangles: out = [lrelu] 0.5*((x-mean)*rstd*(1+gamma)+beta + x*(1+s0)+s1) with
+// gamma | beta = table[class][cy][cx][0..2C) (fp32, s2e_spade_class_table) where (cy, cx) in 0..4 is the pixel's position class
+// {0, 1, interior, H-2, H-1}.  A block takes rectangles uni_list[blockIdx.x], [+gridDim.x], ...; a thread keeps one 16-byte
+// channel group, so its constants are loaded once per rectangle (16-byte loads), and walks the rectangle's pixels four at a
+// time without a division.  gamma_out as s2e_spade_conv_modulate.  (Measured: 2.7 TB/s of x / out / gamma traffic.  A
+// version that streams the whole tensor linearly and skips the dense rectangles' vectors -- per-vector class lookup, all
+// classes' interior rows in registers -- was slower: 1.0 vs 0.59 ms per step.)
+template <typename T>
+__global__ __launch_bounds__(256) void spade_modulate_uniform_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+        const float* __restrict__ style, int sld, const float* __restrict__ table, const uint8_t* __restrict__ cls,
+        const int* __restrict__ uni_list, const int* __restrict__ counts, T* __restrict__ out, T* __restrict__ gout,
+        int H, int W, int C, int tw, int th, int tiles_x, int tiles_y, int lrelu) {
+    constexpr int VEC = Vec<T>::N;
+    const int cg = C / VEC;                                  // channel groups per pixel
+    const int n_uni = counts[1];
+    const int lanes_c = cg < 256 ? cg : 256;                 // channel groups fastest: a wave's accesses are contiguous rows
+    const int pstep = 256 / lanes_c, prow = threadIdx.x / lanes_c;
+    for (int li = blockIdx.x; li < n_uni; li += gridDim.x) {
+        const int r = uni_list[li];
+        const int c = cls[r];
+        const int tx0 = r % tiles_x, ty0 = (r / tiles_x) % tiles_y, n = r / (tiles_x * tiles_y);
+        const int y0 = ty0 * th, x0 = tx0 * tw;
+        const bool inner = y0 >= 2 && x0 >= 2 && y0 + th <= H - 2 && x0 + tw <= W - 2;    // no pixel within two of the border
+        for (int g = threadIdx.x % lanes_c; g < cg; g += lanes_c) {
+            if (prow >= pstep) break;
+            const int c0 = g * VEC;
+            float mu[VEC], rs[VEC], sa[VEC], sb[VEC], gi[VEC], bi[VEC];
+            const f32x4_t* stp = (const f32x4_t*)(stats + ((size_t)n * C + c0) * 2);
+            const f32x4_t* s0p = (const f32x4_t*)(style + (size_t)n * sld + c0);
+            const f32x4_t* s1p = (const f32x4_t*)(style + (size_t)n * sld + C + c0);
+            const float* tint = table + ((size_t)c * 25 + 12) * 2 * C;                 // interior case (cy, cx) = (2, 2)
+            const f32x4_t* tgp = (const f32x4_t*)(tint + c0);
+            const f32x4_t* tbp = (const f32x4_t*)(tint + C + c0);
+#pragma unroll
+            for (int j = 0; j < VEC; j += 4) {
+                const f32x4_t a0 = stp[j / 2], a1 = stp[j / 2 + 1], q0 = s0p[j / 4], q1 = s1p[j / 4], g4 = tgp[j / 4], b4 = tbp[j / 4];
+                mu[j] = a0[0]; rs[j] = a0[1]; mu[j + 1] = a0[2]; rs[j + 1] = a0[3]; mu[j + 2] = a1[0]; rs[j + 2] = a1[1]; mu[j + 3] = a1[2]; rs[j + 3] = a1[3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { sa[j + i] = 1.f + q0[i]; sb[j + i] = q1[i]; gi[j + i] = g4[i]; bi[j + i] = b4[i]; }
+            }
+            auto one = [&](int y, int xx, u32x4_t raw) __attribute__((always_inline)) {
+                float ga[VEC], be[VEC];
+                const int cy = y < 2 ? y : (y >= H - 2 ? 4 - (H - 1 - y) : 2), cx = xx < 2 ? xx : (xx >= W - 2 ? 4 - (W - 1 - xx) : 2);
+                if (inner || (cy == 2 && cx == 2)) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) { ga[j] = gi[j]; be[j] = bi[j]; }
+                } else {                                     // within two pixels of the image border: its own table row
+                    const float* tr = table + ((size_t)c * 25 + cy * 5 + cx) * 2 * C;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) { ga[j] = tr[c0 + j]; be[j] = tr[C + c0 + j]; }
+                }
+                const size_t o = ((size_t)(n * H + y) * W + xx) * C + c0;
+                float f[VEC], v[VEC];
+                unpack16<T>(raw, f);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float xh = (f[j] - mu[j]) * rs[j];
+                    v[j] = 0.5f * (xh * (1.f + ga[j]) + be[j] + f[j] * sa[j] + sb[j]);
+                    if (lrelu) v[j] = lrelu02(v[j]);
+                }
+                *(u32x4_t*)(out + o) = pack16<T>(v);
+                if (gout) *(u32x4_t*)(gout + o) = pack16<T>(ga);
+            };
+            // pixels prow, prow + pstep, ... of the rectangle (row-major), four in flight; (py, px) advance without a division
+            const int npix = tw * th;
+            const int dy = pstep / tw, dx = pstep - dy * tw;
+            int py = prow / tw, px = prow - py * tw;
+            auto step = [&]() __attribute__((always_inline)) { px += dx; py += dy; if (px >= tw) { px -= tw; ++py; } };
+            int pp = prow;
+            for (; pp + 3 * pstep < npix; pp += 4 * pstep) {
+                int yy[4], xs[4]; u32x4_t raw[4]; bool ok[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    yy[k] = y0 + py; xs[k] = x0 + px;
+                    step();
+                    ok[k] = yy[k] < H && xs[k] < W;
+                    raw[k] = u32x4_t{0u, 0u, 0u, 0u};
+                    if (ok[k]) raw[k] = *(const u32x4_t*)(x + ((size_t)(n * H + yy[k]) * W + xs[k]) * C + c0);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (ok[k]) one(yy[k], xs[k], raw[k]);
+            }
+            for (; pp < npix; pp += pstep) {
+                const int y = y0 + py, xx = x0 + px;
+                step();
+                if (y < H && xx < W) one(y, xx, *(const u32x4_t*)(x + ((size_t)(n * H + y) * W + xx) * C + c0));
+            }
+        }
+    }
+}
+
+extern "C" int s2e_spade_modulate_uniform(int dtype, const void* x, const float* stats, const float* style, int style_ld,
+                                          const float* table, const uint8_t* cls, const int* uni_list, const int* counts,
+                                          void* out, void* gamma_out, int N, int H, int W, int C, int tw, int th, int lrelu, void* stream) {
+    if (!x || !stats || !style || !table || !cls || !uni_list || !counts || !out || N <= 0 || H < 5 || W < 5 || C <= 0 || tw <= 0 || th <= 0)
+        S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: bad argument");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: bad dtype %d", dtype);
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_spade_modulate_uniform: C=%d not a multiple of %d", C, vec);
+    if ((((uintptr_t)stats | (uintptr_t)style | (uintptr_t)table) & 15) || (style_ld & 3) || (C & 3))
+        S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: stats, style and table must be 16-byte aligned (style_ld, C multiples of 4)");
+    const int tiles_x = ceil_div(W, tw), tiles_y = ceil_div(H, th);
+    const long rects = (long)N * tiles_x * tiles_y;
+    const int grid = (int)(rects < 2048 ? rects : 2048);
+    const int sld = style_ld > 0 ? style_ld : 2 * C;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16)
+        spade_modulate_uniform_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, stats, style, sld, table, cls, uni_list, counts,
+                                                                  (bf16_t*)out, (bf16_t*)gamma_out, H, W, C, tw, th, tiles_x, tiles_y, lrelu);
+    else
+        spade_modulate_uniform_kernel<float><<<grid, 256, 0, st>>>((const float*)x, stats, style, sld, table, cls, uni_list, counts,
+                                                                 (float*)out, (float*)gamma_out, H, W, C, tw, th, tiles_x, tiles_y, lrelu);
+    S2E_CHECK_LAUNCH("spade_modulate_uniform_kernel");
+    return S2E_OK;
+}

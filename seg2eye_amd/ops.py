@@ -56,7 +56,7 @@ class LaunchProfiler:
     current = None        # the installed profiler (one per process at a time: it times whatever runs on this thread)
 
     def __init__(self):
-        self.records = []     # (family, algorithmic_flops, start_event, end_event, tag, algorithmic_bytes)
+        self.records = []     # (family, algorithmic_flops, start_event, end_event, tag, algorithmic_bytes, executed_flops)
 
     @classmethod
     def install(cls, prof):
@@ -67,7 +67,9 @@ class LaunchProfiler:
         return cls.current is not None
 
     @classmethod
-    def run(cls, family, flops, fn, tag='', nbytes=0.0):
+    def run(cls, family, flops, fn, tag='', nbytes=0.0, executed=None):
+        """executed: the FLOPs the launch really performs when that is less than its algorithmic count (the label-sparse
+        SPADE launch computes only the rectangles that cross a label boundary); default = flops."""
         prof = cls.current
         if prof is None:
             return fn()
@@ -75,16 +77,17 @@ class LaunchProfiler:
         s.record()
         r = fn()
         e.record()
-        prof.records.append((family() if callable(family) else family, flops, s, e, tag, nbytes))
+        prof.records.append((family() if callable(family) else family, flops, s, e, tag, nbytes, flops if executed is None else executed))
         return r
 
     def summary(self):
         """family -> dict(launches, flops, ms, bytes); call after a device synchronize."""
         out = {}
-        for fam, fl, s, e, _, nb in self.records:
-            d = out.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
+        for fam, fl, s, e, _, nb, ex in self.records:
+            d = out.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0, executed_flops=0.0))
             d['launches'] += 1
             d['flops'] += fl
+            d['executed_flops'] += ex
             d['bytes'] += nb
             d['ms'] += s.elapsed_time(e)
         return out
@@ -791,6 +794,44 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     return dx, dgb, dstyle
 
 
+_SPARSE_OFF = os.environ.get('S2E_SPADE_SPARSE', '1') == '0'      # A/B switch: the dense fused launch everywhere
+_SPARSE_MIN_RECTS = int(os.environ.get('S2E_SPADE_SPARSE_RECTS', '256'))
+
+
+def label_rects(label, h, w, dtype, c, nh, flags=0):
+    """Classification of the fused launch's rectangles of the (h, w)-downsampled label map into label-uniform and dense ones
+    (s2e_label_rect_classify) -> (cls, dense_list, uni_list, counts, tw, th), or None when the label-sparse form is off
+    / not worth it for this size.  Inside a trainer step the result is shared by every SPADE of the resolution (and by both
+    forwards' layers: it depends on the label batch only)."""
+    if _SPARSE_OFF:
+        return None
+    n, H, W = label.shape
+    if h < 8 or w < 8:
+        return None
+    tw, th = C.c_int(0), C.c_int(0)
+    dt = L.S2E_BF16 if dtype == torch.bfloat16 else L.S2E_F32
+    if not L.lib().s2e_spade_conv_modulate_rect(dt, n, h, w, c, nh, int(flags), C.byref(tw), C.byref(th)):
+        return None
+    tw, th = tw.value, th.value
+    rects = n * ((h + th - 1) // th) * ((w + tw - 1) // tw)
+    if rects < _SPARSE_MIN_RECTS and not (flags & 4):
+        return None
+    pool = ZeroPool.active()
+    key = ('rects', label.data_ptr(), label._version, n, H, W, h, w, tw, th)
+    if pool is not None and key in pool.step_cache:
+        return pool.step_cache[key]
+    dev = label.device
+    cls = torch.empty(rects, dtype=torch.uint8, device=dev)
+    lists = torch.empty(2, rects, dtype=torch.int32, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    L.check(L.lib().s2e_label_rect_classify(_p(label), n, H, W, h, w, tw, th, _p(cls), _p(lists[0]), _p(lists[1]), _p(counts), _stream()),
+            's2e_label_rect_classify')
+    res = (cls, lists[0], lists[1], counts, tw, th)
+    if pool is not None:
+        pool.step_cache[key] = res
+    return res
+
+
 class SpadeFusedFn(torch.autograd.Function):
     """SpadeParamFn + ModulateFn as ONE forward launch for the layers s2e_spade_conv_modulate takes: the [gamma | beta]
     conv's epilogue applies the SPADE+Style modulation, so gamma and beta never reach HBM (normalization.py:91-105,
@@ -815,14 +856,40 @@ class SpadeFusedFn(torch.autograd.Function):
         gamma = torch.empty_like(x) if train else None
         ld = 0 if off is None else style.shape[1]
         sp = style.data_ptr() + 4 * (off or 0)
+        b_f = b_gb.float().contiguous()
         flops = 2.0 * n * h * w * nh * 2 * c * 9
-        LaunchProfiler.run('conv_patch', flops, lambda: L.check(
-            L.lib().s2e_spade_conv_modulate(_dt(x), _p(actv), _p(wp), _p(b_gb.float().contiguous()), _p(x), _p(stats), sp, ld,
-                                            _p(out), _p(gamma), n, h, w, c, nh, int(lrelu), int(flags), _stream()),
-            's2e_spade_conv_modulate'),
-            tag='F n%d %dx%d c%d->%d k3 s1 +mod%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
-            # algorithmic bytes: actv, packed w, x in; out (and gamma when it is kept) out
-            nbytes=float((actv.numel() + wp.numel() + x.numel() * (3 if train else 2)) * x.element_size()))
+        sparse = None if (flags & 2) else label_rects(label, h, w, x.dtype, c, nh, flags)
+        if sparse is None:
+            LaunchProfiler.run('conv_patch', flops, lambda: L.check(
+                L.lib().s2e_spade_conv_modulate(_dt(x), _p(actv), _p(wp), _p(b_f), _p(x), _p(stats), sp, ld,
+                                                _p(out), _p(gamma), n, h, w, c, nh, int(lrelu), int(flags), _stream()),
+                's2e_spade_conv_modulate'),
+                tag='F n%d %dx%d c%d->%d k3 s1 +mod%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
+                # algorithmic bytes: actv, packed w, x in; out (and gamma when it is kept) out
+                nbytes=float((actv.numel() + wp.numel() + x.numel() * (3 if train else 2)) * x.element_size()))
+        else:
+            # label-sparse: the conv runs on the rectangles that cross a label boundary only; the others read gamma | beta from
+            # the per-class table (s2e_spade_class_table: this layer's [gamma | beta] branch on one-class maps, all 25 border cases)
+            cls, dense_list, uni_list, counts, tw, th = sparse
+            ncls = w_sh.shape[1]
+            table = torch.empty(ncls, 5, 5, 2 * c, dtype=torch.float32, device=x.device)
+            L.check(L.lib().s2e_spade_class_table(_dt(x), _p(_table_of(w_sh)), _p(b_sh.detach().float().contiguous()), _p(wp), _p(b_f),
+                                                  _p(table), ncls, nh, c, _stream()), 's2e_spade_class_table')
+            frac = 1.0
+            if LaunchProfiler.active():                         # executed work of this launch (a sync: profiling runs only)
+                rects = cls.numel()
+                frac = float(int(counts[0])) / max(rects, 1)
+            LaunchProfiler.run('conv_patch', flops, lambda: L.check(
+                L.lib().s2e_spade_conv_modulate_sparse(_dt(x), _p(actv), _p(wp), _p(b_f), _p(x), _p(stats), sp, ld, _p(out), _p(gamma),
+                                                       n, h, w, c, nh, int(lrelu), int(flags), _p(dense_list), _p(counts), _stream()),
+                's2e_spade_conv_modulate_sparse'),
+                tag='F n%d %dx%d c%d->%d k3 s1 +mod sparse%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
+                nbytes=float((actv.numel() + x.numel() * (3 if train else 2)) * frac * x.element_size() + wp.numel() * x.element_size()),
+                executed=flops * frac)
+            LaunchProfiler.run('modulate_fwd', 0.0, lambda: L.check(
+                L.lib().s2e_spade_modulate_uniform(_dt(x), _p(x), _p(stats), sp, ld, _p(table), _p(cls), _p(uni_list), _p(counts), _p(out),
+                                                   _p(gamma), n, h, w, c, tw, th, int(lrelu), _stream()), 's2e_spade_modulate_uniform'),
+                nbytes=float(x.numel() * (3 if train else 2) * (1.0 - frac) * x.element_size()))
         ctx.cfg = (h, w, c)
         ctx.lrelu, ctx.off, ctx.dbig, ctx.batch, ctx.relay = lrelu, off, dbig, bool(batch), bool(relay)
         if train:

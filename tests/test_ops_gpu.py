@@ -36,6 +36,19 @@ def _close(got, ref, dtype, scale=None, what=''):
     assert err <= tol * s, '%s: max err %.3e vs scale %.3e (tol %.1e)' % (what, err, s, tol)
 
 
+def _close_kink(got, ref, dtype, what='', frac=5e-4):
+    """_close for gradients behind a LeakyReLU whose mask is taken from a bf16 value: an element whose pre-activation lies within
+    rounding of zero may take the other slope (its gradient then differs by a factor 5) -- allowed for a `frac` of the elements;
+    everything else must agree as in _close, and so must the relative RMS over all elements."""
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    s_ = max(float(ref.abs().max()), 1e-6)
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 1e-4
+    bad = ((got - ref).abs() > tol * s_).double().mean()
+    rms = float(((got - ref) ** 2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30))
+    assert float(bad) <= frac and rms <= (2e-2 if dtype == torch.bfloat16 else 1e-4), '%s: %.2e of the elements off, rel-RMS %.3e' % (what, float(bad), rms)
+
+
 def nhwc(t):      # NCHW -> NHWC contiguous
     return t.permute(0, 2, 3, 1).contiguous()
 
@@ -251,16 +264,26 @@ def test_spade_params_and_label_conv(cfg, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('sparse', [False, True])
 @pytest.mark.parametrize('cfg', [(2, 64, 64, 32, 32, 64, True, True), (1, 48, 80, 24, 40, 128, False, True), (2, 32, 32, 16, 16, 192, True, False),
-                                 (3, 64, 64, 64, 64, 64, True, True)])
-def test_spade_conv_modulate_fused(cfg, dtype):
+                                 (3, 64, 64, 64, 64, 64, True, True), (2, 128, 128, 128, 128, 64, True, False)])
+def test_spade_conv_modulate_fused(cfg, sparse, dtype):
     """s2e_spade_conv_modulate (the [gamma | beta] conv with the modulation in its epilogue; flags=1 forces the fused kernel at
     any tile count) against the fp64 reference of SPADE_STYLE_Block.forward (normalization.py:184-192) and against the two-launch
-    path, forward (no-grad: gamma never stored; with grad) and every gradient (s2e_modulate_bwd_gamma)."""
+    path, forward (no-grad: gamma never stored; with grad) and every gradient (s2e_modulate_bwd_gamma).
+    sparse: the label-sparse form (flags 4 forces it at these small sizes) on clean nested-ellipse maps -- label-uniform
+    rectangles take gamma / beta from the per-class table, incl. the rectangles on the image border; dense: flags 2."""
     from seg2eye_amd import ops
+    from seg2eye_amd.synthetic import ellipse_labels
     N, H, W, h, w, C, lrelu, relay = cfg
     dev = _dev()
-    lab = _labels(N, H, W, 5)
+    lab = torch.from_numpy(ellipse_labels(N, H, W, 5)[:, 0]) if sparse else _labels(N, H, W, 5)
+    FL = 1 | (4 if sparse else 2)
+    if sparse:                                           # the map must really have both kinds of rectangles
+        rc = ops.label_rects(lab.to(dev), h, w, dtype, C, 128, FL)
+        assert rc is not None
+        nd, nu = int(rc[3][0]), int(rc[3][1])
+        assert nd + nu == rc[0].numel() and nd > 0 and (nu > 0 or h < 64), (nd, nu)     # small maps: every rectangle crosses a boundary
     onehot = torch.zeros(N, 4, H, W).scatter_(1, lab.long().unsqueeze(1), 1.0)
     seg_h = F.interpolate(onehot, size=(h, w), mode='nearest').double()
     x = _rnd((N, C, h, w), 41, dtype) * 1.3 + 0.2
@@ -288,15 +311,17 @@ def test_spade_conv_modulate_fused(cfg, dtype):
     sg = style.to(dev).requires_grad_(True)
     st = ops.in_stats(xg.detach())
     with torch.no_grad():
-        y0 = ops.spade_style_fused(xg, lab.to(dev), *prm, sg, st, lrelu, flags=1)
+        y0 = ops.spade_style_fused(xg, lab.to(dev), *prm, sg, st, lrelu, flags=FL)
     _close(nchw(y0), yr, dtype, what='fused out (no grad)')
-    y = ops.spade_style_fused(xg, lab.to(dev), *prm, sg, st, lrelu, relay=relay, flags=1)
+    y = ops.spade_style_fused(xg, lab.to(dev), *prm, sg, st, lrelu, relay=relay, flags=FL)
     if relay:
         y, xalias = y
         assert xalias.data_ptr() == xg.data_ptr()
     assert torch.equal(y, y0)
     y.backward(nhwc(gy).to(dev))
-    _close(nchw(xg.grad), xr.grad, dtype, what='fused dx')
+    # (sparse + bf16: gamma / beta of the label-uniform rectangles come from a bf16 table, the LeakyReLU mask from the bf16 output:
+    # a few pre-activations within rounding of zero take the other slope than the fp64 reference's)
+    (_close_kink if (sparse and dtype == torch.bfloat16) else _close)(nchw(xg.grad), xr.grad, dtype, what='fused dx')
     _close(sg.grad, sr.grad, dtype, scale=float(sr.grad.abs().max()), what='fused dstyle')
     _close(prm[0].grad, refs[0].grad, dtype, what='fused dw_sh')
     _close(prm[1].grad, refs[1].grad, dtype, what='fused db_sh')
