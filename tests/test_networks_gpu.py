@@ -1090,3 +1090,58 @@ def test_spectralbatch_norm_d_and_e_match_reference():
     for k, p in E.named_parameters():
         ref, got = z['gradE_' + k], checksum(p.grad)
         assert abs(got[0] - ref[0]) + abs(got[1] - ref[1]) <= KINK_TOL * ref[1] + 1e-7, (k, got[:2], ref[:2])
+
+
+def test_label_sparse_forward_under_graph_replay_with_changing_labels():
+    """The label-sparse SPADE forward (ops.label_rects -> s2e_spade_conv_modulate_sparse + s2e_spade_modulate_uniform) decides per
+    rectangle ON THE DEVICE, so a captured hipGraph must follow label maps that change between replays: a full-width trainer
+    (ngf = ndf = 64, 256x256, batch 2, bf16) alternates two batches -- nested ellipses, and a map salted with random classes
+    (fewer uniform rectangles) -- as graph replays and as eager launches; generated images agree (the forward is
+    bit-reproducible; weights drift by Adam's sign flips of near-zero gradients only), and with the sparse form switched off the
+    first iteration gives the same image up to the bf16 rounding of the fused path."""
+    from seg2eye_amd import ops, synthetic as syn
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    b1 = _batch(2, 256, 256, 91)
+    b2 = _batch(2, 256, 256, 92)
+    g = np.random.RandomState(3)
+    lab2 = b2['label'].numpy().copy()
+    salt = g.rand(*lab2.shape) < 0.002
+    lab2[salt] = g.randint(0, 4, size=int(salt.sum())).astype(lab2.dtype)
+    b2 = dict(b2, label=torch.from_numpy(lab2))
+    # the two maps really differ in their rectangle statistics at 256^2
+    counts = []
+    for b in (b1, b2):
+        rc = ops.label_rects(b['label'][:, 0].contiguous().to(DEV), 256, 256, torch.bfloat16, 128, 128)
+        assert rc is not None
+        counts.append(int(rc[3][0]))
+    assert counts[0] < counts[1] < rc[0].numel(), counts
+    res = {}
+    for mode in ('eager', 'graph', 'dense'):
+        old = ops._SPARSE_OFF
+        ops._SPARSE_OFF = mode == 'dense'
+        try:
+            opt = _opt(ngf=64, ndf=64, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='bf16', hip_graphs=(mode == 'graph'))
+            tr = Pix2PixTrainer(opt)
+            m = tr.pix2pix_model
+            for net, seed in ((m.netG, 1), (m.netD, 2), (m.netE, 3)):
+                sd = syn.fill_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed)
+                with torch.no_grad():
+                    for k, v in net.state_dict().items():
+                        v.copy_(torch.from_numpy(sd[k]))
+            imgs = []
+            for it, b in enumerate((b1, b2, b1, b2)):
+                tr.run_generator_one_step(dict(b))
+                tr.run_discriminator_one_step(dict(b))
+                imgs.append(tr.get_latest_generated().detach().float().cpu().clone())
+            if mode == 'graph':
+                assert tr.use_graphs and tr.graph_G is not None
+            res[mode] = imgs
+            del tr, m
+        finally:
+            ops._SPARSE_OFF = old
+        torch.cuda.empty_cache()
+    assert torch.equal(res['eager'][0], res['graph'][0])                               # same weights, same labels: same bits
+    for it in range(1, 4):
+        assert _relrms(res['graph'][it], res['eager'][it]) < 2e-2, (it, _relrms(res['graph'][it], res['eager'][it]))
+    assert _relrms(res['dense'][0], res['eager'][0]) < 5e-3, _relrms(res['dense'][0], res['eager'][0])
+    assert float((res['eager'][1] - res['eager'][0]).abs().max()) > 0.05               # (the batches do differ)
