@@ -33,6 +33,9 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     # HBM-bound families
     'in_stats_partial_kernel': ('in_stats', True), 'in_stats_finalize_kernel': ('in_stats', False),
     'modulate_fwd_kernel': ('modulate_fwd', True),
+    'spade_modulate_uniform_kernel': ('modulate_fwd', True),   # label-uniform rectangles of a label-sparse SPADE forward
+    'label_rect_classify_kernel': ('label_rects', True), 'label_rect_compact_kernel': ('label_rects', False),
+    'spade_class_table_kernel': ('class_table', True),
     'modulate_bwd_reduce_kernel': ('modulate_bwd', True), 'modulate_bwd_coef_kernel': ('modulate_bwd', False),
     'modulate_bwd_apply_kernel': ('modulate_bwd', False),
     'label_conv3x3_kernel': ('label_conv', True),
