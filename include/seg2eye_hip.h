@@ -130,7 +130,7 @@ int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float*
  *   train != 0 (per iteration): v = normalize(W^T u); u = normalize(W v); sigma = u . (W v)   (u, v updated in place)
  *   train == 0:                 sigma = u . (W v)                                              (u, v untouched)
  * layers: DEVICE array of n_layers descriptors.  block_map: DEVICE int32 [n_blocks][3] = {layer, row0, col0}
- * covering every layer with 16-row x 256-column blocks.  t (cols) and s (rows) of all layers are 64-bit fixed-point
+ * covering every layer with the blocks s2e_sn_block_shape reports (rows x columns of one workgroup).  t (cols) and s (rows) of all layers are 64-bit fixed-point
  * accumulators (the blocks' partial sums are combined with INTEGER atomics, so u, v, sigma are bit-reproducible: identical
  * run to run and on every data-parallel replica); they live in `scratch`, which must be ZERO on the first call (the
  * kernels leave it zero again: no fill per iteration).
@@ -139,7 +139,9 @@ typedef struct {
     const float* w; float* u; float* v; long long* t; long long* s;
     int rows, cols;
 } s2e_sn_layer;
-int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map, int n_blocks,
+int s2e_sn_block_shape(int which, int* rows, int* cols);   /* which = 0: tiles of block_map (W v); 1: of block_map_t (W^T u) */
+int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map_t, int n_blocks_t,
+                           const int* block_map, int n_blocks,
                            void* scratch, size_t scratch_bytes, float* sigma, int train, int iterations,
                            float eps, void* stream);
 /* Gradient through W = W_orig / sigma (sigma = u^T W_orig v; u, v constants):

@@ -56,7 +56,8 @@ SIGNATURES = {
     's2e_conv_cout_pad': [_i],
     's2e_conv_k_pad': [_i, _i],
     's2e_pack_conv_weight': [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    's2e_sn_power_iteration': [_vp, _i, _vp, _i, _vp, C.c_size_t, _vp, _i, _i, _f, _vp],
+    's2e_sn_block_shape': [_i, _vp, _vp],
+    's2e_sn_power_iteration': [_vp, _i, _vp, _i, _vp, _i, _vp, C.c_size_t, _vp, _i, _i, _f, _vp],
     's2e_sn_weight_grad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     's2e_grad_block_map': [_vp, _i, _vp],
     's2e_weight_grads_batched': [_vp, _vp, _i, _i, _i, _vp, _vp],

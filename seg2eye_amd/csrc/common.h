@@ -72,6 +72,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// sum over the 64 lanes in six DPP adds (VALU only, unlike the ds_bpermute butterflies above); the total is valid in LANE 63 only
+__device__ __forceinline__ float wave_sum_last(float v) {
+#define S2E_DPP_ADD(ctrl, rmask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
+    S2E_DPP_ADD(0xB1, 0xF);        // quad_perm [1,0,3,2]
+    S2E_DPP_ADD(0x4E, 0xF);        // quad_perm [2,3,0,1]
+    S2E_DPP_ADD(0x141, 0xF);       // row_half_mirror
+    S2E_DPP_ADD(0x140, 0xF);       // row_mirror: every lane of a 16-lane row holds the row's sum
+    S2E_DPP_ADD(0x142, 0xA);       // row_bcast15 into rows 1 and 3
+    S2E_DPP_ADD(0x143, 0xC);       // row_bcast31 into rows 2 and 3
+#undef S2E_DPP_ADD
+    return v;
+}
+
 // XCD-aware bijective remap of a 1-D grid: blocks that share (bid % 8) sit on one XCD
 // (observed round-robin placement; speed only, never correctness) and get a contiguous
 // range of logical tile ids, so neighbouring tiles reuse operand panels in that XCD's L2.

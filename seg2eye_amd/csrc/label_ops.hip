@@ -505,63 +505,75 @@ extern "C" int s2e_label_rect_classify(const uint8_t* label, int N, int H, int W
 // of w_sh[:, c]) the activation at a pixel whose 3x3 window is cut by the image border as m = (my, mx) in {low, none, high}^2
 // (rounded to the activation dtype, as the dense path stores it),
 //     T[c][cy][cx][co] = b[co] + sum_{taps (ty,tx) inside the image at (cy,cx)}  W[co][ty][tx][:] . A[m(cy,ty)][m(cx,tx)][:]
-// with W the PACKED weight the conv launches use (same bf16 values).  One block = 64 output rows x one class; fp32 out.
+// with W the PACKED weight the conv launches use (same bf16 values); fp32 out.
+// Work split: a block = one class x 4 output rows; a WAVE takes one row with its lanes along the 128 hidden channels
+// (coalesced 128-B reads of the packed row, A from LDS), accumulates the 25 position classes per lane and folds the 64 lanes with
+// DPP adds at the end.  (One thread per output row walking its row alone -- 384 dependent 2-byte loads -- took 42 us per launch,
+// 0.5 ms per step, for 60 MFLOP.)
 template <typename T>
 __global__ __launch_bounds__(256) void spade_class_table_kernel(const float* __restrict__ w_sh, const float* __restrict__ b_sh,
         const T* __restrict__ wq, const float* __restrict__ bias, float* __restrict__ table, int ncls, int nh, int C2, int kpad) {
+    constexpr int ROWS = 4;                                  // one row per wave: its 18 weight loads are one latency round
     __shared__ float A[9][128];
-    __shared__ float part[4][25][64];
-    const int c = blockIdx.y, co0 = blockIdx.x * 64;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 9 * nh; i += 256) {                // A[m][ci]
-        const int m = i / nh, ci = i - m * nh, my = m / 3, mx = m - my * 3;
-        float a = b_sh[ci];
+    const int c = blockIdx.y, co0 = blockIdx.x * ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 9 * 128; i += 256) if ((i & 127) >= nh) A[i >> 7][i & 127] = 0.f;       // nh < 128: the unused columns
+    for (int ci = tid; ci < nh; ci += 256) {                 // A[m][ci]: the nine taps of (ci, c) loaded once, all in flight
         const float* wr = w_sh + ((size_t)ci * ncls + c) * 9;
-        for (int ty = 0; ty < 3; ++ty)
-            for (int tx = 0; tx < 3; ++tx) {
+        float w9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w9[t] = wr[t];
+        const float b = b_sh[ci];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {
+            const int my = m / 3, mx = m - my * 3;
+            float a = b;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ty = t / 3, tx = t - ty * 3;
                 const bool ok = !((my == 0 && ty == 0) || (my == 2 && ty == 2) || (mx == 0 && tx == 0) || (mx == 2 && tx == 2));
-                if (ok) a += wr[ty * 3 + tx];
+                if (ok) a += w9[t];
             }
-        a = fmaxf(a, 0.f);
-        A[m][ci] = (float)(T)a;                              // the activation as the dense path stores it
-    }
-    __syncthreads();
-    const int col = tid & 63, pt = tid >> 6;                 // output row co0 + col; taps pt, pt + 4, pt + 8
-    float t25[25];
-#pragma unroll
-    for (int k = 0; k < 25; ++k) t25[k] = 0.f;
-    const T* wrow = wq + (size_t)(co0 + col) * kpad;
-    for (int tap = pt; tap < 9; tap += 4) {
-        float v[9];
-#pragma unroll
-        for (int m = 0; m < 9; ++m) v[m] = 0.f;
-        if (co0 + col < C2)
-            for (int ci = 0; ci < nh; ++ci) {
-                const float wv = load1<T>(wrow + tap * nh + ci);
-#pragma unroll
-                for (int m = 0; m < 9; ++m) v[m] += wv * A[m][ci];
-            }
-        const int ty = tap / 3, tx = tap - ty * 3;           // tap offset (ty - 1, tx - 1)
-#pragma unroll
-        for (int cy = 0; cy < 5; ++cy) {
-            if ((cy == 0 && ty == 0) || (cy == 4 && ty == 2)) continue;                       // neighbour row outside the image
-            const int my = ((cy == 0 && ty == 1) || (cy == 1 && ty == 0)) ? 0 : (((cy == 4 && ty == 1) || (cy == 3 && ty == 2)) ? 2 : 1);
-#pragma unroll
-            for (int cx = 0; cx < 5; ++cx) {
-                if ((cx == 0 && tx == 0) || (cx == 4 && tx == 2)) continue;
-                const int mx = ((cx == 0 && tx == 1) || (cx == 1 && tx == 0)) ? 0 : (((cx == 4 && tx == 1) || (cx == 3 && tx == 2)) ? 2 : 1);
-                t25[cy * 5 + cx] += v[my * 3 + mx];
-            }
+            A[m][ci] = (float)(T)fmaxf(a, 0.f);               // the activation as the dense path stores it
         }
     }
-#pragma unroll
-    for (int k = 0; k < 25; ++k) part[pt][k][col] = t25[k];
     __syncthreads();
-    for (int i = tid; i < 25 * 64; i += 256) {
-        const int k = i >> 6, cc = i & 63;
-        if (co0 + cc >= C2) continue;
-        const float tv = part[0][k][cc] + part[1][k][cc] + part[2][k][cc] + part[3][k][cc] + (bias ? bias[co0 + cc] : 0.f);
-        table[((size_t)c * 25 + k) * C2 + co0 + cc] = tv;
+    for (int r = wave; r < ROWS; r += 4) {
+        const int co = co0 + r;
+        if (co >= C2) break;                                 // wave-uniform
+        float t25[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) t25[k] = 0.f;
+        const T* wrow = wq + (size_t)co * kpad;
+        float wv[9][2];                                      // this lane's channels lane, lane + 64 (nh <= 128) of the nine taps
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wv[tap][j] = lane + 64 * j < nh ? load1<T>(wrow + tap * nh + lane + 64 * j) : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            float v[9];
+#pragma unroll
+            for (int m = 0; m < 9; ++m) v[m] = wv[tap][0] * A[m][lane] + wv[tap][1] * A[m][lane + 64];
+            const int ty = tap / 3, tx = tap - ty * 3;       // tap offset (ty - 1, tx - 1); compile-time under the unroll
+#pragma unroll
+            for (int cy = 0; cy < 5; ++cy) {
+                if ((cy == 0 && ty == 0) || (cy == 4 && ty == 2)) continue;                       // neighbour row outside the image
+                const int my = ((cy == 0 && ty == 1) || (cy == 1 && ty == 0)) ? 0 : (((cy == 4 && ty == 1) || (cy == 3 && ty == 2)) ? 2 : 1);
+#pragma unroll
+                for (int cx = 0; cx < 5; ++cx) {
+                    if ((cx == 0 && tx == 0) || (cx == 4 && tx == 2)) continue;
+                    const int mx = ((cx == 0 && tx == 1) || (cx == 1 && tx == 0)) ? 0 : (((cx == 4 && tx == 1) || (cx == 3 && tx == 2)) ? 2 : 1);
+                    t25[cy * 5 + cx] += v[my * 3 + mx];
+                }
+            }
+        }
+        const float b = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 25; ++k) {
+            const float tot = wave_sum_last(t25[k]);         // valid in lane 63
+            if (lane == 63) table[((size_t)c * 25 + k) * C2 + co] = tot + b;
+        }
     }
 }
 
@@ -572,7 +584,7 @@ extern "C" int s2e_spade_class_table(int dtype, const float* w_sh, const float* 
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_class_table: bad dtype %d", dtype);
     const int bk = dtype == S2E_BF16 ? 64 : 32;
     const int kpad = ceil_div(9 * nh, bk) * bk;
-    const dim3 grid(ceil_div(2 * C, 64), ncls);
+    const dim3 grid(ceil_div(2 * C, 4), ncls);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16) spade_class_table_kernel<bf16_t><<<grid, 256, 0, st>>>(w_sh, b_sh, (const bf16_t*)w_packed, bias, table, ncls, nh, 2 * C, kpad);
     else spade_class_table_kernel<float><<<grid, 256, 0, st>>>(w_sh, b_sh, (const float*)w_packed, bias, table, ncls, nh, 2 * C, kpad);

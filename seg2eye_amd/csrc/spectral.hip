@@ -9,6 +9,7 @@
 // HBM-bound: each power iteration reads every W twice; nothing else is materialised -- in particular
 // W / sigma never exists in memory: the packers divide on the fly while converting to the MFMA layout.
 #include "common.h"
+#include <stdlib.h>
 
 // The partial dot products of the blocks are combined with 64-bit INTEGER atomics on fixed-point values (2^-40 units):
 // integer addition is associative, so t, s -- and with them u, v, sigma -- come out bit-identical whatever order the
@@ -23,21 +24,76 @@ __device__ __forceinline__ void sn_fix_add(long long* dst, float v) {
 }
 __device__ __forceinline__ float sn_unfix(long long q) { return (float)((double)q * (double)SN_UNFIX); }
 
-static constexpr int SN_BR = 16;       // rows per block: all of a block's row loads are in flight together
-static constexpr int SN_BC = 256;      // columns per block (one per thread)
+static constexpr int SN_BR = 32;       // rows per block, two batches of 16: a batch's row loads are all in flight together
+static constexpr int SN_BC = 1024;     // columns per block: four consecutive ones (one 16-byte load per row) per thread
+static constexpr int SN_T_BR = 32, SN_T_V = 1;     // W^T u pass: 32 x 256 tiles, one column per thread (see sn_gemvT_kernel)
+// which = 0: the tiles of the W v pass; 1: of the W^T u pass (its own block map: narrower tiles)
+extern "C" int s2e_sn_block_shape(int which, int* rows, int* cols) {
+    if (rows) *rows = which ? SN_T_BR : SN_BR;
+    if (cols) *cols = which ? 256 * SN_T_V : SN_BC;
+    return S2E_OK;
+}
 
-// ---- t += W^T u over a [SN_BR x SN_BC] block; block_map = {layer, row0, col0}
+// A thread's 16-byte loads need cols % 4 == 0 and an aligned matrix: every layer of the networks here but the encoder's first
+// conv (9 columns), which takes the scalar loops.  Rows past the matrix are CLAMPED to its last row and weighted with zero, so
+// that a batch's 16 loads are unconditional and all in flight together (a guarded load per row compiles to a branch and a
+// wait per row: 2.6 TB/s instead of 4.5).
+typedef const __attribute__((address_space(1))) float* sn_gptr;
+typedef const __attribute__((address_space(1))) f32x4_t* sn_gptr4;
+
+// ---- t += W^T u over a [BR x 256 V] block (V consecutive columns per thread); block_map = {layer, row0, col0}.
+// Measured on the generator's bank (267 MB; a call's duration, same box): 16x256 75 us, 32x256 74, 64x256 75, 128x256 74 --
+// the atomics (one per BR elements) are not what bounds it -- and 73 us with 16-byte loads (V = 4) once the atomics are
+// re-ordered through LDS; on the 22-25 MB banks of D and E the small tiles win (5.4 us against 8.2: more workgroups than CUs).
+template <int BR, int V>
 __global__ __launch_bounds__(256) void sn_gemvT_kernel(const s2e_sn_layer* __restrict__ layers, const int* __restrict__ block_map) {
+    __shared__ float stage[256 * V];
     const int* bm = block_map + 3 * blockIdx.x;
     const s2e_sn_layer L = layers[bm[0]];
-    const int row0 = bm[1], col = bm[2] + threadIdx.x;
-    if (col >= L.cols) return;
-    const int rend = min(L.rows, row0 + SN_BR);
-    float acc = 0.f;
-    const float* wp = L.w + (size_t)row0 * L.cols + col;
-#pragma unroll 16
-    for (int r = row0; r < rend; ++r, wp += L.cols) acc += *wp * L.u[r];
-    sn_fix_add(L.t + col, acc);
+    const int row0 = bm[1], col = bm[2] + V * threadIdx.x;
+    const int nr = min(L.rows - row0, BR);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    if (col < L.cols) {
+        sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + col;
+        sn_gptr up = (sn_gptr)L.u + row0;
+        if (V == 1 || ((L.cols & 3) == 0 && ((uintptr_t)L.w & 15) == 0)) {
+#pragma unroll
+            for (int b = 0; b < BR; b += 16) {
+                float w[16][V];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    sn_gptr src = wp + (size_t)min(b + k, nr - 1) * L.cols;
+                    if constexpr (V == 4) { const f32x4_t q = *(sn_gptr4)src; w[k][0] = q[0]; w[k][1] = q[1]; w[k][2] = q[2]; w[k][3] = q[3]; }
+                    else w[k][0] = *src;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float u = up[min(b + k, nr - 1)] * (b + k < nr ? 1.f : 0.f);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] += w[k][j] * u;
+                }
+            }
+        } else {
+            for (int r = 0; r < nr; ++r)
+                for (int j = 0; j < V; ++j) if (col + j < L.cols) acc[j] += wp[(size_t)r * L.cols + j] * up[r];
+        }
+    }
+    if constexpr (V == 1) {
+        if (col < L.cols) sn_fix_add(L.t + col, acc[0]);
+    } else {
+        // an atomic instruction costs per cache line it touches: hand the sums over through LDS so that the lanes of one
+        // instruction add to 64 CONSECUTIVE columns (8 lines) instead of every fourth (32 lines; measured 118 vs 75 us)
+#pragma unroll
+        for (int j = 0; j < V; ++j) stage[V * threadIdx.x + j] = acc[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = j * 256 + threadIdx.x;
+            if (bm[2] + c < L.cols) sn_fix_add(L.t + bm[2] + c, stage[c]);
+        }
+    }
 }
 
 // ---- one block per layer: v = t / max(|t|, eps)   (train only).  1024 threads and every load of a thread in flight
@@ -79,19 +135,35 @@ __global__ __launch_bounds__(256) void sn_gemv_kernel(const s2e_sn_layer* __rest
     __shared__ float red[SN_BR][4];
     const int* bm = block_map + 3 * blockIdx.x;
     const s2e_sn_layer L = layers[bm[0]];
-    const int row0 = bm[1], col = bm[2] + threadIdx.x;
+    const int row0 = bm[1], col = bm[2] + 4 * threadIdx.x;
     const int nr = min(L.rows - row0, SN_BR);
-    const bool cv = col < L.cols;
-    const float vj = cv ? L.v[col] : 0.f;
-    const float* wp = L.w + (size_t)row0 * L.cols + col;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float p[SN_BR];
+    if ((L.cols & 3) == 0 && ((uintptr_t)L.w & 15) == 0 && ((uintptr_t)L.v & 15) == 0) {
+        const int cc = min(col, L.cols - 4);                   // a thread past the matrix re-reads its last columns, weighted with zero
+        const f32x4_t v4 = *(sn_gptr4)((sn_gptr)L.v + cc);
+        const float on = col < L.cols ? 1.f : 0.f;
+        const f32x4_t vv = {v4[0] * on, v4[1] * on, v4[2] * on, v4[3] * on};
+        sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + cc;
 #pragma unroll
-    for (int k = 0; k < SN_BR; ++k) p[k] = (cv && k < nr) ? wp[(size_t)k * L.cols] * vj : 0.f;
+        for (int b = 0; b < SN_BR; b += 16) {
+            f32x4_t w[16];
 #pragma unroll
-    for (int k = 0; k < SN_BR; ++k) {
-        const float q = wave_sum(p[k]);
-        if (lane == 0) red[k][wave] = q;
+            for (int k = 0; k < 16; ++k) w[k] = *(sn_gptr4)(wp + (size_t)min(b + k, nr - 1) * L.cols);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float q = wave_sum_last((w[k][0] * vv[0] + w[k][1] * vv[1]) + (w[k][2] * vv[2] + w[k][3] * vv[3]));
+                if (lane == 63) red[b + k][wave] = q;
+            }
+        }
+    } else {
+        sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + col;
+        for (int r = 0; r < SN_BR; ++r) {
+            float q = 0.f;
+            if (r < nr)
+                for (int j = 0; j < 4; ++j) if (col + j < L.cols) q += wp[(size_t)r * L.cols + j] * L.v[col + j];
+            q = wave_sum(q);
+            if (lane == 0) red[r][wave] = q;
+        }
     }
     __syncthreads();
     if (threadIdx.x < nr) sn_fix_add(L.s + row0 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
@@ -122,17 +194,18 @@ __global__ __launch_bounds__(SN_NT) void sn_finalize_kernel(const s2e_sn_layer* 
         for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.t[j] = 0;
 }
 
-extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map, int n_blocks,
+extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map_t, int n_blocks_t,
+                                      const int* block_map, int n_blocks,
                                       void* scratch, size_t scratch_bytes, float* sigma, int train, int iterations,
                                       float eps, void* stream) {
-    if (!layers || !block_map || !scratch || !sigma || n_layers <= 0 || n_blocks <= 0 || iterations < 1)
+    if (!layers || !block_map || !block_map_t || !scratch || !sigma || n_layers <= 0 || n_blocks <= 0 || n_blocks_t <= 0 || iterations < 1)
         S2E_FAIL(S2E_ERR_ARG, "s2e_sn_power_iteration: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int iters = train ? iterations : 1;
     (void)scratch_bytes;                                     // the accumulators in `scratch` are cleared by the kernels themselves
     for (int it = 0; it < iters; ++it) {
         if (train) {
-            sn_gemvT_kernel<<<n_blocks, 256, 0, st>>>(layers, block_map);
+            sn_gemvT_kernel<SN_T_BR, SN_T_V><<<n_blocks_t, 256, 0, st>>>(layers, block_map_t);
             sn_norm_v_kernel<<<n_layers, SN_NT, 0, st>>>(layers, eps);
         }
         sn_gemv_kernel<<<n_blocks, 256, 0, st>>>(layers, block_map);

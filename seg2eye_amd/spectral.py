@@ -18,7 +18,6 @@ import torch
 from . import _lib as L
 
 SN_EPS = 1e-12
-_BR, _BC = 16, 256
 
 
 def sn_convs(root):
@@ -62,8 +61,14 @@ class SpectralBank:
                 self.uv_off.append((ou, ov))
         self.uv_arena = arena
         self.scratch = torch.zeros(int(offs[-1]), dtype=torch.int64, device=dev)        # t | s (64-bit fixed point), same offsets
+        lib = L.lib()
+        shapes = []
+        for which in (0, 1):                                  # the W tile one workgroup takes: W v pass, W^T u pass
+            br, bc = C.c_int(), C.c_int()
+            lib.s2e_sn_block_shape(which, C.byref(br), C.byref(bc))
+            shapes.append((br.value, bc.value))
         table = (L.SnLayer * self.n)()
-        bm = []
+        maps = ([], [])
         for i, c in enumerate(self.convs):
             ou, ov = self.uv_off[i]
             table[i].w = c.weight_orig.data_ptr()
@@ -72,12 +77,14 @@ class SpectralBank:
             table[i].s = self.scratch.data_ptr() + 8 * ou
             table[i].t = self.scratch.data_ptr() + 8 * ov
             table[i].rows, table[i].cols = rows[i], cols[i]
-            for r0 in range(0, rows[i], _BR):
-                for c0 in range(0, cols[i], _BC):
-                    bm.append((i, r0, c0))
+            for bm, (_BR, _BC) in zip(maps, shapes):
+                for r0 in range(0, rows[i], _BR):
+                    for c0 in range(0, cols[i], _BC):
+                        bm.append((i, r0, c0))
         raw = np.frombuffer(bytes(table), dtype=np.uint8).copy()
         self.table_dev = torch.from_numpy(raw).to(dev)
-        self.block_map = torch.tensor(bm, dtype=torch.int32, device=dev)
+        self.block_map = torch.tensor(maps[0], dtype=torch.int32, device=dev)
+        self.block_map_t = torch.tensor(maps[1], dtype=torch.int32, device=dev)
         self.rows, self.cols = rows, cols
         self._ptrs = self._current_ptrs()
 
@@ -125,7 +132,8 @@ class SpectralBank:
         from .ops import LaunchProfiler
         wbytes = 4.0 * sum(r * c for r, c in zip(self.rows, self.cols))
         LaunchProfiler.run('spectral_norm', 0.0, lambda: L.check(L.lib().s2e_sn_power_iteration(
-            self.table_dev.data_ptr(), self.n, self.block_map.data_ptr(), self.block_map.shape[0],
+            self.table_dev.data_ptr(), self.n, self.block_map_t.data_ptr(), self.block_map_t.shape[0],
+            self.block_map.data_ptr(), self.block_map.shape[0],
             self.scratch.data_ptr(), self.scratch.numel() * 8, self.sigma.data_ptr(), int(bool(training)),
             int(iterations), SN_EPS, torch.cuda.current_stream().cuda_stream), 's2e_sn_power_iteration'),
             nbytes=wbytes * (2 * int(iterations) if training else 1))     # algorithmic: W^T u and W v each read W once per iteration
