@@ -1141,7 +1141,11 @@ def test_label_sparse_forward_under_graph_replay_with_changing_labels():
             ops._SPARSE_OFF = old
         torch.cuda.empty_cache()
     assert torch.equal(res['eager'][0], res['graph'][0])                               # same weights, same labels: same bits
-    for it in range(1, 4):
-        assert _relrms(res['graph'][it], res['eager'][it]) < 2e-2, (it, _relrms(res['graph'][it], res['eager'][it]))
+    # Iteration 1 is the check that matters: the first replay on a map whose rectangle classes differ from the captured one's
+    # (a stale list would put table values on dense rectangles).  Later iterations only bound the drift: two EAGER runs of
+    # this trainer differ by 0.003 / 0.013 / 0.02-0.03 rel-RMS at iterations 1 / 2 / 3 (weight-gradient atomics, amplified by
+    # Adam's sign flips of near-zero gradients, about doubling per step: tools/check_run_to_run_drift.py).
+    for it, bound in ((1, 1e-2), (2, 4e-2), (3, 1.5e-1)):
+        assert _relrms(res['graph'][it], res['eager'][it]) < bound, (it, _relrms(res['graph'][it], res['eager'][it]))
     assert _relrms(res['dense'][0], res['eager'][0]) < 5e-3, _relrms(res['dense'][0], res['eager'][0])
     assert float((res['eager'][1] - res['eager'][0]).abs().max()) > 0.05               # (the batches do differ)
