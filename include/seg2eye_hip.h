@@ -215,6 +215,15 @@ int s2e_spade_conv_modulate(int dtype, const void* actv, const void* w_packed, c
  * coefficients, then the row-walking blocks' partial sums: plain stores, added up in a fixed order -- no atomics).  mode S2E_NORM_SPADE_STYLE_BATCH: `stats` holds the same {mean, rstd} of the whole batch for every
  * sample (param_free_norm = BatchNorm2d, normalization.py:74-75) and the normalisation's backward sums over N*HW. */
 size_t s2e_modulate_bwd_workspace_bytes(int dtype, int N, int HW, int C);
+/* InstanceNorm2d(affine=False) [+ LeakyReLU 0.2] as ONE call each way (reference discriminator.py:91-94, encoder.py:23-39 via
+ * normalization.py:38-50): out = [lrelu]((x - mean) * rstd); stats (N,C,2) {mean, rstd} out (forward) / in (backward).
+ * Maps of up to 1280 pixels take one launch per call (a block owns all rows of its sample and channels); larger ones run
+ * s2e_in_stats + s2e_modulate_fwd / s2e_modulate_bwd in PLAIN_IN mode.  ws: s2e_in_stats_workspace_bytes (forward),
+ * s2e_modulate_bwd_workspace_bytes (backward); no initialisation needed. */
+int s2e_instance_norm_fwd(int dtype, const void* x, void* out, float* stats, double* ws, int N, int HW, int C,
+                          float eps, int lrelu, void* stream);
+int s2e_instance_norm_bwd(int dtype, const void* g, const void* x, const float* stats, void* dx, double* ws,
+                          int N, int HW, int C, int lrelu, void* stream);
 int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
                      const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                      int N, int HW, int C, int lrelu, int style_ld, void* stream);

@@ -72,6 +72,8 @@ SIGNATURES = {
     's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_in_stats_workspace_bytes': [_i, _i, _i, _i],
     's2e_modulate_bwd_workspace_bytes': [_i, _i, _i, _i],
+    's2e_instance_norm_fwd': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    's2e_instance_norm_bwd': [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     's2e_in_stats': [_i, _vp, _i, _i, _i, _f, _vp, _vp, _vp],
     's2e_modulate_fwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     's2e_modulate_bwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

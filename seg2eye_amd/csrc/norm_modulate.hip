@@ -7,6 +7,7 @@
 // an fp64 workspace with one atomic per (block, channel): no long fp32 chains, and the E[x^2]-E[x]^2
 // finalisation happens in fp64 (cancellation-safe).
 #include "common.h"
+#include <stdlib.h>
 
 static constexpr int kSlabIters = 16;     // row passes per block in the row-walking kernels
 // Row passes per block of the row-walking reduction kernels.  A block ends by writing its per-channel partial sums to
@@ -41,6 +42,168 @@ static RowGeom row_geom(int C, int vec) {
 }
 
 // ------------------------------------------------------------------------------------ in_stats
+// ------------------------------------------------------------------------------------ small maps: one launch
+// A dependent kernel inside a replayed graph costs ~4.6 us however little it does, and the statistics of a small map were
+// two of them (partial sums, finalize), a plain InstanceNorm + LeakyReLU three, its backward three more -- 100+ of a step's
+// 918 launches.  For maps of up to S2E_IN_SMALL_HW pixels (default 1280: 34^2) ONE block owns all rows of (sample, 8 channel
+// groups): thread = (channel group, one of 32 row lanes); fp32 sums per thread, the 32 lanes folded in fp64 in a fixed order
+// (bit-reproducible), and -- APPLY -- the same block normalises its slice in a second pass that re-reads x from L2.
+static int in_small_hw() {
+    static const int v = [] { const char* e = getenv("S2E_IN_SMALL_HW"); return e ? atoi(e) : 1280; }();
+    return v;
+}
+
+template <typename T, int APPLY>
+__global__ __launch_bounds__(256) void in_small_kernel(const T* __restrict__ x, T* __restrict__ out, double* __restrict__ ws,
+                                                       float* __restrict__ stats, int HW, int C, float eps, int lrelu) {
+    constexpr int VEC = Vec<T>::N, CH = 8 * VEC;             // channels per block
+    __shared__ float red[32][CH][2];
+    __shared__ float mr[CH][2];
+    const int tid = threadIdx.x, gx = tid & 7, ry = tid >> 3;
+    const int n = blockIdx.y, c0 = (blockIdx.x * 8 + gx) * VEC;
+    const bool active = c0 < C;
+    const T* base = x + (size_t)n * HW * C + c0;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (active) {
+        int r = ry;
+        for (; r + 96 < HW; r += 128) {                      // four 16-byte loads in flight
+            u32x4_t raw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) raw[k] = *(const u32x4_t*)(base + (size_t)(r + 32 * k) * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float f[VEC];
+                unpack16<T>(raw[k], f);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+            }
+        }
+        for (; r < HW; r += 32) {
+            float f[VEC];
+            unpack16<T>(*(const u32x4_t*)(base + (size_t)r * C), f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[ry][gx * VEC + j][0] = s[j]; red[ry][gx * VEC + j][1] = q[j]; }
+    __syncthreads();
+    if (tid < CH) {
+        const int c = blockIdx.x * CH + tid;
+        double S = 0.0, Q = 0.0;
+        for (int k = 0; k < 32; ++k) { S += (double)red[k][tid][0]; Q += (double)red[k][tid][1]; }
+        const double mean = S / HW;
+        double var = Q / HW - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+        mr[tid][0] = mf; mr[tid][1] = rf;
+        if (c < C) {
+            const size_t i = (size_t)n * C + c;
+            if (ws) { ws[2 * i] = S; ws[2 * i + 1] = Q; }
+            stats[2 * i] = mf; stats[2 * i + 1] = rf;
+        }
+    }
+    if (!APPLY) return;
+    __syncthreads();
+    if (!active) return;
+    float mu[VEC], rs[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mu[j] = mr[gx * VEC + j][0]; rs[j] = mr[gx * VEC + j][1]; }
+    T* obase = out + (size_t)n * HW * C + c0;
+    for (int r = ry; r < HW; r += 128) {
+        u32x4_t raw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) raw[k] = *(const u32x4_t*)(base + (size_t)min(r + 32 * k, HW - 1) * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (r + 32 * k >= HW) continue;
+            float f[VEC], o[VEC];
+            unpack16<T>(raw[k], f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { o[j] = (f[j] - mu[j]) * rs[j]; if (lrelu) o[j] = lrelu02(o[j]); }
+            *(u32x4_t*)(obase + (size_t)(r + 32 * k) * C) = pack16<T>(o);
+        }
+    }
+}
+
+// backward of out = [lrelu]((x - mean) * rstd) for a small map, one launch:  go = g * lrelu'(xhat),
+//   dx = rstd * (go - mean(go) - xhat * mean(go * xhat))
+template <typename T>
+__global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ stats,
+                                                           T* __restrict__ dx, int HW, int C, int lrelu) {
+    constexpr int VEC = Vec<T>::N, CH = 8 * VEC;
+    __shared__ float red[32][CH][2];
+    __shared__ float mm[CH][2];
+    const int tid = threadIdx.x, gx = tid & 7, ry = tid >> 3;
+    const int n = blockIdx.y, c0 = (blockIdx.x * 8 + gx) * VEC;
+    const bool active = c0 < C;
+    const size_t off = (size_t)n * HW * C + c0;
+    float mu[VEC], rs[VEC], s0[VEC], s1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        mu[j] = active ? stats[((size_t)n * C + c0 + j) * 2] : 0.f;
+        rs[j] = active ? stats[((size_t)n * C + c0 + j) * 2 + 1] : 0.f;
+        s0[j] = 0.f; s1[j] = 0.f;
+    }
+    if (active)
+        for (int r = ry; r < HW; r += 64) {                  // two rows x two tensors in flight
+            u32x4_t rg[2], rx[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const size_t o = off + (size_t)min(r + 32 * k, HW - 1) * C;
+                rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (r + 32 * k >= HW) continue;
+                float fg[VEC], fx[VEC];
+                unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float xh = (fx[j] - mu[j]) * rs[j];
+                    const float go = (lrelu && xh < 0.f) ? 0.2f * fg[j] : fg[j];
+                    s0[j] += go; s1[j] += go * xh;
+                }
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[ry][gx * VEC + j][0] = s0[j]; red[ry][gx * VEC + j][1] = s1[j]; }
+    __syncthreads();
+    if (tid < CH) {
+        double A = 0.0, B = 0.0;
+        for (int k = 0; k < 32; ++k) { A += (double)red[k][tid][0]; B += (double)red[k][tid][1]; }
+        mm[tid][0] = (float)(A / HW); mm[tid][1] = (float)(B / HW);
+    }
+    __syncthreads();
+    if (!active) return;
+    float m0[VEC], m1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { m0[j] = mm[gx * VEC + j][0]; m1[j] = mm[gx * VEC + j][1]; }
+    for (int r = ry; r < HW; r += 64) {
+        u32x4_t rg[2], rx[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const size_t o = off + (size_t)min(r + 32 * k, HW - 1) * C;
+            rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (r + 32 * k >= HW) continue;
+            float fg[VEC], fx[VEC], o[VEC];
+            unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (fx[j] - mu[j]) * rs[j];
+                const float go = (lrelu && xh < 0.f) ? 0.2f * fg[j] : fg[j];
+                o[j] = rs[j] * (go - m0[j] - xh * m1[j]);
+            }
+            *(u32x4_t*)(dx + off + (size_t)(r + 32 * k) * C) = pack16<T>(o);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restrict__ x, float* __restrict__ part,
                                                                int HW, int C, int cg, int cgb, int rpp, int iters) {
@@ -128,6 +291,13 @@ extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, floa
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_in_stats: bad dtype %d", dtype);
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_in_stats: C=%d not a multiple of %d", C, vec);
     hipStream_t st = (hipStream_t)stream;
+    if (HW <= in_small_hw()) {                               // small map: statistics in one launch
+        const dim3 sg(ceil_div(C, 8 * vec), N);
+        if (dtype == S2E_BF16) in_small_kernel<bf16_t, 0><<<sg, 256, 0, st>>>((const bf16_t*)x, nullptr, ws, stats, HW, C, eps, 0);
+        else in_small_kernel<float, 0><<<sg, 256, 0, st>>>((const float*)x, nullptr, ws, stats, HW, C, eps, 0);
+        S2E_CHECK_LAUNCH("in_small_kernel");
+        return S2E_OK;
+    }
     const RowGeom g = row_geom(C, vec);
     const int iters = slab_iters_for(HW, g.rpp, N, g.zblocks);
     const int P = ceil_div(HW, g.rpp * iters);
@@ -619,4 +789,44 @@ extern "C" size_t s2e_modulate_bwd_workspace_bytes(int dtype, int N, int HW, int
     const RowGeom rg = row_geom(C, vec);
     const int P = ceil_div(HW, rg.rpp * slab_iters_for(HW, rg.rpp, N, rg.zblocks));
     return (size_t)N * C * 6 * sizeof(double) + (size_t)N * P * C * 4 * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------ plain InstanceNorm (+ LeakyReLU), whole op
+// out = [lrelu 0.2]((x - mean) * rstd) per (sample, channel) over HW (InstanceNorm2d(affine=False), discriminator.py:91-94,
+// encoder.py layers); stats (N,C,2) {mean, rstd} is written for the backward.  Small maps: one launch; others: the
+// statistics kernels, then the element-wise kernel.  ws: s2e_in_stats_workspace_bytes.
+extern "C" int s2e_instance_norm_fwd(int dtype, const void* x, void* out, float* stats, double* ws, int N, int HW, int C,
+                                     float eps, int lrelu, void* stream) {
+    if (!x || !out || !stats || !ws || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_instance_norm_fwd: bad argument");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_instance_norm_fwd: bad dtype %d", dtype);
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_instance_norm_fwd: C=%d not a multiple of %d", C, vec);
+    if (HW <= in_small_hw()) {
+        const dim3 sg(ceil_div(C, 8 * vec), N);
+        hipStream_t st = (hipStream_t)stream;
+        if (dtype == S2E_BF16) in_small_kernel<bf16_t, 1><<<sg, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)out, ws, stats, HW, C, eps, lrelu);
+        else in_small_kernel<float, 1><<<sg, 256, 0, st>>>((const float*)x, (float*)out, ws, stats, HW, C, eps, lrelu);
+        S2E_CHECK_LAUNCH("in_small_kernel");
+        return S2E_OK;
+    }
+    if (const int rc = s2e_in_stats(dtype, x, N, HW, C, eps, ws, stats, stream)) return rc;
+    return s2e_modulate_fwd(dtype, S2E_NORM_PLAIN_IN, x, nullptr, stats, nullptr, out, N, HW, C, lrelu, 0, stream);
+}
+
+// its backward: dx from g, x and the forward's stats.  ws: s2e_modulate_bwd_workspace_bytes (unused for small maps).
+extern "C" int s2e_instance_norm_bwd(int dtype, const void* g, const void* x, const float* stats, void* dx, double* ws,
+                                     int N, int HW, int C, int lrelu, void* stream) {
+    if (!g || !x || !stats || !dx || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_instance_norm_bwd: bad argument");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_instance_norm_bwd: bad dtype %d", dtype);
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_instance_norm_bwd: C=%d not a multiple of %d", C, vec);
+    if (HW <= in_small_hw()) {
+        const dim3 sg(ceil_div(C, 8 * vec), N);
+        hipStream_t st = (hipStream_t)stream;
+        if (dtype == S2E_BF16) in_small_bwd_kernel<bf16_t><<<sg, 256, 0, st>>>((const bf16_t*)g, (const bf16_t*)x, stats, (bf16_t*)dx, HW, C, lrelu);
+        else in_small_bwd_kernel<float><<<sg, 256, 0, st>>>((const float*)g, (const float*)x, stats, (float*)dx, HW, C, lrelu);
+        S2E_CHECK_LAUNCH("in_small_bwd_kernel");
+        return S2E_OK;
+    }
+    return s2e_modulate_bwd(dtype, S2E_NORM_PLAIN_IN, g, x, nullptr, stats, nullptr, dx, nullptr, nullptr, ws, N, HW, C, lrelu, 0, stream);
 }

@@ -947,12 +947,13 @@ class InstanceNormFn(torch.autograd.Function):
     def forward(ctx, x, lrelu):
         _need(x)
         n, h, w, c = x.shape
-        stats = in_stats(x)
+        ws = torch.empty(L.lib().s2e_in_stats_workspace_bytes(_dt(x), n, h * w, c) // 8, dtype=torch.float64, device=x.device)
+        stats = torch.empty(n, c, 2, dtype=torch.float32, device=x.device)
         out = torch.empty_like(x)
         LaunchProfiler.run('modulate_fwd', 0.0, lambda: L.check(
-            L.lib().s2e_modulate_fwd(_dt(x), NORM_PLAIN_IN, _p(x), None, _p(stats), None, _p(out),
-                                     n, h * w, c, int(lrelu), 0, _stream()), 's2e_modulate_fwd'),
-            nbytes=float(2 * x.numel() * x.element_size()))
+            L.lib().s2e_instance_norm_fwd(_dt(x), _p(x), _p(out), _p(stats), _p(ws), n, h * w, c, IN_EPS, int(lrelu), _stream()),
+            's2e_instance_norm_fwd'),
+            nbytes=float(3 * x.numel() * x.element_size()))           # algorithmic: x read for the statistics and again to normalise, out written
         ctx.lrelu = lrelu
         ctx.save_for_backward(x, stats)
         return out
@@ -965,8 +966,8 @@ class InstanceNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         ws = torch.empty(L.lib().s2e_modulate_bwd_workspace_bytes(_dt(x), n, h * w, c) // 8, dtype=torch.float64, device=x.device)
         LaunchProfiler.run('modulate_bwd', 0.0, lambda: L.check(
-            L.lib().s2e_modulate_bwd(_dt(x), NORM_PLAIN_IN, _p(g), _p(x), None, _p(stats), None, _p(dx), None, None,
-                                     _p(ws), n, h * w, c, int(ctx.lrelu), 0, _stream()), 's2e_modulate_bwd'),
+            L.lib().s2e_instance_norm_bwd(_dt(x), _p(g), _p(x), _p(stats), _p(dx), _p(ws), n, h * w, c, int(ctx.lrelu), _stream()),
+            's2e_instance_norm_bwd'),
             nbytes=float(5 * x.numel() * x.element_size()))           # algorithmic: g, x read twice (sums, then dx), dx written
         return dx, None
 

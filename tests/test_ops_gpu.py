@@ -141,7 +141,7 @@ def test_conv2d_forward_backward(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (3, 7, 5, 8), (1, 64, 64, 64), (2, 4, 4, 1024), (2, 8, 8, 48)])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (3, 7, 5, 8), (1, 64, 64, 64), (2, 4, 4, 1024), (2, 8, 8, 48), (2, 34, 34, 72), (1, 36, 36, 16)])
 def test_in_stats_and_instance_norm(shape, dtype):
     from seg2eye_amd import ops
     N, H, W, C = shape
