@@ -715,6 +715,106 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
     }
 }
 
+// SPADE+Style modulation backward of a SMALL map in one launch (gamma-only form: the fused forward's saved gamma, the
+// LeakyReLU mask from the sign of its output): same block shape as in_small_kernel.  Pass 1 writes d[gamma | beta] and sums
+// S0..S3 per (sample, channel); pass 2 re-reads g, out, x, gamma (L2) and writes dx.  The three-launch path reads d beta back in
+// the compute dtype for pass 2; here go is recomputed from g, so dx differs from it by that rounding only.
+template <typename T>
+__global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const T* __restrict__ gamma,
+        const T* __restrict__ fout, const float* __restrict__ stats, const float* __restrict__ style, T* __restrict__ dx, T* __restrict__ dgb,
+        float* __restrict__ dstyle, int HW, int C, int lrelu, int sld, int acc) {
+    constexpr int VEC = Vec<T>::N, CH = 8 * VEC;
+    __shared__ float red[32][CH][4];
+    __shared__ float mm[CH][2];
+    const int tid = threadIdx.x, gx = tid & 7, ry = tid >> 3;
+    const int n = blockIdx.y, c0 = (blockIdx.x * 8 + gx) * VEC;
+    const bool active = c0 < C;
+    const size_t off = (size_t)n * HW * C + c0, off2 = (size_t)n * HW * 2 * C + c0;
+    float mu[VEC], rs[VEC], a[VEC], S[4][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        mu[j] = active ? stats[((size_t)n * C + c0 + j) * 2] : 0.f;
+        rs[j] = active ? stats[((size_t)n * C + c0 + j) * 2 + 1] : 0.f;
+        a[j] = active ? 1.f + style[(size_t)n * sld + c0 + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) S[k][j] = 0.f;
+    }
+    if (active)
+        for (int r = ry; r < HW; r += 64) {
+            u32x4_t rg[2], rx[2], ra[2], ro[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const size_t o = off + (size_t)min(r + 32 * k, HW - 1) * C;
+                rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o); ra[k] = *(const u32x4_t*)(gamma + o);
+                ro[k] = lrelu ? *(const u32x4_t*)(fout + o) : u32x4_t{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (r + 32 * k >= HW) continue;
+                float fg[VEC], fx[VEC], ga[VEC], fo[VEC], dga[VEC], dbe[VEC];
+                unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx); unpack16<T>(ra[k], ga); unpack16<T>(ro[k], fo);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float xh = (fx[j] - mu[j]) * rs[j];
+                    const float go = (lrelu && !(fo[j] > 0.f)) ? 0.2f * fg[j] : fg[j];
+                    dga[j] = 0.5f * go * xh;
+                    dbe[j] = 0.5f * go;
+                    const float gn = 0.5f * go * (1.f + ga[j]);
+                    S[0][j] += gn; S[1][j] += gn * xh; S[2][j] += go * fx[j]; S[3][j] += go;
+                }
+                const size_t o2 = off2 + (size_t)(r + 32 * k) * 2 * C;
+                *(u32x4_t*)(dgb + o2) = pack16<T>(dga);
+                *(u32x4_t*)(dgb + o2 + C) = pack16<T>(dbe);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[ry][gx * VEC + j][k] = S[k][j];
+    __syncthreads();
+    if (tid < CH) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < 32; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] += (double)red[k][tid][q];
+        mm[tid][0] = (float)t[0] / (float)HW; mm[tid][1] = (float)t[1] / (float)HW;
+        const int c = blockIdx.x * CH + tid;
+        if (c < C) {
+            dstyle[(size_t)n * sld + c] += 0.5f * (float)t[2];
+            dstyle[(size_t)n * sld + C + c] += 0.5f * (float)t[3];
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    float m0[VEC], m1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { m0[j] = mm[gx * VEC + j][0]; m1[j] = mm[gx * VEC + j][1]; }
+    for (int r = ry; r < HW; r += 64) {
+        u32x4_t rg[2], rx[2], ra[2], ro[2], rp[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const size_t o = off + (size_t)min(r + 32 * k, HW - 1) * C;
+            rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o); ra[k] = *(const u32x4_t*)(gamma + o);
+            ro[k] = lrelu ? *(const u32x4_t*)(fout + o) : u32x4_t{0u, 0u, 0u, 0u};
+            rp[k] = acc ? *(const u32x4_t*)(dx + o) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (r + 32 * k >= HW) continue;
+            float fg[VEC], fx[VEC], ga[VEC], fo[VEC], prev[VEC], o[VEC];
+            unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx); unpack16<T>(ra[k], ga); unpack16<T>(ro[k], fo); unpack16<T>(rp[k], prev);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (fx[j] - mu[j]) * rs[j];
+                const float go = (lrelu && !(fo[j] > 0.f)) ? 0.2f * fg[j] : fg[j];
+                const float gn = 0.5f * go * (1.f + ga[j]);
+                o[j] = 0.5f * go * a[j] + rs[j] * (gn - m0[j] - xh * m1[j]) + (acc ? prev[j] : 0.f);
+            }
+            *(u32x4_t*)(dx + off + (size_t)(r + 32 * k) * C) = pack16<T>(o);
+        }
+    }
+}
+
 static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, const void* gb, const void* fout, const float* stats,
                              const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                              int N, int HW, int C, int lrelu, int style_ld, void* stream, int stage = 0, double batch_count = 0.0) {
@@ -731,6 +831,15 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_bwd: C=%d not a multiple of %d", C, vec);
     hipStream_t st = (hipStream_t)stream;
+    if (fout && mode == S2E_NORM_SPADE_STYLE && !batch && stage == 0 && HW <= in_small_hw()) {     // small map: one launch
+        const dim3 sg(ceil_div(C, 8 * vec), N);
+        if (dtype == S2E_BF16) spade_small_bwd_kernel<bf16_t><<<sg, 256, 0, st>>>((const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)gb, (const bf16_t*)fout,
+                                                                                stats, style, (bf16_t*)dx, (bf16_t*)dgb, dstyle, HW, C, lrelu, sld, acc);
+        else spade_small_bwd_kernel<float><<<sg, 256, 0, st>>>((const float*)g, (const float*)x, (const float*)gb, (const float*)fout,
+                                                              stats, style, (float*)dx, (float*)dgb, dstyle, HW, C, lrelu, sld, acc);
+        S2E_CHECK_LAUNCH("spade_small_bwd_kernel");
+        return S2E_OK;
+    }
     const RowGeom rg = row_geom(C, vec);
     const int iters = slab_iters_for(HW, rg.rpp, N, rg.zblocks);
     dim3 grid1(ceil_div(HW, rg.rpp * iters), N, rg.zblocks);
