@@ -240,7 +240,10 @@ int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const vo
  *                                 (cy, cx) in {0, 1, interior, H-2, H-1}^2: zero padding makes the two outermost pixel rings differ.
  *                                 w_sh fp32 (nh, ncls, 3, 3), nh <= 128; w_packed as the conv launches take it.
  *   s2e_spade_modulate_uniform  : the modulation of the rectangles uni_list[0 .. counts[1]) with gamma | beta from that table.
- * Together the two launches write every pixel of out (and gamma_out) exactly once. */
+ * Together the two launches write every pixel of out (and gamma_out) exactly once.
+ * flags & 8 of the conv launches / x_up of the uniform one: x is (N, H/2, W/2, C) -- the nearest 2x upsampling that precedes the
+ * block in the generator (generator.py:77-92) is folded into the read of x, the upsampled tensor never exists (no-grad forward:
+ * gamma_out must be NULL; H, W even). */
 int s2e_spade_conv_modulate_rect(int dtype, int N, int H, int W, int C, int nh, int flags, int* tw, int* th);
 int s2e_label_rect_classify(const uint8_t* label, int N, int H, int W, int h, int w, int tw, int th,
                             uint8_t* cls, int* dense_list, int* uni_list, int* counts, void* stream);
@@ -252,7 +255,8 @@ int s2e_spade_class_table(int dtype, const float* w_sh, const float* b_sh, const
                           float* table, int ncls, int nh, int C, void* stream);
 int s2e_spade_modulate_uniform(int dtype, const void* x, const float* stats, const float* style, int style_ld,
                                const float* table, const uint8_t* cls, const int* uni_list, const int* counts,
-                               void* out, void* gamma_out, int N, int H, int W, int C, int tw, int th, int lrelu, void* stream);
+                               void* out, void* gamma_out, int N, int H, int W, int C, int tw, int th, int lrelu, int x_up,
+                               void* stream);
 /* The same backward for a forward that went through s2e_spade_conv_modulate: `gamma` is (N,HW,C) (what that call stored in
  * gamma_out; beta was never written) and the LeakyReLU mask is taken from the sign of the forward's output `out` (N,HW,C).
  * dgb is still (N,HW,2C) = [dgamma | dbeta], the operand of the conv's weight / data gradients.  SPADE_STYLE modes only. */

@@ -83,7 +83,7 @@ SIGNATURES = {
     's2e_label_rect_classify': [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     's2e_spade_conv_modulate_sparse': [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     's2e_spade_class_table': [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    's2e_spade_modulate_uniform': [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    's2e_spade_modulate_uniform': [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     's2e_spade_conv_modulate_supported': [_i, _i, _i, _i, _i, _i, _i],
     's2e_spade_conv_modulate': [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     's2e_colsum': [_i, _vp, _l, _i, _vp, _vp],

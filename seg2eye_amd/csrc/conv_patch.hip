@@ -51,6 +51,7 @@ struct PatchParams {
     const float* mstyle; int msld;    // style codes {s0 | s1}: row n at mstyle + n * msld, 2 * mC floats
     void* mgamma;                     // NULL, or (N, Ho, Wo, mC): gamma (with its bias) is stored for the backward pass
     int mC, mlrelu;
+    int mup;                          // mx is (N, Ho/2, Wo/2, mC): the nearest 2x upsampling that precedes the block, folded into the read
     // FUSE, label-sparse launches: only the rectangles listed in rect_list[0 .. *rect_count) are computed (the others are
     // label-uniform and take gamma / beta from a per-class table: s2e_spade_modulate_uniform); NULL = every rectangle
     const int* rect_list; const int* rect_count;
@@ -389,8 +390,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                 const int oy = q.oy0 + ty, ox = q.ox0 + (tr - ty * TW);
                 live[sw] = lr < EP_ROWS && tr < TW * TH && oy < p.Ho && ox < p.Wo;
                 o[sw] = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.mC + c;
+                const size_t oin = p.mup ? ((size_t)(q.n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.mC + c : o[sw];
                 xx[sw] = u32x4_t{0u, 0u, 0u, 0u};
-                if (live[sw]) xx[sw] = *(const u32x4_t*)(mx + o[sw]);
+                if (live[sw]) xx[sw] = *(const u32x4_t*)(mx + oin);
             }
             if (ep > 0) __syncthreads();
             if (wm == ep) {
@@ -654,6 +656,9 @@ static int spade_conv_modulate_impl(int dtype, const void* actv, const void* w_p
     p.splits = 1; p.cps = nh / (dtype == S2E_BF16 ? 64 : 32); p.tiles = p.tiles_out;
     p.M = N * H * W; p.partial = nullptr;
     p.mx = x; p.mstats = stats; p.mstyle = style; p.msld = style_ld > 0 ? style_ld : 2 * C; p.mgamma = gamma_out;
+    p.mup = (flags & 8) != 0;
+    if (p.mup && ((H | W) & 1)) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: flags 8 (x at half resolution) needs even H, W");
+    if (p.mup && gamma_out) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: flags 8 is for the no-grad forward (no gamma_out)");
     p.mC = C; p.mlrelu = lrelu;
     p.rect_list = rect_list; p.rect_count = rect_count;
     const int grid = p.tiles < cu_count() ? p.tiles : cu_count();

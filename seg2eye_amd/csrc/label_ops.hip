@@ -603,10 +603,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void spade_modulate_uniform_kernel(const T* __restrict__ x, const float* __restrict__ stats,
         const float* __restrict__ style, int sld, const float* __restrict__ table, const uint8_t* __restrict__ cls,
         const int* __restrict__ uni_list, const int* __restrict__ counts, T* __restrict__ out, T* __restrict__ gout,
-        int H, int W, int C, int tw, int th, int tiles_x, int tiles_y, int lrelu) {
+        int H, int W, int C, int tw, int th, int tiles_x, int tiles_y, int lrelu, int x_up) {
     constexpr int VEC = Vec<T>::N;
     const int cg = C / VEC;                                  // channel groups per pixel
     const int n_uni = counts[1];
+    // x_up: x is (N, H/2, W/2, C) and the block's nearest 2x upsampling is folded into the read
+    auto xoff = [&](int n, int y, int xx) __attribute__((always_inline)) -> size_t {
+        return x_up ? ((size_t)(n * (H >> 1) + (y >> 1)) * (W >> 1) + (xx >> 1)) * C : ((size_t)(n * H + y) * W + xx) * C;
+    };
     const int lanes_c = cg < 256 ? cg : 256;                 // channel groups fastest: a wave's accesses are contiguous rows
     const int pstep = 256 / lanes_c, prow = threadIdx.x / lanes_c;
     for (int li = blockIdx.x; li < n_uni; li += gridDim.x) {
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(256) void spade_modulate_uniform_kernel(const T* __
                     step();
                     ok[k] = yy[k] < H && xs[k] < W;
                     raw[k] = u32x4_t{0u, 0u, 0u, 0u};
-                    if (ok[k]) raw[k] = *(const u32x4_t*)(x + ((size_t)(n * H + yy[k]) * W + xs[k]) * C + c0);
+                    if (ok[k]) raw[k] = *(const u32x4_t*)(x + xoff(n, yy[k], xs[k]) + c0);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) if (ok[k]) one(yy[k], xs[k], raw[k]);
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(256) void spade_modulate_uniform_kernel(const T* __
             for (; pp < npix; pp += pstep) {
                 const int y = y0 + py, xx = x0 + px;
                 step();
-                if (y < H && xx < W) one(y, xx, *(const u32x4_t*)(x + ((size_t)(n * H + y) * W + xx) * C + c0));
+                if (y < H && xx < W) one(y, xx, *(const u32x4_t*)(x + xoff(n, y, xx) + c0));
             }
         }
     }
@@ -685,9 +689,11 @@ __global__ __launch_bounds__(256) void spade_modulate_uniform_kernel(const T* __
 
 extern "C" int s2e_spade_modulate_uniform(int dtype, const void* x, const float* stats, const float* style, int style_ld,
                                           const float* table, const uint8_t* cls, const int* uni_list, const int* counts,
-                                          void* out, void* gamma_out, int N, int H, int W, int C, int tw, int th, int lrelu, void* stream) {
+                                          void* out, void* gamma_out, int N, int H, int W, int C, int tw, int th, int lrelu, int x_up,
+                                          void* stream) {
     if (!x || !stats || !style || !table || !cls || !uni_list || !counts || !out || N <= 0 || H < 5 || W < 5 || C <= 0 || tw <= 0 || th <= 0)
         S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: bad argument");
+    if (x_up && (((H | W) & 1) || gamma_out)) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: x_up needs even H, W and no gamma_out (no-grad forward)");
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: bad dtype %d", dtype);
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_spade_modulate_uniform: C=%d not a multiple of %d", C, vec);
@@ -700,10 +706,10 @@ extern "C" int s2e_spade_modulate_uniform(int dtype, const void* x, const float*
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16)
         spade_modulate_uniform_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, stats, style, sld, table, cls, uni_list, counts,
-                                                                  (bf16_t*)out, (bf16_t*)gamma_out, H, W, C, tw, th, tiles_x, tiles_y, lrelu);
+                                                                  (bf16_t*)out, (bf16_t*)gamma_out, H, W, C, tw, th, tiles_x, tiles_y, lrelu, x_up);
     else
         spade_modulate_uniform_kernel<float><<<grid, 256, 0, st>>>((const float*)x, stats, style, sld, table, cls, uni_list, counts,
-                                                                 (float*)out, (float*)gamma_out, H, W, C, tw, th, tiles_x, tiles_y, lrelu);
+                                                                 (float*)out, (float*)gamma_out, H, W, C, tw, th, tiles_x, tiles_y, lrelu, x_up);
     S2E_CHECK_LAUNCH("spade_modulate_uniform_kernel");
     return S2E_OK;
 }

@@ -1,4 +1,6 @@
 """SPADE+Style generator (reference models/networks/generator.py:13-101)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -11,6 +13,9 @@ from ..spectral import sn_begin
 from .architecture import SPADE_STYLE_ResnetBlock
 from .base_network import BaseNetwork, compute_dtype_of
 from .normalization import SegMap
+
+
+_FOLD_UP = os.environ.get('S2E_FOLD_UPSAMPLE', '1') != '0'      # A/B switch: 0 = materialise the upsampled tensor in the no-grad forward too
 
 
 class SPADESTYLEGenerator(BaseNetwork):
@@ -66,6 +71,10 @@ class SPADESTYLEGenerator(BaseNetwork):
             x = self.G_middle_1(x, seg, w, st)
             for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
                 st = blk.input_stats(x, 4)
+                if _FOLD_UP and not (torch.is_grad_enabled() and x.requires_grad):
+                    # no-grad forward (the D step's, inference): the upsampling is folded into the block's two SPADE launches
+                    x = blk(x, seg, w, st, up=True)
+                    continue
                 x = ops.upsample2x(x)
                 # data parallel: when the gradient w.r.t. the input of up_2 (up_0) exists, every parameter gradient of
                 # conv_img / up_3 / up_2 (up_1 / up_0) is final -- tell the trainer, which starts that group's all-reduce

@@ -159,12 +159,19 @@ class SPADE_STYLE_Block(nn.Module):
         self.spade = SPADE(opt.norm_G.replace('spectral', ''), fin, opt.semantic_nc)
         self.adain = ApplyStyle(opt.w_dim, channels=fin, use_wscale=False)
 
-    def forward(self, x, segmap, latent_style, stats=None, lrelu=False, relay=False):
+    def forward(self, x, segmap, latent_style, stats=None, lrelu=False, relay=False, up=False):
         """relay (not in the reference): also return an alias x' of x for the other consumers of x, see
-        ops.spade_style_modulate."""
+        ops.spade_style_modulate.
+        up (not in the reference; no-grad forward, stats given): x is the tensor BEFORE the generator's nearest 2x upsampling
+        (generator.py:77-92); the fused launch reads it at (y/2, x/2) and the upsampled tensor never exists.  Use
+        `takes_folded_upsampling` first."""
         seg = SegMap.of(segmap)
         n, h, w, c = x.shape
         sp = self.spade
+        if up:
+            if torch.is_grad_enabled() and x.requires_grad or stats is None or relay:
+                raise ValueError('SPADE_STYLE_Block: up=True is for the no-grad forward with the statistics given')
+            h, w = 2 * h, 2 * w
         if stats is None:
             stats = spade_stats(x, [sp])
         batch = sp.kind == 'batch'
@@ -175,11 +182,14 @@ class SPADE_STYLE_Block(nn.Module):
             style, kw = sb[1], dict(off=sb[0][id(self.adain.linear)], dbig=sb[2])
         else:
             style, kw = self.adain.linear(latent_style), {}         # (N, 2C) fp32
-        if ops.spade_fused_supported(x, sp.mlp_shared[0].out_channels):
+        fl = 8 if up else 0
+        if ops.spade_fused_supported(x, sp.mlp_shared[0].out_channels, fl):
             # the big layers: [gamma | beta] conv and modulation in ONE launch, gamma / beta never written (ops.SpadeFusedFn)
             return ops.spade_style_fused(x, seg.label, sp.mlp_shared[0].weight, sp.mlp_shared[0].bias, sp.mlp_gamma.weight,
                                          sp.mlp_gamma.bias, sp.mlp_beta.weight, sp.mlp_beta.bias, style, stats, lrelu,
-                                         batch=batch, relay=relay, **kw)
+                                         batch=batch, relay=relay, flags=fl, **kw)
+        if up:
+            x = ops.upsample2x(x)
         gb = sp.gamma_beta(seg, h, w, x.dtype)
         return ops.spade_style_modulate(x, gb, style, stats, lrelu, batch=batch, relay=relay, **kw)
 

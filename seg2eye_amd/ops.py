@@ -840,9 +840,14 @@ class SpadeFusedFn(torch.autograd.Function):
     [dgamma | dbeta] -> the conv's weight / data gradients)."""
 
     @staticmethod
-    def forward(ctx, x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags):
+    def forward(ctx, x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags, grad_mode):
         _need(x, style, stats)
         n, h, w, c = x.shape
+        up = bool(flags & 8)                                  # x is the tensor BEFORE the block's nearest 2x upsampling (no-grad forward)
+        if up:
+            h, w = 2 * h, 2 * w
+            if grad_mode and any(ctx.needs_input_grad):
+                raise ValueError('spade_style_fused: the folded upsampling (flags 8) is for the no-grad forward')
         _, H, W = label.shape
         nh = w_sh.shape[0]
         dtype = x.dtype
@@ -851,9 +856,11 @@ class SpadeFusedFn(torch.autograd.Function):
         plan = packing.current()
         wp = packed_weight(w_gb, dtype, nh, False, None, plan, stable=fused)
         ctx.plan, ctx.plan_gen, ctx.fused = plan, (plan.generation if plan is not None else None), fused
-        train = any(ctx.needs_input_grad)
-        out = torch.empty_like(x)
-        gamma = torch.empty_like(x) if train else None
+        # (inside forward() grad mode is always off and needs_input_grad is set under torch.no_grad() too: whether a backward can
+        # follow is the CALLER's grad mode, handed in.  Without it the D step's no-grad generator forward stored gamma for nothing.)
+        train = bool(grad_mode) and any(ctx.needs_input_grad)
+        out = torch.empty(n, h, w, c, dtype=dtype, device=x.device)
+        gamma = torch.empty_like(out) if train else None
         ld = 0 if off is None else style.shape[1]
         sp = style.data_ptr() + 4 * (off or 0)
         b_f = b_gb.float().contiguous()
@@ -866,7 +873,7 @@ class SpadeFusedFn(torch.autograd.Function):
                 's2e_spade_conv_modulate'),
                 tag='F n%d %dx%d c%d->%d k3 s1 +mod%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
                 # algorithmic bytes: actv, packed w, x in; out (and gamma when it is kept) out
-                nbytes=float((actv.numel() + wp.numel() + x.numel() * (3 if train else 2)) * x.element_size()))
+                nbytes=float((actv.numel() + wp.numel() + x.numel() + out.numel() * (2 if train else 1)) * x.element_size()))
         else:
             # label-sparse: the conv runs on the rectangles that cross a label boundary only; the others read gamma | beta from
             # the per-class table (s2e_spade_class_table: this layer's [gamma | beta] branch on one-class maps, all 25 border cases)
@@ -884,12 +891,12 @@ class SpadeFusedFn(torch.autograd.Function):
                                                        n, h, w, c, nh, int(lrelu), int(flags), _p(dense_list), _p(counts), _stream()),
                 's2e_spade_conv_modulate_sparse'),
                 tag='F n%d %dx%d c%d->%d k3 s1 +mod sparse%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
-                nbytes=float((actv.numel() + x.numel() * (3 if train else 2)) * frac * x.element_size() + wp.numel() * x.element_size()),
+                nbytes=float((actv.numel() + x.numel() + out.numel() * (2 if train else 1)) * frac * x.element_size() + wp.numel() * x.element_size()),
                 executed=flops * frac)
             LaunchProfiler.run('modulate_fwd', 0.0, lambda: L.check(
                 L.lib().s2e_spade_modulate_uniform(_dt(x), _p(x), _p(stats), sp, ld, _p(table), _p(cls), _p(uni_list), _p(counts), _p(out),
-                                                   _p(gamma), n, h, w, c, tw, th, int(lrelu), _stream()), 's2e_spade_modulate_uniform'),
-                nbytes=float(x.numel() * (3 if train else 2) * (1.0 - frac) * x.element_size()))
+                                                   _p(gamma), n, h, w, c, tw, th, int(lrelu), int(up), _stream()), 's2e_spade_modulate_uniform'),
+                nbytes=float((x.numel() + out.numel() * (2 if train else 1)) * (1.0 - frac) * x.element_size()))
         ctx.cfg = (h, w, c)
         ctx.lrelu, ctx.off, ctx.dbig, ctx.batch, ctx.relay = lrelu, off, dbig, bool(batch), bool(relay)
         if train:
@@ -905,15 +912,18 @@ class SpadeFusedFn(torch.autograd.Function):
         x, label, w_sh, w_gb, actv, gamma, out, style, stats = ctx.saved_tensors
         nn_ = (None,) * 8
         if g is None:
-            return (g_relay,) + (None,) * 15
+            return (g_relay,) + (None,) * 16
         dx, dgb, dstyle = _modulate_grads(ctx, g, g_relay, x, gamma, out, style, stats)
         gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b = _spade_param_grads(ctx, dgb, label, w_sh, w_gb, actv)
-        return (dx, None, gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b, dstyle) + (None,) * 7
+        return (dx, None, gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b, dstyle) + (None,) * 8
 
 
 def spade_fused_supported(x, nh, flags=0):
-    """Does s2e_spade_conv_modulate take this layer (x: (N,h,w,C) NHWC, nh = mlp_shared's width)?"""
+    """Does s2e_spade_conv_modulate take this layer (x: (N,h,w,C) NHWC, nh = mlp_shared's width; flags & 8: x is the
+    half-resolution tensor of a folded upsampling)?"""
     n, h, w, c = x.shape
+    if flags & 8:
+        h, w = 2 * h, 2 * w
     if _FUSED_OFF:
         return False
     return bool(L.lib().s2e_spade_conv_modulate_supported(_dt(x), n, h, w, c, nh, int(flags)))
@@ -928,7 +938,8 @@ def spade_style_fused(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lr
     spade_style_modulate."""
     if off is None:
         style = style.float().contiguous()
-    return SpadeFusedFn.apply(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags)
+    return SpadeFusedFn.apply(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags,
+                              torch.is_grad_enabled())
 
 
 def spade_style_modulate(x, gb, style, stats, lrelu, off=None, dbig=None, batch=False, relay=False):

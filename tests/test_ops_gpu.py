@@ -313,6 +313,14 @@ def test_spade_conv_modulate_fused(cfg, sparse, dtype):
     with torch.no_grad():
         y0 = ops.spade_style_fused(xg, lab.to(dev), *prm, sg, st, lrelu, flags=FL)
     _close(nchw(y0), yr, dtype, what='fused out (no grad)')
+    # flags 8: x handed over at HALF resolution, the generator's nearest 2x upsampling folded into the launch's read of x
+    # (no-grad forward) -- the same bits as upsampling first
+    xl = nhwc(_rnd((N, C, h // 2, w // 2), 48, dtype) * 1.1 - 0.1).to(dev)
+    stl = ops.in_stats(xl)
+    with torch.no_grad():
+        y_fold = ops.spade_style_fused(xl, lab.to(dev), *prm, sg, stl, lrelu, flags=FL | 8)
+        y_mat = ops.spade_style_fused(ops.upsample2x(xl), lab.to(dev), *prm, sg, stl, lrelu, flags=FL)
+    assert y_fold.shape == y_mat.shape == (N, h, w, C) and torch.equal(y_fold, y_mat)
     y = ops.spade_style_fused(xg, lab.to(dev), *prm, sg, st, lrelu, relay=relay, flags=FL)
     if relay:
         y, xalias = y
