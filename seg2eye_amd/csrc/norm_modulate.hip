@@ -53,14 +53,14 @@ static int in_small_hw() {
     return v;
 }
 
-template <typename T, int APPLY>
+template <typename T, int APPLY, int G>          // G channel groups per block (8, or 4 when that is what fills the chip)
 __global__ __launch_bounds__(256) void in_small_kernel(const T* __restrict__ x, T* __restrict__ out, double* __restrict__ ws,
                                                        float* __restrict__ stats, int HW, int C, float eps, int lrelu) {
-    constexpr int VEC = Vec<T>::N, CH = 8 * VEC;             // channels per block
-    __shared__ float red[32][CH][2];
+    constexpr int VEC = Vec<T>::N, CH = G * VEC, RL = 256 / G;    // channels per block; row lanes
+    __shared__ float red[RL][CH][2];
     __shared__ float mr[CH][2];
-    const int tid = threadIdx.x, gx = tid & 7, ry = tid >> 3;
-    const int n = blockIdx.y, c0 = (blockIdx.x * 8 + gx) * VEC;
+    const int tid = threadIdx.x, gx = tid % G, ry = tid / G;
+    const int n = blockIdx.y, c0 = (blockIdx.x * G + gx) * VEC;
     const bool active = c0 < C;
     const T* base = x + (size_t)n * HW * C + c0;
     float s[VEC], q[VEC];
@@ -68,10 +68,10 @@ __global__ __launch_bounds__(256) void in_small_kernel(const T* __restrict__ x, 
     for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; }
     if (active) {
         int r = ry;
-        for (; r + 96 < HW; r += 128) {                      // four 16-byte loads in flight
+        for (; r + 3 * RL < HW; r += 4 * RL) {                // four 16-byte loads in flight
             u32x4_t raw[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) raw[k] = *(const u32x4_t*)(base + (size_t)(r + 32 * k) * C);
+            for (int k = 0; k < 4; ++k) raw[k] = *(const u32x4_t*)(base + (size_t)(r + RL * k) * C);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float f[VEC];
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void in_small_kernel(const T* __restrict__ x, 
                 for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
             }
         }
-        for (; r < HW; r += 32) {
+        for (; r < HW; r += RL) {
             float f[VEC];
             unpack16<T>(*(const u32x4_t*)(base + (size_t)r * C), f);
 #pragma unroll
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void in_small_kernel(const T* __restrict__ x, 
     if (tid < CH) {
         const int c = blockIdx.x * CH + tid;
         double S = 0.0, Q = 0.0;
-        for (int k = 0; k < 32; ++k) { S += (double)red[k][tid][0]; Q += (double)red[k][tid][1]; }
+        for (int k = 0; k < RL; ++k) { S += (double)red[k][tid][0]; Q += (double)red[k][tid][1]; }
         const double mean = S / HW;
         double var = Q / HW - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -112,32 +112,32 @@ __global__ __launch_bounds__(256) void in_small_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { mu[j] = mr[gx * VEC + j][0]; rs[j] = mr[gx * VEC + j][1]; }
     T* obase = out + (size_t)n * HW * C + c0;
-    for (int r = ry; r < HW; r += 128) {
+    for (int r = ry; r < HW; r += 4 * RL) {
         u32x4_t raw[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) raw[k] = *(const u32x4_t*)(base + (size_t)min(r + 32 * k, HW - 1) * C);
+        for (int k = 0; k < 4; ++k) raw[k] = *(const u32x4_t*)(base + (size_t)min(r + RL * k, HW - 1) * C);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (r + 32 * k >= HW) continue;
+            if (r + RL * k >= HW) continue;
             float f[VEC], o[VEC];
             unpack16<T>(raw[k], f);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { o[j] = (f[j] - mu[j]) * rs[j]; if (lrelu) o[j] = lrelu02(o[j]); }
-            *(u32x4_t*)(obase + (size_t)(r + 32 * k) * C) = pack16<T>(o);
+            *(u32x4_t*)(obase + (size_t)(r + RL * k) * C) = pack16<T>(o);
         }
     }
 }
 
 // backward of out = [lrelu]((x - mean) * rstd) for a small map, one launch:  go = g * lrelu'(xhat),
 //   dx = rstd * (go - mean(go) - xhat * mean(go * xhat))
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ stats,
                                                            T* __restrict__ dx, int HW, int C, int lrelu) {
-    constexpr int VEC = Vec<T>::N, CH = 8 * VEC;
-    __shared__ float red[32][CH][2];
+    constexpr int VEC = Vec<T>::N, CH = G * VEC, RL = 256 / G;
+    __shared__ float red[RL][CH][2];
     __shared__ float mm[CH][2];
-    const int tid = threadIdx.x, gx = tid & 7, ry = tid >> 3;
-    const int n = blockIdx.y, c0 = (blockIdx.x * 8 + gx) * VEC;
+    const int tid = threadIdx.x, gx = tid % G, ry = tid / G;
+    const int n = blockIdx.y, c0 = (blockIdx.x * G + gx) * VEC;
     const bool active = c0 < C;
     const size_t off = (size_t)n * HW * C + c0;
     float mu[VEC], rs[VEC], s0[VEC], s1[VEC];
@@ -148,16 +148,16 @@ __global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__
         s0[j] = 0.f; s1[j] = 0.f;
     }
     if (active)
-        for (int r = ry; r < HW; r += 64) {                  // two rows x two tensors in flight
+        for (int r = ry; r < HW; r += 2 * RL) {                  // two rows x two tensors in flight
             u32x4_t rg[2], rx[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const size_t o = off + (size_t)min(r + 32 * k, HW - 1) * C;
+                const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
                 rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o);
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                if (r + 32 * k >= HW) continue;
+                if (r + RL * k >= HW) continue;
                 float fg[VEC], fx[VEC];
                 unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx);
 #pragma unroll
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__
     __syncthreads();
     if (tid < CH) {
         double A = 0.0, B = 0.0;
-        for (int k = 0; k < 32; ++k) { A += (double)red[k][tid][0]; B += (double)red[k][tid][1]; }
+        for (int k = 0; k < RL; ++k) { A += (double)red[k][tid][0]; B += (double)red[k][tid][1]; }
         mm[tid][0] = (float)(A / HW); mm[tid][1] = (float)(B / HW);
     }
     __syncthreads();
@@ -181,16 +181,16 @@ __global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__
     float m0[VEC], m1[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { m0[j] = mm[gx * VEC + j][0]; m1[j] = mm[gx * VEC + j][1]; }
-    for (int r = ry; r < HW; r += 64) {
+    for (int r = ry; r < HW; r += 2 * RL) {
         u32x4_t rg[2], rx[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const size_t o = off + (size_t)min(r + 32 * k, HW - 1) * C;
+            const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
             rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o);
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (r + 32 * k >= HW) continue;
+            if (r + RL * k >= HW) continue;
             float fg[VEC], fx[VEC], o[VEC];
             unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx);
 #pragma unroll
@@ -199,10 +199,19 @@ __global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__
                 const float go = (lrelu && xh < 0.f) ? 0.2f * fg[j] : fg[j];
                 o[j] = rs[j] * (go - m0[j] - xh * m1[j]);
             }
-            *(u32x4_t*)(dx + off + (size_t)(r + 32 * k) * C) = pack16<T>(o);
+            *(u32x4_t*)(dx + off + (size_t)(r + RL * k) * C) = pack16<T>(o);
         }
     }
 }
+
+// channel groups per block of the small-map kernels: 8, or 4 when 8 would leave most of the CUs without a block
+static int small_groups(int N, int C, int vec) { return (long)N * ceil_div(C, 8 * vec) < 192 ? 4 : 8; }
+#define S2E_SMALL_LAUNCH(KERNEL, TT, ...) do { \
+    if (small_groups(N, C, vec) == 4) { const dim3 sg(ceil_div(C, 4 * vec), N); KERNEL<TT, 4><<<sg, 256, 0, st>>>(__VA_ARGS__); } \
+    else { const dim3 sg(ceil_div(C, 8 * vec), N); KERNEL<TT, 8><<<sg, 256, 0, st>>>(__VA_ARGS__); } } while (0)
+#define S2E_SMALL_LAUNCH2(KERNEL, TT, AP, ...) do { \
+    if (small_groups(N, C, vec) == 4) { const dim3 sg(ceil_div(C, 4 * vec), N); KERNEL<TT, AP, 4><<<sg, 256, 0, st>>>(__VA_ARGS__); } \
+    else { const dim3 sg(ceil_div(C, 8 * vec), N); KERNEL<TT, AP, 8><<<sg, 256, 0, st>>>(__VA_ARGS__); } } while (0)
 
 template <typename T>
 __global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restrict__ x, float* __restrict__ part,
@@ -292,9 +301,8 @@ extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, floa
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_in_stats: C=%d not a multiple of %d", C, vec);
     hipStream_t st = (hipStream_t)stream;
     if (HW <= in_small_hw()) {                               // small map: statistics in one launch
-        const dim3 sg(ceil_div(C, 8 * vec), N);
-        if (dtype == S2E_BF16) in_small_kernel<bf16_t, 0><<<sg, 256, 0, st>>>((const bf16_t*)x, nullptr, ws, stats, HW, C, eps, 0);
-        else in_small_kernel<float, 0><<<sg, 256, 0, st>>>((const float*)x, nullptr, ws, stats, HW, C, eps, 0);
+        if (dtype == S2E_BF16) S2E_SMALL_LAUNCH2(in_small_kernel, bf16_t, 0, (const bf16_t*)x, nullptr, ws, stats, HW, C, eps, 0);
+        else S2E_SMALL_LAUNCH2(in_small_kernel, float, 0, (const float*)x, nullptr, ws, stats, HW, C, eps, 0);
         S2E_CHECK_LAUNCH("in_small_kernel");
         return S2E_OK;
     }
@@ -719,15 +727,15 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
 // LeakyReLU mask from the sign of its output): same block shape as in_small_kernel.  Pass 1 writes d[gamma | beta] and sums
 // S0..S3 per (sample, channel); pass 2 re-reads g, out, x, gamma (L2) and writes dx.  The three-launch path reads d beta back in
 // the compute dtype for pass 2; here go is recomputed from g, so dx differs from it by that rounding only.
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const T* __restrict__ gamma,
         const T* __restrict__ fout, const float* __restrict__ stats, const float* __restrict__ style, T* __restrict__ dx, T* __restrict__ dgb,
         float* __restrict__ dstyle, int HW, int C, int lrelu, int sld, int acc) {
-    constexpr int VEC = Vec<T>::N, CH = 8 * VEC;
-    __shared__ float red[32][CH][4];
+    constexpr int VEC = Vec<T>::N, CH = G * VEC, RL = 256 / G;
+    __shared__ float red[RL][CH][4];
     __shared__ float mm[CH][2];
-    const int tid = threadIdx.x, gx = tid & 7, ry = tid >> 3;
-    const int n = blockIdx.y, c0 = (blockIdx.x * 8 + gx) * VEC;
+    const int tid = threadIdx.x, gx = tid % G, ry = tid / G;
+    const int n = blockIdx.y, c0 = (blockIdx.x * G + gx) * VEC;
     const bool active = c0 < C;
     const size_t off = (size_t)n * HW * C + c0, off2 = (size_t)n * HW * 2 * C + c0;
     float mu[VEC], rs[VEC], a[VEC], S[4][VEC];
@@ -740,17 +748,17 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
         for (int k = 0; k < 4; ++k) S[k][j] = 0.f;
     }
     if (active)
-        for (int r = ry; r < HW; r += 64) {
+        for (int r = ry; r < HW; r += 2 * RL) {
             u32x4_t rg[2], rx[2], ra[2], ro[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const size_t o = off + (size_t)min(r + 32 * k, HW - 1) * C;
+                const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
                 rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o); ra[k] = *(const u32x4_t*)(gamma + o);
                 ro[k] = lrelu ? *(const u32x4_t*)(fout + o) : u32x4_t{0u, 0u, 0u, 0u};
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                if (r + 32 * k >= HW) continue;
+                if (r + RL * k >= HW) continue;
                 float fg[VEC], fx[VEC], ga[VEC], fo[VEC], dga[VEC], dbe[VEC];
                 unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx); unpack16<T>(ra[k], ga); unpack16<T>(ro[k], fo);
 #pragma unroll
@@ -762,7 +770,7 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
                     const float gn = 0.5f * go * (1.f + ga[j]);
                     S[0][j] += gn; S[1][j] += gn * xh; S[2][j] += go * fx[j]; S[3][j] += go;
                 }
-                const size_t o2 = off2 + (size_t)(r + 32 * k) * 2 * C;
+                const size_t o2 = off2 + (size_t)(r + RL * k) * 2 * C;
                 *(u32x4_t*)(dgb + o2) = pack16<T>(dga);
                 *(u32x4_t*)(dgb + o2 + C) = pack16<T>(dbe);
             }
@@ -774,7 +782,7 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
     __syncthreads();
     if (tid < CH) {
         double t[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int k = 0; k < 32; ++k)
+        for (int k = 0; k < RL; ++k)
 #pragma unroll
             for (int q = 0; q < 4; ++q) t[q] += (double)red[k][tid][q];
         mm[tid][0] = (float)t[0] / (float)HW; mm[tid][1] = (float)t[1] / (float)HW;
@@ -789,18 +797,18 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
     float m0[VEC], m1[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { m0[j] = mm[gx * VEC + j][0]; m1[j] = mm[gx * VEC + j][1]; }
-    for (int r = ry; r < HW; r += 64) {
+    for (int r = ry; r < HW; r += 2 * RL) {
         u32x4_t rg[2], rx[2], ra[2], ro[2], rp[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const size_t o = off + (size_t)min(r + 32 * k, HW - 1) * C;
+            const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
             rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o); ra[k] = *(const u32x4_t*)(gamma + o);
             ro[k] = lrelu ? *(const u32x4_t*)(fout + o) : u32x4_t{0u, 0u, 0u, 0u};
             rp[k] = acc ? *(const u32x4_t*)(dx + o) : u32x4_t{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (r + 32 * k >= HW) continue;
+            if (r + RL * k >= HW) continue;
             float fg[VEC], fx[VEC], ga[VEC], fo[VEC], prev[VEC], o[VEC];
             unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx); unpack16<T>(ra[k], ga); unpack16<T>(ro[k], fo); unpack16<T>(rp[k], prev);
 #pragma unroll
@@ -810,7 +818,7 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
                 const float gn = 0.5f * go * (1.f + ga[j]);
                 o[j] = 0.5f * go * a[j] + rs[j] * (gn - m0[j] - xh * m1[j]) + (acc ? prev[j] : 0.f);
             }
-            *(u32x4_t*)(dx + off + (size_t)(r + 32 * k) * C) = pack16<T>(o);
+            *(u32x4_t*)(dx + off + (size_t)(r + RL * k) * C) = pack16<T>(o);
         }
     }
 }
@@ -832,11 +840,10 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_bwd: C=%d not a multiple of %d", C, vec);
     hipStream_t st = (hipStream_t)stream;
     if (fout && mode == S2E_NORM_SPADE_STYLE && !batch && stage == 0 && HW <= in_small_hw()) {     // small map: one launch
-        const dim3 sg(ceil_div(C, 8 * vec), N);
-        if (dtype == S2E_BF16) spade_small_bwd_kernel<bf16_t><<<sg, 256, 0, st>>>((const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)gb, (const bf16_t*)fout,
-                                                                                stats, style, (bf16_t*)dx, (bf16_t*)dgb, dstyle, HW, C, lrelu, sld, acc);
-        else spade_small_bwd_kernel<float><<<sg, 256, 0, st>>>((const float*)g, (const float*)x, (const float*)gb, (const float*)fout,
-                                                              stats, style, (float*)dx, (float*)dgb, dstyle, HW, C, lrelu, sld, acc);
+        if (dtype == S2E_BF16) S2E_SMALL_LAUNCH(spade_small_bwd_kernel, bf16_t, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)gb, (const bf16_t*)fout,
+                                                 stats, style, (bf16_t*)dx, (bf16_t*)dgb, dstyle, HW, C, lrelu, sld, acc);
+        else S2E_SMALL_LAUNCH(spade_small_bwd_kernel, float, (const float*)g, (const float*)x, (const float*)gb, (const float*)fout,
+                              stats, style, (float*)dx, (float*)dgb, dstyle, HW, C, lrelu, sld, acc);
         S2E_CHECK_LAUNCH("spade_small_bwd_kernel");
         return S2E_OK;
     }
@@ -911,10 +918,9 @@ extern "C" int s2e_instance_norm_fwd(int dtype, const void* x, void* out, float*
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_instance_norm_fwd: C=%d not a multiple of %d", C, vec);
     if (HW <= in_small_hw()) {
-        const dim3 sg(ceil_div(C, 8 * vec), N);
         hipStream_t st = (hipStream_t)stream;
-        if (dtype == S2E_BF16) in_small_kernel<bf16_t, 1><<<sg, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)out, ws, stats, HW, C, eps, lrelu);
-        else in_small_kernel<float, 1><<<sg, 256, 0, st>>>((const float*)x, (float*)out, ws, stats, HW, C, eps, lrelu);
+        if (dtype == S2E_BF16) S2E_SMALL_LAUNCH2(in_small_kernel, bf16_t, 1, (const bf16_t*)x, (bf16_t*)out, ws, stats, HW, C, eps, lrelu);
+        else S2E_SMALL_LAUNCH2(in_small_kernel, float, 1, (const float*)x, (float*)out, ws, stats, HW, C, eps, lrelu);
         S2E_CHECK_LAUNCH("in_small_kernel");
         return S2E_OK;
     }
@@ -930,10 +936,9 @@ extern "C" int s2e_instance_norm_bwd(int dtype, const void* g, const void* x, co
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_instance_norm_bwd: C=%d not a multiple of %d", C, vec);
     if (HW <= in_small_hw()) {
-        const dim3 sg(ceil_div(C, 8 * vec), N);
         hipStream_t st = (hipStream_t)stream;
-        if (dtype == S2E_BF16) in_small_bwd_kernel<bf16_t><<<sg, 256, 0, st>>>((const bf16_t*)g, (const bf16_t*)x, stats, (bf16_t*)dx, HW, C, lrelu);
-        else in_small_bwd_kernel<float><<<sg, 256, 0, st>>>((const float*)g, (const float*)x, stats, (float*)dx, HW, C, lrelu);
+        if (dtype == S2E_BF16) S2E_SMALL_LAUNCH(in_small_bwd_kernel, bf16_t, (const bf16_t*)g, (const bf16_t*)x, stats, (bf16_t*)dx, HW, C, lrelu);
+        else S2E_SMALL_LAUNCH(in_small_bwd_kernel, float, (const float*)g, (const float*)x, stats, (float*)dx, HW, C, lrelu);
         S2E_CHECK_LAUNCH("in_small_bwd_kernel");
         return S2E_OK;
     }
