@@ -32,6 +32,13 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'small_wgrad_reduce_kernel': ('conv_wgrad_small', False),
     # HBM-bound families
     'in_stats_partial_kernel': ('in_stats', True), 'in_stats_finalize_kernel': ('in_stats', False),
+    # small maps, one launch per call: in_small_kernel<T, 0, G> = statistics only (s2e_in_stats), <T, 1, G> = the whole plain
+    # InstanceNorm forward (s2e_instance_norm_fwd, family modulate_fwd).  rocprof prints the template arguments either as
+    # '<..., 0, ...>' or mangled 'Li0E': both spellings are listed
+    'in_small_kernelIDF16bLi0E': ('in_stats', True), 'in_small_kernelIfLi0E': ('in_stats', True),
+    'in_small_kernelIDF16bLi1E': ('modulate_fwd', True), 'in_small_kernelIfLi1E': ('modulate_fwd', True),
+    'in_small_kernel<': ('modulate_fwd', True),
+    'in_small_bwd_kernel': ('modulate_bwd', True), 'spade_small_bwd_kernel': ('modulate_bwd', True),
     'modulate_fwd_kernel': ('modulate_fwd', True),
     'spade_modulate_uniform_kernel': ('modulate_fwd', True),   # label-uniform rectangles of a label-sparse SPADE forward
     'label_rect_classify_kernel': ('label_rects', True), 'label_rect_compact_kernel': ('label_rects', False),
