@@ -253,6 +253,15 @@ int s2e_spade_conv_modulate_sparse(int dtype, const void* actv, const void* w_pa
                                    const int* counts, void* stream);
 int s2e_spade_class_table(int dtype, const float* w_sh, const float* b_sh, const void* w_packed, const float* bias,
                           float* table, int ncls, int nh, int C, void* stream);
+/* s2e_spade_class_table for every label-sparse layer of a forward in one launch (tables at table_base + table_off bytes). */
+typedef struct s2e_class_table_job {
+    const float* w_sh; const float* b_sh; const void* w_packed; const float* bias;
+    long table_off;
+    int nh, C;
+} s2e_class_table_job;
+long s2e_class_table_block_map(const s2e_class_table_job* jobs_host, int n_jobs, int* block_map_host);
+int s2e_spade_class_table_batch(int dtype, const s2e_class_table_job* jobs, const int* block_map, int n_blocks,
+                                void* table_base, int ncls, void* stream);
 int s2e_spade_modulate_uniform(int dtype, const void* x, const float* stats, const float* style, int style_ld,
                                const float* table, const uint8_t* cls, const int* uni_list, const int* counts,
                                void* out, void* gamma_out, int N, int H, int W, int C, int tw, int th, int lrelu, int x_up,
@@ -283,6 +292,19 @@ int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream
  * if relu != 0.  Replaces SPADE.mlp_shared (normalization.py:85-88,97-98) and the generator's
  * fc conv on the downsampled segmap (generator.py:72-73).  weight: the conv's fp32 OIHW weight
  * (Cout, ncls, 3, 3) as it sits in the parameter arena (each block gathers its table from it into LDS). */
+/* All label convs of a generator forward in one launch (the 19 mlp_shared convs of the SPADE layers, normalization.py:97, most of
+ * them a few microseconds of work): jobs is a DEVICE array (cout <= 128 each; outputs at out_base + out_off bytes, so the table
+ * is built once and the per-forward output buffer is one allocation); block_map DEVICE int32 triples from
+ * s2e_label_conv_block_map (block_map_host NULL: count only).  Same numbers as s2e_label_conv3x3 per job. */
+typedef struct s2e_label_conv_job {
+    const float* weight;     /* (cout, ncls, 3, 3) fp32 */
+    const float* bias;       /* (cout) fp32 or NULL */
+    long out_off;            /* bytes from out_base to this job's (N, h, w, cout) output */
+    int h, w, cout, relu;
+} s2e_label_conv_job;
+long s2e_label_conv_block_map(int dtype, const s2e_label_conv_job* jobs_host, int n_jobs, int N, int* block_map_host);
+int s2e_label_conv3x3_batch(int dtype, const uint8_t* label, const s2e_label_conv_job* jobs, const int* block_map,
+                            int n_blocks, void* out_base, int N, int H, int W, int ncls, void* stream);
 int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* weight, const float* bias, void* out,
                       int N, int H, int W, int h, int w, int ncls, int Cout, int relu, void* stream);
 /* out (N,h,w,cpad): channels [0,ncls) one-hot of the nearest-downsampled label, channel ncls =

@@ -28,6 +28,16 @@ class ConvDesc(C.Structure):
         'transposed', 'in_act', 'out_act', 'aux_mode')]
 
 
+class LabelConvJob(C.Structure):
+    _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('out_off', C.c_long), ('h', C.c_int), ('w', C.c_int),
+                ('cout', C.c_int), ('relu', C.c_int)]
+
+
+class ClassTableJob(C.Structure):
+    _fields_ = [('w_sh', C.c_void_p), ('b_sh', C.c_void_p), ('w_packed', C.c_void_p), ('bias', C.c_void_p), ('table_off', C.c_long),
+                ('nh', C.c_int), ('C', C.c_int)]
+
+
 class SnLayer(C.Structure):
     """s2e_sn_layer"""
     _fields_ = [('w', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p), ('t', C.c_void_p), ('s', C.c_void_p),
@@ -87,6 +97,10 @@ SIGNATURES = {
     's2e_spade_conv_modulate_supported': [_i, _i, _i, _i, _i, _i, _i],
     's2e_spade_conv_modulate': [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     's2e_colsum': [_i, _vp, _l, _i, _vp, _vp],
+    's2e_label_conv_block_map': [_i, _vp, _i, _i, _vp],
+    's2e_label_conv3x3_batch': [_i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    's2e_class_table_block_map': [_vp, _i, _vp],
+    's2e_spade_class_table_batch': [_i, _vp, _vp, _i, _vp, _i, _vp],
     's2e_label_conv3x3': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     's2e_onehot_nhwc': [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     's2e_openeds_error': [_i, _vp, _vp, _i, _i, _i, _vp, _vp],
@@ -126,7 +140,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = (C.c_char_p if name == 's2e_last_error' else
                           C.c_size_t if name.endswith('_workspace_bytes') else
-                          C.c_long if name in ('s2e_pack_block_map', 's2e_grad_block_map') else C.c_int)
+                          C.c_long if name in ('s2e_pack_block_map', 's2e_grad_block_map', 's2e_label_conv_block_map', 's2e_class_table_block_map') else C.c_int)
         _lib = L
     return _lib
 

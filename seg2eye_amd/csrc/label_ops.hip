@@ -5,13 +5,14 @@
 // conv3x3(one_hot(nearest_down(label))) == sum over the 9 taps of one table row selected by the
 // neighbour's class: zero MACs, 9 LDS row reads per 16-B output vector.  The [9*ncls][<=128] slice of
 // the table this block needs sits in LDS (<= 18 KiB for ncls = 4).
+// bx of nbx: this block's place among the blocks that walk the pixels of this (layer, channel chunk `by`)
 template <typename T>
-__global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __restrict__ label, const float* __restrict__ weight,
-        const float* __restrict__ bias, T* __restrict__ out, int N, int H, int W, int h, int w, int ncls, int Cout, int relu) {
+__device__ __forceinline__ void label_conv3x3_body(const uint8_t* __restrict__ label, const float* __restrict__ weight,
+        const float* __restrict__ bias, T* __restrict__ out, int N, int H, int W, int h, int w, int ncls, int Cout, int relu,
+        int bx, int nbx, int by, float* tab) {
     constexpr int VEC = Vec<T>::N;
     constexpr int CT = 128;                               // channels per block
-    extern __shared__ __attribute__((aligned(16))) float tab[];   // [9*ncls][CT], bias[CT], uni[ncls][CT]
-    const int cbase = blockIdx.y * CT;
+    const int cbase = by * CT;
     const int cw = min(CT, Cout - cbase);
     const int rows = 9 * ncls;
     // gather table straight from the OIHW conv weight: tab[(tap*ncls + cls)][cc] = weight[cbase+cc][cls][tap]
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
         // instructions per KB stored), not HBM-bound.
         const int ppw = 64 / cgb;
         const int tx = lane % cgb, sub = lane / cgb;
-        for (int base = (blockIdx.x * 4 + wave) * 64; base < npix; base += gridDim.x * 256) {
+        for (int base = (bx * 4 + wave) * 64; base < npix; base += nbx * 256) {
             const int mine = base + lane;
             const unsigned wmine = mine < npix ? load_word(mine) : 0u;
             for (int k = 0; k < cgb; ++k) {
@@ -107,8 +108,37 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
         const int ppb = 256 / cgb;
         const int tx = threadIdx.x % cgb, ty = threadIdx.x / cgb;
         if (ty >= ppb) return;
-        for (int pix = blockIdx.x * ppb + ty; pix < npix; pix += gridDim.x * ppb) emit(load_word(pix), pix, tx);
+        for (int pix = bx * ppb + ty; pix < npix; pix += nbx * ppb) emit(load_word(pix), pix, tx);
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __restrict__ label, const float* __restrict__ weight,
+        const float* __restrict__ bias, T* __restrict__ out, int N, int H, int W, int h, int w, int ncls, int Cout, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];   // [9*ncls][CT], bias[CT], uni[ncls][CT]
+    label_conv3x3_body<T>(label, weight, bias, out, N, H, W, h, w, ncls, Cout, relu, blockIdx.x, gridDim.x, blockIdx.y, tab);
+}
+
+// all label convs of a generator forward in ONE launch (19 mlp_shared convs, most of them a few microseconds of work behind a
+// ~5-us launch): block_map[b] = {job, bx, nbx}; outputs at out_base + job.out_off (one buffer per forward)
+template <typename T>
+__global__ __launch_bounds__(256) void label_conv3x3_batch_kernel(const uint8_t* __restrict__ label, const s2e_label_conv_job* __restrict__ jobs,
+        const int* __restrict__ block_map, char* __restrict__ out_base, int N, int H, int W, int ncls) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    const int* bm = block_map + 3 * blockIdx.x;
+    const s2e_label_conv_job J = jobs[bm[0]];
+    label_conv3x3_body<T>(label, J.weight, J.bias, (T*)(out_base + J.out_off), N, H, W, J.h, J.w, ncls, J.cout, J.relu, bm[1], bm[2], 0, tab);
+}
+
+// blocks along the pixels of one layer (the single launch's grid.x)
+static long label_conv_blocks(int dtype, long npix, int Cout) {
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    const int cw = Cout < 128 ? Cout : 128;
+    const int cgb_h = (cw + vec - 1) / vec;
+    const int ppb = ((64 % cgb_h) == 0 && npix >= 65536) ? 256 : 256 / cgb_h;       // pixels per block per pass
+    const long gx = (npix + ppb - 1) / ppb;
+    static const long cap = [] { const char* e = getenv("S2E_LABEL_GRID"); return e ? atol(e) : 1024L; }();
+    return gx > cap ? cap : gx;
 }
 
 extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* weight, const float* bias, void* out,
@@ -119,19 +149,40 @@ extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* w
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3: bad dtype %d", dtype);
     const long npix = (long)N * h * w;
     if (npix >= (1L << 31)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_label_conv3x3: too many pixels for 32-bit indices");
-    const int vec = dtype == S2E_BF16 ? 8 : 4;
-    const int cw = Cout < 128 ? Cout : 128;
-    const int cgb_h = (cw + vec - 1) / vec;
-    const int ppb = ((64 % cgb_h) == 0 && npix >= 65536) ? 256 : 256 / cgb_h;       // pixels per block per pass
-    long gx = (npix + ppb - 1) / ppb;
-    static const long cap = [] { const char* e = getenv("S2E_LABEL_GRID"); return e ? atol(e) : 1024L; }();
-    if (gx > cap) gx = cap;
+    const long gx = label_conv_blocks(dtype, npix, Cout);
     dim3 grid((unsigned)gx, ceil_div(Cout, 128));
     const size_t lds = (size_t)(9 * ncls + 1 + ncls) * 128 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16) label_conv3x3_kernel<bf16_t><<<grid, 256, lds, st>>>(label, weight, bias, (bf16_t*)out, N, H, W, h, w, ncls, Cout, relu);
     else label_conv3x3_kernel<float><<<grid, 256, lds, st>>>(label, weight, bias, (float*)out, N, H, W, h, w, ncls, Cout, relu);
     S2E_CHECK_LAUNCH("label_conv3x3_kernel");
+    return S2E_OK;
+}
+
+// Batched form: jobs (DEVICE array; every cout <= 128) share the label batch; block_map (DEVICE int32 triples) from
+// s2e_label_conv_block_map, which also serves to count (block_map_host NULL).
+extern "C" long s2e_label_conv_block_map(int dtype, const s2e_label_conv_job* jobs_host, int n_jobs, int N, int* block_map_host) {
+    if (!jobs_host || n_jobs < 0 || N <= 0) return S2E_ERR_ARG;
+    long nb = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const s2e_label_conv_job& J = jobs_host[j];
+        if (J.cout <= 0 || J.cout > 128 || J.h <= 0 || J.w <= 0) return S2E_ERR_ARG;
+        const long gx = label_conv_blocks(dtype, (long)N * J.h * J.w, J.cout);
+        for (long b = 0; b < gx; ++b, ++nb)
+            if (block_map_host) { int* e = block_map_host + 3 * nb; e[0] = j; e[1] = (int)b; e[2] = (int)gx; }
+    }
+    return nb;
+}
+extern "C" int s2e_label_conv3x3_batch(int dtype, const uint8_t* label, const s2e_label_conv_job* jobs, const int* block_map,
+                                       int n_blocks, void* out_base, int N, int H, int W, int ncls, void* stream) {
+    if (!label || !jobs || !block_map || !out_base || n_blocks <= 0 || N <= 0 || ncls <= 0 || ncls > 7)
+        S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3_batch: bad argument");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3_batch: bad dtype %d", dtype);
+    const size_t lds = (size_t)(9 * ncls + 1 + ncls) * 128 * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) label_conv3x3_batch_kernel<bf16_t><<<n_blocks, 256, lds, st>>>(label, jobs, block_map, (char*)out_base, N, H, W, ncls);
+    else label_conv3x3_batch_kernel<float><<<n_blocks, 256, lds, st>>>(label, jobs, block_map, (char*)out_base, N, H, W, ncls);
+    S2E_CHECK_LAUNCH("label_conv3x3_batch_kernel");
     return S2E_OK;
 }
 
@@ -511,11 +562,11 @@ extern "C" int s2e_label_rect_classify(const uint8_t* label, int N, int H, int W
 // DPP adds at the end.  (One thread per output row walking its row alone -- 384 dependent 2-byte loads -- took 42 us per launch,
 // 0.5 ms per step, for 60 MFLOP.)
 template <typename T>
-__global__ __launch_bounds__(256) void spade_class_table_kernel(const float* __restrict__ w_sh, const float* __restrict__ b_sh,
-        const T* __restrict__ wq, const float* __restrict__ bias, float* __restrict__ table, int ncls, int nh, int C2, int kpad) {
+__device__ __forceinline__ void spade_class_table_body(const float* __restrict__ w_sh, const float* __restrict__ b_sh,
+        const T* __restrict__ wq, const float* __restrict__ bias, float* __restrict__ table, int ncls, int nh, int C2, int kpad,
+        int bx, int c, float (*A)[128]) {
     constexpr int ROWS = 4;                                  // one row per wave: its 18 weight loads are one latency round
-    __shared__ float A[9][128];
-    const int c = blockIdx.y, co0 = blockIdx.x * ROWS;
+    const int co0 = bx * ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 9 * 128; i += 256) if ((i & 127) >= nh) A[i >> 7][i & 127] = 0.f;       // nh < 128: the unused columns
     for (int ci = tid; ci < nh; ci += 256) {                 // A[m][ci]: the nine taps of (ci, c) loaded once, all in flight
@@ -577,6 +628,24 @@ __global__ __launch_bounds__(256) void spade_class_table_kernel(const float* __r
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void spade_class_table_kernel(const float* __restrict__ w_sh, const float* __restrict__ b_sh,
+        const T* __restrict__ wq, const float* __restrict__ bias, float* __restrict__ table, int ncls, int nh, int C2, int kpad) {
+    __shared__ float A[9][128];
+    spade_class_table_body<T>(w_sh, b_sh, wq, bias, table, ncls, nh, C2, kpad, blockIdx.x, blockIdx.y, A);
+}
+// the tables of all label-sparse SPADE layers of a forward in one launch: block_map[b] = {job, bx}; grid.y = class
+template <typename T>
+__global__ __launch_bounds__(256) void spade_class_table_batch_kernel(const s2e_class_table_job* __restrict__ jobs,
+        const int* __restrict__ block_map, char* __restrict__ table_base, int ncls, int bk) {
+    __shared__ float A[9][128];
+    const int* bm = block_map + 2 * blockIdx.x;
+    const s2e_class_table_job J = jobs[bm[0]];
+    const int kpad = (9 * J.nh + bk - 1) / bk * bk;
+    spade_class_table_body<T>(J.w_sh, J.b_sh, (const T*)J.w_packed, J.bias, (float*)(table_base + J.table_off), ncls, J.nh, 2 * J.C, kpad,
+                              bm[1], blockIdx.y, A);
+}
+
 extern "C" int s2e_spade_class_table(int dtype, const float* w_sh, const float* b_sh, const void* w_packed, const float* bias,
                                      float* table, int ncls, int nh, int C, void* stream) {
     if (!w_sh || !b_sh || !w_packed || !table || ncls <= 0 || ncls > 8 || nh <= 0 || nh > 128 || C <= 0)
@@ -589,6 +658,31 @@ extern "C" int s2e_spade_class_table(int dtype, const float* w_sh, const float* 
     if (dtype == S2E_BF16) spade_class_table_kernel<bf16_t><<<grid, 256, 0, st>>>(w_sh, b_sh, (const bf16_t*)w_packed, bias, table, ncls, nh, 2 * C, kpad);
     else spade_class_table_kernel<float><<<grid, 256, 0, st>>>(w_sh, b_sh, (const float*)w_packed, bias, table, ncls, nh, 2 * C, kpad);
     S2E_CHECK_LAUNCH("spade_class_table_kernel");
+    return S2E_OK;
+}
+
+extern "C" long s2e_class_table_block_map(const s2e_class_table_job* jobs_host, int n_jobs, int* block_map_host) {
+    if (!jobs_host || n_jobs < 0) return S2E_ERR_ARG;
+    long nb = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (jobs_host[j].C <= 0 || jobs_host[j].nh <= 0 || jobs_host[j].nh > 128) return S2E_ERR_ARG;
+        const int gx = ceil_div(2 * jobs_host[j].C, 4);
+        for (int b = 0; b < gx; ++b, ++nb)
+            if (block_map_host) { block_map_host[2 * nb] = j; block_map_host[2 * nb + 1] = b; }
+    }
+    return nb;
+}
+extern "C" int s2e_spade_class_table_batch(int dtype, const s2e_class_table_job* jobs, const int* block_map, int n_blocks,
+                                           void* table_base, int ncls, void* stream) {
+    if (!jobs || !block_map || !table_base || n_blocks <= 0 || ncls <= 0 || ncls > 8)
+        S2E_FAIL(S2E_ERR_ARG, "s2e_spade_class_table_batch: bad argument");
+    if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_class_table_batch: bad dtype %d", dtype);
+    const int bk = dtype == S2E_BF16 ? 64 : 32;
+    const dim3 grid(n_blocks, ncls);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) spade_class_table_batch_kernel<bf16_t><<<grid, 256, 0, st>>>(jobs, block_map, (char*)table_base, ncls, bk);
+    else spade_class_table_batch_kernel<float><<<grid, 256, 0, st>>>(jobs, block_map, (char*)table_base, ncls, bk);
+    S2E_CHECK_LAUNCH("spade_class_table_batch_kernel");
     return S2E_OK;
 }
 

@@ -55,7 +55,11 @@ class SPADESTYLEGenerator(BaseNetwork):
             raise ValueError('label map is %dx%d but this generator emits %dx%d (SURVEY F5)' % (H, W, self.sh * f, self.sw * f))
         w = w.float()
         bank = sn_begin(self)          # one batched power iteration for all 18 spectral-normed convs
-        with packing.network_scope(self, bank), stylebank.scope(self, w):   # all weight packs: one launch; all style FCs: one GEMM
+        pre = self.__dict__.get('_spade_prepass')
+        if pre is None:
+            pre = self.__dict__['_spade_prepass'] = ops.SpadePrepass()
+        # all weight packs: one launch; all style FCs: one GEMM; all label convs / per-class tables: one launch each
+        with packing.network_scope(self, bank), stylebank.scope(self, w), pre.scope(seg.label, self.cdtype):
             # F.interpolate(seg, (sh, sw)) + fc conv, generator.py:72-73
             x = ops.label_conv3x3(seg.label, self.fc.weight, self.fc.bias, self.sh, self.sw, False, self.cdtype)
             # a block that follows an upsampling takes its input statistics from the tensor BEFORE it (nearest 2x

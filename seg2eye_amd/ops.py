@@ -10,6 +10,8 @@ There is no CPU path: calling an op with a non-CUDA tensor raises.
 import ctypes as C
 import os
 
+import numpy as np
+
 import torch
 
 from . import _lib as L
@@ -424,6 +426,162 @@ def label_conv3x3_raw(label, weight, bias, n, H, W, h, w, cout, relu, dtype):
     return out
 
 
+class SpadePrepass:
+    """The label convs (mlp_shared, normalization.py:97) and per-class tables of ALL SPADE layers of a generator forward as one
+    launch each, at the top of the forward, instead of ~19 + ~6 launches of a few microseconds of work spread over it.
+
+    `with prepass.scope(label, dtype):` around the generator's blocks.  The SPADE ops ask `SpadePrepass.actv(...)` /
+    `.table(...)`: served from the batched launch when the layer is in the plan, computed on the spot (and, on a learning
+    forward, recorded) otherwise.  The plan is learned on the SECOND forward of a shape -- by then the packed [gamma | beta]
+    weights live in the PackPlan's persistent buffers, which the table jobs point at -- and dropped when any tensor it points
+    at has moved (optimizer arena rebuilt, .cuda())."""
+    current = None
+
+    def __init__(self):
+        self.plans = {}            # key -> None (seen once) | dict
+        self.key = None
+        self.rec = None            # learning forward: {'conv': [...], 'table': [...]}
+        self.planned = self.missed = False
+        self.pre = {}              # this forward's batched results
+
+    # ------------------------------------------------------------------ scope
+    class _Scope:
+        def __init__(self, owner, label, dtype):
+            self.o, self.label, self.dtype = owner, label, dtype
+
+        def __enter__(self):
+            o = self.o
+            self.prev = SpadePrepass.current
+            SpadePrepass.current = o
+            n, H, W = self.label.shape
+            o.key = (n, H, W, self.dtype, str(self.label.device))
+            o.pre, o.rec, o.planned, o.missed = {}, None, False, False
+            if _PREPASS_OFF:
+                return o
+            if o.key not in o.plans:
+                o.plans[o.key] = None                              # first forward of this shape: only note it
+            elif o.plans[o.key] is None:
+                o.rec = {'conv': [], 'table': []}                  # second: learn
+            else:
+                plan = o.plans[o.key]
+                if any(t.data_ptr() != ptr for t, ptr in plan['pins']):
+                    o.plans[o.key] = None                          # something moved: learn again next time
+                else:
+                    o._run(plan, self.label, self.dtype)
+                    o.planned = True
+            return o
+
+        def __exit__(self, *exc):
+            o = self.o
+            if o.rec is not None and exc[0] is None and (o.rec['conv'] or o.rec['table']):
+                o.plans[o.key] = o._build(o.rec, self.label, self.dtype)
+            elif o.planned and o.missed:
+                o.plans[o.key] = None
+            o.rec, o.pre, o.key = None, {}, None
+            SpadePrepass.current = self.prev
+            return False
+
+    def scope(self, label, dtype):
+        return SpadePrepass._Scope(self, label, dtype)
+
+    # ------------------------------------------------------------------ plan
+    def _build(self, rec, label, dtype):
+        lib = L.lib()
+        n = label.shape[0]
+        dev = label.device
+        dt = L.S2E_BF16 if dtype == torch.bfloat16 else L.S2E_F32
+        esz = 2 if dtype == torch.bfloat16 else 4
+        plan = {'pins': [], 'conv': None, 'table': None}
+        if rec['conv']:
+            jobs = (L.LabelConvJob * len(rec['conv']))()
+            off, entries = 0, []
+            for i, (w_sh, b_sh, h, w, cout, relu) in enumerate(rec['conv']):
+                jobs[i].weight, jobs[i].bias = w_sh.data_ptr(), (b_sh.data_ptr() if b_sh is not None else None)
+                jobs[i].out_off, jobs[i].h, jobs[i].w, jobs[i].cout, jobs[i].relu = off, h, w, cout, int(relu)
+                entries.append((w_sh.data_ptr(), h, w, off, (n, h, w, cout)))
+                off += (n * h * w * cout * esz + 255) // 256 * 256
+                plan['pins'] += [(w_sh, w_sh.data_ptr())] + ([(b_sh, b_sh.data_ptr())] if b_sh is not None else [])   # (the objects the ops were handed: a re-homed Parameter shows here)
+            nb = lib.s2e_label_conv_block_map(dt, C.byref(jobs), len(rec['conv']), n, None)
+            bm = np.zeros(3 * nb, dtype=np.int32)
+            lib.s2e_label_conv_block_map(dt, C.byref(jobs), len(rec['conv']), n, bm.ctypes.data)
+            plan['conv'] = dict(jobs=torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).to(dev),
+                                map=torch.from_numpy(bm).to(dev), nb=int(nb), bytes=off, entries=entries,
+                                ncls=rec['conv'][0][0].shape[1])
+        if rec['table']:
+            jobs = (L.ClassTableJob * len(rec['table']))()
+            off, entries = 0, []
+            for i, (w_sh, b_sh, wp, b_f, c, nh, ncls) in enumerate(rec['table']):
+                jobs[i].w_sh, jobs[i].b_sh, jobs[i].w_packed, jobs[i].bias = w_sh.data_ptr(), b_sh.data_ptr(), wp.data_ptr(), b_f.data_ptr()
+                jobs[i].table_off, jobs[i].nh, jobs[i].C = off, nh, c
+                entries.append((wp.data_ptr(), off, (ncls, 5, 5, 2 * c)))
+                off += ncls * 25 * 2 * c * 4
+                plan['pins'] += [(w_sh, w_sh.data_ptr()), (b_sh, b_sh.data_ptr()), (wp, wp.data_ptr()), (b_f, b_f.data_ptr())]
+            nb = lib.s2e_class_table_block_map(C.byref(jobs), len(rec['table']), None)
+            bm = np.zeros(2 * nb, dtype=np.int32)
+            lib.s2e_class_table_block_map(C.byref(jobs), len(rec['table']), bm.ctypes.data)
+            plan['table'] = dict(jobs=torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).to(dev),
+                                 map=torch.from_numpy(bm).to(dev), nb=int(nb), bytes=off, entries=entries, ncls=rec['table'][0][6])
+        return plan
+
+    def _run(self, plan, label, dtype):
+        n, H, W = label.shape
+        dt = L.S2E_BF16 if dtype == torch.bfloat16 else L.S2E_F32
+        pc = plan['conv']
+        if pc is not None:
+            buf = torch.empty(pc['bytes'], dtype=torch.uint8, device=label.device)
+            LaunchProfiler.run('label_conv', 0.0, lambda: L.check(
+                L.lib().s2e_label_conv3x3_batch(dt, _p(label), _p(pc['jobs']), _p(pc['map']), pc['nb'], _p(buf), n, H, W, pc['ncls'],
+                                                _stream()), 's2e_label_conv3x3_batch'), nbytes=float(pc['bytes']))
+            for ptr, h, w, off, shape in pc['entries']:
+                numel = shape[0] * shape[1] * shape[2] * shape[3]
+                self.pre[('a', ptr, h, w)] = buf[off:off + numel * (2 if dtype == torch.bfloat16 else 4)].view(dtype).view(shape)
+        pt = plan['table']
+        if pt is not None:
+            tb = torch.empty(pt['bytes'] // 4, dtype=torch.float32, device=label.device)
+            L.check(L.lib().s2e_spade_class_table_batch(dt, _p(pt['jobs']), _p(pt['map']), pt['nb'], _p(tb), pt['ncls'], _stream()),
+                    's2e_spade_class_table_batch')
+            for ptr, off, shape in pt['entries']:
+                self.pre[('t', ptr)] = tb[off // 4:off // 4 + shape[0] * 25 * shape[3]].view(shape)
+
+    # ------------------------------------------------------------------ what the SPADE ops call
+    @classmethod
+    def actv(cls, label, w_sh, b_sh, n, H, W, h, w, nh, dtype):
+        """ReLU(mlp_shared(one-hot label at (h, w))) -- label_conv3x3_raw(..., relu=True) -- from the batched launch if planned."""
+        wt, bt = _table_of(w_sh), b_sh.detach().float().contiguous()
+        cur = cls.current
+        if cur is not None:
+            hit = cur.pre.get(('a', wt.data_ptr(), h, w))
+            if hit is not None and hit.dtype == dtype and hit.shape[0] == n:
+                return hit
+            if cur.planned:
+                cur.missed = True                                   # a planned forward that had to compute on the spot: learn again
+            if cur.rec is not None and nh <= 128 and wt.data_ptr() == w_sh.data_ptr() and bt.data_ptr() == b_sh.data_ptr():
+                cur.rec['conv'].append((w_sh, b_sh, h, w, nh, True))
+        return label_conv3x3_raw(label, wt, bt, n, H, W, h, w, nh, True, dtype)
+
+    @classmethod
+    def table(cls, x_dtype, w_sh, b_sh, wp, b_f, ncls, nh, c, stable):
+        """The per-class [gamma | beta] table of a label-sparse layer (s2e_spade_class_table), from the batched launch if planned.
+        stable: wp and b_f are persistent buffers (PackPlan pack / arena view), i.e. worth pointing a job at."""
+        wt, bt = _table_of(w_sh), b_sh.detach().float().contiguous()
+        cur = cls.current
+        if cur is not None:
+            hit = cur.pre.get(('t', wp.data_ptr()))
+            if hit is not None and tuple(hit.shape) == (ncls, 5, 5, 2 * c):
+                return hit
+            if cur.planned and stable:
+                cur.missed = True
+            if cur.rec is not None and stable and wt.data_ptr() == w_sh.data_ptr() and bt.data_ptr() == b_sh.data_ptr():
+                cur.rec['table'].append((w_sh, b_sh, wp, b_f, c, nh, ncls))
+        table = torch.empty(ncls, 5, 5, 2 * c, dtype=torch.float32, device=wp.device)
+        dt = L.S2E_BF16 if x_dtype == torch.bfloat16 else L.S2E_F32
+        L.check(L.lib().s2e_spade_class_table(dt, _p(wt), _p(bt), _p(wp), _p(b_f), _p(table), ncls, nh, c, _stream()), 's2e_spade_class_table')
+        return table
+
+
+_PREPASS_OFF = os.environ.get('S2E_SPADE_PREPASS', '1') == '0'      # A/B switch: every label conv / class table as its own launch
+
+
 def onehot_nhwc_raw(label, img, h, w, ncls, cpad, dtype):
     _need(label, img)
     n, H, W = label.shape
@@ -640,7 +798,7 @@ class SpadeParamFn(torch.autograd.Function):
         n, H, W = label.shape
         nh, C = w_sh.shape[0], w_g.shape[0]
         fused, w_gb, b_gb = _gb_operands(w_g, b_g, w_b, b_b, nh)
-        actv = label_conv3x3_raw(label, _table_of(w_sh), b_sh.detach().float().contiguous(), n, H, W, h, w, nh, True, dtype)
+        actv = SpadePrepass.actv(label, w_sh, b_sh, n, H, W, h, w, nh, dtype)
         plan = packing.current()
         wp = packed_weight(w_gb, dtype, nh, False, None, plan, stable=fused)
         ctx.plan, ctx.plan_gen, ctx.fused = plan, (plan.generation if plan is not None else None), fused
@@ -852,9 +1010,10 @@ class SpadeFusedFn(torch.autograd.Function):
         nh = w_sh.shape[0]
         dtype = x.dtype
         fused, w_gb, b_gb = _gb_operands(w_g, b_g, w_b, b_b, nh)
-        actv = label_conv3x3_raw(label, _table_of(w_sh), b_sh.detach().float().contiguous(), n, H, W, h, w, nh, True, dtype)
+        actv = SpadePrepass.actv(label, w_sh, b_sh, n, H, W, h, w, nh, dtype)
         plan = packing.current()
         wp = packed_weight(w_gb, dtype, nh, False, None, plan, stable=fused)
+        wp_persistent = fused and plan is not None and plan.lookup(w_gb, dtype, nh, False) is wp
         ctx.plan, ctx.plan_gen, ctx.fused = plan, (plan.generation if plan is not None else None), fused
         # (inside forward() grad mode is always off and needs_input_grad is set under torch.no_grad() too: whether a backward can
         # follow is the CALLER's grad mode, handed in.  Without it the D step's no-grad generator forward stored gamma for nothing.)
@@ -879,9 +1038,7 @@ class SpadeFusedFn(torch.autograd.Function):
             # the per-class table (s2e_spade_class_table: this layer's [gamma | beta] branch on one-class maps, all 25 border cases)
             cls, dense_list, uni_list, counts, tw, th = sparse
             ncls = w_sh.shape[1]
-            table = torch.empty(ncls, 5, 5, 2 * c, dtype=torch.float32, device=x.device)
-            L.check(L.lib().s2e_spade_class_table(_dt(x), _p(_table_of(w_sh)), _p(b_sh.detach().float().contiguous()), _p(wp), _p(b_f),
-                                                  _p(table), ncls, nh, c, _stream()), 's2e_spade_class_table')
+            table = SpadePrepass.table(x.dtype, w_sh, b_sh, wp, b_f, ncls, nh, c, wp_persistent and b_f.data_ptr() == b_gb.data_ptr())
             frac = 1.0
             if LaunchProfiler.active():                         # executed work of this launch (a sync: profiling runs only)
                 rects = cls.numel()

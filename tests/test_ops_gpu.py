@@ -539,3 +539,48 @@ def test_bilinear_resize_matches_torch(hw, dtype):
     _close(y.permute(0, 3, 1, 2), yr, dtype, what='bilinear fwd')
     y.backward(gy.permute(0, 2, 3, 1).contiguous().to(_dev()))
     _close(xg.grad, xr.grad, torch.float32 if dtype == torch.float32 else dtype, what='bilinear bwd')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_spade_prepass_batches_label_convs_and_tables(dtype):
+    """ops.SpadePrepass: from the third forward of a shape on, the label convs (mlp_shared + ReLU) and the per-class tables of
+    every planned layer come out of ONE launch each (s2e_label_conv3x3_batch, s2e_spade_class_table_batch) -- the same bits as
+    the per-layer launches -- and the plan is dropped when a tensor it points at moves."""
+    from seg2eye_amd import ops
+    from seg2eye_amd.synthetic import ellipse_labels
+    dev = _dev()
+    N, H, W = 2, 64, 64
+    lab = torch.from_numpy(ellipse_labels(N, H, W, 5)[:, 0]).to(dev)
+    layers = []
+    for i, (h, w, c) in enumerate([(64, 64, 64), (32, 32, 64), (32, 32, 128), (16, 16, 192), (8, 8, 64)]):
+        w_sh = _rnd((128, 4, 3, 3), 60 + i, torch.float32, 0.3).to(dev)
+        b_sh = _rnd((128,), 70 + i, torch.float32, 0.1).to(dev)
+        w_gb = _rnd((2 * c, 128, 3, 3), 80 + i, torch.float32, 0.03).to(dev)
+        b_gb = _rnd((2 * c,), 90 + i, torch.float32, 0.1).to(dev)
+        wp = ops.pack_weight(w_gb, dtype, 128, False, None)              # persistent for the test: held in `layers`
+        layers.append((w_sh, b_sh, wp, b_gb, h, w, c))
+    pre = ops.SpadePrepass()
+
+    def forward():
+        with pre.scope(lab, dtype):
+            acts = [ops.SpadePrepass.actv(lab, w_sh, b_sh, N, H, W, h, w, 128, dtype) for w_sh, b_sh, wp, b_gb, h, w, c in layers]
+            tabs = [ops.SpadePrepass.table(dtype, w_sh, b_sh, wp, b_gb, 4, 128, c, True) for w_sh, b_sh, wp, b_gb, h, w, c in layers]
+        return acts, tabs
+    a1, t1 = forward()                                                  # noted
+    a2, t2 = forward()                                                  # learned
+    plan = list(pre.plans.values())[0]
+    assert plan is not None and plan['conv']['nb'] > len(layers) and len(plan['table']['entries']) == len(layers)
+    a3, t3 = forward()                                                  # batched
+    base = a3[0].untyped_storage().data_ptr()
+    assert all(a.untyped_storage().data_ptr() == base for a in a3) and a1[0].untyped_storage().data_ptr() != a1[1].untyped_storage().data_ptr()
+    for x, y, z in zip(a1, a2, a3):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    for x, y, z in zip(t1, t2, t3):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    # a weight that moved: the plan is dropped, the forward still gives the right numbers, and it is learned again
+    layers[1][0].data = layers[1][0].data.clone()                       # (what re-homing a Parameter into a new arena does)
+    a4, t4 = forward()
+    assert list(pre.plans.values())[0] is None and all(torch.equal(x, y) for x, y in zip(a1, a4))
+    forward()
+    a6, _ = forward()
+    assert all(torch.equal(x, y) for x, y in zip(a1, a6)) and a6[0].untyped_storage().data_ptr() == a6[1].untyped_storage().data_ptr()
