@@ -227,6 +227,19 @@ int s2e_instance_norm_bwd(int dtype, const void* g, const void* x, const float* 
 int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const void* gb, const float* stats,
                      const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                      int N, int HW, int C, int lrelu, int style_ld, void* stream);
+/* The weight (and bias) gradients of MANY 8-channel-input 3x3 convs in one call -- a generator's 19 mlp_shared convs
+ * (normalization.py:97, backward): x = the one-hot label map at the layer's resolution (N,H,W,8), gy = d(hidden activation),
+ * masked (N,H,W,128), both bf16.  dw_oihw fp32 (128, ncls, 3, 3) -- the parameter's own layout -- and dbias fp32 (128) are
+ * ACCUMULATED into.  jobs is a HOST array (it travels in the kernel arguments).  _supported: bf16, 128 output channels, a map
+ * whose best 128-pixel slab covers it to >= 80 % (16 x 16 and up). */
+typedef struct s2e_wgrad_c8_job {
+    const void* x; const void* gy; float* dw_oihw; float* dbias;
+    int H, W, ncls;
+} s2e_wgrad_c8_job;
+int s2e_wgrad_c8_batch_supported(int dtype, int H, int W, int cout);
+size_t s2e_wgrad_c8_batch_workspace_bytes(int N, const s2e_wgrad_c8_job* jobs, int n_jobs);
+int s2e_wgrad_c8_batch(int dtype, int N, const s2e_wgrad_c8_job* jobs, int n_jobs, void* workspace, size_t workspace_bytes,
+                       void* stream);
 /* Label-sparse form of the fused launch.  gamma / beta at a pixel depend only on the labels of its 5x5 neighbourhood, so a
  * rectangle of the fused launch's tiling (s2e_spade_conv_modulate_rect: tw x th pixels) whose pixels and in-image 2-pixel halo
  * all carry ONE class takes them from a per-class table instead of the convolution -- exact up to fp32 summation order, and

@@ -290,19 +290,17 @@ struct WcParams {
     asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(off_hi) : "memory")
 
 template <int TWS>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_c8_kernel(const WcParams p) {
+__device__ __forceinline__ void conv_wgrad_c8_body(const WcParams& p, int split, int tco, float* __restrict__ tile, char* smem) {
     typedef bf16_t T;
     constexpr int TW = 1 << TWS, TH = 128 >> TWS, PW = TW + 2, PH = TH + 2;
     constexpr int XPIECES = 5;                        // 64 pixels x 16 B per piece; 320 >= 4 x 66
     constexpr int X_BYTES = XPIECES * 1024, G_BYTES = 128 * 256, STAGE = X_BYTES + G_BYTES;
     static_assert(PH * PW <= XPIECES * 64, "patch capacity");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave;                              // 32-co block of this wave
-    const int split = blockIdx.x, tco = blockIdx.y;
     const int s0 = split * p.per_split, s1 = min(p.nslabs, s0 + p.per_split);
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ gg = (const T*)p.gy;
@@ -421,7 +419,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c8_kernel(const WcParams p)
         }
     }
     // partial tile of this workgroup: [128 co][80] (72 weight columns, column 72 = bias sum); an idle split writes zeros
-    float* __restrict__ tile = p.ws + ((size_t)tco * gridDim.x + split) * (128 * 80);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -429,6 +426,50 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c8_kernel(const WcParams p)
             const int col = 32 * c + l31;
             if (col < 80) tile[(cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 80 + col] = acc[c][r];
         }
+}
+
+template <int TWS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_c8_kernel(const WcParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * ((5 * 1024) + 128 * 256)];
+    conv_wgrad_c8_body<TWS>(p, blockIdx.x, blockIdx.y, p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (128 * 80), smem);
+}
+
+// The 8-channel weight gradients of MANY layers (a generator's 19 mlp_shared convs: the one-hot label map against d actv) in one
+// launch.  The jobs travel BY VALUE in the kernel arguments (no device table to upload, and a hipGraph node keeps them):
+// block b belongs to the job whose [first, first + splits) range of blocks holds it.  Cout = 128 for every job.
+struct WcJob { const void* x; const void* gy; float* dw; float* dbias; int H, W, sx, sy, nslabs, per_split, first, splits, ws_tile, ncls; };
+constexpr int WC_MAX_JOBS = 24;
+struct WcBatch { int n, N; WcJob j[WC_MAX_JOBS]; };
+
+template <int TWS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_c8_batch_kernel(const WcBatch b, float* __restrict__ ws) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * ((5 * 1024) + 128 * 256)];
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.j[k + 1].first) ++k;
+    const WcJob& J = b.j[k];
+    WcParams p;
+    p.x = J.x; p.gy = J.gy; p.ws = ws; p.N = b.N; p.H = J.H; p.W = J.W; p.Cout = 128;
+    p.sx = J.sx; p.sy = J.sy; p.nslabs = J.nslabs; p.per_split = J.per_split;
+    const int split = blockIdx.x - J.first;
+    conv_wgrad_c8_body<TWS>(p, split, 0, ws + (size_t)(J.ws_tile + split) * (128 * 80), smem);
+}
+
+// all jobs' partial tiles -> the OIHW gradients: dw[(co * ncls + ci) * 9 + tap] += sum over the job's splits of column tap * 8 + ci
+// (ci < ncls), dbias[co] += column 72.  grid.x = jobs x 37 blocks of 256 outputs (128 x 73), grid.y strides the splits.
+__global__ __launch_bounds__(256) void wgrad_c8_batch_reduce_kernel(const WcBatch b, const float* __restrict__ ws) {
+    const int job = blockIdx.x / 37, idx = (blockIdx.x - job * 37) * 256 + threadIdx.x;
+    if (idx >= 128 * 73) return;
+    const WcJob& J = b.j[job];
+    const int co = idx / 73, j = idx - co * 73;
+    const float* src = ws + (size_t)J.ws_tile * (128 * 80) + (size_t)co * 80 + j;
+    float a = 0.f;
+    for (int s = blockIdx.y; s < J.splits; s += gridDim.y) a += src[(size_t)s * (128 * 80)];
+    if (j < 72) {
+        const int tap = j >> 3, ci = j & 7;
+        if (ci < J.ncls) atomicAdd(J.dw + ((size_t)co * J.ncls + ci) * 9 + tap, a);
+    } else if (J.dbias) {
+        atomicAdd(J.dbias + co, a);
+    }
 }
 
 // dw[co][j] += sum over splits of ws[tco][split][co % 128][j], j < 72; dbias[co] += column 72.  blockIdx.y strides the
@@ -599,5 +640,78 @@ int s2e_wgrad_c8_launch(int slab_w, const void* x, const void* gy, float* dw, fl
     while (bx * by < 512 && by * 2 <= splits) by *= 2;
     wgrad_c8_reduce_kernel<<<dim3(bx, by), 256, 0, st>>>(p.ws, dw, dbias, d->Cout, splits);
     S2E_CHECK_LAUNCH("wgrad_c8_reduce_kernel");
+    return S2E_OK;
+}
+
+// ---- batched form (see conv_wgrad_c8_batch_kernel).  Host-side job descriptions; every job: bf16, x (N,H,W,8) one-hot map,
+// gy (N,H,W,128), 3x3 stride 1 pad 1; dw_oihw fp32 (128, ncls, 3, 3) and dbias fp32 (128) are ACCUMULATED into.
+static int wc_best_slab(int H, int W) {
+    int best = 0; double best_fill = 0.0;
+    for (int tw = 64; tw >= 16; tw >>= 1) {
+        const int th = 128 / tw;
+        const long covered = (long)ceil_div(H, th) * th * ceil_div(W, tw) * tw;
+        const double fill = (double)H * W / (double)covered;
+        if (fill > best_fill + 1e-9) { best_fill = fill; best = tw; }
+    }
+    return best_fill >= 0.8 ? best : 0;
+}
+extern "C" int s2e_wgrad_c8_batch_supported(int dtype, int H, int W, int cout) {
+    return dtype == S2E_BF16 && cout == 128 && wc_best_slab(H, W) != 0;
+}
+static void wc_job_plan(int N, const s2e_wgrad_c8_job& h, WcJob& J, int& slab_w) {
+    slab_w = wc_best_slab(h.H, h.W);
+    J.x = h.x; J.gy = h.gy; J.dw = h.dw_oihw; J.dbias = h.dbias; J.H = h.H; J.W = h.W; J.ncls = h.ncls;
+    J.sx = ceil_div(h.W, slab_w); J.sy = ceil_div(h.H, 128 / slab_w); J.nslabs = N * J.sy * J.sx;
+    int splits = ceil_div(J.nslabs, 8);               // ~8 slabs (1024 pixels) per workgroup
+    if (splits > 512) splits = 512;
+    J.per_split = ceil_div(J.nslabs, splits);
+    J.splits = ceil_div(J.nslabs, J.per_split);
+}
+extern "C" size_t s2e_wgrad_c8_batch_workspace_bytes(int N, const s2e_wgrad_c8_job* jobs, int n_jobs) {
+    if (!jobs || n_jobs <= 0 || N <= 0) return 0;
+    size_t tiles = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!wc_best_slab(jobs[i].H, jobs[i].W)) return 0;
+        WcJob J; int sw;
+        wc_job_plan(N, jobs[i], J, sw);
+        tiles += J.splits;
+    }
+    return tiles * (128 * 80) * sizeof(float);
+}
+extern "C" int s2e_wgrad_c8_batch(int dtype, int N, const s2e_wgrad_c8_job* jobs, int n_jobs, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (!jobs || n_jobs <= 0 || N <= 0 || !workspace) S2E_FAIL(S2E_ERR_ARG, "s2e_wgrad_c8_batch: bad argument");
+    if (dtype != S2E_BF16) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_wgrad_c8_batch: bf16 only");
+    if (workspace_bytes < s2e_wgrad_c8_batch_workspace_bytes(N, jobs, n_jobs)) S2E_FAIL(S2E_ERR_ARG, "s2e_wgrad_c8_batch: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    for (int base = 0; base < n_jobs; base += WC_MAX_JOBS) {          // (more jobs than one argument block holds: several rounds)
+        const int cnt = n_jobs - base < WC_MAX_JOBS ? n_jobs - base : WC_MAX_JOBS;
+        WcBatch all{}; all.n = cnt; all.N = N;
+        int slab[WC_MAX_JOBS];
+        int ws_tile = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const s2e_wgrad_c8_job& h = jobs[base + i];
+            if (!h.x || !h.gy || !h.dw_oihw || h.ncls <= 0 || h.ncls > 8 || !wc_best_slab(h.H, h.W))
+                S2E_FAIL(S2E_ERR_ARG, "s2e_wgrad_c8_batch: bad job %d", base + i);
+            wc_job_plan(N, h, all.j[i], slab[i]);
+            all.j[i].ws_tile = ws_tile;
+            ws_tile += all.j[i].splits;
+        }
+        for (int sw = 64; sw >= 16; sw >>= 1) {                       // one launch per slab shape present
+            WcBatch g{}; g.N = N;
+            int first = 0;
+            for (int i = 0; i < cnt; ++i)
+                if (slab[i] == sw) { g.j[g.n] = all.j[i]; g.j[g.n].first = first; first += all.j[i].splits; ++g.n; }
+            if (!g.n) continue;
+            if (sw == 64) conv_wgrad_c8_batch_kernel<6><<<first, 256, 0, st>>>(g, ws);
+            else if (sw == 32) conv_wgrad_c8_batch_kernel<5><<<first, 256, 0, st>>>(g, ws);
+            else conv_wgrad_c8_batch_kernel<4><<<first, 256, 0, st>>>(g, ws);
+            S2E_CHECK_LAUNCH("conv_wgrad_c8_batch_kernel");
+        }
+        wgrad_c8_batch_reduce_kernel<<<dim3(cnt * 37, 8), 256, 0, st>>>(all, ws);
+        S2E_CHECK_LAUNCH("wgrad_c8_batch_reduce_kernel");
+        ws += (size_t)ws_tile * (128 * 80);
+    }
     return S2E_OK;
 }

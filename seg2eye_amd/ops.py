@@ -200,6 +200,7 @@ class _ZeroScope:
                 self.pool.sink.flush()                       # all queued weight-gradient re-layouts: two launches
             else:
                 self.pool.sink.jobs = []
+                self.pool.sink.c8 = []
         finally:
             self.pool._end()
         return False
@@ -216,8 +217,10 @@ class GradSink:
 
     def __init__(self):
         self.jobs = []
+        self.c8 = []               # deferred 8-channel weight gradients (mlp_shared): (onehot, d actv, dw, db, ncls)
         self.tables = {}
         self.keepalive = None
+        self.keep_c8 = None
 
     @staticmethod
     def push(dwp, dst, cout, cin, taps, cin_pad, w_orig=None, u=None, v=None, sigma=None):
@@ -228,7 +231,39 @@ class GradSink:
         pool.sink.jobs.append((dwp, dst, w_orig, u, v, sigma, int(cout), int(cin), int(taps), int(cin_pad)))
         return True
 
+    @staticmethod
+    def push_c8(oh, dactv, dw, db, ncls):
+        """Queue the weight / bias gradient of a 3x3 conv on the 8-channel one-hot map `oh` (N,h,w,8) with output gradient
+        `dactv` (N,h,w,128), accumulated straight into dw (128,ncls,3,3) / db (128) fp32 at the next flush -- all queued layers
+        in one launch per slab shape (s2e_wgrad_c8_batch).  False: not queued (no scope, or a shape the batch does not take)."""
+        pool = ZeroPool.active()
+        if pool is None or _C8_BATCH_OFF or dw is None or db is None or oh.dtype != torch.bfloat16:
+            return False
+        n, h, w, _ = oh.shape
+        if dactv.shape[-1] != 128 or not L.lib().s2e_wgrad_c8_batch_supported(L.S2E_BF16, h, w, 128):
+            return False
+        pool.sink.c8.append((oh, dactv, dw, db, int(ncls)))
+        return True
+
+    def _flush_c8(self):
+        c8, self.c8 = self.c8, []
+        n = c8[0][0].shape[0]
+        arr = (L.WgradC8Job * len(c8))()
+        for i, (oh, dactv, dw, db, ncls) in enumerate(c8):
+            arr[i].x, arr[i].gy, arr[i].dw_oihw, arr[i].dbias = oh.data_ptr(), dactv.data_ptr(), dw.data_ptr(), db.data_ptr()
+            arr[i].H, arr[i].W, arr[i].ncls = oh.shape[1], oh.shape[2], ncls
+        wsb = L.lib().s2e_wgrad_c8_batch_workspace_bytes(n, C.byref(arr), len(c8))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=c8[0][0].device)
+        flops = sum(2.0 * n * j[0].shape[1] * j[0].shape[2] * 8 * 128 * 9 for j in c8)
+        LaunchProfiler.run('conv_wgrad_patch', flops, lambda: L.check(
+            L.lib().s2e_wgrad_c8_batch(L.S2E_BF16, n, C.byref(arr), len(c8), _p(ws), wsb, _stream()), 's2e_wgrad_c8_batch'),
+            tag='W n%d c8->128 k3 s1 x%d batched' % (n, len(c8)),
+            nbytes=float(sum((j[0].numel() + j[1].numel()) * 2 for j in c8)))
+        self.keep_c8 = (c8, ws)                               # alive until the next flush (stream order covers the rest)
+
     def flush(self):
+        if self.c8:
+            self._flush_c8()
         if not self.jobs:
             return
         jobs, self.jobs = self.jobs, []
@@ -579,6 +614,7 @@ class SpadePrepass:
         return table
 
 
+_C8_BATCH_OFF = os.environ.get('S2E_WGRAD_C8_BATCH', '1') == '0'      # A/B switch: every mlp_shared weight gradient as its own launches
 _PREPASS_OFF = os.environ.get('S2E_SPADE_PREPASS', '1') == '0'      # A/B switch: every label conv / class table as its own launch
 
 
@@ -856,6 +892,8 @@ def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
     # per step; see DESIGN.md "tried and dropped")
     oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
     wdst, bdst = ctx.sh_dst
+    if GradSink.push_c8(oh, dactv, wdst, bdst, ncls):        # inside a trainer step: all mlp_shared gradients in one launch, later
+        return gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b
     dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True, bdst)
     if wdst is not None:
         unpack_weight_grad_into(dwp, wdst, nh, ncls, 3, 3, 8)

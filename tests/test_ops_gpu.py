@@ -584,3 +584,35 @@ def test_spade_prepass_batches_label_convs_and_tables(dtype):
     forward()
     a6, _ = forward()
     assert all(torch.equal(x, y) for x, y in zip(a1, a6)) and a6[0].untyped_storage().data_ptr() == a6[1].untyped_storage().data_ptr()
+
+
+def test_wgrad_c8_batch_matches_per_layer_launches():
+    """s2e_wgrad_c8_batch (all queued mlp_shared weight / bias gradients of a step in one launch per slab shape, written
+    straight in OIHW) against the per-layer path (s2e_conv2d_wgrad -> packed dW -> unpack), through ops.GradSink inside a
+    ZeroPool scope as the trainer uses it; maps the batch does not take (8x8) fall back to the per-layer path."""
+    from seg2eye_amd import ops
+    dev = _dev()
+    N, ncls = 3, 4
+    pool = ops.ZeroPool(dev)
+    cases = [(64, 64), (32, 32), (16, 16), (48, 80), (8, 8)]
+    ins, ref = [], []
+    for i, (h, w) in enumerate(cases):
+        lab = _labels(N, h, w, 100 + i).to(dev)
+        oh = ops.onehot_nhwc_raw(lab, None, h, w, ncls, 8, torch.bfloat16)
+        dactv = nhwc(_rnd((N, 128, h, w), 110 + i, torch.bfloat16)).to(dev)
+        dwp, db = ops.conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ops.ACT_NONE, True)
+        ref.append((ops._unpack_dw(dwp, 128, ncls, 3, 3, 8).contiguous().clone(), db.clone()))
+        ins.append((oh, dactv))
+    dws = [torch.zeros(128, ncls, 3, 3, device=dev) for _ in cases]
+    dbs = [torch.zeros(128, device=dev) for _ in cases]
+    queued = []
+    with pool.scope('t'):
+        for (oh, dactv), dw, db in zip(ins, dws, dbs):
+            queued.append(ops.GradSink.push_c8(oh, dactv, dw, db, ncls))
+        assert len(pool.sink.c8) == sum(queued)
+    assert queued == [True, True, True, True, False]           # 8x8: no 128-pixel slab covers it to 80 %
+    torch.cuda.synchronize()
+    for q, (rw, rb), dw, db in zip(queued, ref, dws, dbs):
+        if q:
+            assert float((dw - rw).abs().max()) <= 1e-4 * float(rw.abs().max()) + 1e-5
+            assert float((db - rb).abs().max()) <= 1e-4 * float(rb.abs().max()) + 1e-5
