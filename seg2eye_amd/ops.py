@@ -248,6 +248,10 @@ class GradSink:
     def _flush_c8(self):
         c8, self.c8 = self.c8, []
         n = c8[0][0].shape[0]
+        rest = [j for j in c8 if j[0].shape[0] != n]         # (a launch shares one batch size: other sizes go in a round of their own)
+        if rest:
+            c8 = [j for j in c8 if j[0].shape[0] == n]
+            self.c8 = rest
         arr = (L.WgradC8Job * len(c8))()
         for i, (oh, dactv, dw, db, ncls) in enumerate(c8):
             arr[i].x, arr[i].gy, arr[i].dw_oihw, arr[i].dbias = oh.data_ptr(), dactv.data_ptr(), dw.data_ptr(), db.data_ptr()
@@ -259,7 +263,9 @@ class GradSink:
             L.lib().s2e_wgrad_c8_batch(L.S2E_BF16, n, C.byref(arr), len(c8), _p(ws), wsb, _stream()), 's2e_wgrad_c8_batch'),
             tag='W n%d c8->128 k3 s1 x%d batched' % (n, len(c8)),
             nbytes=float(sum((j[0].numel() + j[1].numel()) * 2 for j in c8)))
-        self.keep_c8 = (c8, ws)                               # alive until the next flush (stream order covers the rest)
+        self.keep_c8 = (c8, ws, self.keep_c8 if rest else None)   # alive until the next flush (stream order covers the rest)
+        if rest:
+            self._flush_c8()
 
     def flush(self):
         if self.c8:
