@@ -138,12 +138,17 @@ int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float*
 typedef struct {
     const float* w; float* u; float* v; long long* t; long long* s;
     int rows, cols;
+    long long* t2; long long* s2;     /* second accumulator pair (zero like t, s) for chain != 0; may be NULL otherwise */
 } s2e_sn_layer;
+/* chain != 0 (train only; every layer's cols <= s2e_sn_chain_max_cols(), t2 / s2 set): the per-layer normalising launches are
+ * folded into the GEMV passes -- 2 * iterations + 1 launches instead of 4 * iterations; same u, v, sigma up to the fp32
+ * rounding of the norms. */
+int s2e_sn_chain_max_cols(void);
 int s2e_sn_block_shape(int which, int* rows, int* cols);   /* which = 0: tiles of block_map (W v); 1: of block_map_t (W^T u) */
 int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map_t, int n_blocks_t,
                            const int* block_map, int n_blocks,
                            void* scratch, size_t scratch_bytes, float* sigma, int train, int iterations,
-                           float eps, void* stream);
+                           float eps, int chain, void* stream);
 /* Gradient through W = W_orig / sigma (sigma = u^T W_orig v; u, v constants):
  *   gw_orig (=|+=) gW / sigma - (<gW, W_orig> / sigma^2) * u v^T     in OIHW order,
  * with gW given in the packed order of s2e_conv2d_wgrad ([co][(tap)*cin_pad + ci]).  dot_ws: 1 float of scratch, ZERO-FILLED by the caller.

@@ -46,7 +46,7 @@ class ClassTableJob(C.Structure):
 class SnLayer(C.Structure):
     """s2e_sn_layer"""
     _fields_ = [('w', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p), ('t', C.c_void_p), ('s', C.c_void_p),
-                ('rows', C.c_int), ('cols', C.c_int)]
+                ('rows', C.c_int), ('cols', C.c_int), ('t2', C.c_void_p), ('s2', C.c_void_p)]
 
 
 class PackJob(C.Structure):
@@ -72,7 +72,8 @@ SIGNATURES = {
     's2e_conv_k_pad': [_i, _i],
     's2e_pack_conv_weight': [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     's2e_sn_block_shape': [_i, _vp, _vp],
-    's2e_sn_power_iteration': [_vp, _i, _vp, _i, _vp, _i, _vp, C.c_size_t, _vp, _i, _i, _f, _vp],
+    's2e_sn_chain_max_cols': [],
+    's2e_sn_power_iteration': [_vp, _i, _vp, _i, _vp, _i, _vp, C.c_size_t, _vp, _i, _i, _f, _i, _vp],
     's2e_sn_weight_grad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     's2e_grad_block_map': [_vp, _i, _vp],
     's2e_weight_grads_batched': [_vp, _vp, _i, _i, _i, _vp, _vp],

@@ -194,15 +194,144 @@ __global__ __launch_bounds__(SN_NT) void sn_finalize_kernel(const s2e_sn_layer* 
         for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.t[j] = 0;
 }
 
+// ------------------------------------------------------------------------------------ small banks: two launches per iteration
+// For a bank whose layers are all small (cols <= SN_CHAIN_MAX_COLS: the discriminator's and the encoder's -- the encoder runs N
+// iterations per encode, 64 of a step's 80 power-iteration launches) the two per-layer launches of an iteration are folded into
+// the GEMV passes: every block of the W v pass recomputes |t| from the layer's whole t (<= 64 KB of L2-resident accumulators,
+// the same order in every block: the same bits) and normalises its own columns on the fly; every block of the next W^T u pass
+// does the same with s.  Accumulators alternate between two buffers (iteration k adds into t[k & 1] / s[k & 1] and clears the
+// other one's slice it owns), one finalising launch at the end writes u, sigma and leaves all four buffers zero: 2 I + 1
+// launches for I iterations instead of 4 I.
+static constexpr int SN_CHAIN_MAX_COLS = 8192;
+__device__ __forceinline__ float sn_block_sum256(float q, float* red) {
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ long long* sn_tb(const s2e_sn_layer& L, int i) { return i ? L.t2 : L.t; }
+__device__ __forceinline__ long long* sn_sb(const s2e_sn_layer& L, int i) { return i ? L.s2 : L.s; }
+
+__global__ __launch_bounds__(256) void sn_gemvT_chain_kernel(const s2e_sn_layer* __restrict__ layers, const int* __restrict__ block_map,
+                                                             int k, float eps) {
+    __shared__ float red[4];
+    const int* bm = block_map + 3 * blockIdx.x;
+    const s2e_sn_layer L = layers[bm[0]];
+    const int row0 = bm[1], col = bm[2] + threadIdx.x;
+    const int nr = min(L.rows - row0, SN_T_BR);
+    const long long* sp = sn_sb(L, (k - 1) & 1);
+    float inv = 1.f;
+    if (k > 0) {                                             // u = s / max(|s|, eps), s of the previous iteration
+        float q = 0.f;
+        for (int i = threadIdx.x; i < L.rows; i += 256) { const float v = sn_unfix(sp[i]); q += v * v; }
+        inv = 1.f / fmaxf(sqrtf(sn_block_sum256(q, red)), eps);
+    }
+    if (col >= L.cols) return;
+    sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + col;
+    float acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < SN_T_BR; b += 16) {
+        float w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = wp[(size_t)min(b + r, nr - 1) * L.cols];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = row0 + min(b + r, nr - 1);
+            const float u = (k > 0 ? sn_unfix(sp[rr]) * inv : L.u[rr]) * (b + r < nr ? 1.f : 0.f);
+            acc += w[r] * u;
+        }
+    }
+    sn_fix_add(sn_tb(L, k & 1) + col, acc);
+    if (k > 0 && row0 == 0) sn_tb(L, (k - 1) & 1)[col] = 0;       // (consumed by the previous W v pass)
+}
+
+__global__ __launch_bounds__(256) void sn_gemv_chain_kernel(const s2e_sn_layer* __restrict__ layers, const int* __restrict__ block_map,
+                                                            int k, float eps) {
+    __shared__ float red4[4];
+    __shared__ float red[SN_BR][4];
+    const int* bm = block_map + 3 * blockIdx.x;
+    const s2e_sn_layer L = layers[bm[0]];
+    const int row0 = bm[1], col = bm[2] + 4 * threadIdx.x;
+    const int nr = min(L.rows - row0, SN_BR);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long* tp = sn_tb(L, k & 1);
+    float q = 0.f;
+    for (int j = threadIdx.x; j < L.cols; j += 256) { const float v = sn_unfix(tp[j]); q += v * v; }
+    const float inv = 1.f / fmaxf(sqrtf(sn_block_sum256(q, red4)), eps);
+    float vv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vv[j] = col + j < L.cols ? sn_unfix(tp[col + j]) * inv : 0.f;
+    if (row0 == 0) {                                         // v = t / max(|t|, eps): the module's buffer, written once per column
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (col + j < L.cols) L.v[col + j] = vv[j];
+    }
+    const bool vec = (L.cols & 3) == 0 && ((uintptr_t)L.w & 15) == 0;
+    const int cc = vec ? min(col, L.cols - 4) : col;         // a thread past the matrix re-reads its last columns, weighted with zero (vv = 0)
+    sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + cc;
+    if (vec) {
+#pragma unroll
+        for (int b = 0; b < SN_BR; b += 16) {
+            f32x4_t w[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[r] = *(sn_gptr4)(wp + (size_t)min(b + r, nr - 1) * L.cols);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = wave_sum_last((w[r][0] * vv[0] + w[r][1] * vv[1]) + (w[r][2] * vv[2] + w[r][3] * vv[3]));
+                if (lane == 63) red[b + r][wave] = p;
+            }
+        }
+    } else {
+        for (int r = 0; r < SN_BR; ++r) {
+            float p = 0.f;
+            if (r < nr)
+                for (int j = 0; j < 4; ++j) if (col + j < L.cols) p += wp[(size_t)r * L.cols + j] * vv[j];
+            p = wave_sum_last(p);
+            if (lane == 63) red[r][wave] = p;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nr) {
+        sn_fix_add(sn_sb(L, k & 1) + row0 + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
+        if (k > 0 && bm[2] == 0) sn_sb(L, (k - 1) & 1)[row0 + threadIdx.x] = 0;    // (consumed by this iteration's W^T u pass)
+    }
+}
+
+// one block per layer, after the last iteration (which = (iterations - 1) & 1): u = s / max(|s|, eps), sigma = |s|^2 / max(|s|, eps);
+// the two accumulators still holding values are cleared
+__global__ __launch_bounds__(SN_NT) void sn_finalize_chain_kernel(const s2e_sn_layer* __restrict__ layers, float* __restrict__ sigma, int which, float eps) {
+    __shared__ float red[SN_NT / 64];
+    const s2e_sn_layer L = layers[blockIdx.x];
+    long long* sp = sn_sb(L, which);
+    long long* tp = sn_tb(L, which);
+    float q = 0.f;
+    for (int i = threadIdx.x; i < L.rows; i += SN_NT) { const float s = sn_unfix(sp[i]); q += s * s; }
+    const float tot = sn_block_sum(q, red);
+    const float inv = 1.f / fmaxf(sqrtf(tot), eps);
+    for (int i = threadIdx.x; i < L.rows; i += SN_NT) { L.u[i] = sn_unfix(sp[i]) * inv; sp[i] = 0; }
+    if (threadIdx.x == 0) sigma[blockIdx.x] = tot * inv;
+    for (int j = threadIdx.x; j < L.cols; j += SN_NT) tp[j] = 0;
+}
+
+extern "C" int s2e_sn_chain_max_cols(void) { return SN_CHAIN_MAX_COLS; }
+
 extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* block_map_t, int n_blocks_t,
                                       const int* block_map, int n_blocks,
                                       void* scratch, size_t scratch_bytes, float* sigma, int train, int iterations,
-                                      float eps, void* stream) {
+                                      float eps, int chain, void* stream) {
     if (!layers || !block_map || !block_map_t || !scratch || !sigma || n_layers <= 0 || n_blocks <= 0 || n_blocks_t <= 0 || iterations < 1)
         S2E_FAIL(S2E_ERR_ARG, "s2e_sn_power_iteration: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int iters = train ? iterations : 1;
     (void)scratch_bytes;                                     // the accumulators in `scratch` are cleared by the kernels themselves
+    if (train && chain) {                                    // small bank (caller checked s2e_sn_chain_max_cols, t2 / s2 set): 2 I + 1 launches
+        for (int it = 0; it < iters; ++it) {
+            sn_gemvT_chain_kernel<<<n_blocks_t, 256, 0, st>>>(layers, block_map_t, it, eps);
+            sn_gemv_chain_kernel<<<n_blocks, 256, 0, st>>>(layers, block_map, it, eps);
+        }
+        sn_finalize_chain_kernel<<<n_layers, SN_NT, 0, st>>>(layers, sigma, (iters - 1) & 1, eps);
+        S2E_CHECK_LAUNCH("sn chain kernels");
+        return S2E_OK;
+    }
     for (int it = 0; it < iters; ++it) {
         if (train) {
             sn_gemvT_kernel<SN_T_BR, SN_T_V><<<n_blocks_t, 256, 0, st>>>(layers, block_map_t);

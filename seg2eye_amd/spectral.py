@@ -18,6 +18,11 @@ import torch
 from . import _lib as L
 
 SN_EPS = 1e-12
+_CHAIN_OFF = __import__('os').environ.get('S2E_SN_CHAIN', '1') == '0'      # A/B switch: four launches per power iteration for every bank
+
+
+def lib_chain_max_cols():
+    return L.lib().s2e_sn_chain_max_cols()
 
 
 def sn_convs(root):
@@ -60,7 +65,10 @@ class SpectralBank:
                 c._buffers['weight_v'] = vview
                 self.uv_off.append((ou, ov))
         self.uv_arena = arena
-        self.scratch = torch.zeros(int(offs[-1]), dtype=torch.int64, device=dev)        # t | s (64-bit fixed point), same offsets
+        # t | s (64-bit fixed point), same offsets; twice: small banks alternate between two accumulator pairs (chain mode)
+        tot = int(offs[-1])
+        self.scratch = torch.zeros(2 * tot, dtype=torch.int64, device=dev)
+        self.chain = int(max(cols) <= lib_chain_max_cols() and not _CHAIN_OFF)
         lib = L.lib()
         shapes = []
         for which in (0, 1):                                  # the W tile one workgroup takes: W v pass, W^T u pass
@@ -76,6 +84,8 @@ class SpectralBank:
             table[i].v = arena.data_ptr() + 4 * ov
             table[i].s = self.scratch.data_ptr() + 8 * ou
             table[i].t = self.scratch.data_ptr() + 8 * ov
+            table[i].s2 = self.scratch.data_ptr() + 8 * (tot + ou)
+            table[i].t2 = self.scratch.data_ptr() + 8 * (tot + ov)
             table[i].rows, table[i].cols = rows[i], cols[i]
             for bm, (_BR, _BC) in zip(maps, shapes):
                 for r0 in range(0, rows[i], _BR):
@@ -135,7 +145,7 @@ class SpectralBank:
             self.table_dev.data_ptr(), self.n, self.block_map_t.data_ptr(), self.block_map_t.shape[0],
             self.block_map.data_ptr(), self.block_map.shape[0],
             self.scratch.data_ptr(), self.scratch.numel() * 8, self.sigma.data_ptr(), int(bool(training)),
-            int(iterations), SN_EPS, torch.cuda.current_stream().cuda_stream), 's2e_sn_power_iteration'),
+            int(iterations), SN_EPS, self.chain, torch.cuda.current_stream().cuda_stream), 's2e_sn_power_iteration'),
             nbytes=wbytes * (2 * int(iterations) if training else 1))     # algorithmic: W^T u and W v each read W once per iteration
         # the backward of this forward needs u, v as they are NOW (later forwards update them in place)
         if not torch.is_grad_enabled():
