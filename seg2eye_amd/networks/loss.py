@@ -27,16 +27,11 @@ class GANLoss(nn.Module):
         self.real_label, self.fake_label = target_real_label, target_fake_label
         self.opt = opt
 
-    def loss(self, input, target_is_real, for_discriminator=True):
+    def loss(self, input, target_is_real, for_discriminator=True, weight=1.0):
+        """weight (not in the reference): a factor folded into the reduction's scale -- the 1 / num_D of the list form below,
+        instead of a tensor division after it."""
         if self.gan_mode != 'hinge':
-            # the non-default modes (loss.py:58-65, 78-83) act on the few-thousand-element PatchGAN outputs: plain torch
-            x = input.float()
-            if self.gan_mode == 'w':
-                return -x.mean() if target_is_real else x.mean()
-            target = torch.full_like(x, self.real_label if target_is_real else self.fake_label)
-            if self.gan_mode == 'original':
-                return torch.nn.functional.binary_cross_entropy_with_logits(x, target)
-            return torch.nn.functional.mse_loss(x, target)
+            return weight * self._loss_other(input, target_is_real) if weight != 1.0 else self._loss_other(input, target_is_real)
         x = _flat(input)
         n = x.numel()
         if for_discriminator:
@@ -44,16 +39,29 @@ class GANLoss(nn.Module):
         else:
             assert target_is_real, "The generator's hinge loss must be aiming for real"
             mode = LOSS_NEG_MEAN
-        return ops.loss_sum(x, None, mode, 1.0 / n)
+        return ops.loss_sum(x, None, mode, weight / n)
+
+    def _loss_other(self, input, target_is_real):
+        # the non-default modes (loss.py:58-65, 78-83) act on the few-thousand-element PatchGAN outputs: plain torch
+        x = input.float()
+        if self.gan_mode == 'w':
+            return -x.mean() if target_is_real else x.mean()
+        target = torch.full_like(x, self.real_label if target_is_real else self.fake_label)
+        if self.gan_mode == 'original':
+            return torch.nn.functional.binary_cross_entropy_with_logits(x, target)
+        return torch.nn.functional.mse_loss(x, target)
 
     def __call__(self, input, target_is_real, for_discriminator=True):
         if isinstance(input, list):
-            total = 0
+            # mean over the scales of each scale's loss (loss.py:85-99), the 1 / num_D folded into each reduction's scale: the
+            # list form costs one add per extra scale instead of `0 + l`, adds and a division (each a launch, each with a backward)
+            total = None
             for pred_i in input:
                 if isinstance(pred_i, list):
                     pred_i = pred_i[-1]
-                total = total + self.loss(pred_i, target_is_real, for_discriminator).view(1)
-            return total / len(input)
+                term = self.loss(pred_i, target_is_real, for_discriminator, weight=1.0 / len(input)).view(1)
+                total = term if total is None else total + term
+            return total
         return self.loss(input, target_is_real, for_discriminator)
 
 

@@ -6,6 +6,16 @@ from .ops import ZeroPool
 from .pix2pix_model import Pix2PixModel
 
 
+def _total(losses):
+    """sum(losses.values()).mean() (trainers/pix2pix_trainer.py:31,41) without the launches that change nothing: no `0 + l` to
+    start the sum, no mean over a single element."""
+    vals = list(losses.values())
+    t = vals[0]
+    for v in vals[1:]:
+        t = t + v
+    return t.view(()) if t.numel() == 1 else t.mean()
+
+
 class Pix2PixTrainer:
     def __init__(self, opt):
         self.opt = opt
@@ -52,7 +62,7 @@ class Pix2PixTrainer:
         self.optimizer_G.zero_grad()
         with self.pool.scope('G'):                               # all zero-filled scratch of the step: one fill
             g_losses, generated = self.pix2pix_model(data, mode='generator')
-            sum(g_losses.values()).mean().backward()
+            _total(g_losses).backward()
         # keep detached copies only: a live autograd graph would pin last iteration's AccumulateGrad nodes
         # (and their stream), which breaks hipGraph capture
         self.g_losses = {k: v.detach() for k, v in g_losses.items()}
@@ -62,7 +72,7 @@ class Pix2PixTrainer:
         self.optimizer_D.zero_grad()
         with self.pool.scope('D'):
             d_losses = self.pix2pix_model(data, mode='discriminator')
-            sum(d_losses.values()).mean().backward()
+            _total(d_losses).backward()
         self.d_losses = {k: v.detach() for k, v in d_losses.items()}
 
     def run_generator_one_step(self, data):
