@@ -260,8 +260,8 @@ int s2e_wgrad_c8_batch(int dtype, int N, const s2e_wgrad_c8_job* jobs, int n_job
  *   s2e_spade_modulate_uniform  : the modulation of the rectangles uni_list[0 .. counts[1]) with gamma | beta from that table.
  * Together the two launches write every pixel of out (and gamma_out) exactly once.
  * flags & 8 of the conv launches / x_up of the uniform one: x is (N, H/2, W/2, C) -- the nearest 2x upsampling that precedes the
- * block in the generator (generator.py:77-92) is folded into the read of x, the upsampled tensor never exists (no-grad forward:
- * gamma_out must be NULL; H, W even). */
+ * block in the generator (generator.py:77-92) is folded into the read of x, the upsampled tensor is never read (H, W even;
+ * out and gamma_out are at full resolution). */
 int s2e_spade_conv_modulate_rect(int dtype, int N, int H, int W, int C, int nh, int flags, int* tw, int* th);
 int s2e_label_rect_classify(const uint8_t* label, int N, int H, int W, int h, int w, int tw, int th,
                             uint8_t* cls, int* dense_list, int* uni_list, int* counts, void* stream);
@@ -296,10 +296,14 @@ int s2e_modulate_bwd_gamma(int dtype, int mode, const void* g, const void* x, co
  *   stage 1: the row-walking pass only: dgb written, the per-(n,c) fp64 sums left in ws as (N,C,4) {S0, S1, S2, S3};
  *   (caller: all-reduce sum over samples of S0, S1 across the replicas and fold the difference into ws[0,:,0:2])
  *   stage 2: coefficients + dx, with the normalisation count batch_count (= world * N * HW; 0 = N * HW) in BATCH mode.
- * stage 0 = both (the plain calls). */
+ * stage 0 = both (the plain calls).
+ * x_up_w != 0 (gamma-only form, stage 0, per-sample statistics): x is (N, H/2, W/2, C) with W = x_up_w -- the generator's nearest
+ * 2x upsampling in front of the block folded into the read of x, as flags & 8 does in the forward launches; g, gamma, out, dx, dgb
+ * are at full resolution. */
 int s2e_modulate_bwd_staged(int dtype, int mode, const void* g, const void* x, const void* gb, const void* out,
                             const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
-                            int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, void* stream);
+                            int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, int x_up_w,
+                            void* stream);
 /* out[c] += sum_m g[m][c]  (conv bias gradient).  g (M, C); out fp32 (C). */
 int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream);
 

@@ -658,7 +658,6 @@ static int spade_conv_modulate_impl(int dtype, const void* actv, const void* w_p
     p.mx = x; p.mstats = stats; p.mstyle = style; p.msld = style_ld > 0 ? style_ld : 2 * C; p.mgamma = gamma_out;
     p.mup = (flags & 8) != 0;
     if (p.mup && ((H | W) & 1)) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: flags 8 (x at half resolution) needs even H, W");
-    if (p.mup && gamma_out) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_conv_modulate: flags 8 is for the no-grad forward (no gamma_out)");
     p.mC = C; p.mlrelu = lrelu;
     p.rect_list = rect_list; p.rect_count = rect_count;
     const int grid = p.tiles < cu_count() ? p.tiles : cu_count();

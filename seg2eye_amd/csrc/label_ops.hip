@@ -787,7 +787,7 @@ extern "C" int s2e_spade_modulate_uniform(int dtype, const void* x, const float*
                                           void* stream) {
     if (!x || !stats || !style || !table || !cls || !uni_list || !counts || !out || N <= 0 || H < 5 || W < 5 || C <= 0 || tw <= 0 || th <= 0)
         S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: bad argument");
-    if (x_up && (((H | W) & 1) || gamma_out)) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: x_up needs even H, W and no gamma_out (no-grad forward)");
+    if (x_up && ((H | W) & 1)) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: x_up needs even H, W");
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_spade_modulate_uniform: bad dtype %d", dtype);
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_spade_modulate_uniform: C=%d not a multiple of %d", C, vec);

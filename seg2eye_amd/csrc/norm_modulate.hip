@@ -18,6 +18,16 @@ static constexpr int kSlabIters = 16;     // row passes per block in the row-wal
 // sequential row streams suit HBM better than many short ones: S2E_SLAB_BLOCKS blocks in total, same box, whole step:
 // 348.1 / 343.7 / 341.7 / 342.1 img/s at 256 / 1024 / 2048 / 4096 (modulate_bwd 2.41 / 2.61 / 2.73 / 2.71 ms per step; with the
 // atomics, at 256: 2.49) -- default 256, never fewer than 16 passes per block.
+// x handed over at HALF resolution (the generator's nearest 2x upsampling folded into the consumers' reads, xw = W of the full map,
+// 0 = x at full resolution): the pixel row of x that full-resolution pixel `pr` of sample n reads.  (pr + 0.5) * (1 / W) is at
+// least 0.5 / W away from an integer: the fp32 product cannot land on the wrong side.
+__device__ __forceinline__ size_t mod_x_row(int n, int pr, int HW, int xw, float inv_xw) {
+    if (!xw) return (size_t)n * HW + pr;
+    const int y = (int)(((float)pr + 0.5f) * inv_xw);
+    const int xx = pr - y * xw;
+    return (size_t)n * (HW >> 2) + (size_t)(y >> 1) * (xw >> 1) + (xx >> 1);
+}
+
 static int slab_iters_for(int HW, int rpp, int N, int zblocks) {
     static const int target = [] { const char* e = getenv("S2E_SLAB_BLOCKS"); return e ? atoi(e) : 256; }();
     const int per_n = target / (N * zblocks) > 1 ? target / (N * zblocks) : 1;
@@ -491,7 +501,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __restrict__ gin, const T* __restrict__ x,
         const T* __restrict__ gb, const float* __restrict__ stats, const float* __restrict__ style,
         T* __restrict__ dgb, float* __restrict__ part, int HW, int C, int cg, int cgb, int rpp, int lrelu, int sld, int iters,
-        const T* __restrict__ fout) {
+        const T* __restrict__ fout, int xw, float inv_xw) {
     // fout != NULL (S2E_NORM_GAMMA_ONLY): gb holds gamma alone, (N,HW,C); the LeakyReLU mask comes from the sign of the
     // forward's OUTPUT fout (LeakyReLU keeps the sign of its argument) instead of recomputing it from gamma and beta
     constexpr int VEC = Vec<T>::N;
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
         int pr = row0 + ty;
         for (; pr + rpp < pend; pr += 2 * rpp) {
             const size_t r0 = (size_t)n * HW + pr, r1 = r0 + rpp;
-            const u32x4_t x0 = *(const u32x4_t*)(x + r0 * C + c0), x1 = *(const u32x4_t*)(x + r1 * C + c0);
+            const u32x4_t x0 = *(const u32x4_t*)(x + mod_x_row(n, pr, HW, xw, inv_xw) * C + c0), x1 = *(const u32x4_t*)(x + mod_x_row(n, pr + rpp, HW, xw, inv_xw) * C + c0);
             const u32x4_t g0 = *(const u32x4_t*)(gin + r0 * C + c0), g1 = *(const u32x4_t*)(gin + r1 * C + c0);
             u32x4_t a0 = zero4, b0 = zero4, a1 = zero4, b1 = zero4;
             if (MODE == S2E_NORM_SPADE_STYLE) {
@@ -580,7 +590,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
                 if (fout) { if (lrelu) b0 = *(const u32x4_t*)(fout + r0 * C + c0); }
                 else b0 = *(const u32x4_t*)(gb + r0 * gst + C + c0);
             }
-            consume(r0, *(const u32x4_t*)(x + r0 * C + c0), *(const u32x4_t*)(gin + r0 * C + c0), a0, b0);
+            consume(r0, *(const u32x4_t*)(x + mod_x_row(n, pr, HW, xw, inv_xw) * C + c0), *(const u32x4_t*)(gin + r0 * C + c0), a0, b0);
         }
     }
 #pragma unroll
@@ -671,7 +681,7 @@ __global__ void modulate_bwd_coef_kernel(double* __restrict__ ws, const float* _
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __restrict__ gin, const T* __restrict__ x,
         const T* __restrict__ gb, const T* __restrict__ dgb, const f32x4_t* __restrict__ coef, T* __restrict__ dx,
-        int vps, int HW, int C, int cg, int cg_shift, int lrelu, int acc, int gst) {
+        int vps, int HW, int C, int cg, int cg_shift, int lrelu, int acc, int gst, int xw, float inv_xw) {
     constexpr int VEC = Vec<T>::N;
     const int n = blockIdx.y;                              // one sample per grid row: 32-bit indices, no 64-bit division
     // The channel group of a thread does not change over the grid-stride loop when the stride is a multiple of cg
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
         const size_t row = (size_t)n * HW + prow;
         const int c0 = g * VEC;
         float f[VEC], o[VEC];
-        unpack16<T>(*(const u32x4_t*)(x + row * C + c0), f);
+        unpack16<T>(*(const u32x4_t*)(x + mod_x_row(n, prow, HW, xw, inv_xw) * C + c0), f);
         if (!fixed_g) {
             const f32x4_t* kp = coef + (size_t)n * C + c0;
 #pragma unroll
@@ -730,7 +740,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
 template <typename T, int G>
 __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const T* __restrict__ gamma,
         const T* __restrict__ fout, const float* __restrict__ stats, const float* __restrict__ style, T* __restrict__ dx, T* __restrict__ dgb,
-        float* __restrict__ dstyle, int HW, int C, int lrelu, int sld, int acc) {
+        float* __restrict__ dstyle, int HW, int C, int lrelu, int sld, int acc, int xw, float inv_xw) {
     constexpr int VEC = Vec<T>::N, CH = G * VEC, RL = 256 / G;
     __shared__ float red[RL][CH][4];
     __shared__ float mm[CH][2];
@@ -753,7 +763,8 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
-                rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o); ra[k] = *(const u32x4_t*)(gamma + o);
+                rg[k] = *(const u32x4_t*)(g + o); ra[k] = *(const u32x4_t*)(gamma + o);
+                rx[k] = *(const u32x4_t*)(x + mod_x_row(n, min(r + RL * k, HW - 1), HW, xw, inv_xw) * C + c0);
                 ro[k] = lrelu ? *(const u32x4_t*)(fout + o) : u32x4_t{0u, 0u, 0u, 0u};
             }
 #pragma unroll
@@ -802,7 +813,8 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
-            rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o); ra[k] = *(const u32x4_t*)(gamma + o);
+            rg[k] = *(const u32x4_t*)(g + o); ra[k] = *(const u32x4_t*)(gamma + o);
+            rx[k] = *(const u32x4_t*)(x + mod_x_row(n, min(r + RL * k, HW - 1), HW, xw, inv_xw) * C + c0);
             ro[k] = lrelu ? *(const u32x4_t*)(fout + o) : u32x4_t{0u, 0u, 0u, 0u};
             rp[k] = acc ? *(const u32x4_t*)(dx + o) : u32x4_t{0u, 0u, 0u, 0u};
         }
@@ -825,7 +837,8 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
 
 static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, const void* gb, const void* fout, const float* stats,
                              const float* style, void* dx, void* dgb, float* dstyle, double* ws,
-                             int N, int HW, int C, int lrelu, int style_ld, void* stream, int stage = 0, double batch_count = 0.0) {
+                             int N, int HW, int C, int lrelu, int style_ld, void* stream, int stage = 0, double batch_count = 0.0,
+                             int xw = 0) {
     const int sld = style_ld > 0 ? style_ld : 2 * C;
     const int gst = fout ? C : 2 * C;
     const int acc = (mode & S2E_NORM_ACCUMULATE_DX) != 0;
@@ -839,11 +852,14 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (C % vec) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_modulate_bwd: C=%d not a multiple of %d", C, vec);
     hipStream_t st = (hipStream_t)stream;
+    const float inv_xw = xw ? 1.f / (float)xw : 0.f;
+    if (xw && (!fout || batch || stage != 0 || HW % xw || ((HW / xw) | xw) & 1))
+        S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: x at half resolution needs the gamma-only form, per-sample statistics and an even H x W map");
     if (fout && mode == S2E_NORM_SPADE_STYLE && !batch && stage == 0 && HW <= in_small_hw()) {     // small map: one launch
         if (dtype == S2E_BF16) S2E_SMALL_LAUNCH(spade_small_bwd_kernel, bf16_t, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)gb, (const bf16_t*)fout,
-                                                 stats, style, (bf16_t*)dx, (bf16_t*)dgb, dstyle, HW, C, lrelu, sld, acc);
+                                                 stats, style, (bf16_t*)dx, (bf16_t*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw);
         else S2E_SMALL_LAUNCH(spade_small_bwd_kernel, float, (const float*)g, (const float*)x, (const float*)gb, (const float*)fout,
-                              stats, style, (float*)dx, (float*)dgb, dstyle, HW, C, lrelu, sld, acc);
+                              stats, style, (float*)dx, (float*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw);
         S2E_CHECK_LAUNCH("spade_small_bwd_kernel");
         return S2E_OK;
     }
@@ -866,10 +882,10 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
     // them to the caller between the stages: a separate (tiny) launch then; otherwise the coefficient kernel adds up its own
     const bool sums_first = batch || stage == 1;
 #define S2E_LAUNCH_BWD(TT, MM) do { \
-    if (stage != 2) { modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, part, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters, (const TT*)fout); \
+    if (stage != 2) { modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, part, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters, (const TT*)fout, xw, inv_xw); \
         if (sums_first) modulate_bwd_sums_kernel<MM><<<gridc, 256, 0, st>>>(part, ws, N, C, P); } \
     if (stage != 1) { modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, (stage == 2 || sums_first) ? nullptr : part, P, coef, stats, style, dstyle, N, C, HW, sld, batch, batch_count); \
-    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst); } } while (0)
+    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst, xw, inv_xw); } } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_BWD
@@ -894,9 +910,11 @@ extern "C" int s2e_modulate_bwd_gamma(int dtype, int mode, const void* g, const 
 
 extern "C" int s2e_modulate_bwd_staged(int dtype, int mode, const void* g, const void* x, const void* gb, const void* out,
                                        const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
-                                       int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, void* stream) {
+                                       int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, int x_up_w,
+                                       void* stream) {
     if (stage < 0 || stage > 2) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_staged: stage %d", stage);
-    return modulate_bwd_impl(dtype, mode, g, x, gb, out, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream, stage, batch_count);
+    return modulate_bwd_impl(dtype, mode, g, x, gb, out, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream, stage, batch_count,
+                             x_up_w);
 }
 
 extern "C" size_t s2e_modulate_bwd_workspace_bytes(int dtype, int N, int HW, int C) {

@@ -52,7 +52,10 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
             x_s = ops.conv2d_m(self.norm_s(x, seg, latent_style, stats, lrelu=False, up=True), self.conv_s)
             dx = ops.conv2d_m(h0, self.conv_0, None, 1, 1)
             return ops.conv2d_m(self.norm_1(dx, seg, latent_style, None, lrelu=True), self.conv_1, x_s, 1, 1)
+        if not self.learned_shortcut:
+            ops.materialize_upsample(x)                              # the residual reads x itself
         if stats is None:
+            ops.materialize_upsample(x)
             stats = self.input_stats(x)
         # x has two consumers (norm_0 and norm_s, or norm_0 and the residual).  With gradients on, the second one hangs off
         # an alias of x that norm_0 hands out, so its gradient reaches norm_0's backward and is accumulated there in place

@@ -79,7 +79,9 @@ class SPADESTYLEGenerator(BaseNetwork):
                     # no-grad forward (the D step's, inference): the upsampling is folded into the block's two SPADE launches
                     x = blk(x, seg, w, st, up=True)
                     continue
-                x = ops.upsample2x(x)
+                # training forward: the upsampled tensor is allocated but never written -- up_*'s two SPADE launches and their
+                # backward read x at (y/2, x/2) (ops.upsample2x_lazy); whoever cannot writes it first (ops.materialize_upsample)
+                x = ops.upsample2x_lazy(x)
                 # data parallel: when the gradient w.r.t. the input of up_2 (up_0) exists, every parameter gradient of
                 # conv_img / up_3 / up_2 (up_1 / up_0) is final -- tell the trainer, which starts that group's all-reduce
                 # while the rest of the backward runs (Pix2PixModel.create_optimizers lays the arena out in these groups)

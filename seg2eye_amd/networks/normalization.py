@@ -173,6 +173,7 @@ class SPADE_STYLE_Block(nn.Module):
                 raise ValueError('SPADE_STYLE_Block: up=True is for the no-grad forward with the statistics given')
             h, w = 2 * h, 2 * w
         if stats is None:
+            ops.materialize_upsample(x)                              # (a lazily upsampled x: the statistics pass reads it)
             stats = spade_stats(x, [sp])
         batch = sp.kind == 'batch'
         from . import stylebank
@@ -183,7 +184,10 @@ class SPADE_STYLE_Block(nn.Module):
         else:
             style, kw = self.adain.linear(latent_style), {}         # (N, 2C) fp32
         fl = 8 if up else 0
-        if ops.spade_fused_supported(x, sp.mlp_shared[0].out_channels, fl):
+        fusable = ops.spade_fused_supported(x, sp.mlp_shared[0].out_channels, fl)
+        if not fusable or batch:
+            ops.materialize_upsample(x)                              # a lazily upsampled x (ops.upsample2x_lazy): write it now
+        if fusable:
             # the big layers: [gamma | beta] conv and modulation in ONE launch, gamma / beta never written (ops.SpadeFusedFn)
             return ops.spade_style_fused(x, seg.label, sp.mlp_shared[0].weight, sp.mlp_shared[0].bias, sp.mlp_gamma.weight,
                                          sp.mlp_gamma.bias, sp.mlp_beta.weight, sp.mlp_beta.bias, style, stats, lrelu,

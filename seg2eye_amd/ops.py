@@ -955,10 +955,10 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     else gb = gamma alone and fout = the forward's output (s2e_modulate_bwd_gamma).
     relay: the OTHER consumers of x hang off the node's second output, so their gradient arrives here first and the
     element-wise pass adds this layer's dx to it in place -- instead of autograd summing two full tensors."""
-    n, h, w, c = x.shape
+    n, h, w, c = (fout if fout is not None else x).shape          # (x may be the half-resolution source: ctx.x_up_w)
     g = g.contiguous()
     acc = g_relay is not None and g_relay.is_contiguous() and g_relay.dtype == x.dtype
-    dx = g_relay if acc else torch.empty_like(x)
+    dx = g_relay if acc else torch.empty(n, h, w, c, dtype=x.dtype, device=x.device)
     dgb = torch.empty(n, h, w, 2 * c, dtype=x.dtype, device=x.device)
     if ctx.off is None:
         dstyle = ZeroPool.take(style.numel(), torch.float32, x.device).view(style.shape)
@@ -972,13 +972,14 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     mode = (NORM_SPADE_STYLE_BATCH if ctx.batch else NORM_SPADE_STYLE) | (NORM_ACCUMULATE_DX if acc else 0)
     # algorithmic bytes: the two-pass structure is forced by the per-(n,c) sums, so g, x, gamma are read by
     # both passes; dgamma, dbeta and dx are written once: 9 accesses per element of x
-    nb = float(9 * x.numel() * x.element_size())
+    nb = float(9 * n * h * w * c * x.element_size())
     from . import distributed as sdist
     world = sdist.world_size() if ctx.batch else 1
 
     def launch(stage, count):
         return L.check(L.lib().s2e_modulate_bwd_staged(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx), _p(dgb), dsp,
-                                                       _p(ws), n, h * w, c, int(ctx.lrelu), ld, stage, float(count), _stream()),
+                                                       _p(ws), n, h * w, c, int(ctx.lrelu), ld, stage, float(count),
+                                                       int(getattr(ctx, 'x_up_w', 0)), _stream()),
                        's2e_modulate_bwd_staged')
     if world == 1:
         LaunchProfiler.run('modulate_bwd', 0.0, lambda: launch(0, 0.0), nbytes=nb)
@@ -1042,10 +1043,16 @@ class SpadeFusedFn(torch.autograd.Function):
     [dgamma | dbeta] -> the conv's weight / data gradients)."""
 
     @staticmethod
-    def forward(ctx, x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags, grad_mode):
-        _need(x, style, stats)
+    def forward(ctx, x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags, grad_mode, x_low=None):
+        _need(x, style, stats, x_low)
         n, h, w, c = x.shape
-        up = bool(flags & 8)                                  # x is the tensor BEFORE the block's nearest 2x upsampling (no-grad forward)
+        # x_low (training forward): x is a LAZILY upsampled tensor (allocated, never written: ops.upsample2x_lazy) and x_low its
+        # half-resolution source -- the launches read x_low at (y/2, x/2), the backward does too; autograd still sees x, so the
+        # gradient keeps the full-resolution shape
+        xr = x if x_low is None else x_low
+        if x_low is not None:
+            flags = int(flags) | 8
+        up = bool(flags & 8) and x_low is None               # x itself is the tensor BEFORE the upsampling (no-grad forward)
         if up:
             h, w = 2 * h, 2 * w
             if grad_mode and any(ctx.needs_input_grad):
@@ -1071,12 +1078,12 @@ class SpadeFusedFn(torch.autograd.Function):
         sparse = None if (flags & 2) else label_rects(label, h, w, x.dtype, c, nh, flags)
         if sparse is None:
             LaunchProfiler.run('conv_patch', flops, lambda: L.check(
-                L.lib().s2e_spade_conv_modulate(_dt(x), _p(actv), _p(wp), _p(b_f), _p(x), _p(stats), sp, ld,
+                L.lib().s2e_spade_conv_modulate(_dt(x), _p(actv), _p(wp), _p(b_f), _p(xr), _p(stats), sp, ld,
                                                 _p(out), _p(gamma), n, h, w, c, nh, int(lrelu), int(flags), _stream()),
                 's2e_spade_conv_modulate'),
                 tag='F n%d %dx%d c%d->%d k3 s1 +mod%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
                 # algorithmic bytes: actv, packed w, x in; out (and gamma when it is kept) out
-                nbytes=float((actv.numel() + wp.numel() + x.numel() + out.numel() * (2 if train else 1)) * x.element_size()))
+                nbytes=float((actv.numel() + wp.numel() + xr.numel() + out.numel() * (2 if train else 1)) * x.element_size()))
         else:
             # label-sparse: the conv runs on the rectangles that cross a label boundary only; the others read gamma | beta from
             # the per-class table (s2e_spade_class_table: this layer's [gamma | beta] branch on one-class maps, all 25 border cases)
@@ -1088,21 +1095,22 @@ class SpadeFusedFn(torch.autograd.Function):
                 rects = cls.numel()
                 frac = float(int(counts[0])) / max(rects, 1)
             LaunchProfiler.run('conv_patch', flops, lambda: L.check(
-                L.lib().s2e_spade_conv_modulate_sparse(_dt(x), _p(actv), _p(wp), _p(b_f), _p(x), _p(stats), sp, ld, _p(out), _p(gamma),
+                L.lib().s2e_spade_conv_modulate_sparse(_dt(x), _p(actv), _p(wp), _p(b_f), _p(xr), _p(stats), sp, ld, _p(out), _p(gamma),
                                                        n, h, w, c, nh, int(lrelu), int(flags), _p(dense_list), _p(counts), _stream()),
                 's2e_spade_conv_modulate_sparse'),
                 tag='F n%d %dx%d c%d->%d k3 s1 +mod sparse%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
-                nbytes=float((actv.numel() + x.numel() + out.numel() * (2 if train else 1)) * frac * x.element_size() + wp.numel() * x.element_size()),
+                nbytes=float((actv.numel() + xr.numel() + out.numel() * (2 if train else 1)) * frac * x.element_size() + wp.numel() * x.element_size()),
                 executed=flops * frac)
             LaunchProfiler.run('modulate_fwd', 0.0, lambda: L.check(
-                L.lib().s2e_spade_modulate_uniform(_dt(x), _p(x), _p(stats), sp, ld, _p(table), _p(cls), _p(uni_list), _p(counts), _p(out),
-                                                   _p(gamma), n, h, w, c, tw, th, int(lrelu), int(up), _stream()), 's2e_spade_modulate_uniform'),
-                nbytes=float((x.numel() + out.numel() * (2 if train else 1)) * (1.0 - frac) * x.element_size()))
+                L.lib().s2e_spade_modulate_uniform(_dt(x), _p(xr), _p(stats), sp, ld, _p(table), _p(cls), _p(uni_list), _p(counts), _p(out),
+                                                   _p(gamma), n, h, w, c, tw, th, int(lrelu), int(bool(flags & 8)), _stream()), 's2e_spade_modulate_uniform'),
+                nbytes=float((xr.numel() + out.numel() * (2 if train else 1)) * (1.0 - frac) * x.element_size()))
         ctx.cfg = (h, w, c)
         ctx.lrelu, ctx.off, ctx.dbig, ctx.batch, ctx.relay = lrelu, off, dbig, bool(batch), bool(relay)
         if train:
             _gb_grad_targets(ctx, fused, w_sh, b_sh, w_g, b_g, w_b, b_b, nh)
-            ctx.save_for_backward(x, label, w_sh, w_gb, actv, gamma, out, style, stats)
+            ctx.x_up_w = w if x_low is not None else 0
+            ctx.save_for_backward(xr, label, w_sh, w_gb, actv, gamma, out, style, stats)
         if relay:
             ctx.set_materialize_grads(False)
             return out, x.view_as(x)
@@ -1113,10 +1121,10 @@ class SpadeFusedFn(torch.autograd.Function):
         x, label, w_sh, w_gb, actv, gamma, out, style, stats = ctx.saved_tensors
         nn_ = (None,) * 8
         if g is None:
-            return (g_relay,) + (None,) * 16
+            return (g_relay,) + (None,) * 17
         dx, dgb, dstyle = _modulate_grads(ctx, g, g_relay, x, gamma, out, style, stats)
         gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b = _spade_param_grads(ctx, dgb, label, w_sh, w_gb, actv)
-        return (dx, None, gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b, dstyle) + (None,) * 8
+        return (dx, None, gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b, dstyle) + (None,) * 9
 
 
 def spade_fused_supported(x, nh, flags=0):
@@ -1139,8 +1147,15 @@ def spade_style_fused(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lr
     spade_style_modulate."""
     if off is None:
         style = style.float().contiguous()
-    return SpadeFusedFn.apply(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags,
-                              torch.is_grad_enabled())
+    low = lazy_source(x)
+    if low is not None and (batch or not torch.is_grad_enabled()):
+        materialize_upsample(x)                               # (BatchNorm SPADE's staged backward reads x at full resolution)
+        low = None
+    res = SpadeFusedFn.apply(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags,
+                             torch.is_grad_enabled(), low)
+    if relay and low is not None:
+        res[1]._s2e_low = low                                 # the alias handed to x's other consumer is as unwritten as x
+    return res
 
 
 def spade_style_modulate(x, gb, style, stats, lrelu, off=None, dbig=None, batch=False, relay=False):
@@ -1212,6 +1227,49 @@ class Upsample2xFn(torch.autograd.Function):
 
 def upsample2x(x):
     return Upsample2xFn.apply(x)
+
+
+class Upsample2xLazyFn(torch.autograd.Function):
+    """The nearest 2x upsampling as a tensor that is allocated but NOT written: consumers that can read the source at (y/2, x/2)
+    instead (the fused SPADE launches and their backward: flags 8 / x_up_w) take `y._s2e_low`; anyone else calls
+    materialize_upsample(y) first.  Backward: the usual 2x2 sum."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, h, w, c = x.shape
+        return torch.empty(n, 2 * h, 2 * w, c, dtype=x.dtype, device=x.device)
+
+    backward = staticmethod(Upsample2xFn.backward)
+
+
+_LAZY_UP_OFF = os.environ.get('S2E_FOLD_UPSAMPLE_TRAIN', '1') == '0'      # A/B switch: the training forward materialises the upsampled tensor
+
+
+def upsample2x_lazy(x):
+    """upsample2x(x) whose result is written only if somebody asks (materialize_upsample): see Upsample2xLazyFn."""
+    if _LAZY_UP_OFF or not x.is_contiguous() or (x.shape[1] | x.shape[2]) < 1:
+        return upsample2x(x)
+    _need(x)
+    y = Upsample2xLazyFn.apply(x)
+    y._s2e_low = x.detach()
+    return y
+
+
+def lazy_source(y):
+    """The half-resolution source of a lazily upsampled tensor, or None."""
+    return getattr(y, '_s2e_low', None)
+
+
+def materialize_upsample(y):
+    """Write a lazily upsampled tensor (no-op otherwise) -> y."""
+    low = getattr(y, '_s2e_low', None)
+    if low is not None:
+        n, h, w, c = low.shape
+        LaunchProfiler.run('resample', 0.0, lambda: L.check(
+            L.lib().s2e_upsample2x_fwd(_dt(low), _p(low), _p(y), n, h, w, c, _stream()), 's2e_upsample2x_fwd'),
+            nbytes=float(5 * low.numel() * low.element_size()))
+        del y._s2e_low
+    return y
 
 
 class BilinearResizeFn(torch.autograd.Function):
