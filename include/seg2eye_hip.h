@@ -299,11 +299,13 @@ int s2e_modulate_bwd_gamma(int dtype, int mode, const void* g, const void* x, co
  * stage 0 = both (the plain calls).
  * x_up_w != 0 (gamma-only form, stage 0, per-sample statistics): x is (N, H/2, W/2, C) with W = x_up_w -- the generator's nearest
  * 2x upsampling in front of the block folded into the read of x, as flags & 8 does in the forward launches; g, gamma, out, dx, dgb
- * are at full resolution. */
+ * are at full resolution -- unless dx_quad != 0: then dx is (N, H/2, W/2, C), the gradient w.r.t. the half-resolution x itself
+ * (each element the sum over the 2 x 2 pixels it was replicated to: the upsampling's backward folded in), accumulated into
+ * with S2E_NORM_ACCUMULATE_DX. */
 int s2e_modulate_bwd_staged(int dtype, int mode, const void* g, const void* x, const void* gb, const void* out,
                             const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                             int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, int x_up_w,
-                            void* stream);
+                            int dx_quad, void* stream);
 /* out[c] += sum_m g[m][c]  (conv bias gradient).  g (M, C); out fp32 (C). */
 int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream);
 

@@ -733,6 +733,51 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
     }
 }
 
+// The element-wise pass when x is the half-resolution tensor (xw != 0) AND the caller wants the gradient w.r.t. THAT tensor:
+// dx_low[n][y][x] = sum over the 2 x 2 full-resolution pixels it was replicated to (the nearest upsampling's backward folded in:
+// the full-resolution dx never exists).  One thread per low-resolution 16-byte vector; acc adds into dx_low.
+template <typename T>
+__global__ __launch_bounds__(256) void modulate_bwd_apply_quad_kernel(const T* __restrict__ x, const T* __restrict__ gb, const T* __restrict__ dgb,
+        const f32x4_t* __restrict__ coef, T* __restrict__ dx, int HW, int C, int cg, int acc, int gst, int xw, float inv_wl) {
+    constexpr int VEC = Vec<T>::N;
+    const int n = blockIdx.y, wl = xw >> 1, hwl = HW >> 2;
+    const int vps = hwl * cg;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < vps; v += gridDim.x * blockDim.x) {
+        const int pl = v / cg, g = v - pl * cg, c0 = g * VEC;
+        const int yl = (int)(((float)pl + 0.5f) * inv_wl), xl = pl - yl * wl;
+        const size_t lrow = (size_t)n * hwl + pl;
+        f32x4_t K[VEC];
+        const f32x4_t* kp = coef + (size_t)n * C + c0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) K[j] = kp[j];
+        float f[VEC], o[VEC];
+        unpack16<T>(*(const u32x4_t*)(x + lrow * C + c0), f);
+        u32x4_t rga[4], rdb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t row = (size_t)n * HW + (size_t)(2 * yl + (q >> 1)) * xw + 2 * xl + (q & 1);
+            rga[q] = *(const u32x4_t*)(gb + row * gst + c0);
+            rdb[q] = *(const u32x4_t*)(dgb + row * 2 * C + C + c0);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = -4.f * (K[j][2] + f[j] * K[j][3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float ga[VEC], dbe[VEC];
+            unpack16<T>(rga[q], ga); unpack16<T>(rdb[q], dbe);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] += dbe[j] * (K[j][0] + K[j][1] * ga[j]);
+        }
+        if (acc) {
+            float prev[VEC];
+            unpack16<T>(*(const u32x4_t*)(dx + lrow * C + c0), prev);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] += prev[j];
+        }
+        *(u32x4_t*)(dx + lrow * C + c0) = pack16<T>(o);
+    }
+}
+
 // SPADE+Style modulation backward of a SMALL map in one launch (gamma-only form: the fused forward's saved gamma, the
 // LeakyReLU mask from the sign of its output): same block shape as in_small_kernel.  Pass 1 writes d[gamma | beta] and sums
 // S0..S3 per (sample, channel); pass 2 re-reads g, out, x, gamma (L2) and writes dx.  The three-launch path reads d beta back in
@@ -740,7 +785,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
 template <typename T, int G>
 __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const T* __restrict__ gamma,
         const T* __restrict__ fout, const float* __restrict__ stats, const float* __restrict__ style, T* __restrict__ dx, T* __restrict__ dgb,
-        float* __restrict__ dstyle, int HW, int C, int lrelu, int sld, int acc, int xw, float inv_xw) {
+        float* __restrict__ dstyle, int HW, int C, int lrelu, int sld, int acc, int xw, float inv_xw, int quad) {
     constexpr int VEC = Vec<T>::N, CH = G * VEC, RL = 256 / G;
     __shared__ float red[RL][CH][4];
     __shared__ float mm[CH][2];
@@ -808,6 +853,46 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
     float m0[VEC], m1[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { m0[j] = mm[gx * VEC + j][0]; m1[j] = mm[gx * VEC + j][1]; }
+    if (quad) {                                              // dx w.r.t. the half-resolution x: the 2 x 2 sums (see the quad apply kernel)
+        const int wl = xw >> 1, hwl = HW >> 2;
+        const float inv_wl = 2.f * inv_xw;
+        for (int pl = ry; pl < hwl; pl += RL) {
+            const int yl = (int)(((float)pl + 0.5f) * inv_wl), xl = pl - yl * wl;
+            const size_t lo = ((size_t)n * hwl + pl) * C + c0;
+            float fx[VEC], o[VEC];
+            unpack16<T>(*(const u32x4_t*)(x + lo), fx);
+            u32x4_t rg[4], ra[4], ro[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t fo = off + ((size_t)(2 * yl + (q >> 1)) * xw + 2 * xl + (q & 1)) * C;
+                rg[q] = *(const u32x4_t*)(g + fo); ra[q] = *(const u32x4_t*)(gamma + fo);
+                ro[q] = lrelu ? *(const u32x4_t*)(fout + fo) : u32x4_t{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (fx[j] - mu[j]) * rs[j];
+                o[j] = -4.f * rs[j] * (m0[j] + xh * m1[j]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float fg[VEC], ga[VEC], fo2[VEC];
+                unpack16<T>(rg[q], fg); unpack16<T>(ra[q], ga); unpack16<T>(ro[q], fo2);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float go = (lrelu && !(fo2[j] > 0.f)) ? 0.2f * fg[j] : fg[j];
+                    o[j] += 0.5f * go * a[j] + rs[j] * 0.5f * go * (1.f + ga[j]);
+                }
+            }
+            if (acc) {
+                float prev[VEC];
+                unpack16<T>(*(const u32x4_t*)(dx + lo), prev);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] += prev[j];
+            }
+            *(u32x4_t*)(dx + lo) = pack16<T>(o);
+        }
+        return;
+    }
     for (int r = ry; r < HW; r += 2 * RL) {
         u32x4_t rg[2], rx[2], ra[2], ro[2], rp[2];
 #pragma unroll
@@ -838,7 +923,7 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
 static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, const void* gb, const void* fout, const float* stats,
                              const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                              int N, int HW, int C, int lrelu, int style_ld, void* stream, int stage = 0, double batch_count = 0.0,
-                             int xw = 0) {
+                             int xw = 0, int quad = 0) {
     const int sld = style_ld > 0 ? style_ld : 2 * C;
     const int gst = fout ? C : 2 * C;
     const int acc = (mode & S2E_NORM_ACCUMULATE_DX) != 0;
@@ -855,11 +940,12 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
     const float inv_xw = xw ? 1.f / (float)xw : 0.f;
     if (xw && (!fout || batch || stage != 0 || HW % xw || ((HW / xw) | xw) & 1))
         S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: x at half resolution needs the gamma-only form, per-sample statistics and an even H x W map");
+    if (quad && (!xw || mode != S2E_NORM_SPADE_STYLE)) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: dx_quad goes with x_up_w (SPADE_STYLE mode)");
     if (fout && mode == S2E_NORM_SPADE_STYLE && !batch && stage == 0 && HW <= in_small_hw()) {     // small map: one launch
         if (dtype == S2E_BF16) S2E_SMALL_LAUNCH(spade_small_bwd_kernel, bf16_t, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)gb, (const bf16_t*)fout,
-                                                 stats, style, (bf16_t*)dx, (bf16_t*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw);
+                                                 stats, style, (bf16_t*)dx, (bf16_t*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw, quad);
         else S2E_SMALL_LAUNCH(spade_small_bwd_kernel, float, (const float*)g, (const float*)x, (const float*)gb, (const float*)fout,
-                              stats, style, (float*)dx, (float*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw);
+                              stats, style, (float*)dx, (float*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw, quad);
         S2E_CHECK_LAUNCH("spade_small_bwd_kernel");
         return S2E_OK;
     }
@@ -885,7 +971,9 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
     if (stage != 2) { modulate_bwd_reduce_kernel<TT, MM><<<grid1, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, stats, style, (TT*)dgb, part, HW, C, rg.cg, rg.cgb, rg.rpp, lrelu, sld, iters, (const TT*)fout, xw, inv_xw); \
         if (sums_first) modulate_bwd_sums_kernel<MM><<<gridc, 256, 0, st>>>(part, ws, N, C, P); } \
     if (stage != 1) { modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, (stage == 2 || sums_first) ? nullptr : part, P, coef, stats, style, dstyle, N, C, HW, sld, batch, batch_count); \
-    modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst, xw, inv_xw); } } while (0)
+    if (quad) { const int gq = ((HW >> 2) * rg.cg + 255) / 256; \
+        modulate_bwd_apply_quad_kernel<TT><<<dim3(gq < gx_cap ? gq : gx_cap, N), 256, 0, st>>>((const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, HW, C, rg.cg, acc, gst, xw, 2.f * inv_xw); } \
+    else modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst, xw, inv_xw); } } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_BWD
@@ -911,10 +999,10 @@ extern "C" int s2e_modulate_bwd_gamma(int dtype, int mode, const void* g, const 
 extern "C" int s2e_modulate_bwd_staged(int dtype, int mode, const void* g, const void* x, const void* gb, const void* out,
                                        const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                                        int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, int x_up_w,
-                                       void* stream) {
+                                       int dx_quad, void* stream) {
     if (stage < 0 || stage > 2) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_staged: stage %d", stage);
     return modulate_bwd_impl(dtype, mode, g, x, gb, out, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream, stage, batch_count,
-                             x_up_w);
+                             x_up_w, dx_quad);
 }
 
 extern "C" size_t s2e_modulate_bwd_workspace_bytes(int dtype, int N, int HW, int C) {

@@ -39,23 +39,25 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
 
     def forward(self, x, seg, latent_style, stats=None, up=False):
         """up (not in the reference): x is the tensor BEFORE the generator's nearest 2x upsampling and `stats` were taken from
-        it (input_stats(x, 4)).  In the no-grad forward of a block with a learned shortcut x feeds norm_0 and norm_s only, whose
-        fused launches read it at (y/2, x/2): the upsampled tensor -- 4x the bytes, written once and read twice -- never exists.
-        Otherwise the block upsamples first (ops.upsample2x), as generator.py:77-92 does."""
+        it (input_stats(x, 4)).  In a block with a learned shortcut x feeds norm_0 and norm_s only, whose fused launches read it
+        at (y/2, x/2) and whose backward returns the gradient w.r.t. it (the 2 x 2 sums): neither the upsampled tensor -- 4x the
+        bytes, written once and read twice per pass -- nor its gradient ever exists.  Otherwise the block upsamples first
+        (ops.upsample2x), as generator.py:77-92 does."""
         seg = SegMap.of(seg)
         sn_begin(self)                  # no-op inside a generator (its forward already stepped the bank)
-        fold = up and self.learned_shortcut and stats is not None and not (torch.is_grad_enabled() and x.requires_grad)
+        fold = (up and self.learned_shortcut and stats is not None and self.norm_0.spade.kind != 'batch'
+                and self.norm_0.takes_fold(x) and self.norm_s.takes_fold(x))
         if up and not fold:
             x = ops.upsample2x(x)
         if fold:
-            h0 = self.norm_0(x, seg, latent_style, stats, lrelu=True, up=True)
+            if torch.is_grad_enabled() and x.requires_grad:
+                h0, x = self.norm_0(x, seg, latent_style, stats, lrelu=True, relay=True, up=True)
+            else:
+                h0 = self.norm_0(x, seg, latent_style, stats, lrelu=True, up=True)
             x_s = ops.conv2d_m(self.norm_s(x, seg, latent_style, stats, lrelu=False, up=True), self.conv_s)
             dx = ops.conv2d_m(h0, self.conv_0, None, 1, 1)
             return ops.conv2d_m(self.norm_1(dx, seg, latent_style, None, lrelu=True), self.conv_1, x_s, 1, 1)
-        if not self.learned_shortcut:
-            ops.materialize_upsample(x)                              # the residual reads x itself
         if stats is None:
-            ops.materialize_upsample(x)
             stats = self.input_stats(x)
         # x has two consumers (norm_0 and norm_s, or norm_0 and the residual).  With gradients on, the second one hangs off
         # an alias of x that norm_0 hands out, so its gradient reaches norm_0's backward and is accumulated there in place

@@ -75,20 +75,15 @@ class SPADESTYLEGenerator(BaseNetwork):
             x = self.G_middle_1(x, seg, w, st)
             for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
                 st = blk.input_stats(x, 4)
-                if _FOLD_UP and not (torch.is_grad_enabled() and x.requires_grad):
-                    # no-grad forward (the D step's, inference): the upsampling is folded into the block's two SPADE launches
-                    x = blk(x, seg, w, st, up=True)
-                    continue
-                # training forward: the upsampled tensor is allocated but never written -- up_*'s two SPADE launches and their
-                # backward read x at (y/2, x/2) (ops.upsample2x_lazy); whoever cannot writes it first (ops.materialize_upsample)
-                x = ops.upsample2x_lazy(x)
                 # data parallel: when the gradient w.r.t. the input of up_2 (up_0) exists, every parameter gradient of
                 # conv_img / up_3 / up_2 (up_1 / up_0) is final -- tell the trainer, which starts that group's all-reduce
                 # while the rest of the backward runs (Pix2PixModel.create_optimizers lays the arena out in these groups)
                 cb = self.__dict__.get('grad_ready')
                 if cb is not None and torch.is_grad_enabled() and x.requires_grad and blk in (self.up_2, self.up_0):
                     x.register_hook(lambda g, i=(0 if blk is self.up_2 else 1): cb(i))
-                x = blk(x, seg, w, st)
+                # the nearest 2x upsampling is folded into the block (its two SPADE launches read x at (y/2, x/2), forward and
+                # backward: SPADE_STYLE_ResnetBlock.forward(up=True)); a block that cannot fold upsamples first
+                x = blk(x, seg, w, st, up=True) if _FOLD_UP else blk(ops.upsample2x(x), seg, w, st)
             # conv_img(leaky_relu(x)) + tanh, generator.py:99-100: one launch
             y = ops.conv2d(x, self.conv_img.weight, self.conv_img.bias, None, 1, 1, ACT_LRELU, ACT_TANH)
             return y.permute(0, 3, 1, 2)

@@ -159,21 +159,24 @@ class SPADE_STYLE_Block(nn.Module):
         self.spade = SPADE(opt.norm_G.replace('spectral', ''), fin, opt.semantic_nc)
         self.adain = ApplyStyle(opt.w_dim, channels=fin, use_wscale=False)
 
+    def takes_fold(self, x_low):
+        """Does the fused launch take this layer with x handed over BEFORE the nearest 2x upsampling (forward(up=True))?"""
+        return ops.spade_fused_supported(x_low, self.spade.mlp_shared[0].out_channels, 8)
+
     def forward(self, x, segmap, latent_style, stats=None, lrelu=False, relay=False, up=False):
         """relay (not in the reference): also return an alias x' of x for the other consumers of x, see
         ops.spade_style_modulate.
-        up (not in the reference; no-grad forward, stats given): x is the tensor BEFORE the generator's nearest 2x upsampling
-        (generator.py:77-92); the fused launch reads it at (y/2, x/2) and the upsampled tensor never exists.  Use
-        `takes_folded_upsampling` first."""
+        up (not in the reference; stats given): x is the tensor BEFORE the generator's nearest 2x upsampling (generator.py:77-92);
+        the fused launch reads it at (y/2, x/2), its backward returns the gradient w.r.t. that tensor: the upsampled tensor and
+        its gradient never exist.  Layers the fused launch does not take upsample first."""
         seg = SegMap.of(segmap)
         n, h, w, c = x.shape
         sp = self.spade
         if up:
-            if torch.is_grad_enabled() and x.requires_grad or stats is None or relay:
-                raise ValueError('SPADE_STYLE_Block: up=True is for the no-grad forward with the statistics given')
+            if stats is None:
+                raise ValueError('SPADE_STYLE_Block: up=True needs the statistics of x (input_stats(x, 4))')
             h, w = 2 * h, 2 * w
         if stats is None:
-            ops.materialize_upsample(x)                              # (a lazily upsampled x: the statistics pass reads it)
             stats = spade_stats(x, [sp])
         batch = sp.kind == 'batch'
         from . import stylebank
@@ -184,10 +187,7 @@ class SPADE_STYLE_Block(nn.Module):
         else:
             style, kw = self.adain.linear(latent_style), {}         # (N, 2C) fp32
         fl = 8 if up else 0
-        fusable = ops.spade_fused_supported(x, sp.mlp_shared[0].out_channels, fl)
-        if not fusable or batch:
-            ops.materialize_upsample(x)                              # a lazily upsampled x (ops.upsample2x_lazy): write it now
-        if fusable:
+        if ops.spade_fused_supported(x, sp.mlp_shared[0].out_channels, fl) and not (up and batch):
             # the big layers: [gamma | beta] conv and modulation in ONE launch, gamma / beta never written (ops.SpadeFusedFn)
             return ops.spade_style_fused(x, seg.label, sp.mlp_shared[0].weight, sp.mlp_shared[0].bias, sp.mlp_gamma.weight,
                                          sp.mlp_gamma.bias, sp.mlp_beta.weight, sp.mlp_beta.bias, style, stats, lrelu,

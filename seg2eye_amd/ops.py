@@ -955,10 +955,11 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     else gb = gamma alone and fout = the forward's output (s2e_modulate_bwd_gamma).
     relay: the OTHER consumers of x hang off the node's second output, so their gradient arrives here first and the
     element-wise pass adds this layer's dx to it in place -- instead of autograd summing two full tensors."""
-    n, h, w, c = (fout if fout is not None else x).shape          # (x may be the half-resolution source: ctx.x_up_w)
+    n, h, w, c = (fout if fout is not None else x).shape          # (x may be the half-resolution tensor: ctx.x_up_w; dx then is too)
+    quad = int(getattr(ctx, 'x_up_w', 0) != 0)
     g = g.contiguous()
     acc = g_relay is not None and g_relay.is_contiguous() and g_relay.dtype == x.dtype
-    dx = g_relay if acc else torch.empty(n, h, w, c, dtype=x.dtype, device=x.device)
+    dx = g_relay if acc else torch.empty_like(x)
     dgb = torch.empty(n, h, w, 2 * c, dtype=x.dtype, device=x.device)
     if ctx.off is None:
         dstyle = ZeroPool.take(style.numel(), torch.float32, x.device).view(style.shape)
@@ -979,7 +980,7 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     def launch(stage, count):
         return L.check(L.lib().s2e_modulate_bwd_staged(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx), _p(dgb), dsp,
                                                        _p(ws), n, h * w, c, int(ctx.lrelu), ld, stage, float(count),
-                                                       int(getattr(ctx, 'x_up_w', 0)), _stream()),
+                                                       int(getattr(ctx, 'x_up_w', 0)), quad, _stream()),
                        's2e_modulate_bwd_staged')
     if world == 1:
         LaunchProfiler.run('modulate_bwd', 0.0, lambda: launch(0, 0.0), nbytes=nb)
@@ -1043,20 +1044,18 @@ class SpadeFusedFn(torch.autograd.Function):
     [dgamma | dbeta] -> the conv's weight / data gradients)."""
 
     @staticmethod
-    def forward(ctx, x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags, grad_mode, x_low=None):
-        _need(x, style, stats, x_low)
+    def forward(ctx, x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags, grad_mode):
+        _need(x, style, stats)
         n, h, w, c = x.shape
-        # x_low (training forward): x is a LAZILY upsampled tensor (allocated, never written: ops.upsample2x_lazy) and x_low its
-        # half-resolution source -- the launches read x_low at (y/2, x/2), the backward does too; autograd still sees x, so the
-        # gradient keeps the full-resolution shape
-        xr = x if x_low is None else x_low
-        if x_low is not None:
-            flags = int(flags) | 8
-        up = bool(flags & 8) and x_low is None               # x itself is the tensor BEFORE the upsampling (no-grad forward)
+        # flags & 8: x is the tensor BEFORE the block's nearest 2x upsampling.  The launches read it at (y/2, x/2); the backward
+        # does too and returns the gradient w.r.t. THIS tensor (the 2 x 2 sums: the upsampling's backward folded in as well).
+        # Neither the upsampled tensor nor its gradient ever exists.
+        up = bool(flags & 8)
+        xr = x
         if up:
             h, w = 2 * h, 2 * w
-            if grad_mode and any(ctx.needs_input_grad):
-                raise ValueError('spade_style_fused: the folded upsampling (flags 8) is for the no-grad forward')
+            if batch:
+                raise ValueError('spade_style_fused: the folded upsampling (flags 8) is not built for BatchNorm SPADE')
         _, H, W = label.shape
         nh = w_sh.shape[0]
         dtype = x.dtype
@@ -1109,7 +1108,7 @@ class SpadeFusedFn(torch.autograd.Function):
         ctx.lrelu, ctx.off, ctx.dbig, ctx.batch, ctx.relay = lrelu, off, dbig, bool(batch), bool(relay)
         if train:
             _gb_grad_targets(ctx, fused, w_sh, b_sh, w_g, b_g, w_b, b_b, nh)
-            ctx.x_up_w = w if x_low is not None else 0
+            ctx.x_up_w = w if up else 0
             ctx.save_for_backward(xr, label, w_sh, w_gb, actv, gamma, out, style, stats)
         if relay:
             ctx.set_materialize_grads(False)
@@ -1121,10 +1120,10 @@ class SpadeFusedFn(torch.autograd.Function):
         x, label, w_sh, w_gb, actv, gamma, out, style, stats = ctx.saved_tensors
         nn_ = (None,) * 8
         if g is None:
-            return (g_relay,) + (None,) * 17
+            return (g_relay,) + (None,) * 16
         dx, dgb, dstyle = _modulate_grads(ctx, g, g_relay, x, gamma, out, style, stats)
         gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b = _spade_param_grads(ctx, dgb, label, w_sh, w_gb, actv)
-        return (dx, None, gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b, dstyle) + (None,) * 9
+        return (dx, None, gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b, dstyle) + (None,) * 8
 
 
 def spade_fused_supported(x, nh, flags=0):
@@ -1147,15 +1146,8 @@ def spade_style_fused(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lr
     spade_style_modulate."""
     if off is None:
         style = style.float().contiguous()
-    low = lazy_source(x)
-    if low is not None and (batch or not torch.is_grad_enabled()):
-        materialize_upsample(x)                               # (BatchNorm SPADE's staged backward reads x at full resolution)
-        low = None
-    res = SpadeFusedFn.apply(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags,
-                             torch.is_grad_enabled(), low)
-    if relay and low is not None:
-        res[1]._s2e_low = low                                 # the alias handed to x's other consumer is as unwritten as x
-    return res
+    return SpadeFusedFn.apply(x, label, w_sh, b_sh, w_g, b_g, w_b, b_b, style, stats, lrelu, off, dbig, batch, relay, flags,
+                              torch.is_grad_enabled())
 
 
 def spade_style_modulate(x, gb, style, stats, lrelu, off=None, dbig=None, batch=False, relay=False):
@@ -1227,49 +1219,6 @@ class Upsample2xFn(torch.autograd.Function):
 
 def upsample2x(x):
     return Upsample2xFn.apply(x)
-
-
-class Upsample2xLazyFn(torch.autograd.Function):
-    """The nearest 2x upsampling as a tensor that is allocated but NOT written: consumers that can read the source at (y/2, x/2)
-    instead (the fused SPADE launches and their backward: flags 8 / x_up_w) take `y._s2e_low`; anyone else calls
-    materialize_upsample(y) first.  Backward: the usual 2x2 sum."""
-
-    @staticmethod
-    def forward(ctx, x):
-        n, h, w, c = x.shape
-        return torch.empty(n, 2 * h, 2 * w, c, dtype=x.dtype, device=x.device)
-
-    backward = staticmethod(Upsample2xFn.backward)
-
-
-_LAZY_UP_OFF = os.environ.get('S2E_FOLD_UPSAMPLE_TRAIN', '1') == '0'      # A/B switch: the training forward materialises the upsampled tensor
-
-
-def upsample2x_lazy(x):
-    """upsample2x(x) whose result is written only if somebody asks (materialize_upsample): see Upsample2xLazyFn."""
-    if _LAZY_UP_OFF or not x.is_contiguous() or (x.shape[1] | x.shape[2]) < 1:
-        return upsample2x(x)
-    _need(x)
-    y = Upsample2xLazyFn.apply(x)
-    y._s2e_low = x.detach()
-    return y
-
-
-def lazy_source(y):
-    """The half-resolution source of a lazily upsampled tensor, or None."""
-    return getattr(y, '_s2e_low', None)
-
-
-def materialize_upsample(y):
-    """Write a lazily upsampled tensor (no-op otherwise) -> y."""
-    low = getattr(y, '_s2e_low', None)
-    if low is not None:
-        n, h, w, c = low.shape
-        LaunchProfiler.run('resample', 0.0, lambda: L.check(
-            L.lib().s2e_upsample2x_fwd(_dt(low), _p(low), _p(y), n, h, w, c, _stream()), 's2e_upsample2x_fwd'),
-            nbytes=float(5 * low.numel() * low.element_size()))
-        del y._s2e_low
-    return y
 
 
 class BilinearResizeFn(torch.autograd.Function):
