@@ -10,8 +10,14 @@ fp32 accumulate, synthetic 4-class label maps + styles (BASELINE.json metric; co
 Rank 0 prints ONE JSON line.  Besides the driver contract it carries
   roofline     : the dominant kernel (by GPU time: the patch-resident 3x3 conv kernel, MFMA-bound): algorithmic FLOPs
                  of its launches / their HIP-event durations, measured live; `kernels` lists every conv kernel the same way;
+  roofline_hbm : the dominant HBM-bound entry point the same way, against 8 TB/s;
   cpu_baseline : the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded
-                 sample (one G+D step at batch 1 of the same 256x256 ngf=64 workload), rank 0, N=1 only.
+                 sample (G+D steps at batch 8 of the same 256x256 ngf=64 workload), rank 0, N=1 only;
+  dense_labels : the same timed steps on iid random label maps (no label-uniform rectangle: the label-sparse SPADE
+                 launches skip nothing), `eager` the same steps as individual launches instead of hipGraph replays (the mode
+                 the overlapped multi-GPU exchange runs in), `secondary` SURVEY 8(d)'s secondary metric: G-only forward
+                 images/s of config 2 (fp32, eval mode) with its fraction of the fp32 MFMA peak, and the bf16 inference
+                 rate (netE + netG + post-processing).  Rank 0, N=1 only; none of them is inside the timed region.
 """
 import argparse
 import json
@@ -102,7 +108,7 @@ def cpu_step_seconds(opt_kwargs, hw, batch, threads, warm, timed, budget_s):
     return float(np.median(times)), len(times), warmed
 
 
-def cpu_baseline(opt_kwargs, hw, batch, budget_s=75.0):
+def cpu_baseline(opt_kwargs, hw, batch, budget_s=60.0):
     """the CPU restatement runs the identical G+D step (same shapes -- batch 8 -- fp32, same synthetic inputs)
     on this box's host cores: 1 warm-up + up to 3 timed iterations (median), capped at `budget_s` of wall time so that
     the default bench run stays within minutes.  Thread count: measured on the GPU box's 2 x 64-core EPYC 9575F
@@ -122,6 +128,73 @@ def cpu_baseline(opt_kwargs, hw, batch, budget_s=75.0):
     if cores > 8 and left > 20.0:
         sec8, n8, w8 = cpu_step_seconds(opt_kwargs, hw, batch, 8, 0, 1, left)
         out['at_8_threads'] = {'value': batch / sec8, 'seconds_per_step': sec8, 'sample': '%d un-warmed iteration(s)' % n8}
+    if phys > cores:
+        # SURVEY 8(d) says "all physical cores": that figure too, from ONE un-warmed iteration (it is the slow one: ~54 s)
+        seca, na, wa = cpu_step_seconds(opt_kwargs, hw, batch, phys, 0, 1, 1.0)
+        out['all_cores'] = {'value': batch / seca, 'cores': phys, 'seconds_per_step': seca, 'sample': '%d un-warmed iteration(s)' % na}
+    return out
+
+
+def make_dense_label_data(data, seed):
+    """The same batch with iid uniform random labels: every rectangle of every resolution crosses a label boundary."""
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.randint(0, 4, tuple(data['label'].shape), generator=g, dtype=torch.int64).to(data['label'].dtype)
+    return dict(data, label=lab.to(data['label'].device))
+
+
+def timed_steps(step, steps, warm):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+G_FWD_GFLOP_PER_SAMPLE_256 = 273.15      # SURVEY 8(d) / App. A.5: netG forward at 256x256, ngf 64
+
+
+def secondary_metrics(args, dev_index, data):
+    """SURVEY 8(d) "Secondary": G-only forward images/s at config 2 (256x256, batch 8, fp32, eval mode, given style codes)
+    against the fp32 MFMA peak, and the bf16 inference path (netE + netG + resize to 400x640 + 0..255)."""
+    import contextlib, io
+    from seg2eye_amd.options import default_opt
+    from seg2eye_amd.pix2pix_model import Pix2PixModel
+    from seg2eye_amd.postprocessor import ImageProcessor
+    out = {}
+    for dt in ('fp32', 'bf16'):
+        opt = default_opt(ngf=args.ngf, ndf=args.ngf, crop_size=args.size, aspect_ratio=1.0, batchSize=args.batch,
+                          compute_dtype=dt, gpu_ids=[dev_index])
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = Pix2PixModel(opt)
+        fill_weights(model)
+        model.eval()
+        with torch.no_grad():
+            seg, style, _ = model.preprocess_input(dict(data))
+            w, _ = model.encode_w(style)
+
+            def g_only():
+                return model.generate_fake_from_stylecode(seg, w)
+
+            def inference():
+                return ImageProcessor.to_255resized_imagebatch(model.forward(dict(data), mode='inference'))
+            sec = timed_steps(g_only, 20, 5)
+            ent = {'images_per_s': args.batch / sec, 'ms_per_batch': sec * 1e3, 'batch': args.batch}
+            if args.size == 256 and args.ngf == 64:
+                tf = G_FWD_GFLOP_PER_SAMPLE_256 * args.batch / sec / 1e3
+                peak = MFMA_PEAK_F32 if dt == 'fp32' else MFMA_PEAK_BF16
+                ent.update({'algorithmic_tflops': tf, 'peak': peak, 'frac': tf / peak})
+            out['g_forward_' + dt] = ent
+            if dt == 'bf16':
+                sec = timed_steps(inference, 20, 5)
+                out['inference_bf16'] = {'images_per_s': args.batch / sec, 'ms_per_batch': sec * 1e3, 'batch': args.batch,
+                                         'what': 'netE on 4 style images + netG (eval) + resize to 400x640 + 0..255, inputs resident'}
+        del model
+    out['what'] = ('config 2 of BASELINE.json: netG forward only, eval mode, %dx%d batch %d, style codes given; algorithmic FLOPs '
+                   '= SURVEY 8(d) (%.2f GFLOP per sample; the label-sparse launches execute fewer on these ellipse maps)'
+                   % (args.size, args.size, args.batch, G_FWD_GFLOP_PER_SAMPLE_256))
     return out
 
 
@@ -137,6 +210,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='launch eagerly instead of replaying hipGraphs')
+    ap.add_argument('--no-extras', action='store_true', help='skip the dense_labels / eager / secondary measurements')
     args = ap.parse_args()
 
     from seg2eye_amd import distributed as sdist, ops
@@ -189,6 +263,25 @@ def main():
         step()
         torch.cuda.synchronize()
         per_step.append((time.perf_counter() - t1) * 1e3)
+    # Beside the headline (rank 0's line only, one GPU only, never inside the timed region above):
+    extras = {}
+    if world == 1 and not args.no_extras:
+        dense = make_dense_label_data(data, 4321)
+
+        def step_dense():
+            trainer.run_generator_one_step(dict(dense))
+            trainer.run_discriminator_one_step(dict(dense))
+        sec = timed_steps(step_dense, args.steps, 3)
+        extras['dense_labels'] = {'value': args.batch / sec, 'unit': 'images/s', 'ms_per_step': sec * 1e3, 'hip_graphs': graphs_ran,
+                                  'what': 'the same G+D steps on iid uniform random 4-class label maps: no label-uniform '
+                                          'rectangle exists, the label-sparse SPADE launches compute every rectangle'}
+        was = trainer.opt.hip_graphs
+        trainer.opt.hip_graphs = False
+        sec = timed_steps(step, args.steps, 2)
+        extras['eager'] = {'value': args.batch / sec, 'unit': 'images/s', 'ms_per_step': sec * 1e3,
+                           'what': 'the same steps as individual launches (no hipGraph replay): the mode of the overlapped '
+                                   'multi-GPU gradient exchange'}
+        trainer.opt.hip_graphs = was
     # Per-launch HIP events for the roofline.  A graph replay cannot carry per-launch events, so the
     # same step (same kernels, shapes, data) is re-run eagerly right after the timed region with an
     # event pair around every C-ABI call, on the launch stream.
@@ -229,10 +322,13 @@ def main():
         prof = prof.summary()
         if prof:
             peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
-            pmc_rel = os.path.join('profiles', 'r02', 'pmc', 'hbm_traffic.json')
-            pmc = {}
-            if os.path.exists(os.path.join(ROOT, pmc_rel)):   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-                pmc = json.load(open(os.path.join(ROOT, pmc_rel)))
+            # the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]', 'pmc', 'hbm_traffic.json')))
+            pmc_rel, pmc = None, {}
+            if cands:
+                pmc_rel = os.path.relpath(cands[-1], ROOT)
+                pmc = json.load(open(cands[-1]))
 
             def traffic_of(fam):
                 k = pmc.get('kernels', {}).get(fam)
@@ -242,19 +338,21 @@ def main():
             fam = max(mfma, key=lambda k: mfma[k]['ms'])
             d = mfma[fam]
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            exe = d['executed_flops'] / (d['ms'] * 1e-3) / 1e12
             traffic, traffic_src = traffic_of(fam)
-            out['roofline'] = {'kernel': fam, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                               'frac': ach / peak, 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC, separate passes)',
+            # `achieved` / `frac`: the multiply-adds the matrix pipe really EXECUTED (the label-sparse SPADE launches
+            # skip the rectangles they serve from the class table, so the algorithmic count overstates hardware utilisation on
+            # these ellipse maps); the SURVEY 8(d) algorithmic figure -- 2*Cin*Cout*k^2*pixels whatever was skipped -- is kept
+            # beside it as `algorithmic_tflops` / `algorithmic_frac`.  On dense labels (`dense_labels`) the two coincide.
+            out['roofline'] = {'kernel': fam, 'bound': 'mfma', 'achieved': exe, 'peak': peak, 'unit': 'TFLOP/s',
+                               'frac': exe / peak, 'algorithmic_tflops': ach, 'algorithmic_frac': ach / peak,
+                               'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC, separate passes)',
                                'traffic_source': traffic_src,
                                'algorithmic_bytes_per_launch': d['bytes'] / d['launches'],
                                'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                                'launches_per_step': d['launches'] / prof_steps, 'ms_per_step': d['ms'] / prof_steps,
                                'gflop_per_step': d['flops'] / prof_steps / 1e9,
-                               # label-sparse SPADE launches compute only the rectangles that cross a label boundary:
-                               # `achieved` counts their ALGORITHMIC FLOPs (2*Cin*Cout*k^2*pixels), `executed_*` the
-                               # multiply-adds really issued to the matrix pipe
-                               'executed_tflops': d['executed_flops'] / (d['ms'] * 1e-3) / 1e12,
-                               'executed_frac': d['executed_flops'] / (d['ms'] * 1e-3) / 1e12 / peak,
+                               'executed_gflop_per_step': d['executed_flops'] / prof_steps / 1e9,
                                'measured': 'HIP events around every launch, eager re-run of the timed step'}
             if hbm:
                 # the HBM-bound class (north_star: "HBM GB/s against the roofline"): its dominant family by time, algorithmic
@@ -268,10 +366,20 @@ def main():
                                        'traffic_source': tr_src, 'algorithmic_bytes_per_launch': h['bytes'] / h['launches'],
                                        'launches_per_step': h['launches'] / prof_steps, 'ms_per_step': h['ms'] / prof_steps,
                                        'measured': 'HIP events around every C-ABI call (all kernels of the call), eager re-run of the timed step'}
-            out['kernels'] = {k: dict({'launches_per_step': v['launches'] / prof_steps, 'ms_per_step': v['ms'] / prof_steps},
-                                      **({'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} if v['flops'] > 0 else
+            out['kernels'] = {k: dict({'launches_per_step': v['launches'] / prof_steps, 'ms_per_step': v['ms'] / prof_steps,
+                                       'algorithmic_bytes_per_launch': v['bytes'] / max(v['launches'], 1),
+                                       'pmc_bytes_per_launch': traffic_of(k)[0]},
+                                      **({'tflops': v['executed_flops'] / (v['ms'] * 1e-3) / 1e12,
+                                          'algorithmic_tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} if v['flops'] > 0 else
                                          {'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9}))
                               for k, v in prof.items()}
+        out.update(extras)
+        if world == 1 and not args.no_extras:
+            del trainer
+            torch.cuda.empty_cache()
+            out['secondary'] = secondary_metrics(args, dev_index, data)
+        if world > 1:
+            out['rccl_ranks'] = world
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(opt_kwargs, args.size, args.batch)
         print(json.dumps(out), flush=True)

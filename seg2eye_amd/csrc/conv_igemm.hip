@@ -19,6 +19,7 @@
 #include "common.h"
 #include "conv_small.h"
 #include "conv_patch.h"
+#include "conv_stream.h"
 #include <stdlib.h>
 
 struct ConvKParams {
@@ -624,6 +625,7 @@ extern "C" size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d) 
     if (!d) return 0;
     if (s2e_small_conv_kind(dtype, d) != SMALL_NONE) return 0;
     if (s2e_conv_patch_plan(dtype, d, nullptr)) return s2e_conv_patch_workspace_bytes(dtype, d);
+    if (s2e_conv_stream_plan(dtype, d)) return s2e_conv_stream_workspace_bytes(dtype, d);
     int tiles, tiles_n, splits, per;
     plan_splits(dtype, d, &tiles, &tiles_n, &splits, &per);
     return splits > 1 ? (size_t)splits * d->N * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
@@ -670,6 +672,9 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
         f.M = d->N * d->Ho * d->Wo; f.Cout = d->Cout; f.splits = patch_splits; f.partial = (float*)workspace;
         return launch_finish(dtype, f, (hipStream_t)stream);
     }
+    if (s2e_conv_stream_plan(dtype, d))               // every other bf16 vector-channel shape: persistent stream-K kernel
+        return s2e_conv_stream_launch(x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), workspace,
+                                      workspace_bytes, (hipStream_t)stream);
     ConvKParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;

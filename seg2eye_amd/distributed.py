@@ -40,6 +40,31 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+_solo_depth = 0
+
+
+class solo:
+    """`with solo():` -- the enclosed passes run on THIS rank only (rank 0's validation passes in train.py, the Tester):
+    ops that exchange data between replicas as part of a forward or backward (BatchNorm SPADE's batch statistics) must not
+    issue a collective there, because the other ranks are not in the same code path -- they are waiting in the next
+    broadcast -- and a solo all-reduce would pair up with it (hang, or mixed payloads).  Inside, `sync_world_size()` is 1."""
+
+    def __enter__(self):
+        global _solo_depth
+        _solo_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _solo_depth
+        _solo_depth -= 1
+        return False
+
+
+def sync_world_size():
+    """The number of replicas a forward / backward op exchanges data with: world_size(), or 1 inside `solo()`."""
+    return 1 if _solo_depth > 0 else world_size()
+
+
 def get_rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -77,6 +102,16 @@ class FlatGradSync:
         """Group i's gradients are final: start their exchange now (no-op on one process / when already started)."""
         if world_size() > 1 and i not in self._launched:
             self._start(i)
+
+    def reset(self):
+        """Forget launches whose step did not complete (a backward that raised after `launch(0)`): their handles are waited
+        for, so that the next step starts its own exchange instead of treating the groups as already launched."""
+        for h in self._handles:
+            try:
+                h.wait()
+            except Exception:                                # noqa: BLE001 -- the step already failed; do not mask its error
+                pass
+        self._launched, self._handles = set(), []
 
     def all_reduce(self):
         if world_size() == 1:

@@ -60,7 +60,10 @@ class ConvEncoder(BaseNetwork):
         # output channels, the LeakyReLU is the conv's fused input activation.  fp32 (the style code feeds every modulation:
         # the few kFLOP are not worth bf16's three digits).  Outside the pack plan's scope: the concatenated weight is a
         # temporary, packed on the spot.
-        wcat = torch.cat([self.fc_mu.weight, self.fc_var.weight], 0).view(2 * self.opt.w_dim, h.shape[-1], self.so, self.so)
-        bcat = torch.cat([self.fc_mu.bias, self.fc_var.bias], 0)
+        # fc_var's half is DETACHED: logvar is returned but never used (pix2pix_model.py:271-305), so in the reference fc_var's
+        # gradient is None and torch's Adam skips it -- through the concatenation it would receive explicit zeros instead,
+        # which any optimizer with weight decay would act on.
+        wcat = torch.cat([self.fc_mu.weight, self.fc_var.weight.detach()], 0).view(2 * self.opt.w_dim, h.shape[-1], self.so, self.so)
+        bcat = torch.cat([self.fc_mu.bias, self.fc_var.bias.detach()], 0)
         out = ops.conv2d(h.float(), wcat, bcat, None, 1, 0, ACT_LRELU).reshape(h.shape[0], 2 * self.opt.w_dim)
         return out[:, :self.opt.w_dim], out[:, self.opt.w_dim:], feats

@@ -96,12 +96,13 @@ def spade_stats(x, spades, replication=1):
     cnt = float(n * h * w * replication)
     tot = sums.sum(0) * float(replication)                        # (C,2) fp64
     from .. import distributed as sdist
-    if sdist.world_size() > 1:
+    if sdist.sync_world_size() > 1:
         # data-parallel replicas normalise with the statistics of the GLOBAL batch (the per-layer 2*C exchange a
         # synchronised BatchNorm needs; normalization.py:74-75 sees the whole batch on the reference's single GPU).  Equal
         # shards: the count is world * local.  Running buffers then evolve identically on every replica.
+        # (sync_world_size, not world_size: rank 0's validation passes run alone -- distributed.solo -- and use local counts)
         sdist.all_reduce_sum_(tot)
-        cnt *= sdist.world_size()
+        cnt *= sdist.sync_world_size()
     mean = tot[:, 0] / cnt
     var = (tot[:, 1] / cnt - mean * mean).clamp_min(0.0)
     with torch.no_grad():

@@ -976,7 +976,7 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     # (x handed over before the upsampling: its two reads and the dx write are a quarter each: 6.75 accesses)
     nb = float((6.75 if quad else 9.0) * n * h * w * c * x.element_size())
     from . import distributed as sdist
-    world = sdist.world_size() if ctx.batch else 1
+    world = sdist.sync_world_size() if ctx.batch else 1
 
     def launch(stage, count):
         return L.check(L.lib().s2e_modulate_bwd_staged(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx), _p(dgb), dsp,

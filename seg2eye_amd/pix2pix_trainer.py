@@ -36,6 +36,13 @@ class Pix2PixTrainer:
                 # start the all-reduce of its arena slice.  That needs the backward to run as individual launches, not as one
                 # graph replay -- which costs nothing: eager launches run at the graph's rate (the GPU is busy
                 # throughout; 336.6 vs 337.1 img/s on the same box).
+                if getattr(self.opt, 'hip_graphs', False):
+                    from .distributed import get_rank
+                    if get_rank() == 0:
+                        import sys
+                        print('seg2eye_amd: %d replicas: the steps run as individual launches so that the gradient exchange '
+                              'overlaps the backward (--hip_graphs is ignored; --no_overlap_allreduce keeps the graphs and '
+                              'exchanges after the backward)' % world_size(), file=sys.stderr)
                 self.opt.hip_graphs = False
                 self.pix2pix_model.netG.__dict__['grad_ready'] = self._group_ready
             broadcast_flat(self.optimizer_G.flat_p)          # identical replicas at step 0: parameters ...
@@ -60,9 +67,13 @@ class Pix2PixTrainer:
     # ---- step bodies: zero_grad + forward + backward (what a hipGraph captures) -------------------
     def _g_body(self, data):
         self.optimizer_G.zero_grad()
-        with self.pool.scope('G'):                               # all zero-filled scratch of the step: one fill
-            g_losses, generated = self.pix2pix_model(data, mode='generator')
-            _total(g_losses).backward()
+        try:
+            with self.pool.scope('G'):                           # all zero-filled scratch of the step: one fill
+                g_losses, generated = self.pix2pix_model(data, mode='generator')
+                _total(g_losses).backward()
+        except BaseException:
+            self.sync_G.reset()                                  # exchanges the backward hooks started for a step that failed
+            raise
         # keep detached copies only: a live autograd graph would pin last iteration's AccumulateGrad nodes
         # (and their stream), which breaks hipGraph capture
         self.g_losses = {k: v.detach() for k, v in g_losses.items()}

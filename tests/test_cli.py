@@ -114,6 +114,32 @@ def test_train_resume_test_end_to_end(tmp_path):
 
 
 
+@pytest.mark.gpu
+def test_two_rank_train_with_batchnorm_spade_and_rank0_validation(tmp_path):
+    """with the CLI's default --norm_G spectralspadebatch3x3 the SPADE layers exchange their batch statistics
+    between replicas in every training forward / backward.  Rank 0's periodic validation passes run ALONE (train mode, as in
+    the reference) while the other ranks wait in the buffer broadcast that follows: inside them no collective may be issued
+    (distributed.solo), or it would pair up with that broadcast.  Two ranks sharing this GPU over gloo run train.py with
+    validation due every iteration; the run must finish (a mismatched collective hangs or corrupts) and leave checkpoints."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, S2E_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'train.py'), '--name', 'dp', '--checkpoints_dir', str(tmp_path / 'ck'),
+           '--ngf', '8', '--ndf', '8', '--batchSize', '2', '--aspect_ratio', '1.0', '--synthetic_size', '8', '--compute_dtype', 'fp32',
+           '--norm_G', 'spectralspadebatch3x3', '--niter', '1', '--niter_decay', '0', '--print_freq', '2', '--display_freq', '2',
+           '--full_val_freq', '4', '--validation_limit', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert 'Training was successfully finished.' in out.stdout
+    assert (tmp_path / 'ck' / 'dp' / 'latest_net_G.pth').exists()
+
+
 def _fake_openeds_store(seed=0, users=('U001', 'U002', 'U003'), n_ss=(3, 2, 4), n_gen=5):
     """An in-memory stand-in for the OpenEDS H5 file (data/prepare_openeds.py:77-138): /<key>/<user>/{images_ss, labels_ss,
     images_gen, images_seq, labels_gen} uint8 (n, 640, 400) + *_filenames (S13)."""

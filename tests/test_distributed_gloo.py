@@ -49,6 +49,21 @@ def _worker(rank, world, port, out):
         raise AssertionError('a gap in the groups must be refused')
     except ValueError:
         pass
+    # rank-local passes (rank 0's validation in train.py): ops must see ONE replica there and issue no collective
+    assert sdist.sync_world_size() == world
+    with sdist.solo():
+        assert sdist.sync_world_size() == 1 and sdist.world_size() == world
+        with sdist.solo():
+            assert sdist.sync_world_size() == 1
+        assert sdist.sync_world_size() == 1
+    assert sdist.sync_world_size() == world
+    # a step that failed after its first group was launched must not leave the sync thinking that group is in flight
+    opt.flat_g.copy_(local)
+    gsync.launch(0)
+    gsync.reset()
+    assert not gsync._handles and not gsync._launched
+    opt.flat_g.copy_(local)
+    assert abs(gsync.all_reduce() - 1.0 / world) < 1e-12 and torch.equal(opt.flat_g, grouped)
     out[rank] = (p0, local, grouped, opt.flat_g.clone())
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -4,7 +4,7 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
-    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r02/pmc [steps-profiled]
+    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r03/pmc [steps-profiled]
 
 Counters are in KB; FETCH_SIZE is doubled (gfx950 counts a 128-B request as 64 B: MI355X_MICROARCH.md, HBM section).
 Families are seg2eye_amd.ops.LaunchProfiler's -- one per C-ABI entry point (the conv entry points split by
@@ -22,6 +22,7 @@ from collections import defaultdict
 FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the family)
     'conv_patch_kernel': ('conv_patch', True),
     'conv_igemm_kernel': ('conv_igemm', True),
+    'conv_stream_kernel': ('conv_igemm', True), 'conv_stream_fixup_kernel': ('conv_igemm', False),   # (same profiler family: s2e_conv2d's generic shapes)
     'conv_finish_kernel': ('conv_igemm', False),          # (also finishes the patch kernel's channel-chunk splits)
     'fwd_cout1_kernel': ('conv_small', True), 'fwd_cin1_kernel': ('conv_small', True), 'dgrad_cout1_kernel': ('conv_small', True),
     'conv_wgrad_patch_kernel': ('conv_wgrad_patch', True),
@@ -94,8 +95,11 @@ def git_head():
 
 def main():
     fdir, wdir, outdir = sys.argv[1:4]
-    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3          # bench.py --steps 2 --warmup 1 runs 3 (+2 per-step-timed) steps
     fetch, write = read(fdir, 'FETCH_SIZE'), read(wdir, 'WRITE_SIZE')
+    # steps profiled = Adam launches / 2 (one per optimizer per G+D step): bench.py runs warm-up + timed + per-step-timed (+ the
+    # extras') steps, so a count passed by hand goes stale (3 was written for a command that runs 5)
+    adam = [v[0] for k, v in fetch.items() if 'adam_flat' in k] or [v[0] for k, v in write.items() if 'adam_flat' in k]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else (max(1, adam[0] // 2) if adam else 1)
     fams = defaultdict(lambda: {'launches': 0, 'fetch': 0.0, 'write': 0.0})
     rows = []
     for key in sorted(set(fetch) | set(write)):

@@ -55,14 +55,15 @@ class TrainingRun:
         print(head + ' '.join('%s: %.3f' % (name, float(v.float().mean())) for name, v in losses.items()), flush=True)
 
     def quick_validation(self):
-        with torch.no_grad():                                    # (the reference validates the model as it is: train mode)
+        # (the reference validates the model as it is: train mode.  solo: only rank 0 is here -- no per-layer exchange)
+        with torch.no_grad(), dist.solo():
             for t in self.testers:
                 t.run_partial_modes(model=self.trainer.pix2pix_model, epoch=self.epoch, n_steps=self.counter.total_steps_so_far,
                                     log=True, visualize_images=False, limit=self.opt.validation_limit)
         self.trainer.sync_replica_buffers()                      # rank 0's train-mode pass advanced its u, v / BN statistics
 
     def full_validation(self):
-        with torch.no_grad():
+        with torch.no_grad(), dist.solo():
             for t in self.testers:
                 t.run(self.trainer.pix2pix_model, mode='full', epoch=self.epoch, n_steps=self.counter.total_steps_so_far,
                       log=True, write_error_log=self.opt.write_error_log)
