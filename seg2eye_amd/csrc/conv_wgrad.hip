@@ -22,6 +22,8 @@ struct WgradParams {
     int N, Hi, Wi, Cin, Ho, Wo, Cout;
     int KH, KW, stride, pad, in_act;
     int Ktot, M, tiles_k, tiles_co, m_per_split;
+    float* partial;        // NULL: fp32 atomics into dw / dbias.  Else [workgroup][128 x 128 fp32 in accumulator order]: plain stores,
+    float* bpartial;       // [workgroup][128] bias partial sums; conv_wgrad_reduce_kernel adds both up in a FIXED order
 };
 
 template <typename T> struct WgLds;
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     }
     compute((nch - 1) & 1);
 
+    const int wg_id = (split * p.tiles_co + tco) * p.tiles_k + tk;     // = the logical id decoded above
     if (want_bias) {                                      // block-uniform
         __syncthreads();
         float* red = (float*)smem;                        // [RPT][128]
@@ -232,10 +235,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             float a = 0.f;
             for (int r = 0; r < RPT; ++r) a += red[r * 128 + tid];
             const int co = tco * 128 + tid;
-            if (co < p.Cout) atomicAdd(p.dbias + co, a);
+            if (p.partial) p.bpartial[(size_t)wg_id * 128 + tid] = a;
+            else if (co < p.Cout) atomicAdd(p.dbias + co, a);
         }
     }
     // ---- combine: lanes 0..31 of a register hold 32 consecutive k of one co row (128 B)
+    if (p.partial) {                                      // accumulator order, 256-byte coalesced; summed by conv_wgrad_reduce_kernel
+        float* slot = p.partial + (size_t)wg_id * (128 * 128);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slot[(((wave * 2 + mi) * 2 + ni) * 16 + r) * 64 + lane] = acc[mi][ni][r];
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -246,6 +260,67 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                 const int k = tk * 128 + wn * 64 + ni * 32 + l31;
                 if (co < p.Cout && k < p.Ktot) atomicAdd(p.dw + (size_t)co * p.Ktot + k, acc[mi][ni][r]);
             }
+}
+
+// dw += sum over the pixel splits of a (co, k) tile's partial tiles, dbias += sum over splits and k-tile workgroups of the bias
+// partials -- in a FIXED order: the weight gradient is bit-reproducible run to run, which fp32 atomics were not (two
+// runs of a trainer drifted apart through Adam's sign flips of near-zero gradients).
+// Work item = one 64-element piece (one accumulator register of one wave: 256 contiguous bytes) of one tile; its splits are walked
+// by the four waves of a workgroup (wave g takes splits g, g + 4, ...; eight loads in flight), combined through LDS as
+// (g0 + g1) + (g2 + g3).  Workgroups stride over the items: at most 2048 of them however many tiles there are (a 128-tile dW
+// would otherwise launch 32768 tiny workgroups), and a ONE-tile dW with 512 splits still spreads over 256 items.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradParams p, int splits, int items) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t stride = (size_t)p.tiles_co * p.tiles_k * 16384;   // one split further
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int tile = item >> 8, frag = item & 255;              // frag = (wave * 4 + mi * 2 + ni) * 16 + r
+        const float* src = p.partial + (size_t)tile * 16384 + frag * 64 + lane;
+        float a = 0.f;
+        int sidx = g;
+        for (; sidx + 28 < splits; sidx += 32) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sidx + 4 * j) * stride];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += v[j];
+        }
+        for (; sidx < splits; sidx += 4) a += src[(size_t)sidx * stride];
+        red[g][lane] = a;
+        __syncthreads();
+        if (g == 0) {
+            const float tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            const int tco = tile / p.tiles_k, tk = tile - tco * p.tiles_k;
+            const int r = frag & 15, ni = (frag >> 4) & 1, mi = (frag >> 5) & 1, wave = frag >> 6;
+            const int co = tco * 128 + (wave >> 1) * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int k = tk * 128 + (wave & 1) * 64 + ni * 32 + (lane & 31);
+            if (co < p.Cout && k < p.Ktot) p.dw[(size_t)co * p.Ktot + k] += tot;
+        }
+        __syncthreads();
+    }
+    // bias: the first 2 * tiles_co workgroups take 64 channels each; the (split, k-tile) partials of a channel are walked by
+    // the four waves like the splits above
+    if (p.dbias && blockIdx.x < 2 * p.tiles_co) {
+        const int tco = blockIdx.x >> 1, ch = (blockIdx.x & 1) * 64 + lane, co = tco * 128 + ch;
+        const int P = splits * p.tiles_k;                           // partial j = (split j / tiles_k, k-tile j % tiles_k)
+        auto at = [&](int j) __attribute__((always_inline)) -> float {
+            const int sidx = j / p.tiles_k, t = j - sidx * p.tiles_k;
+            return p.bpartial[((size_t)(sidx * p.tiles_co + tco) * p.tiles_k + t) * 128 + ch];
+        };
+        float a = 0.f;
+        int j = g;
+        for (; j + 28 < P; j += 32) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = at(j + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a += v[q];
+        }
+        for (; j < P; j += 4) a += at(j);
+        red[g][lane] = a;
+        __syncthreads();
+        if (g == 0 && co < p.Cout) p.dbias[co] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    }
 }
 
 // ------------------------------------------------------------------------------------ bf16 LDS-DMA variant
@@ -394,6 +469,47 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_glds_kernel(const WgradPara
             }
 }
 
+// Pixel splits of the generic kernel.  Two costs pull against each other (measured per shape, profiles/r01):
+//   * long pixel loops want MANY workgroups: c128->256 @256^2 runs 476 / 497 / 558 TFLOP/s at 512 / 1024 / 2048;
+//   * every split ends with a 64-KB partial tile (or, without a workspace, one fp32 atomic per dW element on addresses shared by
+//     all splits of the tile): a big dW with few pixels (1024->1024 @16^2: 9.4 M elements, 2048 pixels) loses 30 % going from
+//     1 split to 4, and a 1-tile dW (the 8-channel label maps) is best at ~512-deep contention, not 1024 or 2048.
+// So: aim for S2E_WGRAD_WG (2048) workgroups, keep >= 32 pixel chunks per split (64 when dW is large), never more
+// than 512 splits -- unless that leaves the chip under-filled (< 512 workgroups), then allow 16-chunk splits
+// (8-chunk splits for a 1-2 tile dW).
+static void generic_wgrad_plan(const s2e_conv_desc* d, WgradParams* p, int* splits_out) {
+    p->Ktot = d->KH * d->KW * d->Cin;
+    p->M = d->N * d->Ho * d->Wo;
+    p->tiles_k = ceil_div(p->Ktot, 128);
+    p->tiles_co = ceil_div(d->Cout, 128);
+    const int tiles = p->tiles_k * p->tiles_co;
+    static const int target_wg = [] { const char* e = getenv("S2E_WGRAD_WG"); return e ? atoi(e) : 2048; }();
+    int splits = ceil_div(target_wg, tiles);
+    int max_splits = p->M / (tiles >= 64 ? 2048 : 1024);
+    if (max_splits > 512) max_splits = 512;
+    if ((long)tiles * max_splits < 512) {
+        const int fill = ceil_div(512, tiles), cap = p->M / (tiles <= 2 ? 256 : 512);
+        max_splits = fill < cap ? fill : cap;
+    }
+    if (max_splits < 1) max_splits = 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p->m_per_split = ceil_div(ceil_div(p->M, splits), 64) * 64;
+    *splits_out = ceil_div(p->M, p->m_per_split);
+}
+
+// Partial tiles + fixed-order reduction instead of fp32 atomics when a launch has at least this many pixel splits.  Measured
+// (profiles/r03, tools/bench_tail.py): with >= 16 splits on few tiles the atomics contend (E's 64->128 @128^2: 77 -> 70 us,
+// 128->256 @64^2: 72 -> 62, the 1x1 shortcuts 59 -> 48 / 51 -> 40); with 2-8 splits over 100+ tiles the atomics drain in the
+// shadow of the other workgroups' multiplies while the reduction is a second, serial pass (512->512 @16^2: 56 -> 68 us) -- they
+// stay.  One split needs neither (a single workgroup owns the tile: its atomics ARE deterministic).
+// S2E_WGRAD_PARTIAL=<n>: threshold (default 16); 2 = every split launch (bit-reproducible weight gradients of this kernel,
+// ~ +0.4 ms per step); 0 = never.
+static int wgrad_partial_min_splits() {
+    static const int n = [] { const char* e = getenv("S2E_WGRAD_PARTIAL"); return e ? atoi(e) : 16; }();
+    return n;
+}
+
 extern "C" size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_desc* d) {
     if (!d || d->transposed) return 0;
     if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31)) return 0;
@@ -401,7 +517,11 @@ extern "C" size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_des
     if (kind) return s2e_small_wgrad_workspace_bytes(dtype, kind, d);
     if (const int slab_w = s2e_wgrad_patch_plan(dtype, d)) return s2e_wgrad_patch_workspace_bytes(slab_w, d);
     if (const int slab_w = s2e_wgrad_c8_plan(dtype, d)) return s2e_wgrad_c8_workspace_bytes(slab_w, d);
-    return 0;
+    WgradParams p{};                                       // generic kernel: one partial tile (+ 128 bias sums) per workgroup
+    int splits;
+    generic_wgrad_plan(d, &p, &splits);
+    if (wgrad_partial_min_splits() <= 0 || splits < 2 || splits < wgrad_partial_min_splits()) return 0;
+    return (size_t)p.tiles_k * p.tiles_co * splits * (128 * 128 + 128) * sizeof(float);
 }
 
 extern "C" int s2e_conv2d_wgrad_kernel_kind(int dtype, const s2e_conv_desc* d) {
@@ -431,43 +551,29 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
     if (const int slab_w = s2e_wgrad_c8_plan(dtype, d))             // 8-channel (label-map) input: B operand built from a 16-B/pixel patch
         if (workspace && workspace_bytes >= s2e_wgrad_c8_workspace_bytes(slab_w, d))
             return s2e_wgrad_c8_launch(slab_w, x, gy, dw, dbias, d, workspace, (hipStream_t)stream);
-    WgradParams p;
+    WgradParams p{};
     p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
     p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.in_act = d->in_act;
-    p.Ktot = d->KH * d->KW * d->Cin;
-    p.M = d->N * d->Ho * d->Wo;
-    p.tiles_k = ceil_div(p.Ktot, 128);
-    p.tiles_co = ceil_div(d->Cout, 128);
+    int splits;
+    generic_wgrad_plan(d, &p, &splits);
     const int tiles = p.tiles_k * p.tiles_co;
-    // Split the pixels over workgroups.  Two costs pull against each other (measured per shape, profiles/r01):
-    //   * long pixel loops want MANY workgroups: c128->256 @256^2 runs 476 / 497 / 558 TFLOP/s at 512 / 1024 / 2048;
-    //   * every split ends with one fp32 atomic per dW element on addresses shared by all splits of the tile: a big
-    //     dW with few pixels (1024->1024 @16^2: 9.4 M elements, 2048 pixels) loses 30 % going from 1 split to 4,
-    //     and a 1-tile dW (the 8-channel label maps) is best at ~512-deep contention, not 1024 or 2048.
-    // So: aim for S2E_WGRAD_WG (2048) workgroups, keep >= 32 pixel chunks per split (64 when dW is large), never more
-    // than 512 splits -- unless that leaves the chip under-filled (< 512 workgroups), then allow 16-chunk splits
-    // (8-chunk splits for a 1-2 tile dW, whose atomics are few).
-    static const int target_wg = [] { const char* e = getenv("S2E_WGRAD_WG"); return e ? atoi(e) : 2048; }();
-    int splits = ceil_div(target_wg, tiles);
-    int max_splits = p.M / (tiles >= 64 ? 2048 : 1024);
-    if (max_splits > 512) max_splits = 512;
-    if ((long)tiles * max_splits < 512) {
-        const int fill = ceil_div(512, tiles), cap = p.M / (tiles <= 2 ? 256 : 512);
-        max_splits = fill < cap ? fill : cap;
-    }
-    if (max_splits < 1) max_splits = 1;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    p.m_per_split = ceil_div(ceil_div(p.M, splits), 64) * 64;
-    splits = ceil_div(p.M, p.m_per_split);
     hipStream_t st = (hipStream_t)stream;
     static const int br = [] { const char* e = getenv("S2E_WGRAD_BR"); return e ? atoi(e) : 32; }();
+    static const bool glds = [] { const char* e = getenv("S2E_WGRAD_GLDS"); return e ? atoi(e) != 0 : false; }();
+    const bool glds_path = dtype == S2E_BF16 && glds && d->in_act == S2E_ACT_NONE && d->Cin % 8 == 0 && d->Cout % 8 == 0;
     const int g = tiles * splits;
+    // With a workspace the workgroups store their partial tiles and a second kernel adds them up in a fixed order:
+    // deterministic, and cheaper than the atomics once a launch has more than a few splits (64 KB written + read per
+    // workgroup at HBM rate against 64 KB of float atomics at ~1.3 TB/s chip-wide).
+    const size_t need = (size_t)g * (128 * 128 + 128) * sizeof(float);
+    if (wgrad_partial_min_splits() > 0 && splits >= 2 && splits >= wgrad_partial_min_splits() && !glds_path && workspace && workspace_bytes >= need) {
+        p.partial = (float*)workspace;
+        p.bpartial = p.partial + (size_t)g * (128 * 128);
+    }
     if (dtype == S2E_BF16) {
-        static const bool glds = [] { const char* e = getenv("S2E_WGRAD_GLDS"); return e ? atoi(e) != 0 : false; }();
         if (d->Cin % 8 == 0 && d->Cout % 8 == 0) {
-            if (glds && d->in_act == S2E_ACT_NONE) conv_wgrad_glds_kernel<<<g, 256, 0, st>>>(p);
+            if (glds_path) conv_wgrad_glds_kernel<<<g, 256, 0, st>>>(p);
             else if (br == 64) conv_wgrad_kernel<bf16_t, true, 64><<<g, 256, 0, st>>>(p);
             else conv_wgrad_kernel<bf16_t, true, 32><<<g, 256, 0, st>>>(p);
         } else conv_wgrad_kernel<bf16_t, false, 32><<<g, 256, 0, st>>>(p);
@@ -476,5 +582,12 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
         else conv_wgrad_kernel<float, false, 32><<<g, 256, 0, st>>>(p);
     } else S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: bad dtype %d", dtype);
     S2E_CHECK_LAUNCH("conv_wgrad_kernel");
+    if (p.partial) {
+        const int items = tiles * 256;
+        int rgrid = items < 2048 ? items : 2048;
+        if (rgrid < 2 * p.tiles_co) rgrid = 2 * p.tiles_co;
+        conv_wgrad_reduce_kernel<<<rgrid, 256, 0, st>>>(p, splits, items);
+        S2E_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+    }
     return S2E_OK;
 }

@@ -20,7 +20,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _single_rank_collectives()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -38,6 +38,18 @@ def init_from_env(backend=None):
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _single_rank_collectives():
+    """S2E_DIST_SINGLE=1: run every collective of the data-parallel path even in a process group of ONE rank.  It moves no
+    data between GPUs but executes every call an 8-GPU run makes -- RCCL initialisation, asynchronous all-reduces launched
+    from the backward hooks on RCCL's stream, the broadcasts -- on a box with a single GPU (tests/test_networks_gpu.py)."""
+    return os.environ.get('S2E_DIST_SINGLE', '0') == '1'
+
+
+def exchange_active():
+    """Do the data-parallel collectives run?  More than one replica -- or one, when S2E_DIST_SINGLE asks for it."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single_rank_collectives())
 
 
 _solo_depth = 0
@@ -100,7 +112,7 @@ class FlatGradSync:
 
     def launch(self, i):
         """Group i's gradients are final: start their exchange now (no-op on one process / when already started)."""
-        if world_size() > 1 and i not in self._launched:
+        if exchange_active() and i not in self._launched:
             self._start(i)
 
     def reset(self):
@@ -114,7 +126,7 @@ class FlatGradSync:
         self._launched, self._handles = set(), []
 
     def all_reduce(self):
-        if world_size() == 1:
+        if not exchange_active():
             return 1.0
         for i in range(len(self.groups)):
             if i not in self._launched:
@@ -126,13 +138,13 @@ class FlatGradSync:
 
 
 def broadcast_flat(flat, src=0):
-    if world_size() > 1:
+    if exchange_active():
         dist.broadcast(flat, src=src)
 
 
 def all_reduce_sum_(t, group=None):
     """In-place sum over the replicas (no-op on one process); returns t."""
-    if world_size() > 1:
+    if exchange_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -159,7 +171,7 @@ def replica_buffers(nets):
 def broadcast_buffers(nets, src=0):
     """Make the replicas' non-parameter state rank `src`'s (at start-up, and after rank 0 alone ran a train-mode validation
     pass, which advances its u, v and BatchNorm statistics like the reference's does, util/tester.py + SURVEY F7)."""
-    if world_size() == 1:
+    if not exchange_active():
         return
     for t in replica_buffers(nets):
         dist.broadcast(t, src=src)

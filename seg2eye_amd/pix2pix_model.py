@@ -33,6 +33,7 @@ class Pix2PixModel(nn.Module):
         self.opt = opt
         self.cdtype = compute_dtype_of(opt)
         self.netG, self.netD, self.netE = self.initialize_networks(opt)
+        self.netE.logvar_used = False        # (`logvar` enters no loss: pix2pix_model.py:271-305; see ConvEncoder.forward)
         if opt.isTrain:
             self.criterionGAN = networks.GANLoss(opt.gan_mode, opt=opt)
             if not opt.no_vgg_loss:

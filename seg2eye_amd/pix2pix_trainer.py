@@ -1,7 +1,7 @@
 """Pix2PixTrainer (reference trainers/pix2pix_trainer.py:8-88): owns the model and the two optimizers,
 runs one G step / one D step, LR decay, save.  Multi-GPU: when torch.distributed is initialised the
 flat gradient arenas are sum-all-reduced (RCCL) between backward and the Adam launch."""
-from .distributed import FlatGradSync, broadcast_buffers, broadcast_flat, world_size
+from .distributed import FlatGradSync, broadcast_buffers, broadcast_flat, exchange_active, world_size
 from .ops import ZeroPool
 from .pix2pix_model import Pix2PixModel
 
@@ -30,7 +30,7 @@ class Pix2PixTrainer:
             self.old_lr = opt.lr
             self.sync_G = FlatGradSync(self.optimizer_G.flat_g, groups=self.pix2pix_model.grad_groups_G)
             self.sync_D = FlatGradSync(self.optimizer_D.flat_g)
-            if world_size() > 1 and not getattr(opt, 'no_overlap_allreduce', False):
+            if exchange_active() and not getattr(opt, 'no_overlap_allreduce', False):
                 # Overlap the gradient exchange with the backward pass: the generator reports when a group of
                 # blocks has all its gradients (networks/generator.py), we flush that group's queued gradient re-layouts and
                 # start the all-reduce of its arena slice.  That needs the backward to run as individual launches, not as one

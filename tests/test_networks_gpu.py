@@ -1036,6 +1036,36 @@ def test_data_parallel_replicas_stay_bit_identical():
     assert abs(two['G_abs'] - one['G_abs']) <= 1e-4 * one['G_abs'] and abs(two['D_abs'] - one['D_abs']) <= 1e-4 * one['D_abs'], (two, one)
 
 
+def test_rccl_single_rank_overlapped_step_matches_exchange_after_backward():
+    """RCCL itself (backend 'nccl', a process group of ONE rank, S2E_DIST_SINGLE=1) carries every collective of
+    the data-parallel path on this one-GPU box: start-up broadcasts, the asynchronous all-reduces of the generator's gradient
+    groups launched from the backward hooks, the exchange after the backward of the --no_overlap_allreduce mode (under hipGraph
+    replays).  Both modes run the same two G+D iterations from the same weights and must agree (up to Adam's sign flips of
+    near-zero gradients: the weight-gradient atomics are not bit-reproducible, see the trainer tests)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               S2E_DIST_SINGLE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('S2E_DIST_BACKEND', None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_single_rank_check.py'), '--iters', '2'], env=env,
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert r['backend'] == 'nccl' and r['world'] == 1 and r['finite'], r
+    assert r['overlap']['hooked'] and r['overlap']['early_launches'] >= 2 and not r['overlap']['graphs'], r
+    assert not r['after_backward']['hooked'] and r['after_backward']['graphs'], r
+    # per trainer: broadcasts of 2 parameter arenas + the u|v arenas at construction; >= 1 all-reduce per group per step
+    assert r['overlap']['broadcast_calls'] >= 4 and r['overlap']['all_reduce_calls'] >= 2 * 2 * 2, r
+    assert r['after_backward']['all_reduce_calls'] >= 2 * 2, r
+    bound = 2 * 4e-4 * sum(((1 - 0.9 ** t) / (1 - 0.9)) ** 0.5 for t in (1, 2)) + 1e-5
+    assert r['max_abs_diff_G'] <= bound and r['max_abs_diff_D'] <= bound, r
+    for k, v in r['overlap']['losses'].items():
+        assert abs(v - r['after_backward']['losses'][k]) <= 2e-2 * max(1.0, abs(v)), (k, r)
+
+
 def test_batchnorm_spade_statistics_are_synchronised_across_replicas():
     """--norm_G spectralspadebatch3x3 under data parallelism normalises with the statistics of the GLOBAL batch (one
     2*C all-reduce per layer forward, one in its backward): two ranks on halves of a batch reproduce one process on the whole

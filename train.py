@@ -120,8 +120,9 @@ def main(argv=None):
     opt = parse(argv, is_train=True)
     rank, world, local = dist.init_from_env()
     if torch.cuda.is_available():
-        opt.gpu_ids = [local]
-        torch.cuda.set_device(local)
+        dev = local % max(torch.cuda.device_count(), 1)          # (== local on a full node; a 2-rank gloo run may share one GPU)
+        opt.gpu_ids = [dev]
+        torch.cuda.set_device(dev)
     return TrainingRun(opt, rank, world).fit()
 
 
