@@ -18,7 +18,7 @@ PMC="--steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events --no-
 cd "$R"
 # the bench line as the driver runs it (cpu_baseline leg included), then the same command under the kernel trace
 python3 bench.py --steps 50 --warmup 10 > "$O/${P}_bench.json" 2> "$O/${P}_bench.err"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline \
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras \
     > "$O/${P}_bench_under_rocprof.json" 2>/dev/null
 cp /tmp/kt/*/*kernel_stats.csv "$O/${P}_kernel_stats.csv" 2>/dev/null || cp /tmp/kt/*kernel_stats.csv "$O/${P}_kernel_stats.csv"
 python3 tools/profile_step.py > "$O/${P}_per_shape_in_step.log" 2>/dev/null
