@@ -42,6 +42,7 @@ struct PatchParams {
     int flip;                     // data-gradient: patch offset t pairs with weight tap T-1-t
     int out_act, aux_mode;
     int tw, th;                   // rectangle of output pixels: width (<= 64), height; tw * th <= 256 (rows past it idle)
+    int tw_shift;                 // log2(tw) when tw is a power of two (every rectangle of the power-of-two layers), else -1
     int tiles_x, tiles_y, tiles_n, tiles;
     int splits, cps, tiles_out, M;    // split-K over channel chunks: split s owns chunks [s * cps, (s+1) * cps); tiles = tiles_out * splits
     float* partial;                   // splits > 1: fp32 slabs [splits][M][Cout], combined by conv_finish_kernel (conv_igemm.hip)
@@ -265,8 +266,33 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) bv[j] = (p.bias && co < p.Cout) ? p.bias[co + j] : 0.f;
     };
+    // Every LDS access of the epilogues is inline asm and their passes meet at bare s_barriers (round 3): through C++ accesses the
+    // compiler puts s_waitcnt vmcnt(0) in front of each (the next tile's LDS-DMA pieces are in flight and "may alias"), and
+    // __syncthreads() carries one as well -- every pass then waited out the previous pass's stores and the first one the prologue.
+    auto stage_acc = [&](int ep, uint32_t cs0) __attribute__((always_inline)) {
+        if (wm == ep) {
+            const uint32_t wbase = cs0 + (uint32_t)((4 * h) * BN * 4 + (wn * WTN + l31) * 4);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(wbase), "v"(acc[mi][ni][r]),
+                                     "n"((mi * 32 + (r & 3) + 8 * (r >> 2)) * BN * 4 + ni * 32 * 4) : "memory");
+        }
+    };
+    auto lds_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto lds_read4 = [&](uint32_t addr) __attribute__((always_inline)) -> f32x4_t {
+        f32x4_t f;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(addr) : "memory");
+        return f;
+    };
     auto epilogue = [&](const Tile& q, int sbuf) __attribute__((always_inline)) {
-        float* Cs = (float*)(smem + sbuf * P_BYTES);
+        const uint32_t cs0 = lds0 + (uint32_t)(sbuf * P_BYTES);
         const int co = q.tn * BN + cw;
         const bool cok = co < p.Cout;
         constexpr int SWEEPS = EP_ROWS / RPP;
@@ -279,7 +305,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
 #pragma unroll
             for (int sw = 0; sw < SWEEPS; ++sw) {
                 const int tr = ep * EP_ROWS + sw * RPP + tid / TPR;
-                const int ty = tr / TW;
+                // (a 32-bit division is ~40 VALU instructions; the epilogue's index arithmetic, not its stores, was the largest
+                // part of its time in the round-3 ablation: DESIGN 3.1f)
+                const int ty = p.tw_shift >= 0 ? tr >> p.tw_shift : tr / TW;
                 const int oy = q.oy0 + ty, ox = q.ox0 + (tr - ty * TW);
                 live[sw] = cok && tr < TW * TH && oy < p.Ho && ox < p.Wo;
                 o[sw] = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
@@ -287,17 +315,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                 if (live[sw] && resg && p.splits == 1) rr[sw] = *(const u32x4_t*)(resg + o[sw]);
                 if (live[sw] && p.aux_mode != S2E_AUX_NONE && p.splits == 1) aa[sw] = *(const u32x4_t*)(auxg + o[sw]);
             }
-            if (ep > 0) __syncthreads();
-            if (wm == ep) {
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            Cs[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wn * WTN + ni * 32 + l31] = acc[mi][ni][r];
-            }
-            __syncthreads();
+            if (ep > 0) lds_barrier();
+            stage_acc(ep, cs0);
+            lds_barrier();
             if (p.splits > 1) {                       // split-K: raw fp32 partial tile -> this split's slab
                 float* slab = p.partial + (size_t)q.split * p.M * p.Cout;
 #pragma unroll
@@ -306,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                     const int row = sw * RPP + tid / TPR;
 #pragma unroll
                     for (int j = 0; j < VEC; j += 4)
-                        *(f32x4_t*)(slab + o[sw] + j) = *(const f32x4_t*)(Cs + row * BN + cw + j);
+                        *(f32x4_t*)(slab + o[sw] + j) = lds_read4(cs0 + (uint32_t)((row * BN + cw + j) * 4));
                 }
                 continue;
             }
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                 float v[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; j += 4) {
-                    const f32x4_t f = *(const f32x4_t*)(Cs + row * BN + cw + j);
+                    const f32x4_t f = lds_read4(cs0 + (uint32_t)((row * BN + cw + j) * 4));
                     v[j] = f[0] + bv[j]; v[j + 1] = f[1] + bv[j + 1]; v[j + 2] = f[2] + bv[j + 2]; v[j + 3] = f[3] + bv[j + 3];
                 }
                 if (resg) {
@@ -372,7 +392,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         }
     };
     auto epilogue_fused = [&](const Tile& q, int sbuf) __attribute__((always_inline)) {
-        float* Cs = (float*)(smem + sbuf * P_BYTES);
+        const uint32_t cs0 = lds0 + (uint32_t)(sbuf * P_BYTES);
         const T* __restrict__ mx = (const T*)p.mx;
         T* __restrict__ gout = (T*)p.mgamma;
         const int c = q.tn * 64 + fcw;
@@ -386,7 +406,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
             for (int sw = 0; sw < SWEEPS; ++sw) {
                 const int lr = sw * FRPP + tid / FTPR;              // row inside this pass
                 const int tr = ep * EP_ROWS + lr;
-                const int ty = tr / TW;
+                const int ty = p.tw_shift >= 0 ? tr >> p.tw_shift : tr / TW;
                 const int oy = q.oy0 + ty, ox = q.ox0 + (tr - ty * TW);
                 live[sw] = lr < EP_ROWS && tr < TW * TH && oy < p.Ho && ox < p.Wo;
                 o[sw] = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.mC + c;
@@ -394,17 +414,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                 xx[sw] = u32x4_t{0u, 0u, 0u, 0u};
                 if (live[sw]) xx[sw] = *(const u32x4_t*)(mx + oin);
             }
-            if (ep > 0) __syncthreads();
-            if (wm == ep) {
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            Cs[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wn * WTN + ni * 32 + l31] = acc[mi][ni][r];
-            }
-            __syncthreads();
+            if (ep > 0) lds_barrier();
+            stage_acc(ep, cs0);
+            lds_barrier();
 #pragma unroll
             for (int sw = 0; sw < SWEEPS; ++sw) {
                 if (!live[sw]) continue;
@@ -413,8 +425,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                 unpack16<T>(xx[sw], f);
 #pragma unroll
                 for (int j = 0; j < VEC; j += 4) {
-                    const f32x4_t g4 = *(const f32x4_t*)(Cs + row * BN + fcw + j);
-                    const f32x4_t b4 = *(const f32x4_t*)(Cs + row * BN + 64 + fcw + j);
+                    const f32x4_t g4 = lds_read4(cs0 + (uint32_t)((row * BN + fcw + j) * 4));
+                    const f32x4_t b4 = lds_read4(cs0 + (uint32_t)((row * BN + 64 + fcw + j) * 4));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         ga[j + i] = g4[i] + k_bg[j + i];
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
 // many rows as fit 256 pixels and the patch buffer) that keeps >= 80 % of the 256 accumulator rows on image pixels, and
 // enough work items to fill the chip: >= S2E_CONV_PATCH (default 224) output tiles, or fewer tiles with a long K that is
 // split over channel chunks (>= 2 chunks per split) until >= 192 workgroups exist.  Everything else: conv_igemm.hip.
-static double patch_rectangle(const s2e_conv_desc* d, int ks, int* tw_out, int* th_out) {
+double s2e_patch_rectangle(const s2e_conv_desc* d, int ks, int* tw_out, int* th_out) {
     const int cap = 400;                             // PPX of the kernel
     double best_fill = 0.0;
     for (int tw = 64; tw >= 8; --tw) {
@@ -528,7 +540,7 @@ int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan)
     const int grow = d->transposed ? (ks - 1) - 2 * d->pad : 2 * d->pad - (ks - 1);
     if (d->Ho != d->Hi + grow || d->Wo != d->Wi + grow) return 0;
     const int bn = d->Cout > 64 ? 128 : 64;
-    if (patch_rectangle(d, ks, &plan->tw, &plan->th) < 0.8) return 0;
+    if (s2e_patch_rectangle(d, ks, &plan->tw, &plan->th) < 0.8) return 0;
     const long tiles = (long)d->N * ceil_div(d->Ho, plan->th) * ceil_div(d->Wo, plan->tw) * ceil_div(d->Cout, bn);
     const int nch = d->Cin / (8 * vec);
     if (tiles >= min_tiles) return 1;
@@ -576,6 +588,7 @@ int s2e_conv_patch_launch(int dtype, const s2e_patch_plan* plan, const void* x, 
     p.flip = d->transposed ? 1 : 0;
     p.out_act = d->out_act; p.aux_mode = d->aux_mode;
     p.tw = plan->tw; p.th = plan->th;
+    p.tw_shift = (plan->tw & (plan->tw - 1)) == 0 ? __builtin_ctz(plan->tw) : -1;
     const int bn = d->Cout > 64 ? 128 : 64;
     p.tiles_x = ceil_div(d->Wo, p.tw); p.tiles_y = ceil_div(d->Ho, p.th); p.tiles_n = ceil_div(d->Cout, bn);
     p.tiles_out = p.N * p.tiles_y * p.tiles_x * p.tiles_n;
@@ -602,7 +615,7 @@ static int fused_plan(int dtype, int N, int H, int W, int C, int nh, int flags, 
     if (nh % (8 * vec) != 0) return 0;
     *d = s2e_conv_desc{N, H, W, nh, H, W, 2 * C, 3, 3, 1, 1, 0, S2E_ACT_NONE, S2E_ACT_NONE, S2E_AUX_NONE};
     plan->splits = 1; plan->tw = plan->th = 0;
-    const double fill = patch_rectangle(d, 3, &plan->tw, &plan->th);
+    const double fill = s2e_patch_rectangle(d, 3, &plan->tw, &plan->th);
     if (fill < ((flags & 1) ? 0.01 : 0.2)) return 0;
     // among the rectangles that fill as well, the SQUAREST one (16 x 16 before 8 x 32 before 4 x 64): the smallest patch with its
     // halo (324 vs 340 vs 396 pixels of DMA per chunk) and -- what matters for the label-sparse launch -- the shape most
@@ -645,12 +658,16 @@ static int spade_conv_modulate_impl(int dtype, const void* actv, const void* w_p
     if (!fused_plan(dtype, N, H, W, C, nh, flags, &d, &plan))
         S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_spade_conv_modulate: shape N=%d %dx%d C=%d nh=%d is not taken by the fused kernel "
                  "(s2e_spade_conv_modulate_supported); run s2e_conv2d + s2e_modulate_fwd", N, H, W, C, nh);
+    if (const int rc = s2e_spade_conv_modulate_patch2(dtype, actv, w_packed, bias, x, stats, style, style_ld, out, gamma_out, N, H, W, C, nh,
+                                                      lrelu, flags, plan.tw, plan.th, rect_list, rect_count, (hipStream_t)stream))
+        return rc < 0 ? rc : S2E_OK;                  // (the 512-pixel kernel took it: same rectangles, same lists)
     PatchParams p{};
     p.x = actv; p.w = w_packed; p.bias = bias; p.y = out;
     p.N = N; p.Hi = H; p.Wi = W; p.Cin = nh; p.Ho = H; p.Wo = W; p.Cout = 2 * C;
     p.Kpad = ceil_div(9 * nh, dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
     p.org = -1; p.flip = 0; p.out_act = S2E_ACT_NONE; p.aux_mode = S2E_AUX_NONE;
     p.tw = plan.tw; p.th = plan.th;
+    p.tw_shift = (plan.tw & (plan.tw - 1)) == 0 ? __builtin_ctz(plan.tw) : -1;
     p.tiles_x = ceil_div(W, p.tw); p.tiles_y = ceil_div(H, p.th); p.tiles_n = C / 64;
     p.tiles_out = N * p.tiles_y * p.tiles_x * p.tiles_n;
     p.splits = 1; p.cps = nh / (dtype == S2E_BF16 ? 64 : 32); p.tiles = p.tiles_out;

@@ -634,3 +634,28 @@ def test_wgrad_c8_batch_matches_per_layer_launches():
         if q:
             assert float((dw - rw).abs().max()) <= 1e-4 * float(rw.abs().max()) + 1e-5
             assert float((db - rb).abs().max()) <= 1e-4 * float(rb.abs().max()) + 1e-5
+
+
+def test_conv_patch2_experimental_kernel_matches_torch():
+    """csrc/conv_patch2.hip (512-pixel tiles, 32-channel K-steps; OFF by default -- it measured no faster): with
+    S2E_CONV_PATCH2=448 it takes the bench's large 3x3 layers and the fused [gamma | beta] conv + modulation; tools/check_patch2.py
+    compares forward (bias + residual + LeakyReLU), data-gradient (ReLU mask) and the fused launch (dense, and through an odd-length
+    rectangle list) with torch's own convolution in fp32."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, S2E_CONV_PATCH2='448')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_patch2.py')], env=env, capture_output=True, text=True,
+                         timeout=900, cwd=root)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    assert 'worst relative error' in out.stdout
+
+
+def test_conv_stream_kernel_every_shape_matches_torch():
+    """csrc/conv_stream.hip on EVERY shape it can run (S2E_CONV_STREAM=2; by default it takes the long-K tiles only): forward, the
+    stride-2 data-gradients by parity class, split tiles + fix-up -- tools/bench_tail.py checks each against torch in fp32."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, S2E_CONV_STREAM='2', S2E_WGRAD_PARTIAL='2')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_tail.py'), '--iters', '2'], env=env, capture_output=True,
+                         text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
