@@ -47,9 +47,11 @@ def test_argument_errors_are_reported_without_a_gpu():
     d3 = _lib.ConvDesc(8, 256, 256, 128, 256, 256, 256, 3, 3, 1, 1, 0, 0, 0, 0)
     assert L.s2e_conv2d_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d3)) == 0
     # big bf16 3x3 layer: patch-resident weight gradient, one workgroup per CU (256 when no device is visible), each
-    # storing its 9 x 128 x 64 fp32 partial tile; the fp32 build of the same shape stays on the generic (atomics) kernel
+    # storing its 9 x 128 x 64 fp32 partial tile; the fp32 build of the same shape runs the generic kernel, whose 2 x 9 dW tiles
+    # x 114 pixel splits (>= 16 splits: partial tiles + a fixed-order reduction instead of atomics, round 3) each store a
+    # 128 x 128 tile and 128 bias sums
     assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d3)) == 256 * 9 * 128 * 64 * 4
-    assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_F32, ctypes.byref(d3)) == 0
+    assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_F32, ctypes.byref(d3)) == 18 * 114 * (128 * 128 + 128) * 4
     # which kernel the library picks is a function of the shape alone (0 generic, 1 one-channel stream, 2 patch-resident)
     assert L.s2e_conv2d_kernel_kind(_lib.S2E_BF16, ctypes.byref(d3)) == 2
     assert L.s2e_conv2d_kernel_kind(_lib.S2E_F32, ctypes.byref(d3)) == 2
