@@ -110,15 +110,17 @@ int s2e_conv2d(int dtype, const void* x, const void* w_packed, const float* bias
                void* stream);
 /* Weight gradient of the forward conv described by d (d->transposed must be 0):
  * dw[co][(ky*KW+kx)*Cin + ci] += sum_{n,oy,ox} gy[n,oy,ox,co] * in_act(x)[n, oy*s-p+ky, ox*s-p+kx, ci]
- * dw: fp32 (Cout x KH*KW*Cin), row-major, ACCUMULATED into (caller zeroes it); split over pixels
- * with fp32 atomics.  dbias: NULL, or fp32 (Cout) ACCUMULATED with the bias gradient
+ * dw: fp32 (Cout x KH*KW*Cin), row-major, ACCUMULATED into (caller zeroes it); split over pixels:
+ * generic shapes split 16 ways or more (S2E_WGRAD_PARTIAL: the threshold; 2 = every split launch, 0 = never) store
+ * their 128x128 partial tiles in `workspace` and a second kernel sums them in a fixed order into dw (deterministic);
+ * below the threshold, or given no workspace, the splits add into dw with fp32 atomics.  dbias: NULL, or fp32 (Cout) ACCUMULATED with the bias gradient
  * sum_{n,oy,ox} gy[n,oy,ox,co] from the gy tiles the kernel stages anyway (no extra pass over gy).
  * The 1-channel shapes (Cout == 1 or Cin == 1: conv_img, the PatchGAN heads, the encoder's first layer)
  * run as HBM streams whose per-block partial rows go through `workspace` and are summed by a second
  * kernel; the big bf16 3x3 stride-1 layers (patch-resident kernel, one workgroup per CU) store their per-workgroup
  * partial tiles there too (<= 75 MB) and fold them into dw with a reduction pass.
- * s2e_conv2d_wgrad_workspace_bytes(d) is 0 for every other shape (workspace may then be NULL; a patch-kernel shape
- * given no workspace falls back to atomics).  The caller allocates; no initialisation needed. */
+ * s2e_conv2d_wgrad_workspace_bytes(d) is 0 for a shape that needs none (workspace may then be NULL; a patch-kernel or
+ * generic shape given no workspace falls back to atomics).  The caller allocates; no initialisation needed. */
 size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_desc* d);
 int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
                      void* workspace, size_t workspace_bytes, void* stream);
