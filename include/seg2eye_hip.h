@@ -186,7 +186,13 @@ int s2e_weight_grads_batched(const s2e_grad_job* jobs, const int* block_map, int
  * adds them in a fixed order in fp64 -- the statistics are bit-reproducible.  On return the first N*C*2 doubles of ws hold
  * {sum x, sum x^2} per (n, c) (BatchNorm SPADE combines them over the batch). */
 size_t s2e_in_stats_workspace_bytes(int dtype, int N, int HW, int C);
-int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, void* stream);
+/* counters: NULL (the fold is a second launch: the default), or s2e_in_stats_counters(...) unsigned ints that are ZERO: the last
+ * row-walking block of each (sample, channel range) then does the fold -- same order, same bits, one launch -- and leaves them
+ * zero.  Measured SLOWER on MI355X (29.7 us against 10.0 + 8.1 us per call in the train step: every block pays a device-scope
+ * release, which writes back its XCD's L2); kept as an experiment (S2E_IN_STATS_ONE_LAUNCH=1 on the host side). */
+int s2e_in_stats_counters(int dtype, int N, int HW, int C);
+int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, unsigned* counters,
+                 void* stream);
 
 /* ------------------------------------------------------------------ SPADE+Style modulation / IN+LeakyReLU
  * mode S2E_NORM_SPADE_STYLE (SPADE_STYLE_Block.forward normalization.py:184-192 + SPADE.forward :91-105
@@ -368,6 +374,18 @@ int s2e_loss_reduce(int dtype, int mode, const void* a, const void* b, long n, f
  * accumulate != 0 adds into da. */
 int s2e_loss_grad(int dtype, int mode, const void* a, const void* b, long n, float scale, const float* gscale,
                   void* da, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ style FCs (ApplyStyle / FC: models/networks/normalization.py:144-169)
+ * All SPADE+Style layers' style codes from one latent batch:  big[n][s] = LeakyReLU_slope(b[s] + sum_k w[n][k] W[s][k]),
+ * w fp32 (N x K) = the latent codes, W fp32 (S x K) / b fp32 (S) = the layers' FC weights / biases stacked along S, big fp32
+ * (N x S).  N <= 32, K in {8, 16, 32, 64} (s2e_style_fc_supported).  Backward: dpre = (dbig + gbig) * LeakyReLU'(big)
+ * (gbig may be NULL); gW (S x K) and gb (S) are ACCUMULATED into; dw (N x K), when not NULL, is WRITTEN -- a fixed-order
+ * two-level sum over S through `workspace` (s2e_style_fc_bwd_workspace_bytes; no initialisation needed). */
+int s2e_style_fc_supported(int N, int K);
+size_t s2e_style_fc_bwd_workspace_bytes(int N, int K, int S);
+int s2e_style_fc_fwd(const float* w, const float* W, const float* b, float* big, int N, int K, int S, float slope, void* stream);
+int s2e_style_fc_bwd(const float* dbig, const float* gbig, const float* big, const float* w, const float* W, float* gW, float* gb,
+                     float* dw, void* workspace, size_t workspace_bytes, int N, int K, int S, float slope, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam step (pix2pix_model.py:92-110: TTUR betas (0, 0.9), eps 1e-8, --weight_decay as Adam's L2 term)

@@ -90,7 +90,8 @@ SIGNATURES = {
     's2e_modulate_bwd_workspace_bytes': [_i, _i, _i, _i],
     's2e_instance_norm_fwd': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     's2e_instance_norm_bwd': [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    's2e_in_stats': [_i, _vp, _i, _i, _i, _f, _vp, _vp, _vp],
+    's2e_in_stats_counters': [_i, _i, _i, _i],
+    's2e_in_stats': [_i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     's2e_modulate_fwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     's2e_modulate_bwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     's2e_modulate_bwd_gamma': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -125,6 +126,10 @@ SIGNATURES = {
     's2e_lrelu_bwd': [_i, _vp, _vp, _vp, _l, _vp],
     's2e_loss_reduce': [_i, _i, _vp, _vp, _l, _f, _vp, _vp],
     's2e_loss_grad': [_i, _i, _vp, _vp, _l, _f, _vp, _vp, _i, _vp],
+    's2e_style_fc_supported': [_i, _i],
+    's2e_style_fc_bwd_workspace_bytes': [_i, _i, _i],
+    's2e_style_fc_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    's2e_style_fc_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _i, _i, _i, _f, _vp],
     's2e_adam_flat': [_vp, _vp, _vp, _vp, _l, _vp, _vp],
 }
 

@@ -225,9 +225,12 @@ static int small_groups(int N, int C, int vec) { return (long)N * ceil_div(C, 8 
 
 template <typename T>
 __global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restrict__ x, float* __restrict__ part,
-                                                               int HW, int C, int cg, int cgb, int rpp, int iters) {
+                                                               int HW, int C, int cg, int cgb, int rpp, int iters,
+                                                               unsigned* __restrict__ counters, double* __restrict__ ws,
+                                                               float* __restrict__ stats, float eps) {
     constexpr int VEC = Vec<T>::N;
     __shared__ float red[256 * VEC * 2];
+    __shared__ int is_last;
     const int tid = threadIdx.x;
     const int tx = tid % cgb, ty = tid / cgb;
     const int g = blockIdx.z * cgb + tx;
@@ -276,6 +279,35 @@ __global__ __launch_bounds__(256) void in_stats_partial_kernel(const T* __restri
             w[0] = a; w[1] = b;
         }
     }
+    if (!counters) return;                                   // two-launch form: in_stats_finalize_kernel follows
+    // One-launch form: the LAST of the gridDim.x blocks of this (sample, channel range) to get here folds the partial sums --
+    // in block order, in fp64, exactly as the finalize kernel does: the same bits whichever block happens to be last.
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* cnt = counters + n * gridDim.z + blockIdx.z;
+        const unsigned done = atomicAdd(cnt, 1u);
+        is_last = done == gridDim.x - 1;
+        if (is_last) *cnt = 0;                               // left zero for the next launch (hipGraph replays never re-zero it)
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const int c0 = blockIdx.z * cgb * VEC, c1 = min(C, c0 + cgb * VEC), P = gridDim.x;
+    for (int c = c0 + tid; c < c1; c += 256) {
+        double sm = 0.0, q = 0.0;
+        for (int b = 0; b < P; ++b) {
+            const float* w = part + (((size_t)n * P + b) * C + c) * 2;
+            sm += (double)__builtin_nontemporal_load(w); q += (double)__builtin_nontemporal_load(w + 1);
+        }
+        const size_t i = (size_t)n * C + c;
+        ws[2 * i] = sm; ws[2 * i + 1] = q;
+        const double mean = sm / HW;
+        double var = q / HW - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 __global__ void in_stats_finalize_kernel(const float* __restrict__ part, double* __restrict__ ws, float* __restrict__ stats,
@@ -304,7 +336,14 @@ extern "C" size_t s2e_in_stats_workspace_bytes(int dtype, int N, int HW, int C) 
     return (size_t)N * C * 2 * sizeof(double) + (size_t)N * P * C * 2 * sizeof(float);
 }
 
-extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, void* stream) {
+extern "C" int s2e_in_stats_counters(int dtype, int N, int HW, int C) {
+    const int vec = dtype == S2E_BF16 ? 8 : 4;
+    if (N <= 0 || HW <= 0 || C <= 0 || C % vec || HW <= in_small_hw()) return 0;
+    return N * row_geom(C, vec).zblocks;
+}
+
+extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, unsigned* counters,
+                            void* stream) {
     if (!x || !ws || !stats || N <= 0 || HW <= 0 || C <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_in_stats: bad argument");
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_in_stats: bad dtype %d", dtype);
@@ -321,9 +360,10 @@ extern "C" int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, floa
     const int P = ceil_div(HW, g.rpp * iters);
     dim3 grid(P, N, g.zblocks);
     float* part = (float*)(ws + (size_t)N * C * 2);          // [N][P][C][2] floats behind the N*C*2 doubles
-    if (dtype == S2E_BF16) in_stats_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, part, HW, C, g.cg, g.cgb, g.rpp, iters);
-    else in_stats_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)x, part, HW, C, g.cg, g.cgb, g.rpp, iters);
+    if (dtype == S2E_BF16) in_stats_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, part, HW, C, g.cg, g.cgb, g.rpp, iters, counters, ws, stats, eps);
+    else in_stats_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)x, part, HW, C, g.cg, g.cgb, g.rpp, iters, counters, ws, stats, eps);
     S2E_CHECK_LAUNCH("in_stats_partial_kernel");
+    if (counters) return S2E_OK;
     in_stats_finalize_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, ws, stats, N * C, C, P, HW, eps);
     S2E_CHECK_LAUNCH("in_stats_finalize_kernel");
     return S2E_OK;
@@ -1030,7 +1070,7 @@ extern "C" int s2e_instance_norm_fwd(int dtype, const void* x, void* out, float*
         S2E_CHECK_LAUNCH("in_small_kernel");
         return S2E_OK;
     }
-    if (const int rc = s2e_in_stats(dtype, x, N, HW, C, eps, ws, stats, stream)) return rc;
+    if (const int rc = s2e_in_stats(dtype, x, N, HW, C, eps, ws, stats, nullptr, stream)) return rc;
     return s2e_modulate_fwd(dtype, S2E_NORM_PLAIN_IN, x, nullptr, stats, nullptr, out, N, HW, C, lrelu, 0, stream);
 }
 

@@ -1,0 +1,159 @@
+// The style FCs of a generator as one skinny GEMM (ApplyStyle / FC, reference models/networks/normalization.py:144-169:
+// style = LeakyReLU(w @ W^T + b, 0.2) per SPADE+Style layer; networks/stylebank.py stacks the 21 layers' W and b).
+//   forward   big[n][s] = lrelu(b[s] + sum_k w[n][k] W[s][k])                     n < N (batch), s < S (sum of 2C_i), k < K (w_dim)
+//   backward  dpre = (dbig (+ gbig)) * lrelu'(big);  gW[s][k] += sum_n dpre[n][s] w[n][k];  gb[s] += sum_n dpre[n][s];
+//             dw[n][k] = sum_s dpre[n][s] W[s][k]
+// N <= 32 and K in {8, 16, 32, 64}: a thread owns one row s of W (K floats in registers) -- HBM-bound on W, gW (S*K*4 bytes each),
+// one launch each way instead of torch's addmm / leaky_relu / where / mm / addmm_ / sum chain (11 launches, ~110 us per step).
+// dw is a reduction over s: per-block partial sums, added in block order by a second tiny launch (deterministic; no float atomics).
+#include "common.h"
+
+namespace {
+constexpr int SF_THREADS = 256;
+constexpr int SF_MAXN = 32;
+
+template <int K>
+__global__ __launch_bounds__(SF_THREADS) void style_fc_fwd_kernel(const float* __restrict__ w, const float* __restrict__ W,
+                                                                  const float* __restrict__ b, float* __restrict__ big, int N, int S, float slope) {
+    __shared__ float sw[SF_MAXN * K];
+    for (int i = threadIdx.x; i < N * K; i += SF_THREADS) sw[i] = w[i];
+    __syncthreads();
+    const int s = blockIdx.x * SF_THREADS + threadIdx.x;
+    if (s >= S) return;
+    float row[K];
+#pragma unroll
+    for (int k = 0; k < K; k += 4) {
+        const f32x4_t v = *(const f32x4_t*)(W + (size_t)s * K + k);
+        row[k] = v[0]; row[k + 1] = v[1]; row[k + 2] = v[2]; row[k + 3] = v[3];
+    }
+    const float bias = b[s];
+    for (int n = 0; n < N; ++n) {
+        float acc = bias;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc = fmaf(sw[n * K + k], row[k], acc);
+        big[(size_t)n * S + s] = acc > 0.f ? acc : slope * acc;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(SF_THREADS) void style_fc_bwd_kernel(const float* __restrict__ dbig, const float* __restrict__ gbig,
+                                                                  const float* __restrict__ big, const float* __restrict__ w,
+                                                                  const float* __restrict__ W, float* __restrict__ gW, float* __restrict__ gb,
+                                                                  float* __restrict__ partial, int N, int S, float slope) {
+    extern __shared__ float smem[];
+    float* sw = smem;                                  // [N][K]
+    float* sd = sw + SF_MAXN * K;                      // [N][SF_THREADS]: dpre of this block's rows
+    float* sW = sd + SF_MAXN * SF_THREADS;             // [SF_THREADS][K]: this block's rows of W (only when dw is wanted)
+    for (int i = threadIdx.x; i < N * K; i += SF_THREADS) sw[i] = w[i];
+    __syncthreads();
+    const int s = blockIdx.x * SF_THREADS + threadIdx.x;
+    const bool in = s < S;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    float bsum = 0.f;
+    for (int n = 0; n < N; ++n) {
+        float d = 0.f;
+        if (in) {
+            const size_t o = (size_t)n * S + s;
+            d = dbig[o];
+            if (gbig) d += gbig[o];
+            if (!(big[o] > 0.f)) d *= slope;           // LeakyReLU': big > 0 <=> pre-activation > 0
+        }
+        sd[n * SF_THREADS + threadIdx.x] = d;
+        bsum += d;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(d, sw[n * K + k], acc[k]);
+    }
+    if (in) {
+        gb[s] += bsum;
+#pragma unroll
+        for (int k = 0; k < K; k += 4) {
+            f32x4_t* p = (f32x4_t*)(gW + (size_t)s * K + k);
+            f32x4_t v = *p;
+            v[0] += acc[k]; v[1] += acc[k + 1]; v[2] += acc[k + 2]; v[3] += acc[k + 3];
+            *p = v;
+        }
+    }
+    if (!partial) return;
+    // ---- dw[n][k] = sum_s dpre[n][s] W[s][k]: this block's 256 rows; style_fc_dw_fold_kernel adds the blocks' partials in order
+#pragma unroll
+    for (int k = 0; k < K; k += 4) {
+        f32x4_t v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (in) v = *(const f32x4_t*)(W + (size_t)s * K + k);
+        *(f32x4_t*)(sW + threadIdx.x * K + k) = v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < N * K; idx += SF_THREADS) {
+        const int n = idx / K, k = idx % K;
+        float t = 0.f;
+        for (int j = 0; j < SF_THREADS; ++j) t = fmaf(sd[n * SF_THREADS + j], sW[j * K + k], t);
+        partial[(size_t)blockIdx.x * N * K + idx] = t;
+    }
+}
+
+// dw[idx] = sum over the blocks' partial sums, in block order (a second, tiny launch: a last-block fold inside the kernel above
+// needs a device-scope release per block, which on this multi-XCD part writes back the XCD's L2 -- measured 37 us for the pair
+// instead of ~10)
+__global__ __launch_bounds__(SF_THREADS) void style_fc_dw_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, int NK, int blocks) {
+    const int idx = blockIdx.x * SF_THREADS + threadIdx.x;
+    if (idx >= NK) return;
+    float t = 0.f;
+    for (int g = 0; g < blocks; ++g) t += partial[(size_t)g * NK + idx];
+    dw[idx] = t;
+}
+
+size_t bwd_smem(int K) { return (size_t)(SF_MAXN * K + SF_MAXN * SF_THREADS + SF_THREADS * K) * sizeof(float); }
+}  // namespace
+
+extern "C" int s2e_style_fc_supported(int N, int K) { return N >= 1 && N <= SF_MAXN && (K == 8 || K == 16 || K == 32 || K == 64); }
+
+extern "C" size_t s2e_style_fc_bwd_workspace_bytes(int N, int K, int S) {
+    return (size_t)ceil_div(S, SF_THREADS) * N * K * sizeof(float);      // [blocks][N*K] fp32 partial sums of dw; no initialisation needed
+}
+
+extern "C" int s2e_style_fc_fwd(const float* w, const float* W, const float* b, float* big, int N, int K, int S, float slope, void* stream) {
+    if (!w || !W || !b || !big || S <= 0 || !s2e_style_fc_supported(N, K)) S2E_FAIL(S2E_ERR_ARG, "s2e_style_fc_fwd: bad argument (N=%d K=%d S=%d)", N, K, S);
+    const int grid = ceil_div(S, SF_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    switch (K) {
+        case 8: style_fc_fwd_kernel<8><<<grid, SF_THREADS, 0, st>>>(w, W, b, big, N, S, slope); break;
+        case 16: style_fc_fwd_kernel<16><<<grid, SF_THREADS, 0, st>>>(w, W, b, big, N, S, slope); break;
+        case 32: style_fc_fwd_kernel<32><<<grid, SF_THREADS, 0, st>>>(w, W, b, big, N, S, slope); break;
+        default: style_fc_fwd_kernel<64><<<grid, SF_THREADS, 0, st>>>(w, W, b, big, N, S, slope); break;
+    }
+    S2E_CHECK_LAUNCH("style_fc_fwd_kernel");
+    return S2E_OK;
+}
+
+extern "C" int s2e_style_fc_bwd(const float* dbig, const float* gbig, const float* big, const float* w, const float* W, float* gW, float* gb,
+                                float* dw, void* workspace, size_t workspace_bytes, int N, int K, int S, float slope, void* stream) {
+    if (!dbig || !big || !w || !W || !gW || !gb || S <= 0 || !s2e_style_fc_supported(N, K))
+        S2E_FAIL(S2E_ERR_ARG, "s2e_style_fc_bwd: bad argument (N=%d K=%d S=%d)", N, K, S);
+    const int grid = ceil_div(S, SF_THREADS);
+    float* partial = nullptr;
+    if (dw) {
+        if (!workspace || workspace_bytes < s2e_style_fc_bwd_workspace_bytes(N, K, S))
+            S2E_FAIL(S2E_ERR_ARG, "s2e_style_fc_bwd: dw needs %zu bytes of workspace", s2e_style_fc_bwd_workspace_bytes(N, K, S));
+        partial = (float*)workspace;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sm = bwd_smem(K);
+#define S2E_SF(KK) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)style_fc_bwd_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_done = true; } \
+        style_fc_bwd_kernel<KK><<<grid, SF_THREADS, sm, st>>>(dbig, gbig, big, w, W, gW, gb, partial, N, S, slope); } while (0)
+    switch (K) {
+        case 8: S2E_SF(8); break;
+        case 16: S2E_SF(16); break;
+        case 32: S2E_SF(32); break;
+        default: S2E_SF(64); break;
+    }
+#undef S2E_SF
+    S2E_CHECK_LAUNCH("style_fc_bwd_kernel");
+    if (dw) {
+        style_fc_dw_fold_kernel<<<ceil_div(N * K, SF_THREADS), SF_THREADS, 0, st>>>(partial, dw, N * K, grid);
+        S2E_CHECK_LAUNCH("style_fc_dw_fold_kernel");
+    }
+    return S2E_OK;
+}

@@ -62,7 +62,7 @@ class NLayerDiscriminator(BaseNetwork):
             if feat_terms is None:
                 feats.append(h)
                 return h
-            h, term = ops.feat_tap(h, feat_lambda / (h.numel() // 2))
+            h, term = ops.feat_tap(h, feat_lambda / (h.numel() // 2), pooled=True)     # (the terms are stacked and summed by the caller)
             feat_terms.append(term)
             feats.append(h.detach())
             return h

@@ -27,7 +27,7 @@ class GANLoss(nn.Module):
         self.real_label, self.fake_label = target_real_label, target_fake_label
         self.opt = opt
 
-    def loss(self, input, target_is_real, for_discriminator=True, weight=1.0):
+    def loss(self, input, target_is_real, for_discriminator=True, weight=1.0, pooled=False):
         """weight (not in the reference): a factor folded into the reduction's scale -- the 1 / num_D of the list form below,
         instead of a tensor division after it."""
         if self.gan_mode != 'hinge':
@@ -39,7 +39,7 @@ class GANLoss(nn.Module):
         else:
             assert target_is_real, "The generator's hinge loss must be aiming for real"
             mode = LOSS_NEG_MEAN
-        return ops.loss_sum(x, None, mode, weight / n)
+        return ops.loss_sum(x, None, mode, weight / n, pooled)
 
     def _loss_other(self, input, target_is_real):
         # the non-default modes (loss.py:58-65, 78-83) act on the few-thousand-element PatchGAN outputs: plain torch
@@ -59,7 +59,8 @@ class GANLoss(nn.Module):
             for pred_i in input:
                 if isinstance(pred_i, list):
                     pred_i = pred_i[-1]
-                term = self.loss(pred_i, target_is_real, for_discriminator, weight=1.0 / len(input)).view(1)
+                # (a term that is summed with others right here may accumulate in the step's zero pool: ops.loss_sum)
+                term = self.loss(pred_i, target_is_real, for_discriminator, weight=1.0 / len(input), pooled=len(input) > 1).view(1)
                 total = term if total is None else total + term
             return total
         return self.loss(input, target_is_real, for_discriminator)

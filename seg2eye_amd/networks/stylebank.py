@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from .. import _lib as L
 
 _current = None
 
@@ -31,7 +32,16 @@ def current():
 class StyleBankFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, Wcat, bcat, holder, gW, gb, want_grad, anchor=None):
-        big = F.leaky_relu(torch.addmm(bcat, w, Wcat.t()), 0.2)
+        N, K = w.shape
+        # the HIP kernels (csrc/style_fc.hip) take the arena layout -- contiguous fp32 stacks -- and the usual small N, w_dim
+        ctx.hip = bool(w.is_cuda and Wcat.is_contiguous() and bcat.is_contiguous() and Wcat.dtype == torch.float32
+                       and L.lib().s2e_style_fc_supported(N, K))
+        if ctx.hip:
+            big = torch.empty(N, Wcat.shape[0], dtype=torch.float32, device=w.device)
+            L.check(L.lib().s2e_style_fc_fwd(w.data_ptr(), Wcat.data_ptr(), bcat.data_ptr(), big.data_ptr(), N, K, Wcat.shape[0], 0.2,
+                                             torch.cuda.current_stream().cuda_stream), 's2e_style_fc_fwd')
+        else:
+            big = F.leaky_relu(torch.addmm(bcat, w, Wcat.t()), 0.2)
         ctx.set_materialize_grads(False)
         ctx.dst = (gW, gb)
         ctx.dbig = None
@@ -44,10 +54,23 @@ class StyleBankFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gbig):
         w, Wcat, big = ctx.saved_tensors
+        gW, gb = ctx.dst
+        if ctx.hip and gW is not None and gW.is_contiguous() and gb.is_contiguous():
+            N, K = w.shape
+            S = Wcat.shape[0]
+            want_dw = ctx.needs_input_grad[0]
+            dw = torch.empty(N, K, dtype=torch.float32, device=w.device) if want_dw else None
+            wsb = L.lib().s2e_style_fc_bwd_workspace_bytes(N, K, S) if want_dw else 0
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=w.device) if wsb else None
+            gbc = None if gbig is None else gbig.float().contiguous()
+            L.check(L.lib().s2e_style_fc_bwd(ctx.dbig.data_ptr(), None if gbc is None else gbc.data_ptr(), big.data_ptr(), w.data_ptr(),
+                                             Wcat.data_ptr(), gW.data_ptr(), gb.data_ptr(), None if dw is None else dw.data_ptr(),
+                                             None if ws is None else ws.data_ptr(), wsb, N, K, S, 0.2,
+                                             torch.cuda.current_stream().cuda_stream), 's2e_style_fc_bwd')
+            return dw, None, None, None, None, None, None, None
         d = ctx.dbig if gbig is None else ctx.dbig + gbig          # consumers accumulate into dbig directly
         dpre = torch.where(big > 0, d, 0.2 * d)                     # LeakyReLU': big > 0 <=> pre > 0
         dw = dpre @ Wcat if ctx.needs_input_grad[0] else None
-        gW, gb = ctx.dst
         if gW is not None:
             gW.addmm_(dpre.t(), w)
             gb.add_(dpre.sum(0))

@@ -130,6 +130,7 @@ class ZeroPool:
         self.key = None
         self.frozen = False
         self.step_cache = {}    # per-scope memo of derived read-only tensors (cleared at scope entry and exit)
+        self.tails, self.tail_i = {}, 0     # (scope key, i) -> (live, persistent zero-tailed gradient buffer): _live_tail_buffer
         self.sink = GradSink()
 
     def scope(self, key):
@@ -158,7 +159,7 @@ class ZeroPool:
             if hw:
                 self.buf[:hw].zero_()
             self.clean = hw
-        self.key, self.bump = key, 0
+        self.key, self.bump, self.tail_i = key, 0, 0
         self.step_cache = {}
         ZeroPool._active = self
         ZeroPool.serial += 1
@@ -441,6 +442,9 @@ def colsum(g):
     return out
 
 
+_IN_STATS_ONE_LAUNCH = os.environ.get('S2E_IN_STATS_ONE_LAUNCH', '0') == '1'      # experiment (slower: see include/seg2eye_hip.h)
+
+
 def in_stats(x, return_sums=False):
     """(N,H,W,C) -> (N,C,2) fp32 {mean, rstd}; not differentiated here (the IN backward lives in
     modulate_bwd, once per consumer of the statistics).
@@ -449,8 +453,10 @@ def in_stats(x, return_sums=False):
     n, h, w, c = x.shape
     ws = torch.empty(L.lib().s2e_in_stats_workspace_bytes(_dt(x), n, h * w, c) // 8, dtype=torch.float64, device=x.device)
     stats = torch.empty(n, c, 2, dtype=torch.float32, device=x.device)
+    ncnt = L.lib().s2e_in_stats_counters(_dt(x), n, h * w, c) if _IN_STATS_ONE_LAUNCH else 0
+    cnt = ZeroPool.take(ncnt, torch.int32, x.device) if ncnt else None     # zeroed block counters: the fold joins the row pass
     LaunchProfiler.run('in_stats', 0.0, lambda: L.check(
-        L.lib().s2e_in_stats(_dt(x), _p(x), n, h * w, c, IN_EPS, _p(ws), _p(stats), _stream()), 's2e_in_stats'),
+        L.lib().s2e_in_stats(_dt(x), _p(x), n, h * w, c, IN_EPS, _p(ws), _p(stats), _p(cnt), _stream()), 's2e_in_stats'),
         nbytes=float(x.numel() * x.element_size()))                   # algorithmic: x read once
     return (stats, ws[:n * c * 2].view(n, c, 2)) if return_sums else stats
 
@@ -673,6 +679,28 @@ class LivePrefix:
             LivePrefix.n = self.prev
 
 
+def _live_tail_buffer(x, live):
+    """A gradient buffer shaped like x whose samples live.. are ZERO, for a data gradient that only writes samples ..live.
+    Inside a trainer step the i-th such request of a step gets the i-th PERSISTENT buffer of the step's pool (same sequence
+    every step): its tail was zeroed when it was made and nothing writes there -- the data-gradient kernel fills the head, the
+    consumers (FeatTapFn, the IN backward) read it or accumulate into the head only -- so the ten zero-fill launches of a G
+    step's discriminator backward disappear.  Stand-alone: a fresh tensor and one fill."""
+    pool = ZeroPool.active()
+    if pool is not None:
+        key = (pool.key, pool.tail_i)
+        pool.tail_i += 1
+        ent = pool.tails.get(key)
+        if ent is not None and ent[0] == live and ent[1].shape == x.shape and ent[1].dtype == x.dtype and ent[1].device == x.device:
+            return ent[1]
+        if not pool.frozen:                                  # (a captured graph must not start using new persistent memory)
+            t = torch.zeros_like(x)
+            pool.tails[key] = (live, t)
+            return t
+    gx = torch.empty_like(x)
+    gx[live:].zero_()
+    return gx
+
+
 class _LivePrefixGate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, n):
@@ -734,11 +762,10 @@ class Conv2dFn(torch.autograd.Function):
                 g2 = torch.empty_like(gl)
                 L.check(L.lib().s2e_lrelu_bwd(_dt(gl), _p(gl), _p(y), _p(g2), gl.numel(), _stream()), 's2e_lrelu_bwd')
                 gl = g2
-            gx = torch.empty_like(x)
+            gx = _live_tail_buffer(x, live)                    # (samples live.. are zero already)
             wpt = packed_weight(weight, x.dtype, cx, True, sigma, ctx.plan, ctx.plan_gen)
             conv2d_raw(gl, wpt, None, None, x[:live] if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
                        True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE, out=gx[:live])
-            gx[live:].zero_()
             return gx, None, None, None, None, None, None, None, None, None, None
         if out_act == ACT_TANH:
             g2 = torch.empty_like(g)
@@ -1294,15 +1321,83 @@ def seg_image_concat(label, img, ncls=4, cpad=8):
     return SegImageConcatFn.apply(label, img, ncls, cpad)
 
 
+class DInputFn(torch.autograd.Function):
+    """The discriminator's input  cat_batch([cat_ch(one_hot(label), fake); cat_ch(one_hot(label), real)])  (pix2pix_model.py:
+    328-342) as ONE (2N,H,W,cpad) NHWC tensor written by two launches -- one per half, straight from the label map and the two
+    single-channel image batches: no concatenated image batch, no doubled label map.  Differentiable w.r.t. `fake` only; its
+    gradient is channel `ncls` of the first half (one strided copy instead of select_backward's zero-fill + copy)."""
+
+    @staticmethod
+    def forward(ctx, label, fake, real, ncls, cpad):
+        n, H, W = label.shape
+        f, r = fake.reshape(n, H, W), real.reshape(n, H, W).to(fake.dtype)
+        f, r = (f if f.is_contiguous() else f.contiguous()), (r if r.is_contiguous() else r.contiguous())
+        _need(label, f, r)
+        out = torch.empty(2 * n, H, W, cpad, dtype=fake.dtype, device=label.device)
+        for half, img in ((out[:n], f), (out[n:], r)):
+            L.check(L.lib().s2e_onehot_nhwc(_dt(out), _p(label), _p(img), _p(half), n, H, W, H, W, ncls, cpad, _stream()),
+                    's2e_onehot_nhwc')
+        ctx.ncls, ctx.shape = ncls, fake.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = g.shape[0] // 2
+        return None, g[:n, :, :, ctx.ncls].contiguous().view(ctx.shape), None, None, None
+
+
+def d_input(label, fake, real, ncls=4, cpad=8):
+    """label (N,H,W) uint8, fake / real (N,1,H,W) or (N,H,W) -> (2N,H,W,cpad): see DInputFn."""
+    return DInputFn.apply(label, fake, real, ncls, cpad)
+
+
+class SplitHalvesFn(torch.autograd.Function):
+    """t -> (t[:n], t[n:]), n = half the batch (Pix2PixModel.divide_pred).  Two plain slices cost a zero-filled full tensor and
+    a copy EACH on the way back, plus the add that joins them; here the backward fills one tensor with the two halves (or
+    zeros where a half got no gradient)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        ctx.set_materialize_grads(False)
+        n = t.shape[0] // 2
+        ctx.n = n
+        ctx.like = t.detach()
+        return t[:n], t[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None
+        out = torch.empty_like(ctx.like)
+        for dst, g in ((out[:ctx.n], ga), (out[ctx.n:], gb)):
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g)
+        return out
+
+
+def split_halves(t):
+    return SplitHalvesFn.apply(t)
+
+
 # ------------------------------------------------------------------------------ losses
+
+def _loss_slot(device, pooled):
+    """A zeroed fp32 scalar for s2e_loss_reduce to accumulate into.  Pool memory is recycled by the trainer's next step: only
+    for terms that are consumed inside the step (see loss_sum)."""
+    if pooled and ZeroPool.active() is not None:
+        return ZeroPool.take(1, torch.float32, device).view(())
+    return torch.zeros((), dtype=torch.float32, device=device)
+
 
 class LossSumFn(torch.autograd.Function):
     """scale * sum_i f(a_i, b_i) as a 0-dim fp32 tensor (see s2e_loss_reduce for f)."""
 
     @staticmethod
-    def forward(ctx, a, b, mode, scale):
+    def forward(ctx, a, b, mode, scale, pooled=False):
         _need(a, b)
-        out = torch.zeros((), dtype=torch.float32, device=a.device)
+        out = _loss_slot(a.device, pooled)
         L.check(L.lib().s2e_loss_reduce(_dt(a), mode, _p(a), _p(b), a.numel(), float(scale), _p(out), _stream()),
                 's2e_loss_reduce')
         ctx.cfg = (mode, float(scale))
@@ -1317,11 +1412,13 @@ class LossSumFn(torch.autograd.Function):
         da = torch.empty_like(a)
         L.check(L.lib().s2e_loss_grad(_dt(a), mode, _p(a), _p(b), a.numel(), scale, _p(gs), _p(da), 0, _stream()),
                 's2e_loss_grad')
-        return da, None, None, None
+        return da, None, None, None, None
 
 
-def loss_sum(a, b, mode, scale):
-    return LossSumFn.apply(a, b, mode, scale)
+def loss_sum(a, b, mode, scale, pooled=False):
+    """pooled: the caller only COMBINES the result with other terms inside the step (a sum over scales, a stack) and never
+    hands it out: the accumulator may then be a slice of the step's zero pool instead of its own zero-fill launch."""
+    return LossSumFn.apply(a, b, mode, scale, pooled)
 
 
 class FeatTapFn(torch.autograd.Function):
@@ -1334,11 +1431,11 @@ class FeatTapFn(torch.autograd.Function):
     it) and the L1 gradient is accumulated into its fake half in place by s2e_loss_grad(accumulate=1)."""
 
     @staticmethod
-    def forward(ctx, h, scale):
+    def forward(ctx, h, scale, pooled=False):
         _need(h)
         n = h.shape[0] // 2
         a, b = h[:n], h[n:]
-        out = torch.zeros((), dtype=torch.float32, device=h.device)
+        out = _loss_slot(h.device, pooled)
         L.check(L.lib().s2e_loss_reduce(_dt(h), LOSS_L1, _p(a), _p(b), a.numel(), float(scale), _p(out), _stream()),
                 's2e_loss_reduce')
         ctx.scale = float(scale)
@@ -1351,7 +1448,7 @@ class FeatTapFn(torch.autograd.Function):
         h, = ctx.saved_tensors
         n = h.shape[0] // 2
         if gloss is None:
-            return gh, None
+            return gh, None, None
         if gh is None:
             gh = torch.zeros_like(h)
         elif not gh.is_contiguous():
@@ -1360,12 +1457,12 @@ class FeatTapFn(torch.autograd.Function):
         gs = gloss.detach().float().contiguous()
         L.check(L.lib().s2e_loss_grad(_dt(h), LOSS_L1, _p(a), _p(b), a.numel(), ctx.scale, _p(gs), _p(ga), 1, _stream()),
                 's2e_loss_grad')
-        return gh, None
+        return gh, None, None
 
 
-def feat_tap(h, scale):
-    """-> (h, term): see FeatTapFn."""
-    return FeatTapFn.apply(h, scale)
+def feat_tap(h, scale, pooled=False):
+    """-> (h, term): see FeatTapFn.  pooled: as in loss_sum."""
+    return FeatTapFn.apply(h, scale, pooled)
 
 
 # ------------------------------------------------------------------------------ optimizer

@@ -254,9 +254,7 @@ class Pix2PixModel(nn.Module):
     def discriminate(self, seg, fake_image, real_image, feat_lambda=None):
         """D on cat over the batch of [cat(seg, fake); cat(seg, real)] (pix2pix_model.py:328-342); the
         (2N,H,W,8) input is built by one kernel from the label map and the two image batches."""
-        imgs = torch.cat([fake_image[:, 0].to(self.cdtype), real_image[:, 0].to(self.cdtype)], 0).contiguous()
-        labels = torch.cat([seg.label, seg.label], 0)
-        x = ops.seg_image_concat(labels, imgs, self.opt.label_nc, networks.discriminator.D_CPAD)
+        x = ops.d_input(seg.label, fake_image.to(self.cdtype), real_image, self.opt.label_nc, networks.discriminator.D_CPAD)
         if feat_lambda is None:
             return self.divide_pred(self.netD(x))
         out, feat = self.netD(x, feat_lambda=feat_lambda)
@@ -264,9 +262,8 @@ class Pix2PixModel(nn.Module):
 
     @staticmethod
     def divide_pred(pred):
-        fake = [[t[:t.size(0) // 2] for t in p] for p in pred]
-        real = [[t[t.size(0) // 2:] for t in p] for p in pred]
-        return fake, real
+        halves = [[ops.split_halves(t) if t.requires_grad else (t[:t.size(0) // 2], t[t.size(0) // 2:]) for t in p] for p in pred]
+        return [[h[0] for h in p] for p in halves], [[h[1] for h in p] for p in halves]
 
     def use_gpu(self):
         return len(self.opt.gpu_ids) > 0

@@ -64,13 +64,21 @@ class Pix2PixTrainer:
             pool.sink.flush()                                # the group's queued packed-dW -> arena conversions: now
             self.sync_G.launch(i)
 
+    def _one(self):
+        """d(total)/d(total) as a persistent device scalar (autograd would launch a ones_like per backward)."""
+        t = self.__dict__.get('_one_t')
+        if t is None:
+            import torch
+            t = self.__dict__['_one_t'] = torch.ones((), dtype=torch.float32, device=self.pix2pix_model.device())
+        return t
+
     # ---- step bodies: zero_grad + forward + backward (what a hipGraph captures) -------------------
     def _g_body(self, data):
         self.optimizer_G.zero_grad()
         try:
             with self.pool.scope('G'):                           # all zero-filled scratch of the step: one fill
                 g_losses, generated = self.pix2pix_model(data, mode='generator')
-                _total(g_losses).backward()
+                _total(g_losses).backward(self._one())
         except BaseException:
             self.sync_G.reset()                                  # exchanges the backward hooks started for a step that failed
             raise
@@ -83,7 +91,7 @@ class Pix2PixTrainer:
         self.optimizer_D.zero_grad()
         with self.pool.scope('D'):
             d_losses = self.pix2pix_model(data, mode='discriminator')
-            _total(d_losses).backward()
+            _total(d_losses).backward(self._one())
         self.d_losses = {k: v.detach() for k, v in d_losses.items()}
 
     def run_generator_one_step(self, data):

@@ -659,3 +659,106 @@ def test_conv_stream_kernel_every_shape_matches_torch():
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_tail.py'), '--iters', '2'], env=env, capture_output=True,
                          text=True, timeout=900, cwd=root)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize('cfg', [(8, 16, 21888), (1, 16, 300), (4, 8, 1000), (3, 32, 513), (32, 64, 700)])
+def test_style_fc_kernels_match_torch(cfg):
+    """csrc/style_fc.hip vs the torch expression of the stacked ApplyStyle FCs (normalization.py:144-169), forward and backward;
+    the backward's dw (a two-level reduction over S with a last-block fold) must be bit-identical launch to launch."""
+    from seg2eye_amd import _lib as L
+    N, K, S = cfg
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(N, K, generator=g).to(dev)
+    W = (torch.randn(S, K, generator=g) * 0.3).to(dev)
+    b = (torch.randn(S, generator=g) * 0.1).to(dev)
+    dbig = torch.randn(N, S, generator=g).to(dev)
+    gbig = torch.randn(N, S, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.lib().s2e_style_fc_supported(N, K)
+    big = torch.empty(N, S, device=dev)
+    L.check(L.lib().s2e_style_fc_fwd(w.data_ptr(), W.data_ptr(), b.data_ptr(), big.data_ptr(), N, K, S, 0.2, st), 'fwd')
+    ref = F.leaky_relu(torch.addmm(b.double(), w.double(), W.double().t()), 0.2)
+    assert torch.allclose(big.double(), ref, rtol=1e-5, atol=1e-5)
+    wsb = L.lib().s2e_style_fc_bwd_workspace_bytes(N, K, S)
+    outs = []
+    for gb_in in (None, gbig):
+        for rep in range(2):
+            gW = torch.full((S, K), 0.5, device=dev)
+            gb = torch.full((S,), -0.25, device=dev)
+            dw = torch.empty(N, K, device=dev)
+            ws = torch.full((wsb // 4,), float('nan'), device=dev)                      # (no initialisation needed)
+            L.check(L.lib().s2e_style_fc_bwd(dbig.data_ptr(), None if gb_in is None else gb_in.data_ptr(), big.data_ptr(), w.data_ptr(),
+                                             W.data_ptr(), gW.data_ptr(), gb.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, N, K, S, 0.2, st), 'bwd')
+            outs.append((gW, gb, dw))
+        d = dbig.double() if gb_in is None else (dbig + gb_in).double()
+        dpre = torch.where(big.double() > 0, d, 0.2 * d)
+        assert torch.allclose(outs[-1][0].double(), 0.5 + dpre.t() @ w.double(), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(outs[-1][1].double(), -0.25 + dpre.sum(0), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(outs[-1][2].double(), dpre @ W.double(), rtol=1e-4, atol=1e-3 * S ** 0.5)
+        assert torch.equal(outs[-1][2], outs[-2][2])
+    # dw not wanted: no workspace needed
+    gW = torch.zeros(S, K, device=dev)
+    gb = torch.zeros(S, device=dev)
+    L.check(L.lib().s2e_style_fc_bwd(dbig.data_ptr(), None, big.data_ptr(), w.data_ptr(), W.data_ptr(), gW.data_ptr(), gb.data_ptr(),
+                                     None, None, 0, N, K, S, 0.2, st), 'bwd')
+    assert not L.lib().s2e_style_fc_supported(33, 16) and not L.lib().s2e_style_fc_supported(8, 12)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 64, 64, 64), (8, 128, 128, 128), (3, 40, 50, 2064), (1, 256, 256, 8)])
+def test_in_stats_one_launch_equals_two_launches_bitwise(shape, dtype):
+    """The fold of the per-block partial sums done by the last row-walking block (counters given) gives the bits of the separate
+    finalize launch, launch after launch, and leaves the counters zero."""
+    from seg2eye_amd import _lib as L
+    dev = _dev()
+    n, h, w, c = shape
+    x = (_rnd(shape, 3, dtype) * 1.7 + 0.3).to(dev)
+    dt = L.S2E_BF16 if dtype == torch.bfloat16 else L.S2E_F32
+    st = torch.cuda.current_stream().cuda_stream
+    wsb = L.lib().s2e_in_stats_workspace_bytes(dt, n, h * w, c)
+    ncnt = L.lib().s2e_in_stats_counters(dt, n, h * w, c)
+    assert ncnt > 0
+    res = []
+    cnt = torch.zeros(ncnt, dtype=torch.int32, device=dev)
+    for counters in (None, cnt, cnt, cnt):
+        ws = torch.full((wsb // 8,), float('nan'), dtype=torch.float64, device=dev)
+        stats = torch.empty(n, c, 2, device=dev)
+        L.check(L.lib().s2e_in_stats(dt, x.data_ptr(), n, h * w, c, 1e-5, ws.data_ptr(), stats.data_ptr(),
+                                     None if counters is None else counters.data_ptr(), st), 'in_stats')
+        res.append((stats, ws[:n * c * 2].clone()))
+        assert int(cnt.abs().sum()) == 0
+    for stats, sums in res[1:]:
+        assert torch.equal(stats, res[0][0]) and torch.equal(sums, res[0][1])
+    ref = x.double().cpu().view(n, h * w, c)
+    assert torch.allclose(res[0][0][..., 0].double().cpu(), ref.mean(1), rtol=1e-4, atol=1e-4)
+
+
+def test_discriminator_input_and_split_halves():
+    """ops.d_input == the reference's cat([cat(one_hot, fake); cat(one_hot, real)]) with the gradient reaching `fake` only;
+    ops.split_halves == two slices, including a half that receives no gradient."""
+    from seg2eye_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    n, H, W = 3, 20, 28
+    label = torch.randint(0, 4, (n, H, W), generator=g, dtype=torch.uint8).to(dev)
+    fake = torch.randn(n, 1, H, W, generator=g).to(dev).requires_grad_(True)
+    real = torch.randn(n, 1, H, W, generator=g).to(dev)
+    x = ops.d_input(label, fake, real, 4, 8)
+    oh = F.one_hot(label.long(), 4).float()
+    ref = torch.zeros(2 * n, H, W, 8, device=dev)
+    ref[:n, ..., :4], ref[n:, ..., :4] = oh, oh
+    ref[:n, ..., 4], ref[n:, ..., 4] = fake.detach()[:, 0], real[:, 0]
+    assert torch.equal(x, ref)
+    gx = torch.randn(2 * n, H, W, 8, generator=g).to(dev)
+    x.backward(gx)
+    assert torch.equal(fake.grad, gx[:n, ..., 4].unsqueeze(1))
+    t = torch.randn(6, 1, 5, 7, generator=g).to(dev).requires_grad_(True)
+    a, b = ops.split_halves(t)
+    assert torch.equal(a, t[:3]) and torch.equal(b, t[3:])
+    (a * 2.0).sum().backward()
+    assert torch.equal(t.grad[:3], torch.full_like(t[:3], 2.0)) and float(t.grad[3:].abs().sum()) == 0.0
+    t.grad = None
+    a, b = ops.split_halves(t)
+    (a.sum() + 3.0 * b.sum()).backward()
+    assert torch.equal(t.grad[3:], torch.full_like(t[3:], 3.0)) and torch.equal(t.grad[:3], torch.ones_like(t[:3]))

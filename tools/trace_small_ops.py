@@ -42,7 +42,11 @@ def main():
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             out = func(*args, **(kwargs or {}))
             name = func.__name__.split('.')[0]
-            if name in watch:
+            views = ('view', 'detach', 'as_strided', 'slice', 'select', 'permute', 'transpose', 't', 'expand', 'unsqueeze', 'squeeze', 'alias',
+                     '_unsafe_view', 'reshape', 'narrow', 'unbind', 'split', 'chunk', 'empty', 'empty_like', 'empty_strided', 'new_empty',
+                     'is_contiguous', 'sym_size', 'sym_stride', 'size', 'stride', 'lift_fresh', 'is_pinned', 'record_stream', '_local_scalar_dense', 'view_as')
+            on_gpu = any(isinstance(a, torch.Tensor) and a.is_cuda for a in list(args) + [out])
+            if on_gpu and name not in views:
                 numel = 0
                 for a in list(args) + [out]:
                     if isinstance(a, torch.Tensor):
