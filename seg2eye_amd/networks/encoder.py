@@ -32,8 +32,8 @@ class ConvEncoder(BaseNetwork):
         self.fc_mu = nn.Linear(ndf * 8 * s0 * s0, opt.w_dim)
         self.fc_var = nn.Linear(ndf * 8 * s0 * s0, opt.w_dim)
         self.actvn = nn.LeakyReLU(0.2, False)
-        # Pix2PixModel never uses `logvar` (pix2pix_model.py:271-305) and says so (False): fc_var's half of the fused head is then
-        # detached, so that fc_var's gradient stays None as in the reference instead of becoming explicit zeros
+        # Pix2PixModel never uses `logvar` (pix2pix_model.py:271-305) and says so (False): fc_var is then not evaluated (forward
+        # returns logvar = None) and its gradient stays None as in the reference
         self.logvar_used = True
 
     def forward(self, x, get_intermediate_features=False, power_iterations=1):
@@ -63,11 +63,16 @@ class ConvEncoder(BaseNetwork):
         # output channels, the LeakyReLU is the conv's fused input activation.  fp32 (the style code feeds every modulation:
         # the few kFLOP are not worth bf16's three digits).  Outside the pack plan's scope: the concatenated weight is a
         # temporary, packed on the spot.
-        # logvar_used False (set by Pix2PixModel, which never uses logvar): fc_var's half is DETACHED -- in the reference an unused
-        # logvar leaves fc_var's gradient None and torch's Adam skips the parameter; through the concatenation it would receive
-        # explicit zeros instead, which any optimizer with weight decay would act on.
-        wv, bv = (self.fc_var.weight, self.fc_var.bias) if self.logvar_used else (self.fc_var.weight.detach(), self.fc_var.bias.detach())
-        wcat = torch.cat([self.fc_mu.weight, wv], 0).view(2 * self.opt.w_dim, h.shape[-1], self.so, self.so)
-        bcat = torch.cat([self.fc_mu.bias, bv], 0)
+        # logvar_used False (set by Pix2PixModel, which never uses logvar): in the reference an unused logvar leaves fc_var's
+        # gradient None and torch's Adam skips the parameter (through a concatenation it would receive explicit zeros instead,
+        # which any optimizer with weight decay would act on: ADVICE r2) ...
+        if not self.logvar_used:
+            # ... and then fc_var is not evaluated at all: mu alone is fc_mu's weight VIEWED as the conv weight (no concatenation,
+            # half the FC work); logvar comes back as None
+            wmu = self.fc_mu.weight.view(self.opt.w_dim, h.shape[-1], self.so, self.so)
+            mu = ops.conv2d(h.float(), wmu, self.fc_mu.bias, None, 1, 0, ACT_LRELU).reshape(h.shape[0], self.opt.w_dim)
+            return mu, None, feats
+        wcat = torch.cat([self.fc_mu.weight, self.fc_var.weight], 0).view(2 * self.opt.w_dim, h.shape[-1], self.so, self.so)
+        bcat = torch.cat([self.fc_mu.bias, self.fc_var.bias], 0)
         out = ops.conv2d(h.float(), wcat, bcat, None, 1, 0, ACT_LRELU).reshape(h.shape[0], 2 * self.opt.w_dim)
         return out[:, :self.opt.w_dim], out[:, self.opt.w_dim:], feats

@@ -41,6 +41,30 @@ class GANLoss(nn.Module):
             mode = LOSS_NEG_MEAN
         return ops.loss_sum(x, None, mode, weight / n, pooled)
 
+    def undivided(self, pred, for_discriminator):
+        """The same losses from the UNDIVIDED predictions of a [fake | real] batch (list over scales of lists whose last entry
+        is the prediction): for_discriminator -> (loss on the fake half aiming for fake, loss on the real half aiming for
+        real) = __call__(pred_fake, False), __call__(pred_real, True); else the generator's loss on the fake half =
+        __call__(pred_fake, True, for_discriminator=False).  None when this mode / layout has no undivided form (the caller
+        then divides, as the reference does, pix2pix_model.py:344-358)."""
+        if self.gan_mode != 'hinge' or not isinstance(pred, list):
+            return None
+        last = [p[-1] if isinstance(p, list) else p for p in pred]
+        flats = [_flat(t) for t in last]
+        if any((not f.is_contiguous()) or f.shape[0] % 2 for f in flats):
+            return None
+        k = len(flats)
+        totals = None
+        for f in flats:
+            w = 1.0 / k / (f.numel() // 2)
+            if for_discriminator:
+                terms = ops.pair_loss(f, LOSS_HINGE_FAKE, LOSS_HINGE_REAL, w, pooled=k > 1)
+            else:
+                terms = (ops.half_loss(f, False, LOSS_NEG_MEAN, w, pooled=k > 1),)
+            terms = [t.view(1) for t in terms]
+            totals = terms if totals is None else [a + b for a, b in zip(totals, terms)]
+        return tuple(totals) if for_discriminator else totals[0]
+
     def _loss_other(self, input, target_is_real):
         # the non-default modes (loss.py:58-65, 78-83) act on the few-thousand-element PatchGAN outputs: plain torch
         x = input.float()

@@ -709,6 +709,9 @@ class _LivePrefixGate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        pool = ZeroPool.active()
+        if pool is not None and any(live == ctx.n and t.data_ptr() == g.data_ptr() and t.shape == g.shape for live, t in pool.tails.values()):
+            return g, None                                   # one of the step's zero-tailed buffers (_live_tail_buffer): nothing to do
         g = g.clone()
         g[ctx.n:].zero_()
         return g, None
@@ -1413,6 +1416,81 @@ class LossSumFn(torch.autograd.Function):
         L.check(L.lib().s2e_loss_grad(_dt(a), mode, _p(a), _p(b), a.numel(), scale, _p(gs), _p(da), 0, _stream()),
                 's2e_loss_grad')
         return da, None, None, None, None
+
+
+class HalfLossFn(torch.autograd.Function):
+    """scale * sum_i f(t_i) over ONE half of a [fake | real] batch t (2N, ...), NHWC-contiguous; the other half gets no gradient.
+    == loss_sum(t[:N] or t[N:], ...) without the slice: the backward writes the element-wise gradient into the head of a
+    zero-tailed buffer (first half, inside a trainer step: _live_tail_buffer -- one launch, and the LivePrefix gate behind it
+    recognises the buffer) instead of slice_backward's zero-fill + copy."""
+
+    @staticmethod
+    def forward(ctx, t, second, mode, scale, pooled):
+        _need(t)
+        n = t.shape[0] // 2
+        half = t[n:] if second else t[:n]
+        out = _loss_slot(t.device, pooled)
+        L.check(L.lib().s2e_loss_reduce(_dt(t), mode, _p(half), None, half.numel(), float(scale), _p(out), _stream()), 's2e_loss_reduce')
+        ctx.cfg = (bool(second), mode, float(scale), n)
+        ctx.save_for_backward(t)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        t, = ctx.saved_tensors
+        second, mode, scale, n = ctx.cfg
+        gs = gout.detach().float().contiguous()
+        if second:
+            gt = torch.empty_like(t)
+            gt[:n].zero_()
+            dst, src = gt[n:], t[n:]
+        else:
+            gt = _live_tail_buffer(t, n)
+            dst, src = gt[:n], t[:n]
+        L.check(L.lib().s2e_loss_grad(_dt(t), mode, _p(src), None, src.numel(), scale, _p(gs), _p(dst), 0, _stream()), 's2e_loss_grad')
+        return gt, None, None, None, None
+
+
+class PairLossFn(torch.autograd.Function):
+    """(scale * sum f_a(t[:N]), scale * sum f_b(t[N:])) for a [fake | real] batch t: the discriminator's two hinge terms from
+    the undivided prediction; the backward fills ONE gradient tensor with two launches (no slice_backward, no add)."""
+
+    @staticmethod
+    def forward(ctx, t, mode_a, mode_b, scale, pooled):
+        _need(t)
+        n = t.shape[0] // 2
+        outs = []
+        for half, mode in ((t[:n], mode_a), (t[n:], mode_b)):
+            out = _loss_slot(t.device, pooled)
+            L.check(L.lib().s2e_loss_reduce(_dt(t), mode, _p(half), None, half.numel(), float(scale), _p(out), _stream()), 's2e_loss_reduce')
+            outs.append(out)
+        ctx.cfg = (mode_a, mode_b, float(scale), n)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(t)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        t, = ctx.saved_tensors
+        mode_a, mode_b, scale, n = ctx.cfg
+        if ga is None and gb is None:
+            return None, None, None, None, None
+        gt = torch.empty_like(t)
+        for dst, src, mode, g in ((gt[:n], t[:n], mode_a, ga), (gt[n:], t[n:], mode_b, gb)):
+            if g is None:
+                dst.zero_()
+                continue
+            gs = g.detach().float().contiguous()
+            L.check(L.lib().s2e_loss_grad(_dt(t), mode, _p(src), None, src.numel(), scale, _p(gs), _p(dst), 0, _stream()), 's2e_loss_grad')
+        return gt, None, None, None, None
+
+
+def half_loss(t, second, mode, scale, pooled=False):
+    return HalfLossFn.apply(t, second, mode, scale, pooled)
+
+
+def pair_loss(t, mode_a, mode_b, scale, pooled=False):
+    return PairLossFn.apply(t, mode_a, mode_b, scale, pooled)
 
 
 def loss_sum(a, b, mode, scale, pooled=False):

@@ -168,12 +168,13 @@ class Pix2PixModel(nn.Module):
             p.requires_grad_(False)
         try:
             fused_feat = not self.opt.no_ganFeat_loss
-            out = self.discriminate(seg, fake_image, target_image, feat_lambda=self.opt.lambda_feat if fused_feat else None)
-            (pred_fake, pred_real), feat = (out if fused_feat else (out, None))
+            pred, feat = self.discriminate(seg, fake_image, target_image, feat_lambda=self.opt.lambda_feat if fused_feat else None,
+                                           divide=False)
         finally:
             for p, f in zip(d_params, flags):
                 p.requires_grad_(f)
-        G_losses['GAN'] = self.criterionGAN(pred_fake, True, for_discriminator=False)
+        gan = self.criterionGAN.undivided(pred, for_discriminator=False)      # (the hinge loss straight from the [fake | real] batch)
+        G_losses['GAN'] = gan if gan is not None else self.criterionGAN(self.divide_pred(pred)[0], True, for_discriminator=False)
         if opt.lambda_l2:                                    # pix2pix_model.py:196-200 (nn.MSELoss)
             l2 = F.mse_loss(fake_image.float(), target_image.float()).view(1)
             G_losses['L2/weighted'] = l2 * opt.lambda_l2
@@ -220,7 +221,11 @@ class Pix2PixModel(nn.Module):
         with torch.no_grad():
             fake_image, _, _ = self.generate_fake(seg, real_image)
         fake_image = fake_image.detach()
-        pred_fake, pred_real = self.discriminate(seg, fake_image, target_image)
+        pred, _ = self.discriminate(seg, fake_image, target_image, divide=False)
+        both = self.criterionGAN.undivided(pred, for_discriminator=True)
+        if both is not None:
+            return {'D/Fake': both[0], 'D/real': both[1]}
+        pred_fake, pred_real = self.divide_pred(pred)
         return {'D/Fake': self.criterionGAN(pred_fake, False, for_discriminator=True),
                 'D/real': self.criterionGAN(pred_real, True, for_discriminator=True)}
 
@@ -251,14 +256,15 @@ class Pix2PixModel(nn.Module):
         latent_style, feats = self.encode_w(style_image, aggregate_features)
         return self.generate_fake_from_stylecode(seg, latent_style), latent_style, feats
 
-    def discriminate(self, seg, fake_image, real_image, feat_lambda=None):
+    def discriminate(self, seg, fake_image, real_image, feat_lambda=None, divide=True):
         """D on cat over the batch of [cat(seg, fake); cat(seg, real)] (pix2pix_model.py:328-342); the
-        (2N,H,W,8) input is built by one kernel from the label map and the two image batches."""
+        (2N,H,W,8) input is built by two launches from the label map and the two image batches.
+        divide=False (the loss code of this class): -> (undivided predictions, feature-matching term or None)."""
         x = ops.d_input(seg.label, fake_image.to(self.cdtype), real_image, self.opt.label_nc, networks.discriminator.D_CPAD)
-        if feat_lambda is None:
-            return self.divide_pred(self.netD(x))
-        out, feat = self.netD(x, feat_lambda=feat_lambda)
-        return self.divide_pred(out), feat
+        out, feat = self.netD(x, feat_lambda=feat_lambda) if feat_lambda is not None else (self.netD(x), None)
+        if not divide:
+            return out, feat
+        return self.divide_pred(out) if feat_lambda is None else (self.divide_pred(out), feat)
 
     @staticmethod
     def divide_pred(pred):
