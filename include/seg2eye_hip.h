@@ -76,7 +76,10 @@ int s2e_conv_k_pad(int dtype, int k);            /* columns of a packed weight m
  * sigma: NULL, or a DEVICE fp32 scalar: the packed weight is w / *sigma (spectral norm applied on
  * the fly; W/sigma is never materialised in fp32).
  * transposed = 0: packed[co][(ky*kw+kx)*cin_pad + ci]           (cout_pad(cout) x k_pad(kh*kw*cin_pad))
- * transposed = 1: packed[ci][(ky*kw+kx)*cout + co]              (cout_pad(cin_pad) x k_pad(kh*kw*cout)) */
+ * transposed = 1: packed[ci][(ky*kw+kx)*cout + co]              (cout_pad(cin_pad) x k_pad(kh*kw*cout))
+ * transposed | 2: the SOURCE is stored channels-last, w[co][ky][kx][ci] (the fp32 masters of a trainer: DESIGN 3.4b); needs
+ * cin_pad == cin and cin % 8 == 0.  Same outputs; the forward pack is then a streaming convert, the transposed one a tile
+ * transpose per tap.  s2e_pack_job.transposed takes the same values. */
 int s2e_pack_conv_weight(int dtype, const float* w_oihw, void* packed, const float* sigma, int cout, int cin,
                          int kh, int kw, int cin_pad, int transposed, void* stream);
 /* Batched weight pack: every conv of a network in ONE launch (a network packs 20-50 weight matrices per
@@ -141,6 +144,8 @@ typedef struct {
     const float* w; float* u; float* v; long long* t; long long* s;
     int rows, cols;
     long long* t2; long long* s2;     /* second accumulator pair (zero like t, s) for chain != 0; may be NULL otherwise */
+    int cin, taps;                    /* taps > 1: w is stored channels-last, [co][tap][ci] (cols = taps * cin, cin % 4 == 0), while v
+                                       * keeps torch's (ci, tap) order: the kernels translate.  0, 0: w's columns are v's order. */
 } s2e_sn_layer;
 /* chain != 0 (train only; every layer's cols <= s2e_sn_chain_max_cols(), t2 / s2 set): the per-layer normalising launches are
  * folded into the GEMV passes -- 2 * iterations + 1 launches instead of 4 * iterations; same u, v, sigma up to the fp32
@@ -158,6 +163,19 @@ int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, const int* 
 int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, const float* u, const float* v, const float* sigma,
                        float* dot_ws, float* gw_orig, int cout, int cin, int kh, int kw, int cin_pad, int accumulate,
                        void* stream);
+/* The same chain rule IN PLACE, for masters stored channels-last ([co][tap][ci] = the packed order, so that s2e_conv2d_wgrad
+ * accumulates straight into the parameter's gradient): g = g / sigma - (<g, W_orig> / sigma^2) u v^T for every job, two
+ * launches, deterministic (per-block partial dot products, added in a fixed order).  g and w: the (rows x taps*cin) matrices in
+ * memory order, cin % 8 == 0; u (rows), v (cin*taps, torch's (ci, tap) order), sigma: as above.  s2e_sngrad_block_map fills
+ * part0 / nparts / vmem0 of the HOST jobs and the {job, chunk} pairs; partials: s2e_sngrad_scratch_floats floats (one per block, then
+ * every layer's v re-ordered to W's memory order by the first launch), no initialisation needed. */
+typedef struct s2e_sngrad_job {
+    float* g; const float* w; const float* u; const float* v; const float* sigma;
+    int rows, cin, taps, part0, nparts, vmem0;
+} s2e_sngrad_job;
+long s2e_sngrad_block_map(s2e_sngrad_job* jobs_host, int n_jobs, int* block_map_host);
+long s2e_sngrad_scratch_floats(const s2e_sngrad_job* jobs_host, int n_jobs);     /* size of `partials`, after s2e_sngrad_block_map */
+int s2e_sn_grads_inplace(const s2e_sngrad_job* jobs, const int* block_map, int n_blocks, float* partials, void* stream);
 /* gw_oihw[co][ci][ky][kx] (=|+=) gw_packed[co][(ky*kw+kx)*cin_pad + ci]: packed weight gradient -> torch layout. */
 int s2e_unpack_weight_grad(const float* gw_packed, float* gw_oihw, int cout, int cin, int kh, int kw, int cin_pad,
                            int accumulate, void* stream);

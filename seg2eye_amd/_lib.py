@@ -46,7 +46,7 @@ class ClassTableJob(C.Structure):
 class SnLayer(C.Structure):
     """s2e_sn_layer"""
     _fields_ = [('w', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p), ('t', C.c_void_p), ('s', C.c_void_p),
-                ('rows', C.c_int), ('cols', C.c_int), ('t2', C.c_void_p), ('s2', C.c_void_p)]
+                ('rows', C.c_int), ('cols', C.c_int), ('t2', C.c_void_p), ('s2', C.c_void_p), ('cin', C.c_int), ('taps', C.c_int)]
 
 
 class PackJob(C.Structure):
@@ -60,6 +60,12 @@ class GradJob(C.Structure):
     _fields_ = [('gw_packed', C.c_void_p), ('out', C.c_void_p), ('w_orig', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p),
                 ('sigma', C.c_void_p), ('cout', C.c_int), ('cin', C.c_int), ('taps', C.c_int), ('cin_pad', C.c_int),
                 ('dot_index', C.c_int), ('reserved', C.c_int)]
+
+
+class SnGradJob(C.Structure):
+    """s2e_sngrad_job"""
+    _fields_ = [('g', C.c_void_p), ('w', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p), ('sigma', C.c_void_p),
+                ('rows', C.c_int), ('cin', C.c_int), ('taps', C.c_int), ('part0', C.c_int), ('nparts', C.c_int), ('vmem0', C.c_int)]
 
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -76,6 +82,9 @@ SIGNATURES = {
     's2e_sn_power_iteration': [_vp, _i, _vp, _i, _vp, _i, _vp, C.c_size_t, _vp, _i, _i, _f, _i, _vp],
     's2e_sn_weight_grad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     's2e_grad_block_map': [_vp, _i, _vp],
+    's2e_sngrad_block_map': [_vp, _i, _vp],
+    's2e_sngrad_scratch_floats': [_vp, _i],
+    's2e_sn_grads_inplace': [_vp, _vp, _i, _vp, _vp],
     's2e_weight_grads_batched': [_vp, _vp, _i, _i, _i, _vp, _vp],
     's2e_unpack_weight_grad': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     's2e_pack_block_map': [_i, _vp, _i, _vp],
@@ -154,7 +163,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = (C.c_char_p if name == 's2e_last_error' else
                           C.c_size_t if name.endswith('_workspace_bytes') else
-                          C.c_long if name in ('s2e_pack_block_map', 's2e_grad_block_map', 's2e_label_conv_block_map', 's2e_class_table_block_map') else C.c_int)
+                          C.c_long if name in ('s2e_pack_block_map', 's2e_grad_block_map', 's2e_sngrad_block_map', 's2e_sngrad_scratch_floats', 's2e_label_conv_block_map', 's2e_class_table_block_map') else C.c_int)
         _lib = L
     return _lib
 

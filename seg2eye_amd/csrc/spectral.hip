@@ -23,6 +23,12 @@ __device__ __forceinline__ void sn_fix_add(long long* dst, float v) {
     atomicAdd((unsigned long long*)dst, (unsigned long long)__double2ll_rn((double)v * (double)SN_FIX));
 }
 __device__ __forceinline__ float sn_unfix(long long q) { return (float)((double)q * (double)SN_UNFIX); }
+// Channels-last masters (L.taps > 1: weight_orig stored [co][tap][ci]): W's MEMORY columns run (tap, ci) while the
+// module's `weight_v` buffer keeps torch's (ci, tap) order -- state_dict, replica broadcast and the reference's u, v tests see
+// no difference.  The accumulator t is internal and stays in memory order; only the three places that touch v translate.
+__device__ __forceinline__ int sn_vidx(const s2e_sn_layer& L, int col) {
+    return L.taps > 1 ? (col % L.cin) * L.taps + col / L.cin : col;
+}
 
 static constexpr int SN_BR = 32;       // rows per block, two batches of 16: a batch's row loads are all in flight together
 static constexpr int SN_BC = 1024;     // columns per block: four consecutive ones (one 16-byte load per row) per thread
@@ -120,11 +126,11 @@ __global__ __launch_bounds__(SN_NT) void sn_norm_v_kernel(const s2e_sn_layer* __
         for (int k = 0; k < SN_MAXL; ++k) q += t[k] * t[k];
         const float inv = 1.f / fmaxf(sqrtf(sn_block_sum(q, red)), eps);
 #pragma unroll
-        for (int k = 0; k < SN_MAXL; ++k) { const int j = threadIdx.x + k * SN_NT; if (j < L.cols) L.v[j] = t[k] * inv; }
+        for (int k = 0; k < SN_MAXL; ++k) { const int j = threadIdx.x + k * SN_NT; if (j < L.cols) L.v[sn_vidx(L, j)] = t[k] * inv; }
     } else {
         for (int j = threadIdx.x; j < L.cols; j += SN_NT) { const float t = sn_unfix(L.t[j]); q += t * t; }
         const float inv = 1.f / fmaxf(sqrtf(sn_block_sum(q, red)), eps);
-        for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.v[j] = sn_unfix(L.t[j]) * inv;
+        for (int j = threadIdx.x; j < L.cols; j += SN_NT) L.v[sn_vidx(L, j)] = sn_unfix(L.t[j]) * inv;
     }
     // s is accumulated (atomics) by the next launch: clear it here instead of a separate zero-fill launch per iteration
     for (int i = threadIdx.x; i < L.rows; i += SN_NT) L.s[i] = 0;
@@ -140,7 +146,9 @@ __global__ __launch_bounds__(256) void sn_gemv_kernel(const s2e_sn_layer* __rest
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if ((L.cols & 3) == 0 && ((uintptr_t)L.w & 15) == 0 && ((uintptr_t)L.v & 15) == 0) {
         const int cc = min(col, L.cols - 4);                   // a thread past the matrix re-reads its last columns, weighted with zero
-        const f32x4_t v4 = *(sn_gptr4)((sn_gptr)L.v + cc);
+        f32x4_t v4;
+        if (L.taps > 1) { const int j0 = sn_vidx(L, cc); v4 = f32x4_t{L.v[j0], L.v[j0 + L.taps], L.v[j0 + 2 * L.taps], L.v[j0 + 3 * L.taps]}; }   // (cin % 4 == 0: one tap)
+        else v4 = *(sn_gptr4)((sn_gptr)L.v + cc);
         const float on = col < L.cols ? 1.f : 0.f;
         const f32x4_t vv = {v4[0] * on, v4[1] * on, v4[2] * on, v4[3] * on};
         sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + cc;
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void sn_gemv_kernel(const s2e_sn_layer* __rest
         for (int r = 0; r < SN_BR; ++r) {
             float q = 0.f;
             if (r < nr)
-                for (int j = 0; j < 4; ++j) if (col + j < L.cols) q += wp[(size_t)r * L.cols + j] * L.v[col + j];
+                for (int j = 0; j < 4; ++j) if (col + j < L.cols) q += wp[(size_t)r * L.cols + j] * L.v[sn_vidx(L, col + j)];
             q = wave_sum(q);
             if (lane == 0) red[r][wave] = q;
         }
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void sn_gemv_chain_kernel(const s2e_sn_layer* 
     for (int j = 0; j < 4; ++j) vv[j] = col + j < L.cols ? sn_unfix(tp[col + j]) * inv : 0.f;
     if (row0 == 0) {                                         // v = t / max(|t|, eps): the module's buffer, written once per column
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (col + j < L.cols) L.v[col + j] = vv[j];
+        for (int j = 0; j < 4; ++j) if (col + j < L.cols) L.v[sn_vidx(L, col + j)] = vv[j];
     }
     const bool vec = (L.cols & 3) == 0 && ((uintptr_t)L.w & 15) == 0;
     const int cc = vec ? min(col, L.cols - 4) : col;         // a thread past the matrix re-reads its last columns, weighted with zero (vv = 0)
@@ -400,6 +408,60 @@ __device__ __forceinline__ void pack_tr_block(const float* __restrict__ w, T* __
     }
 }
 
+// forward pack from a CHANNELS-LAST source w[co][tap][ci] (cin_pad == cin, cin % 8 == 0): the source row IS the packed row, so the
+// pack is a streaming convert of the (rows_pad x kpad) output: a thread owns 8 consecutive columns (two 16-byte loads, one
+// 16/32-byte store), a block 2048 consecutive elements of the flattened output; padding rows / the K tail are written as zeros.
+static constexpr int PACK_CL_ELEMS = 2048;
+template <typename T>
+__device__ __forceinline__ void pack_fwd_cl_block(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
+                                                  int cout, int K, int rows_pad, int kpad, int bx) {
+    const long idx = (long)bx * PACK_CL_ELEMS + 8 * threadIdx.x;
+    if (idx >= (long)rows_pad * kpad) return;
+    const int row = (int)(idx / kpad), col = (int)(idx - (long)row * kpad);      // (kpad % 8 == 0: the 8 columns share a row)
+    const float inv = sigma ? 1.f / *sigma : 1.f;
+    float f[8];
+    if (row < cout && col < K) {                                                  // (K % 8 == 0: all 8 real or all 8 padding)
+        const f32x4_t a = *(const f32x4_t*)(w + (size_t)row * K + col), b = *(const f32x4_t*)(w + (size_t)row * K + col + 4);
+        f[0] = a[0] * inv; f[1] = a[1] * inv; f[2] = a[2] * inv; f[3] = a[3] * inv;
+        f[4] = b[0] * inv; f[5] = b[1] * inv; f[6] = b[2] * inv; f[7] = b[3] * inv;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.f;
+    }
+    if constexpr (std::is_same<T, float>::value) {
+        *(u32x4_t*)(out + idx) = pack16<float>(f);
+        *(u32x4_t*)(out + idx + 4) = pack16<float>(f + 4);
+    } else {
+        *(u32x4_t*)(out + idx) = pack16<bf16_t>(f);
+    }
+}
+
+// transposed pack from a CHANNELS-LAST source w[co][tap][ci] (cin_pad == cin): one block = 64 co x 64 ci of ONE tap, a plain
+// tile transpose -- rows of 64 consecutive ci in, rows of 64 consecutive co out.  by = tap * ceil(rows_pad / 64) + ci chunk.
+template <typename T>
+__device__ __forceinline__ void pack_tr_cl_block(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
+                                                 int cout, int cin, int taps, int rows_pad, int kpad, int bx, int by, float* lds) {
+    // lds: [64 co][65]
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gyc = (rows_pad + 63) / 64;
+    const int tap = by / gyc, ci0 = (by - tap * gyc) * 64, co0 = bx * 64;
+    const float inv = sigma ? 1.f / *sigma : 1.f;
+    for (int m = q; m < 64; m += 4) {
+        const int co = co0 + m, ci = ci0 + lane;
+        lds[m * 65 + lane] = (co < cout && ci < cin) ? w[((size_t)co * taps + tap) * cin + ci] * inv : 0.f;
+    }
+    __syncthreads();
+    if (co0 + lane < cout)
+        for (int cil = q; cil < 64; cil += 4)
+            if (ci0 + cil < rows_pad) out[(size_t)(ci0 + cil) * kpad + (size_t)tap * cout + co0 + lane] = (T)lds[lane * 65 + cil];
+    if (bx == 0 && tap == 0) {                               // K tail [taps*cout, kpad) of this block's rows
+        const int tail = kpad - taps * cout;
+        for (int cil = q; cil < 64; cil += 4)
+            if (ci0 + cil < rows_pad)
+                for (int k = lane; k < tail; k += 64) out[(size_t)(ci0 + cil) * kpad + taps * cout + k] = (T)0.f;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
                                                        int cout, int cin, int taps, int cin_pad, int kpad) {
@@ -412,6 +474,17 @@ __global__ __launch_bounds__(256) void pack_tr_kernel(const float* __restrict__ 
     extern __shared__ float lds[];
     pack_tr_block<T>(w, out, sigma, cout, cin, taps, rows_pad, kpad, blockIdx.x, blockIdx.y, lds);
 }
+template <typename T>
+__global__ __launch_bounds__(256) void pack_fwd_cl_kernel(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
+                                                          int cout, int K, int rows_pad, int kpad) {
+    pack_fwd_cl_block<T>(w, out, sigma, cout, K, rows_pad, kpad, blockIdx.x);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pack_tr_cl_kernel(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
+                                                         int cout, int cin, int taps, int rows_pad, int kpad) {
+    extern __shared__ float lds[];
+    pack_tr_cl_block<T>(w, out, sigma, cout, cin, taps, rows_pad, kpad, blockIdx.x, blockIdx.y, lds);
+}
 // every conv of a network in one launch: block_map = {job, bx, by} per block (s2e_pack_block_map)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batch_kernel(const s2e_pack_job* __restrict__ jobs, const int* __restrict__ block_map,
@@ -420,7 +493,15 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const s2e_pack_job* __r
     const int* bm = block_map + 3 * blockIdx.x;
     const s2e_pack_job J = jobs[bm[0]];
     const float* sg = J.sigma_index >= 0 ? sigma_base + J.sigma_index : nullptr;
-    if (!J.transposed) {
+    if (J.transposed == 2) {                                 // channels-last source (s2e_pack_job: transposed bit 1), forward
+        const int kpad = (J.taps * J.cin + (dtype == S2E_BF16 ? 63 : 31)) / (dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
+        const int rows = J.cout <= 32 ? 32 : (J.cout <= 64 ? 64 : (J.cout + 127) / 128 * 128);
+        pack_fwd_cl_block<T>(J.w, (T*)J.out, sg, J.cout, J.taps * J.cin, rows, kpad, bm[1]);
+    } else if (J.transposed & 2) {                           // ... transposed
+        const int kpad = (J.taps * J.cout + (dtype == S2E_BF16 ? 63 : 31)) / (dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
+        const int rows = J.cin_pad <= 32 ? 32 : (J.cin_pad <= 64 ? 64 : (J.cin_pad + 127) / 128 * 128);
+        pack_tr_cl_block<T>(J.w, (T*)J.out, sg, J.cout, J.cin, J.taps, rows, kpad, bm[1], bm[2], lds);
+    } else if (!J.transposed) {
         const int kpad = (J.taps * J.cin_pad + (dtype == S2E_BF16 ? 63 : 31)) / (dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
         pack_fwd_block<T>(J.w, (T*)J.out, sg, J.cout, J.cin, J.taps, J.cin_pad, kpad, bm[1], bm[2], lds);
     } else {
@@ -437,9 +518,26 @@ extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, con
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_pack_conv_weight: bad dtype %d", dtype);
     const int taps = kh * kw;
     if (taps > 64) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_pack_conv_weight: kernel %dx%d too large", kh, kw);
-    const int rows = s2e_conv_cout_pad(transposed ? cin_pad : cout);
-    const int kpad = s2e_conv_k_pad(dtype, taps * (transposed ? cout : cin_pad));
+    const bool tr = (transposed & 1) != 0;
+    const int rows = s2e_conv_cout_pad(tr ? cin_pad : cout);
+    const int kpad = s2e_conv_k_pad(dtype, taps * (tr ? cout : cin_pad));
     hipStream_t st = (hipStream_t)stream;
+    if (transposed & 2) {                                    // source in channels-last order w[co][tap][ci]
+        if (cin_pad != cin) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_pack_conv_weight: a channels-last source needs cin_pad == cin");
+        if (cin % 8) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_pack_conv_weight: a channels-last source needs cin %% 8 == 0");
+        if (!tr) {                                           // forward: the source row IS the packed row: a streaming convert
+            const int grid = ceil_div((long)rows * kpad, PACK_CL_ELEMS);
+            if (dtype == S2E_BF16) pack_fwd_cl_kernel<bf16_t><<<grid, 256, 0, st>>>(w, (bf16_t*)packed, sigma, cout, taps * cin, rows, kpad);
+            else pack_fwd_cl_kernel<float><<<grid, 256, 0, st>>>(w, (float*)packed, sigma, cout, taps * cin, rows, kpad);
+        } else {
+            dim3 grid(ceil_div(cout, 64), taps * ceil_div(rows, 64));
+            const size_t lds = (size_t)64 * 65 * sizeof(float);
+            if (dtype == S2E_BF16) pack_tr_cl_kernel<bf16_t><<<grid, 256, lds, st>>>(w, (bf16_t*)packed, sigma, cout, cin, taps, rows, kpad);
+            else pack_tr_cl_kernel<float><<<grid, 256, lds, st>>>(w, (float*)packed, sigma, cout, cin, taps, rows, kpad);
+        }
+        S2E_CHECK_LAUNCH("pack kernels (channels-last source)");
+        return S2E_OK;
+    }
     if (!transposed) {
         dim3 grid(rows / 4, ceil_div(cin_pad, 64));
         const size_t lds = (size_t)4 * 64 * taps * sizeof(float);
@@ -456,14 +554,15 @@ extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, con
 }
 
 extern "C" long s2e_pack_block_map(int dtype, const s2e_pack_job* jobs_host, int n_jobs, int* block_map_host) {
-    (void)dtype;
     if (!jobs_host || n_jobs < 0) return S2E_ERR_ARG;
     long nb = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const s2e_pack_job& J = jobs_host[j];
         int gx, gy;
-        if (!J.transposed) { gx = s2e_conv_cout_pad(J.cout) / 4; gy = ceil_div(J.cin_pad, 64); }
-        else               { gx = ceil_div(J.cout, 64);      gy = ceil_div(s2e_conv_cout_pad(J.cin_pad), 8); }
+        if (J.transposed == 2)  { gx = ceil_div((long)s2e_conv_cout_pad(J.cout) * s2e_conv_k_pad(dtype, J.taps * J.cin), PACK_CL_ELEMS); gy = 1; }
+        else if (J.transposed & 2) { gx = ceil_div(J.cout, 64);   gy = J.taps * ceil_div(s2e_conv_cout_pad(J.cin_pad), 64); }
+        else if (!J.transposed) { gx = s2e_conv_cout_pad(J.cout) / 4; gy = ceil_div(J.cin_pad, 64); }
+        else                    { gx = ceil_div(J.cout, 64);      gy = ceil_div(s2e_conv_cout_pad(J.cin_pad), 8); }
         if (block_map_host)
             for (int y = 0; y < gy; ++y)
                 for (int x = 0; x < gx; ++x) {
@@ -480,7 +579,8 @@ extern "C" int s2e_pack_conv_weights(int dtype, const s2e_pack_job* jobs, const 
     if (!jobs || !block_map || n_blocks <= 0 || max_taps <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_pack_conv_weights: bad argument");
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_pack_conv_weights: bad dtype %d", dtype);
     if (max_taps > 16) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_pack_conv_weights: more than 16 taps");
-    const size_t lds = (size_t)64 * (8 * max_taps + 1) * sizeof(float);
+    size_t lds = (size_t)64 * (8 * max_taps + 1) * sizeof(float);
+    if (lds < (size_t)64 * 65 * sizeof(float)) lds = (size_t)64 * 65 * sizeof(float);      // (the channels-last tile transpose)
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16) pack_batch_kernel<bf16_t><<<n_blocks, 256, lds, st>>>(jobs, block_map, sigma_base, dtype);
     else pack_batch_kernel<float><<<n_blocks, 256, lds, st>>>(jobs, block_map, sigma_base, dtype);
@@ -723,5 +823,98 @@ extern "C" int s2e_sn_weight_grad(const float* gw_packed, const float* w_orig, c
         sn_grad_apply_kernel<<<grid, 256, 0, st>>>(gw_packed, u, v, sigma, dot_ws, gw_orig, cout, cin, taps, cin_pad, accumulate);
     }
     S2E_CHECK_LAUNCH("sn_weight_grad kernels");
+    return S2E_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ the same gradient IN PLACE (channels-last masters)
+// With the fp32 masters stored in the packed order [co][tap][ci] the weight-gradient kernels accumulate straight into the
+// parameter's slice of the gradient arena; what is left of the chain rule above is element-wise and in place:
+//     g[i] = g[i] / sigma - (<g, W_orig> / sigma^2) u[row] v[col]           (row = i / K, col = i % K, K = taps * cin)
+// Launch 1: every block stores the partial dot product of its 16 Ki-element chunk (plain store).  Launch 2: every block of a
+// layer first adds that layer's partials in the same fixed order (deterministic: no float atomics), then rewrites its chunk.
+// 16 bytes of traffic per element, all of it contiguous (the OIHW re-layout moved 20, half of it in 4-byte strides).
+static constexpr int SNI_CHUNK = 16384;     // elements per block: 256 threads x 16 float4
+__global__ __launch_bounds__(256) void sn_grad_inplace_dot_kernel(const s2e_sngrad_job* __restrict__ jobs, const int* __restrict__ block_map,
+                                                                  float* __restrict__ partials) {
+    __shared__ float red[4];
+    const int* bm = block_map + 2 * blockIdx.x;
+    const s2e_sngrad_job J = jobs[bm[0]];
+    const long total = (long)J.rows * J.cin * J.taps;
+    const long i0 = (long)bm[1] * SNI_CHUNK, i1 = i0 + SNI_CHUNK < total ? i0 + SNI_CHUNK : total;
+    float q = 0.f;
+    for (long i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {         // (total % 4 == 0: cin % 8 == 0)
+        const f32x4_t a = *(const f32x4_t*)(J.g + i), b = *(const f32x4_t*)(J.w + i);
+        q += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+    }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[J.part0 + bm[1]] = (red[0] + red[1]) + (red[2] + red[3]);
+    // the layer's first block also lays v out in W's MEMORY order for the second launch (one 16-byte load per four columns there
+    // instead of four strided ones)
+    if (bm[1] == 0) {
+        const int K = J.cin * J.taps;
+        float* vm = partials + J.vmem0;
+        for (int col = threadIdx.x; col < K; col += 256) { const int tap = col / J.cin, ci = col - tap * J.cin; vm[col] = J.v[(size_t)ci * J.taps + tap]; }
+    }
+}
+__global__ __launch_bounds__(256) void sn_grad_inplace_apply_kernel(const s2e_sngrad_job* __restrict__ jobs, const int* __restrict__ block_map,
+                                                                    const float* __restrict__ partials) {
+    __shared__ float red[4];
+    const int* bm = block_map + 2 * blockIdx.x;
+    const s2e_sngrad_job J = jobs[bm[0]];
+    float q = 0.f;
+    for (int k = threadIdx.x; k < J.nparts; k += 256) q += partials[J.part0 + k];
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    const float dot = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.f / *J.sigma;
+    const float c = dot * inv * inv;
+    const int K = J.cin * J.taps;
+    const float* vm = partials + J.vmem0;
+    const long total = (long)J.rows * K;
+    const long i0 = (long)bm[1] * SNI_CHUNK, i1 = i0 + SNI_CHUNK < total ? i0 + SNI_CHUNK : total;
+    long i = i0 + 4 * threadIdx.x;
+    int row = (int)(i / K), col = (int)(i - (long)row * K);          // (one 64-bit division per thread; then stepped)
+    for (; i < i1; i += 1024, col += 1024) {
+        while (col >= K) { col -= K; ++row; }
+        const float cu = c * J.u[row];
+        const f32x4_t vv = *(const f32x4_t*)(vm + col);             // (v in memory order: written by the first launch)
+        f32x4_t a = *(const f32x4_t*)(J.g + i);
+        a[0] = a[0] * inv - cu * vv[0];
+        a[1] = a[1] * inv - cu * vv[1];
+        a[2] = a[2] * inv - cu * vv[2];
+        a[3] = a[3] * inv - cu * vv[3];
+        *(f32x4_t*)(J.g + i) = a;
+    }
+}
+extern "C" long s2e_sngrad_block_map(s2e_sngrad_job* jobs_host, int n_jobs, int* block_map_host) {
+    if (!jobs_host || n_jobs < 0) return S2E_ERR_ARG;
+    long nb = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        s2e_sngrad_job& J = jobs_host[j];
+        const long total = (long)J.rows * J.cin * J.taps;
+        const int chunks = (int)((total + SNI_CHUNK - 1) / SNI_CHUNK);
+        J.part0 = (int)nb; J.nparts = chunks;                // (one partial per block: the block index IS the slot)
+        for (int c = 0; c < chunks; ++c, ++nb)
+            if (block_map_host) { block_map_host[2 * nb] = j; block_map_host[2 * nb + 1] = c; }
+    }
+    long off = (nb + 3) / 4 * 4;                             // behind the partials: every layer's v in memory order
+    for (int j = 0; j < n_jobs; ++j) { jobs_host[j].vmem0 = (int)off; off += (long)jobs_host[j].cin * jobs_host[j].taps; }
+    return nb;
+}
+extern "C" long s2e_sngrad_scratch_floats(const s2e_sngrad_job* jobs_host, int n_jobs) {
+    if (!jobs_host || n_jobs <= 0) return 0;
+    const s2e_sngrad_job& J = jobs_host[n_jobs - 1];        // (after s2e_sngrad_block_map: the last layer's v region ends the scratch)
+    return (long)J.vmem0 + (long)J.cin * J.taps;
+}
+extern "C" int s2e_sn_grads_inplace(const s2e_sngrad_job* jobs, const int* block_map, int n_blocks, float* partials, void* stream) {
+    if (!jobs || !block_map || n_blocks <= 0 || !partials) S2E_FAIL(S2E_ERR_ARG, "s2e_sn_grads_inplace: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    sn_grad_inplace_dot_kernel<<<n_blocks, 256, 0, st>>>(jobs, block_map, partials);
+    sn_grad_inplace_apply_kernel<<<n_blocks, 256, 0, st>>>(jobs, block_map, partials);
+    S2E_CHECK_LAUNCH("in-place spectral-norm gradient kernels");
     return S2E_OK;
 }

@@ -219,6 +219,7 @@ class GradSink:
     def __init__(self):
         self.jobs = []
         self.c8 = []               # deferred 8-channel weight gradients (mlp_shared): (onehot, d actv, dw, db, ncls)
+        self.inplace = []          # deferred in-place spectral-norm chain rules (channels-last masters): push_inplace
         self.tables = {}
         self.keepalive = None
         self.keep_c8 = None
@@ -231,6 +232,43 @@ class GradSink:
             return False
         pool.sink.jobs.append((dwp, dst, w_orig, u, v, sigma, int(cout), int(cin), int(taps), int(cin_pad)))
         return True
+
+    @staticmethod
+    def push_inplace(g_rows, weight, u, v, sigma, rows, cin, taps):
+        """g_rows (rows, taps*cin): a spectral-normed conv's weight gradient, accumulated by the wgrad kernel straight into the
+        parameter's channels-last arena slice; weight: weight_orig (same layout).  Applies dW_orig = g/sigma - (<g, W>/sigma^2) u v^T
+        in place -- at the next flush of the step's sink (all layers: one launch pair), or right away outside a trainer step."""
+        job = (g_rows, _cl_rows(weight), u, v, sigma, int(rows), int(cin), int(taps))
+        pool = ZeroPool.active()
+        if pool is not None:
+            pool.sink.inplace.append(job)
+        else:
+            GradSink._run_inplace([job], None)
+
+    @staticmethod
+    def _run_inplace(jobs, cache):
+        key = tuple(tuple(t.data_ptr() for t in j[:5]) + j[5:] for j in jobs)
+        ent = cache.get(('inplace', key)) if cache is not None else None
+        if ent is None:
+            dev = jobs[0][0].device
+            arr = (L.SnGradJob * len(jobs))()
+            for i, (g, w, u, v, sg, rows, cin, taps) in enumerate(jobs):
+                a = arr[i]
+                a.g, a.w, a.u, a.v, a.sigma = g.data_ptr(), w.data_ptr(), u.data_ptr(), v.data_ptr(), sg.data_ptr()
+                a.rows, a.cin, a.taps = rows, cin, taps
+            nb = L.lib().s2e_sngrad_block_map(C.byref(arr), len(jobs), None)
+            bm = np.zeros(2 * nb, dtype=np.int32)
+            L.lib().s2e_sngrad_block_map(C.byref(arr), len(jobs), bm.ctypes.data)       # (also fills part0 / nparts of the jobs)
+            jobs_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+            nscratch = int(L.lib().s2e_sngrad_scratch_floats(C.byref(arr), len(jobs)))
+            ent = (jobs_dev, torch.from_numpy(bm).to(dev), int(nb), torch.empty(nscratch, dtype=torch.float32, device=dev))
+            if cache is not None:
+                cache[('inplace', key)] = ent
+        jobs_dev, map_dev, nb, partials = ent
+        nbytes = float(sum(j[0].numel() * 16 for j in jobs))          # g and W read for the dot product, g read and written
+        LaunchProfiler.run('weight_grad_relayout', 0.0, lambda: L.check(
+            L.lib().s2e_sn_grads_inplace(jobs_dev.data_ptr(), map_dev.data_ptr(), nb, partials.data_ptr(), _stream()),
+            's2e_sn_grads_inplace'), nbytes=nbytes)
 
     @staticmethod
     def push_c8(oh, dactv, dw, db, ncls):
@@ -271,6 +309,10 @@ class GradSink:
     def flush(self):
         if self.c8:
             self._flush_c8()
+        if self.inplace:
+            jobs, self.inplace = self.inplace, []
+            GradSink._run_inplace(jobs, self.tables)
+            self.keep_inplace = jobs                         # the tensors stay referenced until the next flush
         if not self.jobs:
             return
         jobs, self.jobs = self.jobs, []
@@ -314,15 +356,18 @@ def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False, sigma=None):
     """OIHW fp32 -> MFMA B-operand matrix in the compute dtype; divided by the device scalar `sigma`
     (spectral norm) on the fly when given."""
     w = w_oihw.detach()
-    if w.dtype != torch.float32 or not w.is_contiguous():
-        w = w.float().contiguous()
-    _need(w, sigma)
     cout, cin, kh, kw = w.shape
     cin_pad = cin if cin_pad is None else cin_pad
+    # a weight stored channels-last (optim.FlatAdam) is packed from where it lies: rows in, rows out
+    cl = w.dtype == torch.float32 and not w.is_contiguous() and _cl_dense(w) and cin_pad == cin
+    if not cl and (w.dtype != torch.float32 or not w.is_contiguous()):
+        w = w.float().contiguous()
+    _need(_cl_rows(w) if cl else w, sigma)
+    transposed = int(bool(transposed)) | (2 if cl else 0)
     dt = L.S2E_BF16 if dtype == torch.bfloat16 else L.S2E_F32
     lib = L.lib()
-    rows = lib.s2e_conv_cout_pad(cin_pad if transposed else cout)
-    kpad = lib.s2e_conv_k_pad(dt, kh * kw * (cout if transposed else cin_pad))
+    rows = lib.s2e_conv_cout_pad(cin_pad if (transposed & 1) else cout)
+    kpad = lib.s2e_conv_k_pad(dt, kh * kw * (cout if (transposed & 1) else cin_pad))
     out = torch.empty(rows, kpad, dtype=dtype, device=w.device)
     L.check(lib.s2e_pack_conv_weight(dt, _p(w), _p(out), _p(sigma), cout, cin, kh, kw, cin_pad, int(transposed), _stream()),
             's2e_pack_conv_weight')
@@ -372,16 +417,22 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     return y
 
 
-def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False, dbias_out=None):
+def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False, dbias_out=None, dw_out=None):
     """-> (dw, db): dw (Cout, KH*KW*Cin) fp32 in packed order; db (Cout) fp32 or None.  Both live in one
     zero-filled buffer (ZeroPool scratch when the bias gradient is not returned).  dbias_out: an fp32 (Cout) tensor to ACCUMULATE the bias
-    gradient into instead (e.g. the parameter's slice of the gradient arena); then db is None."""
-    _need(x, gy, dbias_out)
+    gradient into instead (e.g. the parameter's slice of the gradient arena); then db is None.
+    dw_out: an fp32 (Cout, KH*KW*Cin) row-major tensor to ACCUMULATE the weight gradient into instead of a fresh zeroed buffer
+    (the gradient of a parameter stored channels-last: _cl_rows(p.grad)); returned as dw."""
+    _need(x, gy, dbias_out, dw_out)
     n, hi, wi, cin = x.shape
     _, ho, wo, cout = gy.shape
     k = kh * kw * cin
     own_b = want_bias and dbias_out is None
-    if own_b:                                            # db goes back to autograd (may become a .grad): never pooled
+    if dw_out is not None:
+        if tuple(dw_out.shape) != (cout, k) or dw_out.dtype != torch.float32 or not dw_out.is_contiguous():
+            raise ValueError('conv2d_wgrad_raw: dw_out must be a contiguous fp32 (%d, %d) tensor' % (cout, k))
+        dw, db = dw_out, (torch.zeros(cout, dtype=torch.float32, device=x.device) if own_b else None)
+    elif own_b:                                          # db goes back to autograd (may become a .grad): never pooled
         buf = torch.zeros(cout * k + cout, dtype=torch.float32, device=x.device)
         dw, db = buf[:cout * k].view(cout, k), buf[cout * k:]
     else:
@@ -399,6 +450,18 @@ def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=Fals
     return dw, db
 
 
+def _cl_dense(t):
+    """A 4-D tensor whose memory is one dense block in [d0][d2][d3][d1] order: a conv weight stored channels-last
+    (optim.FlatAdam), i.e. already in the packed order of the MFMA kernels."""
+    return t is not None and t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _cl_rows(t):
+    """(Cout, KH*KW*Cin) row-major view of a channels-last conv weight's (or gradient's) memory."""
+    co, ci, kh, kw = t.shape
+    return t.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+
+
 def _grad_dst(p):
     """The tensor a backward kernel may accumulate this parameter's gradient into directly: its .grad when
     that already exists as a contiguous fp32 tensor (optim.FlatAdam keeps .grad as a view of the gradient
@@ -406,20 +469,25 @@ def _grad_dst(p):
     if p is None or not p.is_leaf:                       # (a non-leaf's .grad is never an arena view; asking for it warns)
         return None
     g = getattr(p, 'grad', None)
-    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
+    if g is None or g.dtype != torch.float32 or not (g.is_contiguous() or _cl_dense(g)) or not g.is_cuda:
         return None
     return g
 
 
 def _adjacent(a, b):
-    """b starts exactly where a ends in the same storage (both contiguous)."""
-    return (a is not None and b is not None and a.is_contiguous() and b.is_contiguous()
+    """b starts exactly where a ends in the same storage (both dense: contiguous, or channels-last conv weights)."""
+    return (a is not None and b is not None and (a.is_contiguous() or _cl_dense(a)) and (b.is_contiguous() or _cl_dense(b))
+            and a.is_contiguous() == b.is_contiguous()
             and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
             and b.storage_offset() == a.storage_offset() + a.numel())
 
 
 def _span2(a, shape):
-    """View of `a`'s storage starting at a, with `shape` (covers a and the tensor laid out right after it)."""
+    """View of `a`'s storage starting at a, with `shape` (covers a and the tensor laid out right after it, which is stacked
+    along dimension 0); in a's memory order -- row-major, or channels-last for a conv weight stored that way."""
+    if len(shape) == 4 and not a.is_contiguous() and _cl_dense(a):
+        co, ci, kh, kw = shape
+        return a.detach().as_strided(shape, (kh * kw * ci, 1, kw * ci, ci))
     strides, st = [], 1
     for d in reversed(shape):
         strides.append(st)
@@ -784,10 +852,19 @@ class Conv2dFn(torch.autograd.Function):
             gx = conv2d_raw(g, wpt, None, None, x if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
                             True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
         want_b = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        wdst = ctx.wdst
+        if ctx.needs_input_grad[1] and wdst is not None and cx == cin and _cl_dense(wdst):
+            # the parameter's gradient lies in the packed order (channels-last arena, or any 1x1 conv): the kernel accumulates
+            # straight into it; spectral norm's chain rule is then applied in place (queued: one launch pair per step)
+            _, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, ctx.bdst if want_b else None, dw_out=_cl_rows(wdst))
+            if sigma is not None:
+                GradSink.push_inplace(_cl_rows(wdst), weight, u, v, sigma, cout, cin, kh * kw)
+        elif ctx.needs_input_grad[1]:
             bdst = ctx.bdst if want_b else None
             dwp, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, bdst)
-            wdst = ctx.wdst
+            if wdst is not None and not wdst.is_contiguous():
+                wdst = None                                  # (a channels-last .grad fed a channel-padded input: through autograd)
+            w_oihw = weight.detach() if weight.is_contiguous() else weight.detach().contiguous()
             if sigma is None:
                 if wdst is not None:
                     unpack_weight_grad_into(dwp, wdst, cout, cin, kh, kw, cx)
@@ -795,10 +872,10 @@ class Conv2dFn(torch.autograd.Function):
                     gw = _unpack_dw(dwp, cout, cin, kh, kw, cx)
             else:
                 acc = wdst is not None
-                if not (acc and GradSink.push(dwp, wdst, cout, cin, kh * kw, cx, weight.detach(), u, v, sigma)):
+                if not (acc and GradSink.push(dwp, wdst, cout, cin, kh * kw, cx, w_oihw, u, v, sigma)):
                     out = wdst if acc else torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
                     dot = ZeroPool.take(1, torch.float32, x.device)
-                    L.check(L.lib().s2e_sn_weight_grad(_p(dwp), _p(weight.detach()), _p(u), _p(v), _p(sigma), _p(dot), _p(out),
+                    L.check(L.lib().s2e_sn_weight_grad(_p(dwp), _p(w_oihw), _p(u), _p(v), _p(sigma), _p(dot), _p(out),
                                                        cout, cin, kh, kw, cx, int(acc), _stream()), 's2e_sn_weight_grad')
                     gw = None if acc else out
         elif want_b:
@@ -914,7 +991,9 @@ def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
     c2, nh = w_gb.shape[0], w_gb.shape[1]
     ncls = w_sh.shape[1]
     gw_g = gb_g = gw_b = gb_b = gw_sh = gb_sh = None
-    if ctx.gb_dst is not None:
+    if ctx.gb_dst is not None and _cl_dense(ctx.gb_dst[0]):       # channels-last arena: straight into [dW_gamma; dW_beta]
+        conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1], dw_out=_cl_rows(ctx.gb_dst[0]))
+    elif ctx.gb_dst is not None:
         dwp, _ = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1])
         unpack_weight_grad_into(dwp, ctx.gb_dst[0], c2, nh, 3, 3, nh)
     else:

@@ -2,16 +2,35 @@
 so the optimizer step is a single HIP launch (s2e_adam_flat) and the data-parallel gradient exchange is
 an all-reduce over contiguous slices with no packing.  Mirrors torch.optim.Adam as the reference
 configures it (models/pix2pix_model.py:92-110): TTUR betas (0, 0.9), eps 1e-8, weight_decay 0."""
+import os
+
 import torch
 
 from . import ops
 
 _ALIGN = 4          # elements; keeps every parameter 16-byte aligned inside the arena
+_ALIGN_CL = 64      # elements; channels-last conv weights start on 256-byte boundaries (see FlatAdam.__init__)
+# S2E_WEIGHTS_CL=0: every parameter keeps torch's (Cout, Cin, KH, KW) memory order in the arenas (A/B switch, DESIGN 3.4b)
+_WEIGHTS_CL = os.environ.get('S2E_WEIGHTS_CL', '1') != '0'
+
+
+def _arena_view(flat, off, p, cl):
+    """The parameter-shaped view of its arena slice: plain, or -- conv weights, cl -- the (Cout, Cin, KH, KW) view of a slice
+    stored [Cout][KH][KW][Cin] (torch's channels_last): same values, same logical shape, other strides."""
+    t = flat[off:off + p.numel()]
+    if cl:
+        co, ci, kh, kw = p.shape
+        return t.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+    return t.view(p.shape)
 
 
 class FlatAdam:
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, never_updated=()):
-        """never_updated: parameters that are in the optimizer but never receive a gradient (netE.fc_var: `logvar` enters no
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, never_updated=(), channels_last=None):
+        """channels_last (default: on, S2E_WEIGHTS_CL): a conv weight whose input-channel count is a multiple of 8 is stored
+        [Cout][KH][KW][Cin] in the arenas -- the order the MFMA kernels' packed matrices and weight gradients use -- and exposed
+        as a (Cout, Cin, KH, KW) view: state_dict values, shapes and every element-wise use are unchanged, while the
+        weight-gradient kernels accumulate straight into `.grad` and the packs read rows instead of gathering.
+        never_updated: parameters that are in the optimizer but never receive a gradient (netE.fc_var: `logvar` enters no
         loss, pix2pix_model.py:307-314).  torch.optim.Adam SKIPS a parameter whose .grad is None -- no moment update and, what
         matters, no weight decay -- so they are laid out at the END of the arenas and the Adam launch stops before them."""
         skip = {id(p) for p in never_updated}
@@ -28,10 +47,17 @@ class FlatAdam:
         if not plist:
             raise ValueError('FlatAdam got an empty parameter list')
         dev = plist[0].device
+        use_cl = _WEIGHTS_CL if channels_last is None else bool(channels_last)
+        self.cl = [bool(use_cl and p.dim() == 4 and p.shape[1] % 8 == 0 and p.is_cuda) for p in plist]
         self.offsets, n = [], 0
-        for p in plist:
+        for p, cl in zip(plist, self.cl):
             if p.dtype != torch.float32:
                 raise TypeError('FlatAdam keeps fp32 master parameters')
+            if cl and n % _ALIGN_CL:
+                # a channels-last weight starts on a 256-byte boundary: its gradient is the target of the weight-gradient
+                # kernels' 128-byte row-segment atomics, which cost per cache line touched (measured +25 % on the 16-byte-aligned
+                # slices).  Stacked weights ([W_gamma; W_beta]: sizes are multiples of 64 elements) stay back to back.
+                n = (n + _ALIGN_CL - 1) // _ALIGN_CL * _ALIGN_CL
             self.offsets.append(n)
             n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = n
@@ -41,11 +67,11 @@ class FlatAdam:
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         with torch.no_grad():
-            for p, off in zip(plist, self.offsets):
-                view = self.flat_p[off:off + p.numel()].view(p.shape)
+            for p, off, cl in zip(plist, self.offsets, self.cl):
+                view = _arena_view(self.flat_p, off, p, cl)
                 view.copy_(p.data)
                 p.data = view                                           # parameter now aliases the arena
-                p.grad = self.flat_g[off:off + p.numel()].view(p.shape)  # autograd accumulates in place
+                p.grad = _arena_view(self.flat_g, off, p, cl)           # autograd accumulates in place
         self.params = plist
         self.betas = (float(betas[0]), float(betas[1]))                   # (0, 0.9) must be floats
         self.eps = float(eps)
@@ -61,10 +87,10 @@ class FlatAdam:
 
     def rebind_grads(self):
         """Re-attach .grad views if something replaced them (e.g. a zero_grad(set_to_none=True))."""
-        for p, off in zip(self.params, self.offsets):
+        for p, off, cl in zip(self.params, self.offsets, self.cl):
             g = p.grad
-            want = self.flat_g[off:off + p.numel()].view(p.shape)
-            if g is None or g.data_ptr() != want.data_ptr():
+            want = _arena_view(self.flat_g, off, p, cl)
+            if g is None or g.data_ptr() != want.data_ptr() or g.stride() != want.stride():
                 if g is not None:
                     want.copy_(g)
                 p.grad = want
@@ -84,10 +110,18 @@ class FlatAdam:
         k = self.numel_active
         ops.adam_flat_step(self.flat_p[:k], self.flat_g[:k], self.flat_m[:k], self.flat_v[:k], self.hyper)
 
+    def _layout(self):
+        """What the flat moment arrays mean: element i belongs to which parameter, in which memory order."""
+        return {'offsets': list(self.offsets), 'channels_last': [bool(c) for c in self.cl]}
+
     def state_dict(self):
-        return {'step': self.step_count, 'm': self.flat_m, 'v': self.flat_v, 'lr': self.param_groups[0]['lr']}
+        return {'step': self.step_count, 'm': self.flat_m, 'v': self.flat_v, 'lr': self.param_groups[0]['lr'], 'layout': self._layout()}
 
     def load_state_dict(self, sd):
+        lay = sd.get('layout')
+        if (lay is None and any(self.cl)) or (lay is not None and lay != self._layout()):
+            raise ValueError('FlatAdam.load_state_dict: the saved moments were laid out for another arena (parameter order / '
+                             'channels-last weights differ); they cannot be loaded element by element')
         self.step_count = int(sd['step'])
         self.flat_m.copy_(sd['m'])
         self.flat_v.copy_(sd['v'])

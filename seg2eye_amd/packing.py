@@ -37,7 +37,7 @@ class PackPlan:
 
     @staticmethod
     def key(w, dtype, cin_pad, transposed):
-        return (w.data_ptr(), tuple(w.shape), dtype, int(cin_pad), bool(transposed))
+        return (w.data_ptr(), tuple(w.shape), tuple(w.stride()), dtype, int(cin_pad), bool(transposed))
 
     # ---------------------------------------------------------------- learning
     def record(self, w, dtype, cin_pad, transposed, sigma):
@@ -45,7 +45,12 @@ class PackPlan:
         if k in self.jobs:
             return
         sidx = -1 if sigma is None else int(sigma.storage_offset())
-        self.jobs[k] = dict(w=w.detach(), dtype=dtype, cin_pad=int(cin_pad), transposed=bool(transposed), sigma_index=sidx, out=None)
+        from .ops import _cl_dense
+        wd = w.detach()
+        cl = bool(wd.dtype == torch.float32 and not wd.is_contiguous() and _cl_dense(wd) and int(cin_pad) == wd.shape[1])
+        if not cl and (wd.dtype != torch.float32 or not wd.is_contiguous()):
+            return                                           # (needs a converted copy: packed one by one, ops.pack_weight)
+        self.jobs[k] = dict(w=wd, dtype=dtype, cin_pad=int(cin_pad), transposed=bool(transposed), sigma_index=sidx, out=None, cl=cl)
         self.dirty = True
 
     def lookup(self, w, dtype, cin_pad, transposed, generation=None):
@@ -80,7 +85,8 @@ class PackPlan:
                     j['out'] = torch.empty(rows, kpad, dtype=dtype, device=dev)
                 j['stale'] = True
                 arr[i].w, arr[i].out, arr[i].sigma_index = j['w'].data_ptr(), j['out'].data_ptr(), j['sigma_index']
-                arr[i].cout, arr[i].cin, arr[i].taps, arr[i].cin_pad, arr[i].transposed = cout, cin, kh * kw, j['cin_pad'], int(j['transposed'])
+                arr[i].cout, arr[i].cin, arr[i].taps, arr[i].cin_pad = cout, cin, kh * kw, j['cin_pad']
+                arr[i].transposed = int(j['transposed']) | (2 if j['cl'] else 0)      # bit 1: the source is stored channels-last
             n_fwd = sum(1 for j in jobs if not j['transposed'])
             nb_fwd = lib.s2e_pack_block_map(dt, C.byref(arr), n_fwd, None) if n_fwd else 0
             nb_all = lib.s2e_pack_block_map(dt, C.byref(arr), len(jobs), None)

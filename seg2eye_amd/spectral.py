@@ -87,6 +87,13 @@ class SpectralBank:
             table[i].s2 = self.scratch.data_ptr() + 8 * (tot + ou)
             table[i].t2 = self.scratch.data_ptr() + 8 * (tot + ov)
             table[i].rows, table[i].cols = rows[i], cols[i]
+            w = c.weight_orig
+            if w.dim() == 4 and not w.is_contiguous():
+                # a master stored channels-last (optim.FlatAdam): W's memory columns run (tap, ci); weight_v keeps torch's order
+                # and the kernels translate (s2e_sn_layer.cin / taps)
+                if not w.permute(0, 2, 3, 1).is_contiguous() or w.shape[1] % 4:
+                    raise L.Seg2EyeHipError('spectral norm: weight_orig of %s is neither contiguous nor channels-last' % (tuple(w.shape),))
+                table[i].cin, table[i].taps = w.shape[1], w.shape[2] * w.shape[3]
             for bm, (_BR, _BC) in zip(maps, shapes):
                 for r0 in range(0, rows[i], _BR):
                     for c0 in range(0, cols[i], _BC):
@@ -104,7 +111,7 @@ class SpectralBank:
             self._build()
 
     def _current_ptrs(self):
-        return tuple((c.weight_orig.data_ptr(), c.weight_u.data_ptr(), c.weight_v.data_ptr()) for c in self.convs)
+        return tuple((c.weight_orig.data_ptr(), c.weight_u.data_ptr(), c.weight_v.data_ptr(), c.weight_orig.stride()) for c in self.convs)
 
     # ------------------------------------------------------------------ per-forward
     def step(self, training, iterations=1):

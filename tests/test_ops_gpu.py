@@ -442,8 +442,9 @@ def test_adam_flat_matches_torch(wd):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('arena', [None, 'channels_last', 'torch_order'])
 @pytest.mark.parametrize('cfg', [(16, 24, 3, 1, 1), (64, 130, 4, 2, 2), (8, 8, 1, 1, 0)])
-def test_fused_spectral_norm_conv_matches_torch(cfg, dtype):
+def test_fused_spectral_norm_conv_matches_torch(cfg, arena, dtype):
     """SpectralBank (batched power iteration) + sigma-in-the-pack-kernel + fused gradient through sigma
     against torch.nn.utils.spectral_norm in fp64: train-mode forward (u, v updated), gradient w.r.t.
     weight_orig, a second forward, eval-mode forward, and a 3-iteration step."""
@@ -456,6 +457,14 @@ def test_fused_spectral_norm_conv_matches_torch(cfg, dtype):
     ref = torch.nn.utils.spectral_norm(torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, bias=True)).double()
     mine = torch.nn.Sequential(copy.deepcopy(ref).float()).to(dev)
     conv = mine[0]
+    if arena is not None:
+        # the parameters in an optimizer arena: weight_orig stored channels-last (the weight gradient lands in .grad directly,
+        # spectral norm's chain rule runs in place, the power iteration reads W's columns in (tap, ci) order while weight_v
+        # keeps torch's order) or in torch's order (re-layout kernels)
+        from seg2eye_amd.optim import FlatAdam
+        fa = FlatAdam(list(mine.parameters()), lr=1e-3, channels_last=arena == 'channels_last')
+        assert conv.weight_orig.is_contiguous() == (arena != 'channels_last' or k == 1)
+        assert conv.weight_orig.grad.data_ptr() >= fa.flat_g.data_ptr()
     x = _rnd((2, cin, 12, 12), 3, dtype)
     xr = x.double().requires_grad_(True)
     xg = nhwc(x).to(dev).requires_grad_(True)
@@ -466,7 +475,10 @@ def test_fused_spectral_norm_conv_matches_torch(cfg, dtype):
         yr = ref(xr)
         gy = _rnd(tuple(yr.shape), 10 + rnd, dtype)
         yr.backward(gy.double())
-        conv.zero_grad()
+        if arena is None:
+            conv.zero_grad()
+        else:
+            fa.zero_grad()                                   # (keeps the .grad views of the arena)
         sn_begin(mine)
         y = ops.conv2d_m(xg, conv, None, s, p)
         y.backward(nhwc(gy).to(dev))
@@ -762,3 +774,20 @@ def test_discriminator_input_and_split_halves():
     a, b = ops.split_halves(t)
     (a.sum() + 3.0 * b.sum()).backward()
     assert torch.equal(t.grad[3:], torch.full_like(t[3:], 3.0)) and torch.equal(t.grad[:3], torch.ones_like(t[:3]))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(256, 128, 3, 3), (48, 24, 3, 3), (130, 64, 4, 4), (72, 8, 1, 1), (1, 512, 4, 4), (32, 16, 5, 5)])
+def test_pack_of_channels_last_master_equals_pack_of_torch_order(shape, dtype):
+    """s2e_pack_conv_weight(transposed | 2) -- the streaming convert / the per-tap tile transpose from a [co][tap][ci] master --
+    writes the very matrix the OIHW packers write (padding rows, K tail and the division by sigma included)."""
+    from seg2eye_amd import ops
+    dev = _dev()
+    w = _rnd(shape, 31, torch.float32, 0.3).to(dev)
+    wcl = w.contiguous(memory_format=torch.channels_last)
+    sigma = torch.tensor([1.7], device=dev)
+    for tr in (False, True):
+        for sg in (None, sigma):
+            a = ops.pack_weight(w, dtype, None, tr, sg)
+            b = ops.pack_weight(wcl, dtype, None, tr, sg)
+            assert a.shape == b.shape and torch.equal(a, b), (shape, tr, sg is not None)
