@@ -609,6 +609,27 @@ __global__ __launch_bounds__(256) void modulate_bwd_reduce_kernel(const T* __res
         };
         const u32x4_t zero4 = {0u, 0u, 0u, 0u};
         int pr = row0 + ty;
+        // UR rows per trip: the loads of all UR rows (up to 4 * UR 16-byte loads) are issued before any row is consumed.  One
+        // block per CU and 2 rows in flight kept 32 KB per CU on the way -- half of what the HBM latency-bandwidth product asks.
+        constexpr int UR = 4;
+        for (; pr + (UR - 1) * rpp < pend; pr += UR * rpp) {
+            u32x4_t xs[UR], gs[UR], as[UR], bs[UR];
+            size_t rr[UR];
+#pragma unroll
+            for (int k = 0; k < UR; ++k) {
+                rr[k] = (size_t)n * HW + pr + k * rpp;
+                xs[k] = *(const u32x4_t*)(x + mod_x_row(n, pr + k * rpp, HW, xw, inv_xw) * C + c0);
+                gs[k] = *(const u32x4_t*)(gin + rr[k] * C + c0);
+                as[k] = zero4; bs[k] = zero4;
+                if (MODE == S2E_NORM_SPADE_STYLE) {
+                    as[k] = *(const u32x4_t*)(gb + rr[k] * gst + c0);
+                    if (fout) { if (lrelu) bs[k] = *(const u32x4_t*)(fout + rr[k] * C + c0); }
+                    else bs[k] = *(const u32x4_t*)(gb + rr[k] * gst + C + c0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UR; ++k) consume(rr[k], xs[k], gs[k], as[k], bs[k]);
+        }
         for (; pr + rpp < pend; pr += 2 * rpp) {
             const size_t r0 = (size_t)n * HW + pr, r1 = r0 + rpp;
             const u32x4_t x0 = *(const u32x4_t*)(x + mod_x_row(n, pr, HW, xw, inv_xw) * C + c0), x1 = *(const u32x4_t*)(x + mod_x_row(n, pr + rpp, HW, xw, inv_xw) * C + c0);
