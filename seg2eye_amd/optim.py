@@ -73,6 +73,7 @@ class FlatAdam:
                 p.data = view                                           # parameter now aliases the arena
                 p.grad = _arena_view(self.flat_g, off, p, cl)           # autograd accumulates in place
         self.params = plist
+        self._grad_strides = [p.grad.stride() for p in plist]
         self.betas = (float(betas[0]), float(betas[1]))                   # (0, 0.9) must be floats
         self.eps = float(eps)
         self.step_count = 0
@@ -87,13 +88,15 @@ class FlatAdam:
 
     def rebind_grads(self):
         """Re-attach .grad views if something replaced them (e.g. a zero_grad(set_to_none=True))."""
-        for p, off, cl in zip(self.params, self.offsets, self.cl):
+        base, strides = self.flat_g.data_ptr(), self._grad_strides
+        for i, p in enumerate(self.params):
             g = p.grad
-            want = _arena_view(self.flat_g, off, p, cl)
-            if g is None or g.data_ptr() != want.data_ptr() or g.stride() != want.stride():
-                if g is not None:
-                    want.copy_(g)
-                p.grad = want
+            if g is not None and g.data_ptr() == base + 4 * self.offsets[i] and g.stride() == strides[i]:
+                continue                                     # (the common case, checked without building a view per parameter)
+            want = _arena_view(self.flat_g, self.offsets[i], p, self.cl[i])
+            if g is not None:
+                want.copy_(g)
+            p.grad = want
 
     def sync_hyper(self, grad_scale=1.0):
         """Push lr / grad_scale to the device only when they changed (never inside a graph)."""
