@@ -665,7 +665,8 @@ def test_full_size_train_step_matches_oracle():
     assert float(d.mean()) < 3e-2 and float(d.max()) < 0.5, (float(d.mean()), float(d.max()))
 
 
-def test_bench_two_ranks_dry_run():
+@pytest.mark.parametrize('exchange', ['after_backward', 'overlap'])
+def test_bench_two_ranks_dry_run(exchange):
     """bench.py's multi-rank control flow (barriers, max-over-ranks timing, the eager event pass on EVERY rank -- a step
     contains the gradient all-reduce, so rank 0 alone would wait for ever -- and the final barrier) with two ranks sharing
     this box's GPU over gloo.  RCCL refuses two ranks on one device; the collective calls are the same."""
@@ -677,7 +678,7 @@ def test_bench_two_ranks_dry_run():
     env = dict(os.environ, S2E_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
                           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
-                          '--gpus', '2', '--steps', '2', '--warmup', '1', '--ngf', '16', '--batch', '2'],
+                          '--gpus', '2', '--steps', '2', '--warmup', '1', '--ngf', '16', '--batch', '2', '--exchange', exchange],
                          env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -685,6 +686,8 @@ def test_bench_two_ranks_dry_run():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and 'roofline' in d and 'cpu_baseline' not in d
+    # the default keeps the hipGraph replays and exchanges after the backward; the overlapped exchange needs eager launches
+    assert d['config']['gradient_exchange'] == exchange and d['hip_graphs'] == (exchange == 'after_backward')
 
 
 # ------------------------------------------------------------------------------------------ config 3 AS BENCHED
