@@ -25,4 +25,7 @@ python3 tools/profile_step.py > "$O/${P}_per_shape_in_step.log" 2>/dev/null
 (cd tools && python3 bench_spade_fused.py > "../$O/${P}_spade_fused_microbench.log" 2>/dev/null)
 python3 tools/bench_inference.py > "$O/${P}_inference.log" 2>/dev/null
 python3 tools/check_cfg5.py > "$O/${P}_cfg5_640x384_bs4.log" 2>/dev/null
+python3 tools/trace_copies.py > "$O/${P}_torch_launches_per_step.log" 2>/dev/null
+python3 tools/bench_pack.py > "$O/${P}_weight_pack_microbench.log" 2>/dev/null
+python3 tools/bench_mm.py > "$O/${P}_hipblaslt_same_gemm_shapes.log" 2>/dev/null
 tail -c 1500 "$O/${P}_bench.json"

@@ -50,6 +50,11 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'adam_flat_kernel': ('adam', True),
     'pack_batch_kernel': ('weight_pack', True),
     'grad_unpack_batch_kernel': ('weight_grad_relayout', True), 'grad_dot_batch_kernel': ('weight_grad_relayout', False),
+    # channels-last masters (round 3): the in-place spectral-norm chain rule is the same profiler family
+    'sn_grad_inplace_apply_kernel': ('weight_grad_relayout', True), 'sn_grad_inplace_dot_kernel': ('weight_grad_relayout', False),
+    'style_fc_fwd_kernel': ('style_fc', True), 'style_fc_bwd_kernel': ('style_fc', True), 'style_fc_dw_fold_kernel': ('style_fc', False),
+    'sn_gemvT_chain_kernel': ('spectral_norm', True), 'sn_gemv_chain_kernel': ('spectral_norm', False), 'sn_finalize_chain_kernel': ('spectral_norm', False),
+    'conv_wgrad_reduce_kernel': ('conv_wgrad', False),
     'sn_gemvT_kernel': ('spectral_norm', True), 'sn_gemv_kernel': ('spectral_norm', False),     # launches = power ITERATIONS
     'sn_norm_v_kernel': ('spectral_norm', False), 'sn_finalize_kernel': ('spectral_norm', False),
     'upsample2x_fwd_kernel': ('resample', True), 'upsample2x_bwd_kernel': ('resample', True),
