@@ -405,6 +405,16 @@ int s2e_style_fc_fwd(const float* w, const float* W, const float* b, float* big,
 int s2e_style_fc_bwd(const float* dbig, const float* gbig, const float* big, const float* w, const float* W, float* gW, float* gb,
                      float* dw, void* workspace, size_t workspace_bytes, int N, int K, int S, float slope, void* stream);
 
+/* The encoder's head (models/networks/encoder.py:68-71: fc_mu / fc_var on LeakyReLU(x).view(M, -1)) on the NHWC feature map:
+ *     y[m][n] = b[n] + sum_{p,c} LeakyReLU_slope(x[m][p][c]) * W[n][c*P + p]      (torch flattens (c, p))
+ * x (M, P, C) in `dtype`; W (N x C*P), b, y (M x N), dy: fp32.  M <= 64, N <= 32 (s2e_fc_head_supported).  Backward, one pass:
+ * dx (M, P, C) in `dtype` is WRITTEN (NULL: skipped), dW (N x C*P) and db (N) are ACCUMULATED into (NULL: skipped). */
+int s2e_fc_head_supported(int M, int N);
+int s2e_fc_head_fwd(int dtype, const void* x, const float* W, const float* b, float* y, int M, int P, int C, int N, float slope,
+                    void* stream);
+int s2e_fc_head_bwd(int dtype, const void* x, const float* W, const float* dy, void* dx, float* dW, float* db, int M, int P, int C,
+                    int N, float slope, void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam step (pix2pix_model.py:92-110: TTUR betas (0, 0.9), eps 1e-8, --weight_decay as Adam's L2 term)
  * over one flat fp32 arena: g = g*grad_scale + weight_decay*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;

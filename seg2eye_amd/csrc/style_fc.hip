@@ -157,3 +157,103 @@ extern "C" int s2e_style_fc_bwd(const float* dbig, const float* gbig, const floa
     }
     return S2E_OK;
 }
+
+// ------------------------------------------------------------------------------------ the encoder's head
+// ConvEncoder: mu = fc_mu(LeakyReLU(x).view(M, -1)) (reference models/networks/encoder.py:68-71) on the NHWC feature map x
+// (M, P = so*so pixels, C channels): torch flattens (c, p), so
+//     y[m][n] = b[n] + sum_{p,c} lrelu(x[m][p][c]) * W[n][c*P + p]                       M <= 64 samples, N <= 32 outputs
+// As a 4x4 valid convolution on the implicit-GEMM kernel this was ONE 128-row tile walking K = 8192 alone (37 us for 8 MFLOP),
+// plus two packs, a dtype conversion, a generic data / weight gradient and their re-layout.  Here: one block per sample forward;
+// one thread per (p, c) backward, which produces dx, dW and db in the same pass.  x in the compute dtype, everything else fp32.
+namespace {
+constexpr int FH_MAXN = 32, FH_MAXM = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void fc_head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                                          float* __restrict__ y, int P, int C, int N, float slope) {
+    __shared__ float red[4][FH_MAXN];
+    const int m = blockIdx.x, K = P * C;
+    float acc[FH_MAXN];
+#pragma unroll
+    for (int n = 0; n < FH_MAXN; ++n) acc[n] = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const int pp = k / C, c = k - pp * C;
+        float v = load1<T>(x + (size_t)m * K + k);
+        v = v > 0.f ? v : slope * v;
+        const float* wp = W + (size_t)c * P + pp;
+#pragma unroll
+        for (int n = 0; n < FH_MAXN; ++n)
+            if (n < N) acc[n] = fmaf(v, wp[(size_t)n * K], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < FH_MAXN; ++n) {
+        if (n < N) {                                         // (uniform: every lane takes the shuffles)
+            const float s = wave_sum(acc[n]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][n] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < N) y[(size_t)m * N + threadIdx.x] = b[threadIdx.x] + (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fc_head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ W, const float* __restrict__ dy,
+                                                          T* __restrict__ dx, float* __restrict__ dW, float* __restrict__ db,
+                                                          int M, int P, int C, int N, float slope) {
+    __shared__ float sdy[FH_MAXM * FH_MAXN];
+    const int K = P * C;
+    for (int i = threadIdx.x; i < M * N; i += 256) sdy[i] = dy[i];
+    __syncthreads();
+    if (blockIdx.x == 0 && db && threadIdx.x < N) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += sdy[m * N + threadIdx.x];
+        db[threadIdx.x] += s;
+    }
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int pp = k / C, c = k - pp * C;
+    const size_t kw = (size_t)c * P + pp;
+    float wv[FH_MAXN], gw[FH_MAXN];
+#pragma unroll
+    for (int n = 0; n < FH_MAXN; ++n) { wv[n] = n < N ? W[(size_t)n * K + kw] : 0.f; gw[n] = 0.f; }
+    for (int m = 0; m < M; ++m) {
+        const float xv = load1<T>(x + (size_t)m * K + k);
+        const float a = xv > 0.f ? xv : slope * xv;
+        float g = 0.f;
+#pragma unroll
+        for (int n = 0; n < FH_MAXN; ++n)
+            if (n < N) { const float d = sdy[m * N + n]; gw[n] = fmaf(d, a, gw[n]); g = fmaf(d, wv[n], g); }
+        if (dx) store1<T>(dx + (size_t)m * K + k, xv > 0.f ? g : slope * g);
+    }
+    if (dW) {
+#pragma unroll
+        for (int n = 0; n < FH_MAXN; ++n)
+            if (n < N) dW[(size_t)n * K + kw] += gw[n];
+    }
+}
+}  // namespace
+
+extern "C" int s2e_fc_head_supported(int M, int N) { return M >= 1 && M <= FH_MAXM && N >= 1 && N <= FH_MAXN; }
+
+extern "C" int s2e_fc_head_fwd(int dtype, const void* x, const float* W, const float* b, float* y, int M, int P, int C, int N, float slope,
+                               void* stream) {
+    if (!x || !W || !b || !y || P <= 0 || C <= 0 || !s2e_fc_head_supported(M, N)) S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_fwd: bad argument (M=%d N=%d)", M, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2E_BF16) fc_head_fwd_kernel<bf16_t><<<M, 256, 0, st>>>((const bf16_t*)x, W, b, y, P, C, N, slope);
+    else if (dtype == S2E_F32) fc_head_fwd_kernel<float><<<M, 256, 0, st>>>((const float*)x, W, b, y, P, C, N, slope);
+    else S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_fwd: bad dtype %d", dtype);
+    S2E_CHECK_LAUNCH("fc_head_fwd_kernel");
+    return S2E_OK;
+}
+
+extern "C" int s2e_fc_head_bwd(int dtype, const void* x, const float* W, const float* dy, void* dx, float* dW, float* db, int M, int P, int C,
+                               int N, float slope, void* stream) {
+    if (!x || !W || !dy || P <= 0 || C <= 0 || !s2e_fc_head_supported(M, N)) S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_bwd: bad argument (M=%d N=%d)", M, N);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ceil_div((long)P * C, 256);
+    if (dtype == S2E_BF16) fc_head_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, W, dy, (bf16_t*)dx, dW, db, M, P, C, N, slope);
+    else if (dtype == S2E_F32) fc_head_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, W, dy, (float*)dx, dW, db, M, P, C, N, slope);
+    else S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_bwd: bad dtype %d", dtype);
+    S2E_CHECK_LAUNCH("fc_head_bwd_kernel");
+    return S2E_OK;
+}

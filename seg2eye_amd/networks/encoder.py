@@ -69,8 +69,10 @@ class ConvEncoder(BaseNetwork):
         if not self.logvar_used:
             # ... and then fc_var is not evaluated at all: mu alone is fc_mu's weight VIEWED as the conv weight (no concatenation,
             # half the FC work); logvar comes back as None
-            wmu = self.fc_mu.weight.view(self.opt.w_dim, h.shape[-1], self.so, self.so)
-            mu = ops.conv2d(h.float(), wmu, self.fc_mu.bias, None, 1, 0, ACT_LRELU).reshape(h.shape[0], self.opt.w_dim)
+            mu = ops.fc_head(h, self.fc_mu.weight, self.fc_mu.bias, 0.2)      # one launch each way (csrc/style_fc.hip)
+            if mu is None:                                                    # (more than 64 style images / 32 outputs: the conv form)
+                wmu = self.fc_mu.weight.view(self.opt.w_dim, h.shape[-1], self.so, self.so)
+                mu = ops.conv2d(h.float(), wmu, self.fc_mu.bias, None, 1, 0, ACT_LRELU).reshape(h.shape[0], self.opt.w_dim)
             return mu, None, feats
         wcat = torch.cat([self.fc_mu.weight, self.fc_var.weight], 0).view(2 * self.opt.w_dim, h.shape[-1], self.so, self.so)
         bcat = torch.cat([self.fc_mu.bias, self.fc_var.bias], 0)

@@ -899,6 +899,47 @@ def conv2d_m(x, conv, residual=None, stride=1, pad=0, in_act=ACT_NONE, out_act=A
     return conv2d(x, weight, bias, residual, stride, pad, in_act, out_act, sn)
 
 
+# ------------------------------------------------------------------------------ the encoder's head
+class FcHeadFn(torch.autograd.Function):
+    """y = fc(LeakyReLU(x).view(M, -1)) for an NHWC feature map x (M,h,w,C) and an nn.Linear whose input features are torch's
+    (c, y, x) flattening (reference models/networks/encoder.py:68-71): s2e_fc_head_fwd / _bwd.  The weight / bias gradients are
+    accumulated into the parameters' .grad when that is an fp32 arena view (None then goes back to autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope):
+        _need(x, weight, bias)
+        m, h, w, c = x.shape
+        n = weight.shape[0]
+        y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        L.check(L.lib().s2e_fc_head_fwd(_dt(x), _p(x), _p(weight), _p(bias), _p(y), m, h * w, c, n, float(slope), _stream()), 's2e_fc_head_fwd')
+        ctx.slope = float(slope)
+        ctx.wdst, ctx.bdst = _grad_dst(weight), _grad_dst(bias)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        m, h, w, c = x.shape
+        n = weight.shape[0]
+        g = gy.float().contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        wdst = ctx.wdst if (ctx.wdst is not None and ctx.wdst.is_contiguous()) else None
+        dw = wdst if wdst is not None else (torch.zeros_like(weight) if ctx.needs_input_grad[1] else None)
+        db = ctx.bdst if ctx.bdst is not None else (torch.zeros(n, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[2] else None)
+        L.check(L.lib().s2e_fc_head_bwd(_dt(x), _p(x), _p(weight), _p(g), _p(dx), _p(dw), _p(db), m, h * w, c, n, ctx.slope, _stream()),
+                's2e_fc_head_bwd')
+        return dx, (None if wdst is not None else dw), (None if ctx.bdst is not None else db), None
+
+
+def fc_head(x, weight, bias, slope=0.2):
+    """-> (M, N) fp32, or None when the shape is outside the kernel's range (the caller then takes the convolution form)."""
+    if (weight.dtype != torch.float32 or not weight.is_contiguous() or bias is None or weight.shape[1] != x.shape[1] * x.shape[2] * x.shape[3]
+            or not L.lib().s2e_fc_head_supported(x.shape[0], weight.shape[0])):
+        return None
+    return FcHeadFn.apply(x.contiguous(), weight, bias, slope)
+
+
 # ------------------------------------------------------------------------------ label-map convs
 
 class LabelConvFn(torch.autograd.Function):

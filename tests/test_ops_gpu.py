@@ -791,3 +791,31 @@ def test_pack_of_channels_last_master_equals_pack_of_torch_order(shape, dtype):
             a = ops.pack_weight(w, dtype, None, tr, sg)
             b = ops.pack_weight(wcl, dtype, None, tr, sg)
             assert a.shape == b.shape and torch.equal(a, b), (shape, tr, sg is not None)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(32, 4, 512, 16), (3, 4, 64, 5), (64, 2, 24, 32), (1, 4, 8, 1)])
+def test_fc_head_matches_torch_linear_on_leaky_relu_of_nchw_flatten(cfg, dtype):
+    """ops.fc_head == fc(LeakyReLU(x).view(M, -1)) with torch's (c, y, x) flattening (encoder.py:68-71), forward, dx, dW, db;
+    gradients accumulate into an existing .grad."""
+    from seg2eye_amd import ops
+    M, so, C, N = cfg
+    dev = _dev()
+    x = _rnd((M, C, so, so), 41, dtype)
+    lin = torch.nn.Linear(C * so * so, N).double()
+    xr = x.double().requires_grad_(True)
+    yr = lin(F.leaky_relu(xr, 0.2).view(M, -1))
+    gy = _rnd((M, N), 42, torch.float32)
+    yr.backward(gy.double())
+    w = torch.nn.Parameter(lin.weight.detach().float().to(dev))
+    b = torch.nn.Parameter(lin.bias.detach().float().to(dev))
+    w.grad, b.grad = torch.full_like(w, 0.25), torch.full_like(b, -0.5)
+    xg = nhwc(x).to(dev).requires_grad_(True)
+    y = ops.fc_head(xg, w, b, 0.2)
+    assert y is not None and y.dtype == torch.float32
+    _close(y, yr, torch.float32, what='fc head y')
+    y.backward(gy.to(dev))
+    _close(nchw(xg.grad), xr.grad, dtype, what='fc head dx')
+    _close(w.grad - 0.25, lin.weight.grad, torch.float32, what='fc head dW')
+    _close(b.grad + 0.5, lin.bias.grad, torch.float32, what='fc head db')
+    assert ops.fc_head(torch.zeros(65, so, so, C, device=dev, dtype=dtype), w, b) is None
