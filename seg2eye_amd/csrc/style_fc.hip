@@ -166,37 +166,51 @@ extern "C" int s2e_style_fc_bwd(const float* dbig, const float* gbig, const floa
 // plus two packs, a dtype conversion, a generic data / weight gradient and their re-layout.  Here: one block per sample forward;
 // one thread per (p, c) backward, which produces dx, dW and db in the same pass.  x in the compute dtype, everything else fp32.
 namespace {
-constexpr int FH_MAXN = 32, FH_MAXM = 64;
+constexpr int FH_MAXN = 32, FH_MAXM = 64, FH_FWD_THREADS = 1024;
 
-template <typename T>
-__global__ __launch_bounds__(256) void fc_head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+// Threads walk W's columns kw = c*P + p (coalesced rows of W, the 512-KB operand); x is the small one: the forward stages the
+// sample's row in LDS (LeakyReLU applied once), the backward reads / writes it through L1 with a (p, c) stride.
+template <typename T, int NMAX>
+__global__ __launch_bounds__(FH_FWD_THREADS) void fc_head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
                                                           float* __restrict__ y, int P, int C, int N, float slope) {
-    __shared__ float red[4][FH_MAXN];
+    extern __shared__ float sx[];                    // [P][C + 1] LeakyReLU(x[m]) in memory order (p, c)
+    __shared__ float red[FH_FWD_THREADS / 64][FH_MAXN];
     const int m = blockIdx.x, K = P * C;
-    float acc[FH_MAXN];
+    for (int k = threadIdx.x; k < K; k += FH_FWD_THREADS) {     // rows padded by one float: the gather below walks p at a fixed c
+        const float v = load1<T>(x + (size_t)m * K + k);
+        const int pp = k / C;
+        sx[k + pp] = v > 0.f ? v : slope * v;
+    }
+    __syncthreads();
+    float acc[NMAX];
 #pragma unroll
-    for (int n = 0; n < FH_MAXN; ++n) acc[n] = 0.f;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const int pp = k / C, c = k - pp * C;
-        float v = load1<T>(x + (size_t)m * K + k);
-        v = v > 0.f ? v : slope * v;
-        const float* wp = W + (size_t)c * P + pp;
+    for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+    // (a trip is one L2 round trip for its N loads of W: 1024 threads keep the trips few -- 256 threads took 32 of them, 70 us)
+#pragma unroll 2
+    for (int kw = threadIdx.x; kw < K; kw += FH_FWD_THREADS) {
+        const int c = kw / P, pp = kw - c * P;
+        const float v = sx[pp * (C + 1) + c];
 #pragma unroll
-        for (int n = 0; n < FH_MAXN; ++n)
-            if (n < N) acc[n] = fmaf(v, wp[(size_t)n * K], acc[n]);
+        for (int n = 0; n < NMAX; ++n)
+            if (n < N) acc[n] = fmaf(v, W[(size_t)n * K + kw], acc[n]);
     }
 #pragma unroll
-    for (int n = 0; n < FH_MAXN; ++n) {
+    for (int n = 0; n < NMAX; ++n) {
         if (n < N) {                                         // (uniform: every lane takes the shuffles)
             const float s = wave_sum(acc[n]);
             if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][n] = s;
         }
     }
     __syncthreads();
-    if (threadIdx.x < N) y[(size_t)m * N + threadIdx.x] = b[threadIdx.x] + (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < N) {
+        float s = b[threadIdx.x];
+#pragma unroll
+        for (int wv = 0; wv < FH_FWD_THREADS / 64; ++wv) s += red[wv][threadIdx.x];
+        y[(size_t)m * N + threadIdx.x] = s;
+    }
 }
 
-template <typename T>
+template <typename T, int NMAX>
 __global__ __launch_bounds__(256) void fc_head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ W, const float* __restrict__ dy,
                                                           T* __restrict__ dx, float* __restrict__ dW, float* __restrict__ db,
                                                           int M, int P, int C, int N, float slope) {
@@ -209,25 +223,34 @@ __global__ __launch_bounds__(256) void fc_head_bwd_kernel(const T* __restrict__ 
         for (int m = 0; m < M; ++m) s += sdy[m * N + threadIdx.x];
         db[threadIdx.x] += s;
     }
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
-    const int pp = k / C, c = k - pp * C;
-    const size_t kw = (size_t)c * P + pp;
-    float wv[FH_MAXN], gw[FH_MAXN];
+    const int kw = blockIdx.x * 256 + threadIdx.x;   // W's column
+    if (kw >= K) return;
+    const int c = kw / P, pp = kw - c * P;
+    const size_t k = (size_t)pp * C + c;             // x's element
+    float wv[NMAX], gw[NMAX];
 #pragma unroll
-    for (int n = 0; n < FH_MAXN; ++n) { wv[n] = n < N ? W[(size_t)n * K + kw] : 0.f; gw[n] = 0.f; }
-    for (int m = 0; m < M; ++m) {
-        const float xv = load1<T>(x + (size_t)m * K + k);
-        const float a = xv > 0.f ? xv : slope * xv;
-        float g = 0.f;
+    for (int n = 0; n < NMAX; ++n) { wv[n] = n < N ? W[(size_t)n * K + kw] : 0.f; gw[n] = 0.f; }
+    for (int m0 = 0; m0 < M; m0 += 4) {                  // four samples' loads in flight
+        float xs[4];
 #pragma unroll
-        for (int n = 0; n < FH_MAXN; ++n)
-            if (n < N) { const float d = sdy[m * N + n]; gw[n] = fmaf(d, a, gw[n]); g = fmaf(d, wv[n], g); }
-        if (dx) store1<T>(dx + (size_t)m * K + k, xv > 0.f ? g : slope * g);
+        for (int j = 0; j < 4; ++j) xs[j] = load1<T>(x + (size_t)min(m0 + j, M - 1) * K + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + j;
+            if (m < M) {
+                const float xv = xs[j];
+                const float a = xv > 0.f ? xv : slope * xv;
+                float g = 0.f;
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n)
+                    if (n < N) { const float d = sdy[m * N + n]; gw[n] = fmaf(d, a, gw[n]); g = fmaf(d, wv[n], g); }
+                if (dx) store1<T>(dx + (size_t)m * K + k, xv > 0.f ? g : slope * g);
+            }
+        }
     }
     if (dW) {
 #pragma unroll
-        for (int n = 0; n < FH_MAXN; ++n)
+        for (int n = 0; n < NMAX; ++n)
             if (n < N) dW[(size_t)n * K + kw] += gw[n];
     }
 }
@@ -238,9 +261,13 @@ extern "C" int s2e_fc_head_supported(int M, int N) { return M >= 1 && M <= FH_MA
 extern "C" int s2e_fc_head_fwd(int dtype, const void* x, const float* W, const float* b, float* y, int M, int P, int C, int N, float slope,
                                void* stream) {
     if (!x || !W || !b || !y || P <= 0 || C <= 0 || !s2e_fc_head_supported(M, N)) S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_fwd: bad argument (M=%d N=%d)", M, N);
+    if ((size_t)P * C * sizeof(float) > 48 * 1024) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_fc_head_fwd: a sample row of %d x %d features does not fit the LDS stage", P, C);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2E_BF16) fc_head_fwd_kernel<bf16_t><<<M, 256, 0, st>>>((const bf16_t*)x, W, b, y, P, C, N, slope);
-    else if (dtype == S2E_F32) fc_head_fwd_kernel<float><<<M, 256, 0, st>>>((const float*)x, W, b, y, P, C, N, slope);
+    const size_t lds = (size_t)P * (C + 1) * sizeof(float);
+#define S2E_FH(TT, NM) fc_head_fwd_kernel<TT, NM><<<M, FH_FWD_THREADS, lds, st>>>((const TT*)x, W, b, y, P, C, N, slope)
+    if (dtype == S2E_BF16) { if (N <= 16) S2E_FH(bf16_t, 16); else S2E_FH(bf16_t, 32); }
+    else if (dtype == S2E_F32) { if (N <= 16) S2E_FH(float, 16); else S2E_FH(float, 32); }
+#undef S2E_FH
     else S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_fwd: bad dtype %d", dtype);
     S2E_CHECK_LAUNCH("fc_head_fwd_kernel");
     return S2E_OK;
@@ -251,8 +278,10 @@ extern "C" int s2e_fc_head_bwd(int dtype, const void* x, const float* W, const f
     if (!x || !W || !dy || P <= 0 || C <= 0 || !s2e_fc_head_supported(M, N)) S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_bwd: bad argument (M=%d N=%d)", M, N);
     hipStream_t st = (hipStream_t)stream;
     const int grid = ceil_div((long)P * C, 256);
-    if (dtype == S2E_BF16) fc_head_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, W, dy, (bf16_t*)dx, dW, db, M, P, C, N, slope);
-    else if (dtype == S2E_F32) fc_head_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, W, dy, (float*)dx, dW, db, M, P, C, N, slope);
+#define S2E_FH(TT, NM) fc_head_bwd_kernel<TT, NM><<<grid, 256, 0, st>>>((const TT*)x, W, dy, (TT*)dx, dW, db, M, P, C, N, slope)
+    if (dtype == S2E_BF16) { if (N <= 16) S2E_FH(bf16_t, 16); else S2E_FH(bf16_t, 32); }
+    else if (dtype == S2E_F32) { if (N <= 16) S2E_FH(float, 16); else S2E_FH(float, 32); }
+#undef S2E_FH
     else S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_bwd: bad dtype %d", dtype);
     S2E_CHECK_LAUNCH("fc_head_bwd_kernel");
     return S2E_OK;

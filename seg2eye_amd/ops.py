@@ -932,10 +932,13 @@ class FcHeadFn(torch.autograd.Function):
         return dx, (None if wdst is not None else dw), (None if ctx.bdst is not None else db), None
 
 
+_FC_HEAD_OFF = os.environ.get('S2E_FC_HEAD', '1') == '0'      # A/B switch: the encoder's head as a 4x4 valid convolution
+
+
 def fc_head(x, weight, bias, slope=0.2):
     """-> (M, N) fp32, or None when the shape is outside the kernel's range (the caller then takes the convolution form)."""
-    if (weight.dtype != torch.float32 or not weight.is_contiguous() or bias is None or weight.shape[1] != x.shape[1] * x.shape[2] * x.shape[3]
-            or not L.lib().s2e_fc_head_supported(x.shape[0], weight.shape[0])):
+    if (_FC_HEAD_OFF or weight.dtype != torch.float32 or not weight.is_contiguous() or bias is None or weight.shape[1] != x.shape[1] * x.shape[2] * x.shape[3]
+            or weight.shape[1] * 4 > 48 * 1024 or not L.lib().s2e_fc_head_supported(x.shape[0], weight.shape[0])):
         return None
     return FcHeadFn.apply(x.contiguous(), weight, bias, slope)
 
