@@ -1009,25 +1009,23 @@ class SpadeParamFn(torch.autograd.Function):
         return (None,) + _spade_param_grads(ctx, ggb.contiguous(), label, w_sh, w_gb, actv) + (None, None, None)
 
 
-_GB_VIEWS = {}
-
-
 def _gb_operands(w_g, b_g, w_b, b_b, nh):
     """[W_gamma; W_beta] and [b_gamma; b_beta] as single tensors: zero-copy views when the four parameters sit back to
     back in the optimizer arena (Pix2PixModel orders them so), concatenated copies otherwise.  -> (fused, w_gb, b_gb)"""
     C = w_g.shape[0]
-    # (asked ~90 times per step with the same eight tensors: the answer for parameters that alias an arena is memoised on the
+    # (asked ~90 times per step with the same tensors: the answer for parameters that alias an arena is memoised, keyed on the
     # storage addresses -- the views are of the arena and stay valid as long as the parameters stay where they are)
     key = (w_g.data_ptr(), w_b.data_ptr(), b_g.data_ptr(), b_b.data_ptr(), w_g.stride(), nh, C)
-    hit = _GB_VIEWS.get(key)
-    if hit is not None:
-        return hit
+    memo = getattr(w_g, '_s2e_gb_memo', None)               # (kept ON the parameter: it lives exactly as long as the arena it views)
+    if memo is not None and memo[0] == key:
+        return memo[1]
     fused = _adjacent(w_g, w_b) and _adjacent(b_g, b_b)
     if fused:
         res = (True, _span2(w_g, (2 * C, nh, 3, 3)), _span2(b_g, (2 * C,)))
-        if len(_GB_VIEWS) > 4096:
-            _GB_VIEWS.clear()
-        _GB_VIEWS[key] = res
+        try:
+            w_g._s2e_gb_memo = (key, res)
+        except AttributeError:                               # (a plain tensor slot-less view: no memo)
+            pass
         return res
     return False, torch.cat([w_g.detach(), w_b.detach()], 0), torch.cat([b_g.detach(), b_b.detach()], 0)
 
