@@ -48,7 +48,8 @@ class FlatAdam:
             raise ValueError('FlatAdam got an empty parameter list')
         dev = plist[0].device
         use_cl = _WEIGHTS_CL if channels_last is None else bool(channels_last)
-        self.cl = [bool(use_cl and p.dim() == 4 and p.shape[1] % 8 == 0 and p.is_cuda) for p in plist]
+        # (by default only for parameters on the GPU -- the layout exists for the HIP kernels; an explicit True lays out CPU tensors too)
+        self.cl = [bool(use_cl and p.dim() == 4 and p.shape[1] % 8 == 0 and (p.is_cuda or channels_last is True)) for p in plist]
         self.offsets, n = [], 0
         for p, cl in zip(plist, self.cl):
             if p.dtype != torch.float32:

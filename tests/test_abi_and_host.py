@@ -181,6 +181,63 @@ def test_flat_adam_arena_aliases_parameters():
     assert float(FlatAdam(list(torch.nn.Linear(2, 2).parameters()), lr=1e-3, weight_decay=0.1).hyper[6]) == pytest.approx(0.1)
 
 
+def test_flat_adam_channels_last_arena_layout():
+    """Conv weights with Cin % 8 == 0 are stored [Cout][KH][KW][Cin] in the arenas, 256-byte aligned, and exposed as
+    (Cout,Cin,KH,KW) views: same values, state_dict unchanged; the moments' layout is tagged and a mismatching load refused."""
+    from seg2eye_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3), torch.nn.Conv2d(16, 24, 3), torch.nn.Conv2d(4, 8, 3), torch.nn.Linear(5, 3))
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    opt = FlatAdam(list(net.parameters()), lr=1e-3, channels_last=True)
+    w0, w2 = net[0].weight, net[2].weight
+    assert opt.cl == [True, False, True, False, False, False, False, False]            # (Cin = 4 keeps torch's order)
+    assert w0.shape == (16, 8, 3, 3) and w0.stride() == (72, 1, 24, 8) and not w0.is_contiguous()
+    assert w0.permute(0, 2, 3, 1).is_contiguous() and w0.grad.stride() == w0.stride() and w2.is_contiguous()
+    assert all(opt.offsets[i] % 64 == 0 for i, c in enumerate(opt.cl) if c)
+    assert (w0.data_ptr() - opt.flat_p.data_ptr()) % 256 == 0
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k                                              # values by logical index: unchanged
+    # the arena really is [co][ky][kx][ci]
+    off = opt.offsets[0]
+    assert torch.equal(opt.flat_p[off:off + w0.numel()].view(16, 3, 3, 8), before['0.weight'].permute(0, 2, 3, 1))
+    x = torch.randn(2, 8, 12, 12)
+    net[:2](x).sum().backward()                                                         # torch's own kernels accumulate into the views
+    ref = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3), torch.nn.Conv2d(16, 24, 3))
+    ref.load_state_dict({k: v for k, v in before.items() if k[0] in '01'})
+    ref(x).sum().backward()
+    assert torch.allclose(w0.grad, ref[0].weight.grad, atol=1e-5) and w0.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * off
+    sd = opt.state_dict()
+    assert sd['layout']['channels_last'] == opt.cl
+    opt.load_state_dict(sd)
+    other = FlatAdam(list(torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3), torch.nn.Conv2d(16, 24, 3), torch.nn.Conv2d(4, 8, 3),
+                                              torch.nn.Linear(5, 3)).parameters()), lr=1e-3, channels_last=False)
+    with pytest.raises(ValueError):
+        other.load_state_dict(sd)
+
+
+def test_channels_last_pack_and_inplace_gradient_maps_are_host_only():
+    """s2e_pack_block_map with the channels-last source bit (transposed | 2) and s2e_sngrad_block_map / _scratch_floats: pure
+    host code."""
+    from seg2eye_amd import _lib
+    L = _lib.lib()
+    jobs = (_lib.PackJob * 2)()
+    jobs[0].cout, jobs[0].cin, jobs[0].taps, jobs[0].cin_pad, jobs[0].transposed = 256, 128, 9, 128, 2      # forward: 2048 elements per block
+    jobs[1].cout, jobs[1].cin, jobs[1].taps, jobs[1].cin_pad, jobs[1].transposed = 256, 128, 9, 128, 3      # transposed: 64 x 64 tile per tap
+    n0 = L.s2e_pack_block_map(_lib.S2E_BF16, ctypes.byref(jobs), 1, None)
+    n = L.s2e_pack_block_map(_lib.S2E_BF16, ctypes.byref(jobs), 2, None)
+    assert n0 == 256 * 1152 // 2048 and n - n0 == (256 // 64) * 9 * (128 // 64)
+    sj = (_lib.SnGradJob * 2)()
+    sj[0].rows, sj[0].cin, sj[0].taps = 64, 64, 9          # 36864 elements: 3 chunks of 16384
+    sj[1].rows, sj[1].cin, sj[1].taps = 8, 8, 1            # 64 elements: 1 chunk
+    nb = L.s2e_sngrad_block_map(ctypes.byref(sj), 2, None)
+    assert nb == 4 and (sj[0].part0, sj[0].nparts, sj[1].part0, sj[1].nparts) == (0, 3, 3, 1)
+    bm = np.zeros(2 * nb, dtype=np.int32)
+    assert L.s2e_sngrad_block_map(ctypes.byref(sj), 2, bm.ctypes.data) == nb
+    assert bm.reshape(-1, 2).tolist() == [[0, 0], [0, 1], [0, 2], [1, 0]]
+    assert (sj[0].vmem0, sj[1].vmem0) == (4, 4 + 576) and L.s2e_sngrad_scratch_floats(ctypes.byref(sj), 2) == 4 + 576 + 8
+    assert L.s2e_sn_grads_inplace(None, None, 0, None, None) == -1
+
+
 def test_checkpoint_roundtrip_and_module_prefix(tmp_path):
     from seg2eye_amd import checkpoint, networks
     from seg2eye_amd.options import default_opt
