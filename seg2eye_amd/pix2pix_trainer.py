@@ -34,8 +34,10 @@ class Pix2PixTrainer:
                 # Overlap the gradient exchange with the backward pass: the generator reports when a group of
                 # blocks has all its gradients (networks/generator.py), we flush that group's queued gradient re-layouts and
                 # start the all-reduce of its arena slice.  That needs the backward to run as individual launches, not as one
-                # graph replay -- which costs nothing: eager launches run at the graph's rate (the GPU is busy
-                # throughout; 336.6 vs 337.1 img/s on the same box).
+                # graph replay.  Since round 3 that has a price: the replayed step (19.7 ms) is shorter than the host needs to
+                # enqueue ~900 launches (22.0 ms per eager step on a slow host, 20.1 on a fast one), so
+                # --no_overlap_allreduce + --hip_graphs is the faster combination when only little of the exchange can be hidden
+                # (bench.py's default for --gpus N).
                 if getattr(self.opt, 'hip_graphs', False):
                     from .distributed import get_rank
                     if get_rank() == 0:
@@ -137,8 +139,8 @@ class Pix2PixTrainer:
             try:
                 self._capture(data)
             except Exception as e:                           # noqa: BLE001 -- any capture failure: run eager instead
-                # Eager runs the same kernels at the same rate (the GPU is busy throughout); a failed capture
-                # must not take a multi-GPU job down.  The step that triggered the capture has not run yet.
+                # Eager runs the same kernels (10 % slower on a slow host: DESIGN 6); a failed capture must not take a multi-GPU
+                # job down.  The step that triggered the capture has not run yet.
                 import sys
                 import torch
                 print('seg2eye_amd: hipGraph capture failed (%s: %s) -- continuing without graphs' % (type(e).__name__, e),
