@@ -81,7 +81,10 @@ class LaunchProfiler:
         s.record()
         r = fn()
         e.record()
-        prof.records.append((family() if callable(family) else family, flops, s, e, tag, nbytes, flops if executed is None else executed))
+        # (family / tag / nbytes may be callables: evaluated only here, i.e. only while a profiler is installed -- formatting a
+        # tag string and summing tensor sizes for each of ~1000 launches cost ~2 ms of host time per eager step)
+        prof.records.append((family() if callable(family) else family, flops, s, e, tag() if callable(tag) else tag,
+                             nbytes() if callable(nbytes) else nbytes, flops if executed is None else executed))
         return r
 
     def summary(self):
@@ -412,10 +415,10 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     LaunchProfiler.run(lambda: _CONV_FAMILY[L.lib().s2e_conv2d_kernel_kind(_dt(x), C.byref(d))], flops, lambda: L.check(
         L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _p(ws), wsb,
                            _stream()), 's2e_conv2d'),
-        tag='%s n%d %dx%d c%d->%d k%d s%d' % ('D' if transposed else 'F', n, hi, wi, cin, cout, kh, stride),
+        tag=lambda: '%s n%d %dx%d c%d->%d k%d s%d' % ('D' if transposed else 'F', n, hi, wi, cin, cout, kh, stride),
         # algorithmic bytes: every operand once (x, packed w, y, + residual / mask tensor when present)
-        nbytes=float((x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0)
-                      + (aux.numel() if aux is not None else 0)) * x.element_size()))
+        nbytes=lambda: float((x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0)
+                              + (aux.numel() if aux is not None else 0)) * x.element_size()))
     return y
 
 
@@ -447,8 +450,8 @@ def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=Fals
                        2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
         L.lib().s2e_conv2d_wgrad(_dt(x), _p(x), _p(gy), _p(dw), _p(dbp), C.byref(d), _p(ws), wsb, _stream()),
         's2e_conv2d_wgrad'),
-        tag='W n%d %dx%d c%d->%d k%d s%d' % (n, hi, wi, cin, cout, kh, stride),
-        nbytes=float((x.numel() + gy.numel()) * x.element_size() + dw.numel() * 4))
+        tag=lambda: 'W n%d %dx%d c%d->%d k%d s%d' % (n, hi, wi, cin, cout, kh, stride),
+        nbytes=lambda: float((x.numel() + gy.numel()) * x.element_size() + dw.numel() * 4))
     return dw, db
 
 
@@ -1247,9 +1250,9 @@ class SpadeFusedFn(torch.autograd.Function):
                 L.lib().s2e_spade_conv_modulate(_dt(x), _p(actv), _p(wp), _p(b_f), _p(xr), _p(stats), sp, ld,
                                                 _p(out), _p(gamma), n, h, w, c, nh, int(lrelu), int(flags), _stream()),
                 's2e_spade_conv_modulate'),
-                tag='F n%d %dx%d c%d->%d k3 s1 +mod%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
+                tag=lambda: 'F n%d %dx%d c%d->%d k3 s1 +mod%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
                 # algorithmic bytes: actv, packed w, x in; out (and gamma when it is kept) out
-                nbytes=float((actv.numel() + wp.numel() + xr.numel() + out.numel() * (2 if train else 1)) * x.element_size()))
+                nbytes=lambda: float((actv.numel() + wp.numel() + xr.numel() + out.numel() * (2 if train else 1)) * x.element_size()))
         else:
             # label-sparse: the conv runs on the rectangles that cross a label boundary only; the others read gamma | beta from
             # the per-class table (s2e_spade_class_table: this layer's [gamma | beta] branch on one-class maps, all 25 border cases)
@@ -1264,8 +1267,8 @@ class SpadeFusedFn(torch.autograd.Function):
                 L.lib().s2e_spade_conv_modulate_sparse(_dt(x), _p(actv), _p(wp), _p(b_f), _p(xr), _p(stats), sp, ld, _p(out), _p(gamma),
                                                        n, h, w, c, nh, int(lrelu), int(flags), _p(dense_list), _p(counts), _stream()),
                 's2e_spade_conv_modulate_sparse'),
-                tag='F n%d %dx%d c%d->%d k3 s1 +mod sparse%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
-                nbytes=float((actv.numel() + xr.numel() + out.numel() * (2 if train else 1)) * frac * x.element_size() + wp.numel() * x.element_size()),
+                tag=lambda: 'F n%d %dx%d c%d->%d k3 s1 +mod sparse%s' % (n, h, w, nh, 2 * c, '' if train else ' nograd'),
+                nbytes=lambda: float((actv.numel() + xr.numel() + out.numel() * (2 if train else 1)) * frac * x.element_size() + wp.numel() * x.element_size()),
                 executed=flops * frac)
             LaunchProfiler.run('modulate_fwd', 0.0, lambda: L.check(
                 L.lib().s2e_spade_modulate_uniform(_dt(x), _p(xr), _p(stats), sp, ld, _p(table), _p(cls), _p(uni_list), _p(counts), _p(out),
