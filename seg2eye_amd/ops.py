@@ -397,6 +397,23 @@ _CONV_FAMILY = ('conv_igemm', 'conv_small', 'conv_patch')
 _WGRAD_FAMILY = ('conv_wgrad', 'conv_wgrad_small', 'conv_wgrad_patch')
 
 
+_CONV_PLANS = {}
+
+
+def _conv_plan(wgrad, dt, *shape):
+    """(s2e_conv_desc, workspace bytes) of a launch, memoised per shape: a step repeats the same ~150 shapes, and building the
+    ctypes structure + asking the library for the workspace size cost ~3 us of host time per launch."""
+    key = (wgrad, dt) + shape
+    ent = _CONV_PLANS.get(key)
+    if ent is None:
+        d = ConvDesc(*shape)
+        wsb = (L.lib().s2e_conv2d_wgrad_workspace_bytes if wgrad else L.lib().s2e_conv2d_workspace_bytes)(dt, C.byref(d))
+        if len(_CONV_PLANS) > 8192:
+            _CONV_PLANS.clear()
+        ent = _CONV_PLANS[key] = (d, wsb)
+    return ent
+
+
 def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transposed=False,
                in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE, out=None):
     _need(x, wp, bias, residual, aux)
@@ -405,15 +422,15 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     y = torch.empty(n, ho, wo, cout, dtype=x.dtype, device=x.device) if out is None else out
     if out is not None and (tuple(out.shape) != (n, ho, wo, cout) or out.dtype != x.dtype or not out.is_contiguous()):
         raise ValueError('conv2d_raw: out must be a contiguous %s tensor with the shape of the result' % (x.dtype,))
-    d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, int(transposed), in_act, out_act, aux_mode)
+    dt = _dt(x)
+    d, wsb = _conv_plan(False, dt, n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, int(transposed), in_act, out_act, aux_mode)
     # algorithmic FLOPs = those of the forward conv this launch computes or differentiates (a stride-2
     # data-gradient executes 4x that on structural zeros; not counted)
     pix = hi * wi if transposed else ho * wo
     flops = 2.0 * n * pix * cin * cout * kh * kw
-    wsb = L.lib().s2e_conv2d_workspace_bytes(_dt(x), C.byref(d))          # > 0 only for split-K shapes
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
-    LaunchProfiler.run(lambda: _CONV_FAMILY[L.lib().s2e_conv2d_kernel_kind(_dt(x), C.byref(d))], flops, lambda: L.check(
-        L.lib().s2e_conv2d(_dt(x), _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _p(ws), wsb,
+    LaunchProfiler.run(lambda: _CONV_FAMILY[L.lib().s2e_conv2d_kernel_kind(dt, C.byref(d))], flops, lambda: L.check(
+        L.lib().s2e_conv2d(dt, _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _p(ws), wsb,
                            _stream()), 's2e_conv2d'),
         tag=lambda: '%s n%d %dx%d c%d->%d k%d s%d' % ('D' if transposed else 'F', n, hi, wi, cin, cout, kh, stride),
         # algorithmic bytes: every operand once (x, packed w, y, + residual / mask tensor when present)
@@ -443,8 +460,7 @@ def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=Fals
     else:
         dw, db = ZeroPool.take(cout * k, torch.float32, x.device).view(cout, k), None
     dbp = db if own_b else dbias_out
-    d = ConvDesc(n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
-    wsb = L.lib().s2e_conv2d_wgrad_workspace_bytes(_dt(x), C.byref(d))    # > 0 only for the 1-channel shapes
+    d, wsb = _conv_plan(True, _dt(x), n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     LaunchProfiler.run(lambda: _WGRAD_FAMILY[L.lib().s2e_conv2d_wgrad_kernel_kind(_dt(x), C.byref(d))],
                        2.0 * n * ho * wo * cin * cout * kh * kw, lambda: L.check(
