@@ -106,3 +106,9 @@ __global__ void s2e_zero_kernel(uint32_t* __restrict__ p, size_t n_words);
 int s2e_zero_async(void* ptr, size_t bytes, hipStream_t st);
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// S2E_DETERMINISTIC=1 (read once per process): every gradient of the train step is summed in a fixed order -- the generic weight
+// gradient's partial tiles for every split launch, one reduction pass instead of several combined with float atomics, the patch
+// weight gradient's bias sums through the workspace -- so that two runs of a trainer produce the same bits.
+// Costs ~0.5 ms per step; off by default.  (The logged loss VALUES and the bilinear resize's backward still use float atomics.)
+int s2e_deterministic(void);

@@ -412,6 +412,7 @@ int s2e_small_wgrad_launch(int dtype, int kind, const s2e_conv_desc* d, const Sm
     else            { if (dtype == S2E_BF16) small_wgrad_go<bf16_t, 4>(kind, p, grid, lds, ws, st); else small_wgrad_go<float, 4>(kind, p, grid, lds, ws, st); }
     int slabs = grid / 32;
     slabs = slabs < 1 ? 1 : (slabs > 8 ? 8 : slabs);
+    if (s2e_deterministic()) slabs = 1;              // (several row slabs are combined with float atomics)
     small_wgrad_reduce_kernel<<<dim3((nout + 63) / 64, slabs), 256, 0, st>>>(ws, grid, nout, p.dw);
     S2E_CHECK_LAUNCH("small wgrad kernels");
     return S2E_OK;

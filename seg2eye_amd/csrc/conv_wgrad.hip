@@ -507,7 +507,14 @@ static void generic_wgrad_plan(const s2e_conv_desc* d, WgradParams* p, int* spli
 // ~ +0.4 ms per step); 0 = never.
 static int wgrad_partial_min_splits() {
     static const int n = [] { const char* e = getenv("S2E_WGRAD_PARTIAL"); return e ? atoi(e) : 16; }();
-    return n;
+    return s2e_deterministic() ? 2 : n;
+}
+// Partial tiles + fixed-order reduce for this launch?  S2E_DETERMINISTIC: always -- even an unsplit launch adds its k-tile
+// workgroups' bias sums with one float atomic each (9 addends for K = 1152: order-dependent in the last bit).
+static bool wgrad_use_partial(int splits) {
+    if (s2e_deterministic()) return true;
+    const int n = wgrad_partial_min_splits();
+    return n > 0 && splits >= 2 && splits >= n;
 }
 
 extern "C" size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_desc* d) {
@@ -520,7 +527,7 @@ extern "C" size_t s2e_conv2d_wgrad_workspace_bytes(int dtype, const s2e_conv_des
     WgradParams p{};                                       // generic kernel: one partial tile (+ 128 bias sums) per workgroup
     int splits;
     generic_wgrad_plan(d, &p, &splits);
-    if (wgrad_partial_min_splits() <= 0 || splits < 2 || splits < wgrad_partial_min_splits()) return 0;
+    if (!wgrad_use_partial(splits)) return 0;
     return (size_t)p.tiles_k * p.tiles_co * splits * (128 * 128 + 128) * sizeof(float);
 }
 
@@ -567,7 +574,7 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
     // deterministic, and cheaper than the atomics once a launch has more than a few splits (64 KB written + read per
     // workgroup at HBM rate against 64 KB of float atomics at ~1.3 TB/s chip-wide).
     const size_t need = (size_t)g * (128 * 128 + 128) * sizeof(float);
-    if (wgrad_partial_min_splits() > 0 && splits >= 2 && splits >= wgrad_partial_min_splits() && !glds_path && workspace && workspace_bytes >= need) {
+    if (wgrad_use_partial(splits) && !glds_path && workspace && workspace_bytes >= need) {
         p.partial = (float*)workspace;
         p.bpartial = p.partial + (size_t)g * (128 * 128);
     }

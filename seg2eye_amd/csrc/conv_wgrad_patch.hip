@@ -32,6 +32,7 @@ __device__ __attribute__((aligned(16))) const uint32_t wz_zero16[4] = {0u, 0u, 0
 struct WpParams {
     const void* x; const void* gy; float* dw; float* dbias;
     float* ws;                    // per-workgroup partial tiles [wg][9][128][64] (NULL: atomics straight into dw)
+    float* bws;                   // S2E_DETERMINISTIC: per-workgroup bias sums [wg][128] (NULL: one atomic per workgroup into dbias)
     int N, H, W, Cin, Cout, Ktot;
     int sx, sy, nslabs;           // slabs per image in x and y; N * sy * sx
     int per_split, tiles_co, tiles_ci;
@@ -260,9 +261,21 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
         __syncthreads();
         if (tid < 128) {
             const int co = tco * 128 + tid;
-            if (co < p.Cout) atomicAdd(p.dbias + co, red[tid] + red[128 + tid]);
+            if (p.bws) p.bws[(size_t)logical_id * 128 + tid] = red[tid] + red[128 + tid];      // folded in workgroup order afterwards
+            else if (co < p.Cout) atomicAdd(p.dbias + co, red[tid] + red[128 + tid]);
         }
     }
+}
+
+// S2E_DETERMINISTIC: dbias[co] += the workgroups' bias sums of co's tile, in logical workgroup order (split, then ci tile)
+__global__ __launch_bounds__(128) void wgrad_patch_bias_reduce_kernel(const float* __restrict__ bws, float* __restrict__ dbias, int Cout,
+                                                                      int tiles_co, int tiles_ci, int splits) {
+    const int tco = blockIdx.x, co = tco * 128 + threadIdx.x;
+    if (co >= Cout) return;
+    float a = 0.f;
+    for (int s = 0; s < splits; ++s)
+        for (int tci = 0; tci < tiles_ci; ++tci) a += bws[(size_t)((s * tiles_co + tco) * tiles_ci + tci) * 128 + threadIdx.x];
+    dbias[co] += a;
 }
 
 // ------------------------------------------------------------------------------------ Cin = 8 (the label-map convs)
@@ -563,8 +576,9 @@ size_t s2e_wgrad_patch_workspace_bytes(int slab_w, const s2e_conv_desc* d) {
     static const bool on = [] { const char* e = getenv("S2E_WGRAD_PATCH_WS"); return e ? atoi(e) != 0 : true; }();
     WpParams p{}; int splits;
     wp_plan(slab_w, d, p, splits);
-    if (!on || splits < 4) return 0;
-    return (size_t)p.tiles_co * p.tiles_ci * splits * (9 * 128 * 64) * sizeof(float);
+    const int min_splits = s2e_deterministic() ? 2 : 4;   // (one split: every dW element has a single writer already)
+    if (!on || splits < min_splits) return s2e_deterministic() ? (size_t)p.tiles_co * p.tiles_ci * splits * 128 * sizeof(float) : 0;
+    return (size_t)p.tiles_co * p.tiles_ci * splits * (9 * 128 * 64 + (s2e_deterministic() ? 128 : 0)) * sizeof(float);
 }
 
 int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
@@ -573,8 +587,12 @@ int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw,
     wp_plan(slab_w, d, p, splits);
     p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
     const size_t need = s2e_wgrad_patch_workspace_bytes(slab_w, d);
-    p.ws = (need && workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
     const int nwg = p.tiles_co * p.tiles_ci * splits;
+    const bool have = need && workspace && workspace_bytes >= need;
+    const bool tiles_ws = have && need >= (size_t)nwg * (9 * 128 * 64) * sizeof(float);
+    p.ws = tiles_ws ? (float*)workspace : nullptr;
+    // S2E_DETERMINISTIC: the workgroups' bias sums go through the tail of the workspace and are folded in a fixed order
+    p.bws = (have && s2e_deterministic() && dbias) ? (float*)workspace + (tiles_ws ? (size_t)nwg * (9 * 128 * 64) : 0) : nullptr;
     if (slab_w == 64) conv_wgrad_patch_kernel<6><<<nwg, 512, 0, st>>>(p);
     else if (slab_w == 32) conv_wgrad_patch_kernel<5><<<nwg, 512, 0, st>>>(p);
     else conv_wgrad_patch_kernel<4><<<nwg, 512, 0, st>>>(p);
@@ -583,9 +601,13 @@ int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw,
         const long threads = (long)d->Cout * (9 * d->Cin / 4);
         const int bx = (int)((threads + 255) / 256);
         int by = 1;
-        while (bx * by < 1024 && by * 2 <= splits) by *= 2;
+        while (!s2e_deterministic() && bx * by < 1024 && by * 2 <= splits) by *= 2;     // (by > 1: partial sums combined with float atomics)
         wgrad_patch_reduce_kernel<<<dim3(bx, by), 256, 0, st>>>(p.ws, dw, d->Cout, d->Cin, p.tiles_co, p.tiles_ci, splits);
         S2E_CHECK_LAUNCH("wgrad_patch_reduce_kernel");
+    }
+    if (p.bws) {
+        wgrad_patch_bias_reduce_kernel<<<p.tiles_co, 128, 0, st>>>(p.bws, dbias, d->Cout, p.tiles_co, p.tiles_ci, splits);
+        S2E_CHECK_LAUNCH("wgrad_patch_bias_reduce_kernel");
     }
     return S2E_OK;
 }
@@ -638,7 +660,7 @@ int s2e_wgrad_c8_launch(int slab_w, const void* x, const void* gy, float* dw, fl
     S2E_CHECK_LAUNCH("conv_wgrad_c8_kernel");
     const int bx = ceil_div((long)d->Cout * 73, 256);
     int by = 1;
-    while (bx * by < 512 && by * 2 <= splits) by *= 2;
+    while (!s2e_deterministic() && bx * by < 512 && by * 2 <= splits) by *= 2;
     wgrad_c8_reduce_kernel<<<dim3(bx, by), 256, 0, st>>>(p.ws, dw, dbias, d->Cout, splits);
     S2E_CHECK_LAUNCH("wgrad_c8_reduce_kernel");
     return S2E_OK;
@@ -710,7 +732,7 @@ extern "C" int s2e_wgrad_c8_batch(int dtype, int N, const s2e_wgrad_c8_job* jobs
             else conv_wgrad_c8_batch_kernel<4><<<first, 256, 0, st>>>(g, ws);
             S2E_CHECK_LAUNCH("conv_wgrad_c8_batch_kernel");
         }
-        wgrad_c8_batch_reduce_kernel<<<dim3(cnt * 37, 8), 256, 0, st>>>(all, ws);
+        wgrad_c8_batch_reduce_kernel<<<dim3(cnt * 37, s2e_deterministic() ? 1 : 8), 256, 0, st>>>(all, ws);
         S2E_CHECK_LAUNCH("wgrad_c8_batch_reduce_kernel");
         ws += (size_t)ws_tile * (128 * 80);
     }

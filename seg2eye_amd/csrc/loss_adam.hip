@@ -2,6 +2,7 @@
 // Adam step, and the library's error/version entry points.
 #include "common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ error state
 static thread_local char g_err[512] = "";
@@ -12,6 +13,10 @@ void s2e_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* s2e_last_error(void) { return g_err; }
+int s2e_deterministic(void) {
+    static const int v = [] { const char* e = getenv("S2E_DETERMINISTIC"); return e ? atoi(e) != 0 : 0; }();
+    return v;
+}
 extern "C" int s2e_version(void) { return 1; }
 
 // ------------------------------------------------------------------------------------ zero fill (see common.h)

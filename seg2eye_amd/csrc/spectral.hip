@@ -912,6 +912,7 @@ extern "C" long s2e_sngrad_scratch_floats(const s2e_sngrad_job* jobs_host, int n
 }
 extern "C" int s2e_sn_grads_inplace(const s2e_sngrad_job* jobs, const int* block_map, int n_blocks, float* partials, void* stream) {
     if (!jobs || !block_map || n_blocks <= 0 || !partials) S2E_FAIL(S2E_ERR_ARG, "s2e_sn_grads_inplace: bad argument");
+    // (cin % 8 == 0 of every job is the caller's to guarantee: the jobs live in device memory)
     hipStream_t st = (hipStream_t)stream;
     sn_grad_inplace_dot_kernel<<<n_blocks, 256, 0, st>>>(jobs, block_map, partials);
     sn_grad_inplace_apply_kernel<<<n_blocks, 256, 0, st>>>(jobs, block_map, partials);

@@ -243,6 +243,8 @@ class GradSink:
         """g_rows (rows, taps*cin): a spectral-normed conv's weight gradient, accumulated by the wgrad kernel straight into the
         parameter's channels-last arena slice; weight: weight_orig (same layout).  Applies dW_orig = g/sigma - (<g, W>/sigma^2) u v^T
         in place -- at the next flush of the step's sink (all layers: one launch pair), or right away outside a trainer step."""
+        if cin % 8:
+            raise ValueError('GradSink.push_inplace: Cin = %d is not a multiple of 8' % cin)
         job = (g_rows, _cl_rows(weight), u, v, sigma, int(rows), int(cin), int(taps))
         pool = ZeroPool.active()
         if pool is not None:
@@ -874,8 +876,9 @@ class Conv2dFn(torch.autograd.Function):
                             True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
         want_b = has_bias and ctx.needs_input_grad[2]
         wdst = ctx.wdst
-        if ctx.needs_input_grad[1] and wdst is not None and cx == cin and _cl_dense(wdst):
-            # the parameter's gradient lies in the packed order (channels-last arena, or any 1x1 conv): the kernel accumulates
+        if ctx.needs_input_grad[1] and wdst is not None and cx == cin and cin % 8 == 0 and _cl_dense(wdst):
+            # the parameter's gradient lies in the packed order (channels-last arena, or any 1x1 conv; Cin % 8 == 0 -- a 1-channel
+            # weight is "channels-last" too, but the in-place kernels work on 16-byte groups of one tap): the kernel accumulates
             # straight into it; spectral norm's chain rule is then applied in place (queued: one launch pair per step)
             _, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, ctx.bdst if want_b else None, dw_out=_cl_rows(wdst))
             if sigma is not None:

@@ -1182,3 +1182,18 @@ def test_label_sparse_forward_under_graph_replay_with_changing_labels():
         assert _relrms(res['graph'][it], res['eager'][it]) < bound, (it, _relrms(res['graph'][it], res['eager'][it]))
     assert _relrms(res['dense'][0], res['eager'][0]) < 5e-3, _relrms(res['dense'][0], res['eager'][0])
     assert float((res['eager'][1] - res['eager'][0]).abs().max()) > 0.05               # (the batches do differ)
+
+
+def test_deterministic_mode_gives_bit_identical_training_runs():
+    """S2E_DETERMINISTIC=1: every gradient of the step is summed in a fixed order, so two trainers from the same
+    weights on the same batches end with the same BITS in both parameter arenas -- eager launches and hipGraph replays.  A
+    child process each: the library reads the switch once."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ['--graphs']):
+        env = dict(os.environ, S2E_DETERMINISTIC='1')
+        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_deterministic.py'), '--ngf', '32', '--iters', '3'] + extra,
+                             env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+        assert d['bit_identical'] and d['deterministic_env'] == '1', d
