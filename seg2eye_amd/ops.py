@@ -366,7 +366,7 @@ def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False, sigma=None):
     cout, cin, kh, kw = w.shape
     cin_pad = cin if cin_pad is None else cin_pad
     # a weight stored channels-last (optim.FlatAdam) is packed from where it lies: rows in, rows out
-    cl = w.dtype == torch.float32 and not w.is_contiguous() and _cl_dense(w) and cin_pad == cin
+    cl = w.dtype == torch.float32 and not w.is_contiguous() and _cl_dense(w) and cin_pad == cin and cin % 8 == 0
     if not cl and (w.dtype != torch.float32 or not w.is_contiguous()):
         w = w.float().contiguous()
     _need(_cl_rows(w) if cl else w, sigma)

@@ -47,7 +47,7 @@ class PackPlan:
         sidx = -1 if sigma is None else int(sigma.storage_offset())
         from .ops import _cl_dense
         wd = w.detach()
-        cl = bool(wd.dtype == torch.float32 and not wd.is_contiguous() and _cl_dense(wd) and int(cin_pad) == wd.shape[1])
+        cl = bool(wd.dtype == torch.float32 and not wd.is_contiguous() and _cl_dense(wd) and int(cin_pad) == wd.shape[1] and wd.shape[1] % 8 == 0)
         if not cl and (wd.dtype != torch.float32 or not wd.is_contiguous()):
             return                                           # (needs a converted copy: packed one by one, ops.pack_weight)
         self.jobs[k] = dict(w=wd, dtype=dtype, cin_pad=int(cin_pad), transposed=bool(transposed), sigma_index=sidx, out=None, cl=cl)

@@ -100,7 +100,7 @@ class SpectralBank:
             if w.dim() == 4 and not w.is_contiguous():
                 # a master stored channels-last (optim.FlatAdam): W's memory columns run (tap, ci); weight_v keeps torch's order
                 # and the kernels translate (s2e_sn_layer.cin / taps)
-                if not w.permute(0, 2, 3, 1).is_contiguous() or w.shape[1] % 4:
+                if not w.permute(0, 2, 3, 1).is_contiguous() or w.shape[1] % 8:
                     raise L.Seg2EyeHipError('spectral norm: weight_orig of %s is neither contiguous nor channels-last' % (tuple(w.shape),))
                 table[i].cin, table[i].taps = w.shape[1], w.shape[2] * w.shape[3]
             for bm, (_BR, _BC) in zip(maps, shapes):
