@@ -206,6 +206,30 @@ def secondary_metrics(args, dev_index, data):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) as
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` in a CHILD process and hand its exit status
+    back.  This process has not touched the GPU (counting devices does not initialise HIP) and never does -- a process that
+    has must not be replaced by, or fork into, another GPU program.  More ranks than GPUs are refused unless
+    S2E_DIST_BACKEND=gloo asks for the dry run in which the ranks share a device (RCCL refuses two ranks on one GPU)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if n > have and os.environ.get('S2E_DIST_BACKEND') != 'gloo':
+        print('bench.py: --gpus %d but %d GPU(s) visible (S2E_DIST_BACKEND=gloo runs the ranks on shared devices as a dry run)'
+              % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:                         # a free rendezvous port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: what this pool's driver supports (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode     # the ranks inherit stdout: rank 0's JSON line passes through
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -219,11 +243,13 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-extras', action='store_true', help='skip the dense_labels / eager / secondary measurements')
-    ap.add_argument('--exchange', default='after_backward', choices=['after_backward', 'overlap'],
-                    help='--gpus > 1: all-reduce the gradient arenas after the backward (hipGraph replays stay; the default: a '
-                         'replayed step is 19.7 ms against 22.0 ms for the eager launches the overlapped exchange needs, and only '
-                         '15 %% of the gradient bytes are final before the last tenth of the backward) or group by group during it')
+    ap.add_argument('--exchange', default='overlap', choices=['after_backward', 'overlap'],
+                    help='--gpus > 1: all-reduce each gradient group of the G arena as soon as the backward has finished it (the '
+                         'G step replays as one hipGraph segment per group, the collective of group k runs beside segment k+1; '
+                         'the default) or all-reduce the whole arena after the backward (one graph, one exposed exchange)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     from seg2eye_amd import distributed as sdist, ops
     from seg2eye_amd.options import default_opt
@@ -237,7 +263,7 @@ def main():
 
     opt_kwargs = dict(ngf=args.ngf, ndf=args.ngf, crop_size=args.size, aspect_ratio=1.0, batchSize=args.batch,
                       compute_dtype=args.dtype, gpu_ids=[dev_index], hip_graphs=not args.no_graphs,
-                      no_overlap_allreduce=(world > 1 and args.exchange == 'after_backward'))
+                      no_overlap_allreduce=(args.exchange == 'after_backward'))
     opt = default_opt(**opt_kwargs)
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -329,7 +355,8 @@ def main():
                                    '%dx%d, batch %d per GPU, ngf=ndf=%d, 4 style images, synthetic ellipse labels'
                                    % (args.size, args.size, args.batch, args.ngf),
                        'global_batch': global_batch, 'parallelism': 'dp%d' % world,
-                       'gradient_exchange': ('none' if world == 1 else args.exchange)},
+                       'gradient_exchange': (args.exchange if sdist.exchange_active() else 'none'),
+                       'graph_segments_G': (len(trainer.graph_G.segments) if graphs_ran else 0)},
             'losses': losses,
         }
         out['ms_per_step_median'] = float(np.median(per_step))

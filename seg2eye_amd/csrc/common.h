@@ -60,6 +60,13 @@ template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
                    f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16),
                    f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16)};
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> one dword of two bf16 (RNE) in ONE v_cvt_pk_bf16_f32 (pack16 converts element by element: cvt + shift + or per pair)
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 template <typename T> __device__ __forceinline__ float load1(const T* p) { return (float)*p; }
 template <typename T> __device__ __forceinline__ void store1(T* p, float v) { *p = (T)v; }
 

@@ -624,7 +624,7 @@ static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tile
 extern "C" size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d) {
     if (!d) return 0;
     if (s2e_small_conv_kind(dtype, d) != SMALL_NONE) return 0;
-    if (s2e_conv_patch2_plan(dtype, d, nullptr)) return 0;
+    if (s2e_conv_duo_plan(dtype, d, nullptr)) return 0;
     if (s2e_conv_patch_plan(dtype, d, nullptr)) return s2e_conv_patch_workspace_bytes(dtype, d);
     if (s2e_conv_stream_plan(dtype, d)) return s2e_conv_stream_workspace_bytes(dtype, d);
     int tiles, tiles_n, splits, per;
@@ -635,7 +635,7 @@ extern "C" size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d) 
 extern "C" int s2e_conv2d_kernel_kind(int dtype, const s2e_conv_desc* d) {
     if (!d) return S2E_KERNEL_GENERIC;
     if (s2e_small_conv_kind(dtype, d) != SMALL_NONE) return S2E_KERNEL_SMALL;
-    return (s2e_conv_patch2_plan(dtype, d, nullptr) || s2e_conv_patch_plan(dtype, d, nullptr)) ? S2E_KERNEL_PATCH : S2E_KERNEL_GENERIC;
+    return (s2e_conv_duo_plan(dtype, d, nullptr) || s2e_conv_patch_plan(dtype, d, nullptr)) ? S2E_KERNEL_PATCH : S2E_KERNEL_GENERIC;
 }
 
 extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* bias, const void* res,
@@ -659,8 +659,8 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
         return s2e_small_conv_launch(dtype, kind, sp, (hipStream_t)stream);
     }
     s2e_patch_plan pplan;
-    if (s2e_conv_patch2_plan(dtype, d, &pplan))       // the big bf16 3x3 layers with >= 128 output channels: 512-pixel tiles
-        return s2e_conv_patch2_launch(&pplan, x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), (hipStream_t)stream);
+    if (!(res && d->aux_mode != S2E_AUX_NONE) && s2e_conv_duo_plan(dtype, d, &pplan))       // the big bf16 3x3 layers with >= 128 output channels: two staggered workgroups per CU (conv_duo.hip)
+        return s2e_conv_duo_launch(&pplan, x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), (hipStream_t)stream);
     if (s2e_conv_patch_plan(dtype, d, &pplan)) {      // big 3x3 / 4x4 stride-1 layers: patch-resident kernel
         const int patch_splits = pplan.splits;
         const size_t need = s2e_conv_patch_workspace_bytes(dtype, d);

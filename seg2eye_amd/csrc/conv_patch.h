@@ -16,11 +16,12 @@ int s2e_conv_patch_launch(int dtype, const s2e_patch_plan* plan, const void* x, 
 // returns the fraction of the 256 accumulator rows that land on image pixels
 double s2e_patch_rectangle(const s2e_conv_desc* d, int ks, int* tw_out, int* th_out);
 
-// Second generation (conv_patch2.hip): 512 pixels (two rectangles) x 128 channels per workgroup, 32-channel K-steps; bf16 3x3.
-int s2e_conv_patch2_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan);
-int s2e_conv_patch2_launch(const s2e_patch_plan* plan, const void* x, const void* w, const float* bias, const void* res,
-                           const void* aux, void* y, const s2e_conv_desc* d, int kpad, hipStream_t st);
-int s2e_spade_conv_modulate_patch2(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
-                                   const float* stats, const float* style, int style_ld, void* out, void* gamma_out,
-                                   int N, int H, int W, int C, int nh, int lrelu, int flags, int tw, int th,
-                                   const int* rect_list, const int* rect_count, hipStream_t st);
+// Duo form (conv_duo.hip): two independent 4-wave workgroups per CU, half a tile out of phase; 256 pixels x 128 channels per
+// workgroup, 32-channel K-steps, wave-private epilogue; bf16 3x3.
+int s2e_conv_duo_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan);
+int s2e_conv_duo_launch(const s2e_patch_plan* plan, const void* x, const void* w, const float* bias, const void* res,
+                        const void* aux, void* y, const s2e_conv_desc* d, int kpad, hipStream_t st);
+int s2e_spade_conv_modulate_duo(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
+                                const float* stats, const float* style, int style_ld, void* out, void* gamma_out,
+                                int N, int H, int W, int C, int nh, int lrelu, int flags, int tw, int th,
+                                const int* rect_list, const int* rect_count, hipStream_t st);

@@ -658,9 +658,9 @@ static int spade_conv_modulate_impl(int dtype, const void* actv, const void* w_p
     if (!fused_plan(dtype, N, H, W, C, nh, flags, &d, &plan))
         S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_spade_conv_modulate: shape N=%d %dx%d C=%d nh=%d is not taken by the fused kernel "
                  "(s2e_spade_conv_modulate_supported); run s2e_conv2d + s2e_modulate_fwd", N, H, W, C, nh);
-    if (const int rc = s2e_spade_conv_modulate_patch2(dtype, actv, w_packed, bias, x, stats, style, style_ld, out, gamma_out, N, H, W, C, nh,
+    if (const int rc = s2e_spade_conv_modulate_duo(dtype, actv, w_packed, bias, x, stats, style, style_ld, out, gamma_out, N, H, W, C, nh,
                                                       lrelu, flags, plan.tw, plan.th, rect_list, rect_count, (hipStream_t)stream))
-        return rc < 0 ? rc : S2E_OK;                  // (the 512-pixel kernel took it: same rectangles, same lists)
+        return rc < 0 ? rc : S2E_OK;                  // (the duo kernel took it: same rectangles, same lists)
     PatchParams p{};
     p.x = actv; p.w = w_packed; p.bias = bias; p.y = out;
     p.N = N; p.Hi = H; p.Wi = W; p.Cin = nh; p.Ho = H; p.Wo = W; p.Cout = 2 * C;

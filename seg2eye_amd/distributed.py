@@ -116,13 +116,11 @@ class FlatGradSync:
             self._start(i)
 
     def reset(self):
-        """Forget launches whose step did not complete (a backward that raised after `launch(0)`): their handles are waited
-        for, so that the next step starts its own exchange instead of treating the groups as already launched."""
-        for h in self._handles:
-            try:
-                h.wait()
-            except Exception:                                # noqa: BLE001 -- the step already failed; do not mask its error
-                pass
+        """Forget launches whose step did not complete (a backward that raised after `launch(0)`), so that the next step starts
+        its own exchange instead of treating the groups as already launched.  The handles are DROPPED, not waited for: when the
+        failure is local to this rank the peers never issue the matching collective, and a wait here would hold the real
+        exception back until the process group's timeout.  A job whose ranks have diverged is over either way; the
+        caller re-raises."""
         self._launched, self._handles = set(), []
 
     def all_reduce(self):

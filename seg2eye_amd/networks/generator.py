@@ -64,23 +64,31 @@ class SPADESTYLEGenerator(BaseNetwork):
             x = ops.label_conv3x3(seg.label, self.fc.weight, self.fc.bias, self.sh, self.sw, False, self.cdtype)
             # a block that follows an upsampling takes its input statistics from the tensor BEFORE it (nearest 2x
             # replication changes neither mean nor variance): a quarter of the bytes for the same numbers
+            # data parallel: when the gradient w.r.t. the input of a stage's EARLIEST block exists, every parameter gradient of
+            # that stage is final -- tell the trainer, which starts the stage's all-reduce (and, replaying hipGraphs, closes a
+            # graph segment there) while the rest of the backward runs.  Stages = Pix2PixModel.create_optimizers' arena groups:
+            # 0 (conv_img, up_3, up_2), 1 (up_1, up_0), 2 G_middle_1, 3 G_middle_0, 4 head_0; the rest leaves after the backward.
+            cb = self.__dict__.get('grad_ready') if torch.is_grad_enabled() else None
+
+            def mark(t, i):
+                if cb is not None and t.requires_grad:
+                    t.register_hook(lambda g, i=i: cb(i))
+            mark(x, 4)
             x = self.head_0(x, seg, w)
             st = self.G_middle_0.input_stats(x, 4)
+            mark(x, 3)
             x = ops.upsample2x(x)
             x = self.G_middle_0(x, seg, w, st)
             st = None
+            mark(x, 2)
             if self.opt.num_upsampling_layers == 'more':
                 st = self.G_middle_1.input_stats(x, 4)
                 x = ops.upsample2x(x)
             x = self.G_middle_1(x, seg, w, st)
             for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
                 st = blk.input_stats(x, 4)
-                # data parallel: when the gradient w.r.t. the input of up_2 (up_0) exists, every parameter gradient of
-                # conv_img / up_3 / up_2 (up_1 / up_0) is final -- tell the trainer, which starts that group's all-reduce
-                # while the rest of the backward runs (Pix2PixModel.create_optimizers lays the arena out in these groups)
-                cb = self.__dict__.get('grad_ready')
-                if cb is not None and torch.is_grad_enabled() and x.requires_grad and blk in (self.up_2, self.up_0):
-                    x.register_hook(lambda g, i=(0 if blk is self.up_2 else 1): cb(i))
+                if blk is self.up_2 or blk is self.up_0:
+                    mark(x, 0 if blk is self.up_2 else 1)
                 # the nearest 2x upsampling is folded into the block (its two SPADE launches read x at (y/2, x/2), forward and
                 # backward: SPADE_STYLE_ResnetBlock.forward(up=True)); a block that cannot fold upsamples first
                 x = blk(x, seg, w, st, up=True) if _FOLD_UP else blk(ops.upsample2x(x), seg, w, st)

@@ -123,6 +123,25 @@ class ZeroPool:
     ALIGN = 256
     _active = None     # the pool whose scope is open
     serial = 0         # scopes begun so far, over all pools (lets per-scope state elsewhere notice a new step)
+    _zeroed = {}       # gradient arena base pointer -> (bytes, ZeroPool.serial when optim.FlatAdam.zero_grad last cleared it)
+
+    @classmethod
+    def arena_zeroed(cls, flat_g):
+        """optim.FlatAdam.zero_grad reports here: this gradient arena is all zeros as of now."""
+        cls._zeroed[flat_g.data_ptr()] = (flat_g.numel() * flat_g.element_size(), cls.serial)
+
+    @classmethod
+    def grad_is_fresh(cls, g):
+        """Is `g` (a view of a gradient arena) known to have been ZERO when the open scope began -- cleared by zero_grad after
+        the previous scope and before this one?  Only then may a kernel sequence that REWRITES the gradient (spectral norm's
+        in-place chain rule) stand in for one that accumulates."""
+        if cls._active is None:
+            return False
+        ptr = g.data_ptr()
+        for base, (nbytes, serial) in cls._zeroed.items():
+            if base <= ptr < base + nbytes:
+                return serial == cls.serial - 1
+        return False
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -166,6 +185,7 @@ class ZeroPool:
             self.clean = hw
         self.key, self.bump, self.tail_i = key, 0, 0
         self.step_cache = {}
+        self.sink.inplace_done = set()
         ZeroPool._active = self
         ZeroPool.serial += 1
 
@@ -225,6 +245,7 @@ class GradSink:
         self.jobs = []
         self.c8 = []               # deferred 8-channel weight gradients (mlp_shared): (onehot, d actv, dw, db, ncls)
         self.inplace = []          # deferred in-place spectral-norm chain rules (channels-last masters): push_inplace
+        self.inplace_done = set()  # gradient slices whose chain rule has already RUN in the open scope (see inplace_allowed)
         self.tables = {}
         self.keepalive = None
         self.keep_c8 = None
@@ -239,18 +260,31 @@ class GradSink:
         return True
 
     @staticmethod
+    def inplace_allowed(wdst):
+        """May the weight-gradient kernel accumulate a SPECTRAL-NORMED layer's raw gradient straight into `wdst` (its channels-
+        last .grad), to be rewritten in place by the chain rule g <- g/sigma - (<g, W>/sigma^2) u v^T at the next flush?  The
+        rewrite equals "accumulate the chain-ruled gradient" only if wdst held ZEROS before this step's contributions and the
+        rule runs ONCE over their sum (it is linear in g).  So: inside a trainer step (ZeroPool scope) whose gradient arena
+        zero_grad cleared right before the scope, and not after this slice's rule has already run in the scope (a second
+        backward behind a flush).  Everything else -- stand-alone ops, gradient accumulation over several backwards, plain
+        .grad tensors -- takes the packed scratch + accumulate path."""
+        pool = ZeroPool.active()
+        return pool is not None and ZeroPool.grad_is_fresh(wdst) and wdst.data_ptr() not in pool.sink.inplace_done
+
+    @staticmethod
     def push_inplace(g_rows, weight, u, v, sigma, rows, cin, taps):
         """g_rows (rows, taps*cin): a spectral-normed conv's weight gradient, accumulated by the wgrad kernel straight into the
         parameter's channels-last arena slice; weight: weight_orig (same layout).  Applies dW_orig = g/sigma - (<g, W>/sigma^2) u v^T
-        in place -- at the next flush of the step's sink (all layers: one launch pair), or right away outside a trainer step."""
+        in place at the next flush of the step's sink (all layers: one launch pair).  Callers ask `inplace_allowed` first.  A layer
+        used twice before a flush queues ONE job: both raw contributions are in g already and the rule is linear."""
         if cin % 8:
             raise ValueError('GradSink.push_inplace: Cin = %d is not a multiple of 8' % cin)
-        job = (g_rows, _cl_rows(weight), u, v, sigma, int(rows), int(cin), int(taps))
         pool = ZeroPool.active()
-        if pool is not None:
-            pool.sink.inplace.append(job)
-        else:
-            GradSink._run_inplace([job], None)
+        if pool is None:
+            raise RuntimeError('GradSink.push_inplace outside a trainer step: the in-place chain rule needs a gradient known to be fresh')
+        if any(j[0].data_ptr() == g_rows.data_ptr() for j in pool.sink.inplace):
+            return
+        pool.sink.inplace.append((g_rows, _cl_rows(weight), u, v, sigma, int(rows), int(cin), int(taps)))
 
     @staticmethod
     def _run_inplace(jobs, cache):
@@ -318,6 +352,7 @@ class GradSink:
             self._flush_c8()
         if self.inplace:
             jobs, self.inplace = self.inplace, []
+            self.inplace_done.update(j[0].data_ptr() for j in jobs)
             GradSink._run_inplace(jobs, self.tables)
             self.keep_inplace = jobs                         # the tensors stay referenced until the next flush
         if not self.jobs:
@@ -345,8 +380,8 @@ class GradSink:
             jobs_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
             map_dev = torch.from_numpy(bm).to(dev)
             ent = (jobs_dev, map_dev, int(nb), max(j[8] for j in jobs), nsn)
-            if len(self.tables) > 8:
-                self.tables.clear()
+            if len(self.tables) > 64:                        # (a step flushes once per all-reduce group: up to 2 x 7 tables + the in-place ones;
+                self.tables.clear()                          #  a table rebuilt inside a hipGraph capture would be a host-to-device copy there)
             self.tables[key] = ent
         jobs_dev, map_dev, nb, max_taps, nsn = ent
         dots = ZeroPool.take(max(nsn, 1), torch.float32, dev)
@@ -876,7 +911,10 @@ class Conv2dFn(torch.autograd.Function):
                             True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
         want_b = has_bias and ctx.needs_input_grad[2]
         wdst = ctx.wdst
-        if ctx.needs_input_grad[1] and wdst is not None and cx == cin and cin % 8 == 0 and _cl_dense(wdst):
+        direct = ctx.needs_input_grad[1] and wdst is not None and cx == cin and cin % 8 == 0 and _cl_dense(wdst)
+        if direct and sigma is not None and not GradSink.inplace_allowed(wdst):
+            direct = False                                   # (the chain rule must ACCUMULATE here: packed scratch, below)
+        if direct:
             # the parameter's gradient lies in the packed order (channels-last arena, or any 1x1 conv; Cin % 8 == 0 -- a 1-channel
             # weight is "channels-last" too, but the in-place kernels work on 16-byte groups of one tap): the kernel accumulates
             # straight into it; spectral norm's chain rule is then applied in place (queued: one launch pair per step)

@@ -86,6 +86,7 @@ class FlatAdam:
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
+        ops.ZeroPool.arena_zeroed(self.flat_g)               # (lets the in-place spectral-norm chain rule know the arena is fresh)
 
     def rebind_grads(self):
         """Re-attach .grad views if something replaced them (e.g. a zero_grad(set_to_none=True))."""
@@ -124,11 +125,30 @@ class FlatAdam:
     def load_state_dict(self, sd):
         lay = sd.get('layout')
         if (lay is None and any(self.cl)) or (lay is not None and lay != self._layout()):
+            if lay is None and len(sd['m']) == sum((p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN for p in self.params):
+                return self._load_torch_order(sd)            # saved before channels-last masters: convert per parameter
             raise ValueError('FlatAdam.load_state_dict: the saved moments were laid out for another arena (parameter order / '
-                             'channels-last weights differ); they cannot be loaded element by element')
+                             'channels-last weights differ); they cannot be loaded element by element (a state saved with '
+                             'S2E_WEIGHTS_CL=0 -- every parameter in torch order, no alignment gaps -- is converted)')
         self.step_count = int(sd['step'])
         self.flat_m.copy_(sd['m'])
         self.flat_v.copy_(sd['v'])
+        self.param_groups[0]['lr'] = float(sd['lr'])
+        self.hyper[4:5].fill_(float(self.step_count))
+        self.sync_hyper(self._hyper_host[1])
+
+    def _load_torch_order(self, sd):
+        """A state dict without 'layout': moments saved when every parameter lay in torch's order, back to back (4-element
+        alignment) -- before channels-last masters, or with S2E_WEIGHTS_CL=0.  Copied per parameter BY LOGICAL INDEX through
+        the arena views, so channels-last slices and their 256-byte alignment gaps do not matter."""
+        off = 0
+        with torch.no_grad():
+            for i, p in enumerate(self.params):
+                n = p.numel()
+                for flat, key in ((self.flat_m, 'm'), (self.flat_v, 'v')):
+                    _arena_view(flat, self.offsets[i], p, self.cl[i]).copy_(sd[key][off:off + n].view(p.shape))
+                off += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.step_count = int(sd['step'])
         self.param_groups[0]['lr'] = float(sd['lr'])
         self.hyper[4:5].fill_(float(self.step_count))
         self.sync_hyper(self._hyper_host[1])

@@ -76,10 +76,11 @@ class Pix2PixModel(nn.Module):
         # same parameter SET as the reference (netG + netE).  The ORDER inside the flat arena serves three things:
         #  * each SPADE's gamma / beta conv weights (and biases) back to back, so [gamma | beta] is one zero-copy matrix;
         #  * the style FCs of all SPADE+Style layers back to back (weights, then biases): one GEMM for all (networks/stylebank.py);
-        #  * the blocks grouped by WHEN their gradients become final in the backward pass -- late blocks (conv_img, up_3, up_2)
-        #    first, then up_1 / up_0, then everything that completes at the very end (middle / head blocks, fc, the style FCs,
+        #  * the blocks grouped by WHEN their gradients become final in the backward pass -- (conv_img, up_3, up_2) first, then
+        #    (up_1, up_0), G_middle_1, G_middle_0, head_0, then everything that completes at the very end (fc, the style FCs,
         #    netE) -- so that a data-parallel run can all-reduce a group's contiguous slice while the backward is still running
-        #    (distributed.FlatGradSync.launch; self.grad_groups_G = the element ranges, in completion order).
+        #    (distributed.FlatGradSync.launch; self.grad_groups_G = the element ranges, in completion order;
+        #    networks/generator.py reports group i when the gradient w.r.t. the input of its earliest block exists).
         from .networks.normalization import SPADE, SPADE_STYLE_Block
         fcs = [m.adain.linear for m in self.netG.modules() if isinstance(m, SPADE_STYLE_Block)]
         fc_params = [f.weight for f in fcs] + [f.bias for f in fcs if f.bias is not None]
@@ -100,14 +101,16 @@ class Pix2PixModel(nn.Module):
                         out.append(q)
             return out
         G = self.netG
-        late = block_params([m for m in (getattr(G, n, None) for n in ('conv_img', 'up_3', 'up_2')) if m is not None])
-        mid = block_params([m for m in (getattr(G, n, None) for n in ('up_1', 'up_0')) if m is not None])
+        # completion groups, in the order the backward finishes them (round 4: the three 1024-channel blocks -- 85 % of the bytes --
+        # leave one by one instead of riding with everything that completes at the very end)
+        stages = [('conv_img', 'up_3', 'up_2'), ('up_1', 'up_0'), ('G_middle_1',), ('G_middle_0',), ('head_0',)]
+        staged = [block_params([m for m in (getattr(G, n, None) for n in names) if m is not None]) for names in stages]
         dead = list(self.netE.fc_var.parameters())          # logvar enters no loss: never a gradient (torch's Adam skips them)
         dead_ids = {id(q) for q in dead}
-        early = block_params([G]) + fc_params + [q for q in self.netE.parameters() if id(q) not in dead_ids]   # rest of netG, FCs, netE
-        G_params = late + mid + early
+        early = block_params([G]) + fc_params + [q for q in self.netE.parameters() if id(q) not in dead_ids]   # fc, style FCs, netE
+        G_params = [q for grp in staged for q in grp] + early
         self._arena_groups_G_dead = dead
-        self._arena_groups_G = [len(late), len(mid), len(early)]
+        self._arena_groups_G = [len(grp) for grp in staged] + [len(early)]
         if opt.no_TTUR:
             beta1, beta2, G_lr, D_lr = opt.beta1, opt.beta2, opt.lr, opt.lr
         else:

@@ -1,6 +1,8 @@
 """Pix2PixTrainer (reference trainers/pix2pix_trainer.py:8-88): owns the model and the two optimizers,
 runs one G step / one D step, LR decay, save.  Multi-GPU: when torch.distributed is initialised the
 flat gradient arenas are sum-all-reduced (RCCL) between backward and the Adam launch."""
+import os
+
 from .distributed import FlatGradSync, broadcast_buffers, broadcast_flat, exchange_active, world_size
 from .ops import ZeroPool
 from .pix2pix_model import Pix2PixModel
@@ -14,6 +16,23 @@ def _total(losses):
     for v in vals[1:]:
         t = t + v
     return t.view(()) if t.numel() == 1 else t.mean()
+
+
+class _StepGraph:
+    """One captured step body: a single hipGraph, or a chain of segments cut where a gradient group completes
+    (`groups[k]` = the arena group that is final after segment k)."""
+
+    def __init__(self, segments, groups):
+        self.segments, self.groups = segments, groups
+
+    def pool(self):
+        return self.segments[0].pool()
+
+    def replay(self, launch=None):
+        for k, g in enumerate(self.segments):
+            g.replay()
+            if launch is not None and k < len(self.groups):
+                launch(self.groups[k])
 
 
 class Pix2PixTrainer:
@@ -30,22 +49,15 @@ class Pix2PixTrainer:
             self.old_lr = opt.lr
             self.sync_G = FlatGradSync(self.optimizer_G.flat_g, groups=self.pix2pix_model.grad_groups_G)
             self.sync_D = FlatGradSync(self.optimizer_D.flat_g)
+            self._segments = None                            # while the G step is being captured in segments: (graphs, groups, mode)
+            self._quiet_hooks = False                        # capture warm-up passes: hooks flush but exchange nothing
             if exchange_active() and not getattr(opt, 'no_overlap_allreduce', False):
                 # Overlap the gradient exchange with the backward pass: the generator reports when a group of
-                # blocks has all its gradients (networks/generator.py), we flush that group's queued gradient re-layouts and
-                # start the all-reduce of its arena slice.  That needs the backward to run as individual launches, not as one
-                # graph replay.  Since round 3 that has a price: the replayed step (19.7 ms) is shorter than the host needs to
-                # enqueue ~900 launches (22.0 ms per eager step on a slow host, 20.1 on a fast one), so
-                # --no_overlap_allreduce + --hip_graphs is the faster combination when only little of the exchange can be hidden
-                # (bench.py's default for --gpus N).
-                if getattr(self.opt, 'hip_graphs', False):
-                    from .distributed import get_rank
-                    if get_rank() == 0:
-                        import sys
-                        print('seg2eye_amd: %d replicas: the steps run as individual launches so that the gradient exchange '
-                              'overlaps the backward (--hip_graphs is ignored; --no_overlap_allreduce keeps the graphs and '
-                              'exchanges after the backward)' % world_size(), file=sys.stderr)
-                self.opt.hip_graphs = False
+                # blocks has all its gradients (networks/generator.py); we flush that group's queued gradient re-layouts and
+                # start the all-reduce of its arena slice.  With --hip_graphs the G step is captured as one graph SEGMENT per
+                # group (round 4): a hook that fires during capture ends the current segment and begins the next, and a replayed
+                # step is `replay segment k; start group k's all-reduce` -- the collective runs on the backend's stream while the
+                # next segment replays.  (Rounds 1-3 had to choose: eager launches + overlap, or graphs + one exposed exchange.)
                 self.pix2pix_model.netG.__dict__['grad_ready'] = self._group_ready
             broadcast_flat(self.optimizer_G.flat_p)          # identical replicas at step 0: parameters ...
             broadcast_flat(self.optimizer_D.flat_p)
@@ -59,19 +71,35 @@ class Pix2PixTrainer:
         broadcast_buffers([m.netG, m.netD, m.netE])
 
     def _group_ready(self, i):
-        """Backward hook (data parallel, eager): parameter group i of the G arena is final.  Only during the G step's backward --
+        """Backward hook (data parallel): parameter group i of the G arena is final.  Only during the G step's backward --
         the D step's no-grad generator forward registers no hooks."""
         pool = ZeroPool.active()
-        if pool is self.pool and pool.key == 'G':
-            pool.sink.flush()                                # the group's queued packed-dW -> arena conversions: now
+        if pool is not self.pool or pool.key != 'G':
+            return
+        pool.sink.flush()                                    # the group's queued packed-dW -> arena conversions: now
+        if self._segments is not None:
+            self._next_segment(i)                            # capturing: the segment ends here, replay launches the exchange
+        elif not self._quiet_hooks:
             self.sync_G.launch(i)
 
+    def _next_segment(self, group):
+        import torch
+        segs, groups, mode = self._segments
+        segs[-1].capture_end()
+        groups.append(group)
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=segs[0].pool(), capture_error_mode=mode)
+        segs.append(g)
+
     def _train_mode(self):
-        """model.train() -- when something put it (or any of its modules) into eval mode; re-setting the flag on all ~260
-        modules every step cost 2 ms of host time per eager step."""
-        m = self.pix2pix_model
-        if not m.training or not all(x.training for x in (m.netG, m.netD, m.netE) if x is not None):
-            m.train()
+        """model.train() -- when something put it or ANY of its modules into eval mode (a validation pass, a caller freezing one
+        SPADE block: spectral norm's power iteration and BatchNorm's running statistics stop there).  Reading ~260 flags costs
+        ~15 us; re-setting them every step cost 2 ms of host time per eager step."""
+        mods = self.__dict__.get('_all_modules')
+        if mods is None:
+            mods = self.__dict__['_all_modules'] = list(self.pix2pix_model.modules())
+        if not all(x.training for x in mods):
+            self.pix2pix_model.train()
 
     def _one(self):
         """d(total)/d(total) as a persistent device scalar (autograd would launch a ones_like per backward)."""
@@ -109,7 +137,7 @@ class Pix2PixTrainer:
         if self.use_graphs:
             self._stage_inputs(data)                         # captures on first use; turns graphs off if that fails
         if self.use_graphs:
-            self.graph_G.replay()
+            self.graph_G.replay(self.sync_G.launch)          # (segment k, then group k's exchange beside segment k+1)
             for k, v in getattr(self, '_static_log', {}).items():   # the replay refreshed these in place: log this step's values
                 self.pix2pix_model.add_to_loss_log(k, v.clone())
         else:
@@ -145,6 +173,9 @@ class Pix2PixTrainer:
                 import torch
                 print('seg2eye_amd: hipGraph capture failed (%s: %s) -- continuing without graphs' % (type(e).__name__, e),
                       file=sys.stderr)
+                if os.environ.get('S2E_DEBUG_CAPTURE'):
+                    import traceback
+                    traceback.print_exc()
                 torch.cuda.synchronize()
                 self.opt.hip_graphs = False
                 self._static, self.graph_G, self.graph_D = None, None, None
@@ -175,10 +206,14 @@ class Pix2PixTrainer:
         bn_snap = [t.clone() for t in bn_bufs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self._g_body(self._static)
-                self._d_body(self._static)
+        self._quiet_hooks = True                             # (the warm-up passes exchange nothing: every rank runs them alike)
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._g_body(self._static)
+                    self._d_body(self._static)
+        finally:
+            self._quiet_hooks = False
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.pool.freeze()                                   # the graphs hold raw pointers into the pool
@@ -187,9 +222,13 @@ class Pix2PixTrainer:
         multi = torch.distributed.is_available() and torch.distributed.is_initialized()
         mode = {'capture_error_mode': 'thread_local'} if multi else {}
         try:
-            graph_G = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_G, **mode):
-                self._g_body(self._static)
+            if m.netG.__dict__.get('grad_ready') is not None:
+                graph_G = self._capture_segmented(self._g_body, mode.get('capture_error_mode', 'global'))
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **mode):
+                    self._g_body(self._static)
+                graph_G = _StepGraph([g], [])
             graph_D = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_D, pool=graph_G.pool(), **mode):
                 self._d_body(self._static)
@@ -204,6 +243,29 @@ class Pix2PixTrainer:
             # tensors: remember them, a replay refreshes their values and run_generator_one_step re-registers them
             self._static_log = {k: v[-1] for k, v in m.loss_log.items() if len(v)}
             m.reset_loss_log()
+
+    def _capture_segmented(self, body, mode):
+        """Capture `body` as a chain of hipGraphs that share one memory pool: `_group_ready` -- a backward hook -- closes the
+        current segment and opens the next wherever a gradient group completes.  The backward runs on THIS thread while
+        capturing (autograd's device thread would end a capture another thread began)."""
+        import gc
+        import torch
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        segs, groups = [torch.cuda.CUDAGraph()], []
+        with torch.cuda.stream(stream), torch.autograd.set_multithreading_enabled(False):
+            segs[0].capture_begin(capture_error_mode=mode)
+            self._segments = (segs, groups, mode)
+            try:
+                body(self._static)
+            finally:
+                self._segments = None
+                segs[-1].capture_end()
+        torch.cuda.current_stream().wait_stream(stream)
+        return _StepGraph(segs, groups)
 
     def get_latest_losses(self, include_log_losses=False):
         losses = {**self.g_losses, **self.d_losses}

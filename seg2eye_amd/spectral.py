@@ -27,10 +27,10 @@ def lib_chain_max_cols():
 
 def sn_convs(root):
     """The spectral-normed convs under `root`, memoised on the module (every block's forward asks; walking the module tree
-    each time cost 2 ms of host time per eager step).  The memo is keyed on the number of modules under root, so adding or
-    removing a submodule re-scans."""
+    each time cost 2 ms of host time per eager step).  The memo is keyed on the number of modules in the whole subtree
+    (~50 us for the generator's 260), so adding, removing or wrapping a submodule at any depth re-scans."""
     memo = root.__dict__.get('_sn_convs_memo')
-    n = sum(1 for _ in root.children())
+    n = sum(1 for _ in root.modules())
     if memo is not None and memo[0] == n and all(hasattr(m, 'weight_orig') for m in memo[1]):
         return memo[1]
     convs = [m for m in root.modules() if isinstance(m, torch.nn.Conv2d) and hasattr(m, 'weight_orig')]

@@ -60,8 +60,11 @@ def _worker(rank, world, port, out):
     # a step that failed after its first group was launched must not leave the sync thinking that group is in flight
     opt.flat_g.copy_(local)
     gsync.launch(0)
-    gsync.reset()
+    in_flight = list(gsync._handles)
+    gsync.reset()                                        # drops the handles WITHOUT waiting (a peer may never issue its half: ADVICE r3)
     assert not gsync._handles and not gsync._launched
+    for h in in_flight:                                  # (here both ranks did launch: let the collectives finish before reusing the arena)
+        h.wait()
     opt.flat_g.copy_(local)
     assert abs(gsync.all_reduce() - 1.0 / world) < 1e-12 and torch.equal(opt.flat_g, grouped)
     out[rank] = (p0, local, grouped, opt.flat_g.clone())

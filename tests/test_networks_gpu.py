@@ -667,27 +667,37 @@ def test_full_size_train_step_matches_oracle():
 
 @pytest.mark.parametrize('exchange', ['after_backward', 'overlap'])
 def test_bench_two_ranks_dry_run(exchange):
-    """bench.py's multi-rank control flow (barriers, max-over-ranks timing, the eager event pass on EVERY rank -- a step
-    contains the gradient all-reduce, so rank 0 alone would wait for ever -- and the final barrier) with two ranks sharing
-    this box's GPU over gloo.  RCCL refuses two ranks on one device; the collective calls are the same."""
-    import json, os, socket, subprocess, sys
+    """`python bench.py --gpus 2` with NO launcher: bench.py starts its own two ranks in a child process; here
+    they share this box's GPU over gloo (S2E_DIST_BACKEND=gloo: RCCL refuses two ranks on one device; the collective calls
+    are the same).  Covers the multi-rank control flow -- barriers, max-over-ranks timing, the eager event pass on EVERY rank
+    (a step contains the gradient all-reduce, so rank 0 alone would wait for ever), the final barrier -- and that BOTH
+    exchanges run on hipGraph replays: the overlapped one as one graph segment per gradient group."""
+    import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, S2E_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
-                          '--gpus', '2', '--steps', '2', '--warmup', '1', '--ngf', '16', '--batch', '2', '--exchange', exchange],
-                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--ngf', '16',
+                          '--batch', '2', '--exchange', exchange], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 prints ONE line
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2' and d['rccl_ranks'] == 2
     assert d['value'] > 0 and 'roofline' in d and 'cpu_baseline' not in d
-    # the default keeps the hipGraph replays and exchanges after the backward; the overlapped exchange needs eager launches
-    assert d['config']['gradient_exchange'] == exchange and d['hip_graphs'] == (exchange == 'after_backward')
+    assert d['config']['gradient_exchange'] == exchange and d['hip_graphs'] is True, d['config']
+    assert d['config']['graph_segments_G'] == (6 if exchange == 'overlap' else 1), d['config']
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """--gpus N beyond the visible devices is refused (exit status 2) before anything is launched -- unless the gloo dry run is asked for."""
+    import os, subprocess, sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'S2E_DIST_BACKEND')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(torch.cuda.device_count() + 1)], env=env,
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 2 and 'GPU(s) visible' in out.stderr, (out.returncode, out.stderr[-500:])
 
 
 # ------------------------------------------------------------------------------------------ config 3 AS BENCHED
@@ -1058,15 +1068,22 @@ def test_rccl_single_rank_overlapped_step_matches_exchange_after_backward():
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert r['backend'] == 'nccl' and r['world'] == 1 and r['finite'], r
-    assert r['overlap']['hooked'] and r['overlap']['early_launches'] >= 2 and not r['overlap']['graphs'], r
-    assert not r['after_backward']['hooked'] and r['after_backward']['graphs'], r
+    assert r['overlap']['hooked'] and r['overlap']['early_launches'] >= 2 * 5 and not r['overlap']['graphs'], r
+    # round 4: the overlapped exchange ON hipGraph replays -- the G step is six graph segments (five gradient groups + the rest),
+    # the first five groups' all-reduces are started between segments in every iteration
+    og = r['overlap_graphs']
+    assert og['hooked'] and og['graphs'] and og['segments'] == 6 and og['early_launches'] >= 2 * 5, r
+    assert not r['after_backward']['hooked'] and r['after_backward']['graphs'] and r['after_backward']['segments'] == 1, r
     # per trainer: broadcasts of 2 parameter arenas + the u|v arenas at construction; >= 1 all-reduce per group per step
     assert r['overlap']['broadcast_calls'] >= 4 and r['overlap']['all_reduce_calls'] >= 2 * 2 * 2, r
+    assert og['all_reduce_calls'] >= 2 * (6 + 1), r
     assert r['after_backward']['all_reduce_calls'] >= 2 * 2, r
     bound = 2 * 4e-4 * sum(((1 - 0.9 ** t) / (1 - 0.9)) ** 0.5 for t in (1, 2)) + 1e-5
     assert r['max_abs_diff_G'] <= bound and r['max_abs_diff_D'] <= bound, r
-    for k, v in r['overlap']['losses'].items():
-        assert abs(v - r['after_backward']['losses'][k]) <= 2e-2 * max(1.0, abs(v)), (k, r)
+    assert r['max_abs_diff_G_segmented'] <= bound and r['max_abs_diff_D_segmented'] <= bound, r
+    for tag in ('overlap', 'overlap_graphs'):
+        for k, v in r[tag]['losses'].items():
+            assert abs(v - r['after_backward']['losses'][k]) <= 2e-2 * max(1.0, abs(v)), (tag, k, r)
 
 
 def test_batchnorm_spade_statistics_are_synchronised_across_replicas():

@@ -480,8 +480,18 @@ def test_fused_spectral_norm_conv_matches_torch(cfg, arena, dtype):
         else:
             fa.zero_grad()                                   # (keeps the .grad views of the arena)
         sn_begin(mine)
-        y = ops.conv2d_m(xg, conv, None, s, p)
-        y.backward(nhwc(gy).to(dev))
+        if arena == 'channels_last':
+            # as inside a trainer step: the weight gradient lands in the arena slice and the chain rule rewrites it in place
+            # (s2e_sn_grads_inplace) when the scope's sink flushes; outside a step the accumulate path runs (test below)
+            pool = ops.ZeroPool(dev)
+            with pool.scope('t'):
+                y = ops.conv2d_m(xg, conv, None, s, p)
+                y.backward(nhwc(gy).to(dev))
+                if cin % 8 == 0:
+                    assert len(pool.sink.inplace) == 1
+        else:
+            y = ops.conv2d_m(xg, conv, None, s, p)
+            y.backward(nhwc(gy).to(dev))
         _close(nchw(y), yr, dtype, what='sn y (round %d)' % rnd)
         _close(conv.weight_orig.grad, ref.weight_orig.grad, dtype, what='sn dW_orig (round %d)' % rnd)
         _close(conv.bias.grad, ref.bias.grad, dtype, what='sn db')
@@ -498,6 +508,74 @@ def test_fused_spectral_norm_conv_matches_torch(cfg, arena, dtype):
     _close(conv.weight_v, ref.weight_v, torch.float32, what='v (3 iters)')
     sd = mine.state_dict()
     assert set(sd) == {'0.bias', '0.weight_orig', '0.weight_u', '0.weight_v'}
+
+
+@pytest.mark.parametrize('cfg', [(16, 24, 1, 1, 0), (16, 24, 3, 1, 1), (64, 72, 3, 1, 1)])
+@pytest.mark.parametrize('where', ['plain_grad', 'arena', 'arena_in_step', 'arena_in_step_twice', 'arena_flushed_between'])
+def test_spectral_norm_weight_gradient_accumulates(cfg, where):
+    """a spectral-normed conv's weight gradient must ACCUMULATE like torch's whenever .grad is not fresh --
+    backward twice without zero_grad (gradient accumulation), a layer applied twice in one step, a second backward behind a
+    flush -- on a contiguous 1x1 weight and on channels-last 3x3 weights, with a plain .grad tensor and with an optimizer arena.
+    The in-place chain rule (g <- g/sigma - <g, W>/sigma^2 u v^T on the arena slice) may only stand in when the slice was zero
+    at the start of the step and the rule runs once over the summed raw gradient; everything else takes the accumulate path."""
+    import copy
+    from seg2eye_amd import ops
+    from seg2eye_amd.optim import FlatAdam
+    from seg2eye_amd.spectral import sn_begin
+    cin, cout, k, s, p = cfg
+    dev = _dev()
+    torch.manual_seed(11)
+    ref = torch.nn.utils.spectral_norm(torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, bias=False)).double()
+    mine = torch.nn.Sequential(copy.deepcopy(ref).float()).to(dev)
+    conv = mine[0]
+    fa = None
+    if where == 'plain_grad':
+        conv.weight_orig.grad = torch.zeros_like(conv.weight_orig, memory_format=torch.channels_last)
+    else:
+        fa = FlatAdam(list(mine.parameters()), lr=1e-3, channels_last=True)
+    xs = [_rnd((2, cin, 10, 10), 20 + i, torch.float32) for i in range(2)]
+    gys = None
+    ref.train(); mine.train()
+    ref.zero_grad()
+    # reference: ONE power iteration (one forward in train mode), both inputs through the same normalised weight, gradients summed
+    ref(xs[0].double())                                       # advances u, v once
+    ref.eval()                                                # (further forwards reuse u, v: what sn_begin once + two convs does)
+    outs = [ref(x.double()) for x in xs]
+    gys = [_rnd(tuple(o.shape), 30 + i, torch.float32) for i, o in enumerate(outs)]
+    for o, g in zip(outs, gys):
+        o.backward(g.double())
+    want = ref.weight_orig.grad
+    pool = ops.ZeroPool(dev)
+    if fa is not None:
+        fa.zero_grad()
+    sn_begin(mine)
+    xg = [nhwc(x).to(dev).requires_grad_(True) for x in xs]
+    gg = [nhwc(g).to(dev) for g in gys]
+    if where in ('plain_grad', 'arena'):
+        for x, g in zip(xg, gg):                              # two backwards, no zero_grad between, no trainer step around them
+            ops.conv2d_m(x, conv, None, s, p).backward(g)
+    elif where == 'arena_in_step':
+        with pool.scope('t'):                                 # one trainer step: the layer applied twice, one backward
+            y0, y1 = ops.conv2d_m(xg[0], conv, None, s, p), ops.conv2d_m(xg[1], conv, None, s, p)
+            torch.autograd.backward([y0, y1], gg)
+            assert len(pool.sink.inplace) <= 1                # (queued once: both raw contributions are in .grad, the rule is linear)
+    elif where == 'arena_in_step_twice':
+        with pool.scope('t'):                                 # two backwards inside one step
+            for x, g in zip(xg, gg):
+                ops.conv2d_m(x, conv, None, s, p).backward(g)
+    else:
+        with pool.scope('t'):                                 # a flush between the two backwards: the second must not rewrite
+            ops.conv2d_m(xg[0], conv, None, s, p).backward(gg[0])
+            pool.sink.flush()
+            ops.conv2d_m(xg[1], conv, None, s, p).backward(gg[1])
+    _close(conv.weight_orig.grad, want, torch.float32, what='accumulated sn dW_orig (%s)' % where)
+    if fa is not None:                                        # a second step WITHOUT zero_grad: the arena is not fresh any more
+        with pool.scope('t'):
+            ops.conv2d_m(xg[0], conv, None, s, p).backward(gg[0])
+        ref.weight_orig.grad = None
+        outs = ref(xs[0].double())
+        outs.backward(gys[0].double())
+        _close(conv.weight_orig.grad, want + ref.weight_orig.grad, torch.float32, what='stale arena (%s)' % where)
 
 
 @pytest.mark.parametrize('forced', [True, False])
@@ -648,15 +726,16 @@ def test_wgrad_c8_batch_matches_per_layer_launches():
             assert float((db - rb).abs().max()) <= 1e-4 * float(rb.abs().max()) + 1e-5
 
 
-def test_conv_patch2_experimental_kernel_matches_torch():
-    """csrc/conv_patch2.hip (512-pixel tiles, 32-channel K-steps; OFF by default -- it measured no faster): with
-    S2E_CONV_PATCH2=448 it takes the bench's large 3x3 layers and the fused [gamma | beta] conv + modulation; tools/check_patch2.py
-    compares forward (bias + residual + LeakyReLU), data-gradient (ReLU mask) and the fused launch (dense, and through an odd-length
-    rectangle list) with torch's own convolution in fp32."""
+@pytest.mark.parametrize('duo', ['512', '0'])
+def test_patch_conv_kernels_match_torch_at_bench_shapes(duo):
+    """The two patch-resident 3x3 kernels at the bench's shapes against torch's own convolution in fp32 (tools/check_duo.py):
+    forward with bias + residual + LeakyReLU, data-gradient with the ReLU mask, and the fused [gamma | beta] conv + SPADE+Style
+    modulation, dense and through an odd-length rectangle list.  S2E_CONV_DUO=512 (the default): csrc/conv_duo.hip, two
+    workgroups per CU, takes them; =0: csrc/conv_patch.hip runs the same checks (it keeps every shape the duo plan declines)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, S2E_CONV_PATCH2='448')
-    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_patch2.py')], env=env, capture_output=True, text=True,
+    env = dict(os.environ, S2E_CONV_DUO=duo)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_duo.py')], env=env, capture_output=True, text=True,
                          timeout=900, cwd=root)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
     assert 'worst relative error' in out.stdout

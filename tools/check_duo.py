@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""The 512-pixel patch kernel (csrc/conv_patch2.hip) against torch's own convolution at the bench shapes: forward with bias +
+"""The duo patch kernel (csrc/conv_duo.hip: two staggered workgroups per CU; S2E_CONV_DUO = minimum work items) against torch's own convolution at the bench shapes: forward with bias +
 residual + LeakyReLU, data-gradient with the ReLU mask, and the fused [gamma | beta] conv + SPADE+Style modulation (dense and
 through a rectangle list with an ODD number of rectangles), each timed with HIP events.
-    python tools/check_patch2.py                       # S2E_CONV_PATCH2=0 runs the same checks on the first-generation kernel"""
+    S2E_CONV_DUO=512 python tools/check_duo.py      # S2E_CONV_DUO=0 runs the same checks on conv_patch.hip"""
 import ctypes as C
 import os
 import sys

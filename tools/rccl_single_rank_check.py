@@ -3,9 +3,10 @@
 that every collective of the data-parallel path is really issued -- the start-up broadcasts of the parameter arenas and of the
 spectral-norm / BatchNorm buffers, the asynchronous all-reduces of the generator's gradient groups launched from the backward
 hooks (on RCCL's stream, while the backward continues), the wait before Adam.  No byte crosses a link, but every call the
-8-GPU run makes is executed.  Two trainers from the same weights run the same G+D iterations, one with the overlapped
-exchange (eager launches + hooks), one with --no_overlap_allreduce (hipGraph replays + one exchange after the backward);
-prints one JSON line with the largest parameter difference and the losses.
+8-GPU run makes is executed.  Three trainers from the same weights run the same G+D iterations: the overlapped exchange with
+eager launches (hooks start each group's all-reduce), the overlapped exchange with hipGraphs (the G step replays as one graph
+SEGMENT per gradient group, group k's all-reduce is started between segments k and k+1), and --no_overlap_allreduce (one graph,
+one exchange after the backward); prints one JSON line with the largest parameter differences and the losses.
 
     RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 S2E_DIST_SINGLE=1 python tools/rccl_single_rank_check.py
 """
@@ -51,7 +52,8 @@ def main():
         return real_bc(*a, **k)
     dist.all_reduce, dist.broadcast = counting_all_reduce, counting_broadcast
     res = {}
-    for tag, kw in (('overlap', dict(hip_graphs=False)), ('after_backward', dict(hip_graphs=True, no_overlap_allreduce=True))):
+    for tag, kw in (('overlap', dict(hip_graphs=False)), ('overlap_graphs', dict(hip_graphs=True)),
+                    ('after_backward', dict(hip_graphs=True, no_overlap_allreduce=True))):
         opt = default_opt(ngf=args.ngf, ndf=args.ngf, crop_size=256, aspect_ratio=1.0, batchSize=args.batch, compute_dtype=args.dtype,
                           gpu_ids=[0], **kw)
         before = dict(calls)
@@ -74,13 +76,15 @@ def main():
         res[tag] = dict(G=tr.optimizer_G.flat_p.detach().clone(), D=tr.optimizer_D.flat_p.detach().clone(),
                         losses={k: float(v.detach().float().mean()) for k, v in tr.get_latest_losses().items()},
                         hooked=hooked, early_launches=len(launched_early), graphs=bool(tr.use_graphs and tr.graph_G is not None),
+                        segments=(len(tr.graph_G.segments) if tr.use_graphs and tr.graph_G is not None else 0),
                         all_reduce_calls=calls['all_reduce'] - before['all_reduce'], broadcast_calls=calls['broadcast'] - before['broadcast'])
-    a, b = res['overlap'], res['after_backward']
+    a, b, c = res['overlap'], res['after_backward'], res['overlap_graphs']
+    strip = lambda r: {k: v for k, v in r.items() if k not in ('G', 'D')}
     out = {'backend': dist.get_backend(), 'world': world, 'iters': args.iters,
            'max_abs_diff_G': float((a['G'] - b['G']).abs().max()), 'max_abs_diff_D': float((a['D'] - b['D']).abs().max()),
-           'finite': bool(torch.isfinite(a['G']).all() and torch.isfinite(b['G']).all()),
-           'overlap': {k: v for k, v in a.items() if k not in ('G', 'D')},
-           'after_backward': {k: v for k, v in b.items() if k not in ('G', 'D')}}
+           'max_abs_diff_G_segmented': float((c['G'] - b['G']).abs().max()), 'max_abs_diff_D_segmented': float((c['D'] - b['D']).abs().max()),
+           'finite': bool(torch.isfinite(a['G']).all() and torch.isfinite(b['G']).all() and torch.isfinite(c['G']).all()),
+           'overlap': strip(a), 'overlap_graphs': strip(c), 'after_backward': strip(b)}
     print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
