@@ -131,6 +131,17 @@ class ZeroPool:
         cls._zeroed[flat_g.data_ptr()] = (flat_g.numel() * flat_g.element_size(), cls.serial)
 
     @classmethod
+    def arena_touched(cls, g):
+        """A gradient that is NOT the raw sum of this step's contributions was (or is about to be) accumulated into `g`'s arena
+        outside the in-place protocol -- e.g. a spectral-normed layer's chain-ruled gradient through the accumulate path: the
+        arena no longer counts as fresh until the next zero_grad."""
+        ptr = g.data_ptr()
+        for base, (nbytes, _) in cls._zeroed.items():
+            if base <= ptr < base + nbytes:
+                cls._zeroed[base] = (nbytes, -1)
+                return
+
+    @classmethod
     def grad_is_fresh(cls, g):
         """Is `g` (a view of a gradient arena) known to have been ZERO when the open scope began -- cleared by zero_grad after
         the previous scope and before this one?  Only then may a kernel sequence that REWRITES the gradient (spectral norm's
@@ -914,6 +925,8 @@ class Conv2dFn(torch.autograd.Function):
         direct = ctx.needs_input_grad[1] and wdst is not None and cx == cin and cin % 8 == 0 and _cl_dense(wdst)
         if direct and sigma is not None and not GradSink.inplace_allowed(wdst):
             direct = False                                   # (the chain rule must ACCUMULATE here: packed scratch, below)
+        if ctx.needs_input_grad[1] and sigma is not None and not direct and ctx.wdst is not None:
+            ZeroPool.arena_touched(ctx.wdst)                 # (.grad now holds a chain-ruled part: no in-place rewrite before zero_grad)
         if direct:
             # the parameter's gradient lies in the packed order (channels-last arena, or any 1x1 conv; Cin % 8 == 0 -- a 1-channel
             # weight is "channels-last" too, but the in-place kernels work on 16-byte groups of one tap): the kernel accumulates
