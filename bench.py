@@ -108,22 +108,24 @@ def cpu_step_seconds(opt_kwargs, hw, batch, threads, warm, timed, budget_s):
     return float(np.median(times)), len(times), warmed
 
 
-def cpu_baseline(opt_kwargs, hw, batch, budget_s=60.0):
+def cpu_baseline(opt_kwargs, hw, batch, budget_s=30.0, extras=False):
     """the CPU restatement runs the identical G+D step (same shapes -- batch 8 -- fp32, same synthetic inputs)
-    on this box's host cores: 1 warm-up + up to 3 timed iterations (median), capped at `budget_s` of wall time so that
+    on this box's host cores: 1 warm-up + up to 2 timed iterations (median), capped at `budget_s` of wall time so that
     the default bench run stays within minutes.  Thread count: measured on the GPU box's 2 x 64-core EPYC 9575F
     (profiles/r02/cpu_baseline_sweep.txt: 54 / 28 / 19.0 / 18.5 / 21 s per step at 128 / 64 / 32 / 16 / 8 threads) the step is
     fastest at 16-32 threads and 3x slower on all 128 physical cores (oneDNN across two sockets), so `cores` =
-    min(physical, 32) -- the host's best, stated -- and the figure at 8 threads (SURVEY 6's survey numbers were taken on 8
-    vCPUs) is reported beside it from one un-warmed iteration when budget remains."""
+    min(physical, 32) -- the host's best, stated.  extras (--cpu-baseline-extras): also the figure at 8 threads (SURVEY 6's
+    survey numbers were taken on 8 vCPUs) and on all physical cores, one un-warmed iteration each (~75 s more)."""
     phys = _physical_cores()
     cores = max(1, min(phys, 32))
     t0 = time.time()
-    sec, n, warmed = cpu_step_seconds(opt_kwargs, hw, batch, cores, 1, 3, budget_s)
+    sec, n, warmed = cpu_step_seconds(opt_kwargs, hw, batch, cores, 1, 2, budget_s)
     out = {'value': batch / sec, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
            'sample': 'G+D train step of oracle/seg2eye_oracle.py (torch %s CPU fp32) at batch %d, %dx%d, ngf=ndf=%d: %d warm-up + '
                      'median of %d timed iteration(s), %.1f s per step, %d threads of %d physical cores'
                      % (torch.__version__, batch, hw, hw, opt_kwargs['ngf'], warmed, n, sec, cores, phys)}
+    if not extras:                                   # (the default run spends its lease on the GPU: ~35 s of CPU work here)
+        return out
     left = budget_s + 45.0 - (time.time() - t0)
     if cores > 8 and left > 20.0:
         sec8, n8, w8 = cpu_step_seconds(opt_kwargs, hw, batch, 8, 0, 1, left)
@@ -200,6 +202,7 @@ def secondary_metrics(args, dev_index, data):
                 out['inference_bf16'] = {'images_per_s': args.batch / sec, 'ms_per_batch': sec * 1e3, 'batch': args.batch,
                                          'what': 'netE on 4 style images + netG (eval) + resize to 400x640 + 0..255, inputs resident'}
         del model
+    out.update(secondary_train_steps(args, dev_index))
     out['what'] = ('config 2 of BASELINE.json: netG forward only, eval mode, %dx%d batch %d, style codes given; algorithmic FLOPs '
                    '= SURVEY 8(d) (%.2f GFLOP per sample); frac = the rate on dense (iid) label maps / the dense MFMA peak of the dtype'
                    % (args.size, args.size, args.batch, G_FWD_GFLOP_PER_SAMPLE_256))
@@ -230,6 +233,46 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode     # the ranks inherit stdout: rank 0's JSON line passes through
 
 
+TRAIN_GFLOP_PER_SAMPLE = {(256, 256): 1239.4, (640, 384): 4528.9}     # G step + D step, ngf = ndf = 64
+
+
+def secondary_train_steps(args, dev_index):
+    """Two more G+D train-step rates beside the headline, hipGraph replays, inputs resident:
+    train_step_fp32 -- the reference's own arithmetic (fp32 storage, exact-fp32 MFMA) on the headline's workload;
+    cfg5_bs4 -- config 5's per-GPU workload: 640x384 (--crop_size 384 --aspect_ratio 0.6), batch 4, bf16."""
+    import contextlib, io
+    from seg2eye_amd.options import default_opt
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    from seg2eye_amd import synthetic as syn
+    out = {}
+    dev = torch.device('cuda', dev_index)
+    for key, kw, (h, w), batch, steps in (('train_step_fp32', dict(crop_size=args.size, aspect_ratio=1.0, compute_dtype='fp32'), (args.size, args.size), args.batch, 5),
+                                          ('cfg5_bs4', dict(crop_size=384, aspect_ratio=0.6, compute_dtype='bf16'), (640, 384), 4, 10)):
+        opt = default_opt(ngf=args.ngf, ndf=args.ngf, batchSize=batch, gpu_ids=[dev_index], hip_graphs=True, **kw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr = Pix2PixTrainer(opt)
+        fill_weights(tr.pix2pix_model)
+        b = syn.make_batch(batch, h, w, seed=1234)
+        data = {'label': torch.from_numpy(b['label']).to(dev), 'style_image': torch.from_numpy(b['style_image']).to(dev),
+                'target': torch.from_numpy(b['target']).to(dev), 'filename': b['filename']}
+
+        def step():
+            tr.run_generator_one_step(dict(data))
+            tr.run_discriminator_one_step(dict(data))
+        sec = timed_steps(step, steps, 3)
+        losses = {k: float(v.detach().float().mean()) for k, v in tr.get_latest_losses().items()}
+        ent = {'images_per_s': batch / sec, 'ms_per_step': sec * 1e3, 'batch': batch, 'size': [h, w], 'dtype': kw['compute_dtype'],
+               'hip_graphs': bool(tr.use_graphs and tr.graph_G is not None), 'finite': bool(all(np.isfinite(list(losses.values()))))}
+        gf = TRAIN_GFLOP_PER_SAMPLE.get((h, w)) if args.ngf == 64 else None
+        if gf:
+            peak = MFMA_PEAK_F32 if kw['compute_dtype'] == 'fp32' else MFMA_PEAK_BF16
+            ent.update({'algorithmic_tflops': gf * batch / sec / 1e3, 'peak': peak, 'algorithmic_frac': gf * batch / sec / 1e3 / peak})
+        out[key] = ent
+        del tr
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -240,6 +283,7 @@ def main():
     ap.add_argument('--ngf', type=int, default=64)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-extras', action='store_true', help='also time the CPU oracle on 8 threads and on all physical cores')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-extras', action='store_true', help='skip the dense_labels / eager / secondary measurements')
@@ -412,7 +456,10 @@ def main():
                                        'pmc_bytes_per_launch': traffic_of(k)[0]},
                                       **({'tflops': v['executed_flops'] / (v['ms'] * 1e-3) / 1e12,
                                           'algorithmic_tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} if v['flops'] > 0 else
-                                         {'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9}))
+                                         {'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9,
+                                          # the rate of the bytes the PMC passes MEASURED (algorithmic counts overstate a kernel that is
+                                          # latency-bound or served from cache: label_conv, spectral_norm -- VERDICT r3 #6)
+                                          'gbs_pmc': (traffic_of(k)[0] * v['launches'] / (v['ms'] * 1e-3) / 1e9) if traffic_of(k)[0] else None}))
                               for k, v in prof.items()}
         out.update(extras)
         if world == 1 and not args.no_extras:
@@ -422,7 +469,7 @@ def main():
         if world > 1:
             out['rccl_ranks'] = world
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(opt_kwargs, args.size, args.batch)
+            out['cpu_baseline'] = cpu_baseline(opt_kwargs, args.size, args.batch, extras=args.cpu_baseline_extras)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

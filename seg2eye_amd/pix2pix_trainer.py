@@ -134,9 +134,7 @@ class Pix2PixTrainer:
     def run_generator_one_step(self, data):
         """trainers/pix2pix_trainer.py:26-35.  With opt.hip_graphs the body is one graph replay."""
         self._train_mode()
-        if self.use_graphs:
-            self._stage_inputs(data)                         # captures on first use; turns graphs off if that fails
-        if self.use_graphs:
+        if self.use_graphs and self._stage_inputs(data):     # (captures on first use; turns graphs off if that fails)
             self.graph_G.replay(self.sync_G.launch)          # (segment k, then group k's exchange beside segment k+1)
             for k, v in getattr(self, '_static_log', {}).items():   # the replay refreshed these in place: log this step's values
                 self.pix2pix_model.add_to_loss_log(k, v.clone())
@@ -147,9 +145,7 @@ class Pix2PixTrainer:
     def run_discriminator_one_step(self, data):
         """trainers/pix2pix_trainer.py:37-45."""
         self._train_mode()
-        if self.use_graphs:
-            self._stage_inputs(data)
-        if self.use_graphs:
+        if self.use_graphs and self._stage_inputs(data):
             self.graph_D.replay()
         else:
             self._d_body(data)
@@ -161,8 +157,9 @@ class Pix2PixTrainer:
         return bool(getattr(self.opt, 'hip_graphs', False))
 
     def _stage_inputs(self, data):
-        """Copy the batch into the static input buffers the graphs read (capturing on first use).
-        Shapes are fixed for the lifetime of the graphs."""
+        """Copy the batch into the static input buffers the graphs read (capturing on first use).  True: replay.  False: this
+        step runs as individual launches -- the capture failed (graphs are off from now on), or this batch has another shape
+        than the one the graphs were captured for (they stay for the batches that have it)."""
         if self._static is None:
             try:
                 self._capture(data)
@@ -180,13 +177,14 @@ class Pix2PixTrainer:
                 self.opt.hip_graphs = False
                 self._static, self.graph_G, self.graph_D = None, None, None
                 self.pool.unfreeze()
-                return
+                return False
+        if any(tuple(data[k].shape) != tuple(buf.shape) for k, buf in self._static.items()):
+            return False                                     # (an epoch's ragged last batch: this step runs as individual launches)
         for k, buf in self._static.items():
             src = data[k]
             if src.data_ptr() != buf.data_ptr():
-                if tuple(src.shape) != tuple(buf.shape):
-                    raise ValueError('hip_graphs: %s changed shape %s -> %s' % (k, tuple(buf.shape), tuple(src.shape)))
                 buf.copy_(src, non_blocking=True)
+        return True
 
     def _capture(self, data):
         import torch

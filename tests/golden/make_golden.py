@@ -83,7 +83,19 @@ def checksum(t):
     return np.concatenate([[t.sum().item(), t.abs().sum().item()], t[idx].numpy()])
 
 
+def max_aggr_fixture(args, syn):
+    """T4: --style_aggr_method max (pix2pix_model.py:271-278; the aggregation the paper's figure states): w = max over the four
+    style images of netE's mu, so netE's gradient reaches only the arg-max image per (sample, component).  One G step + one D
+    step of the reference trainer, ngf=ndf=8, 256x256, N=2; the style codes themselves are stored too (encode_only)."""
+    small_trainer_fixture(args, syn, 'trainer_max_ngf8_256.npz', seed=29, with_w=True, grads=('E',), style_aggr_method='max')
+
+
 def style_trainer_fixture(args, syn):
+    small_trainer_fixture(args, syn, 'trainer_style_ngf8_256.npz', seed=23, lambda_l2=15.0, lambda_l1=2.0, lambda_style_w=0.5,
+                          lambda_style_feat=0.001, lambda_gram=10000.0)
+
+
+def small_trainer_fixture(args, syn, fname, seed, with_w=False, grads=(), **opt_kw):
     """T2: the reference's own training recipe switches the optional losses on (scripts/current_runs_spadestyle.sh,
     run name '..._l2_15_lambda_w_0.5_lambda_feat_0.001_lambda_gram_10000_...'): L2 + the three style-consistency terms
     that re-encode the generated image (pix2pix_model.py:196-229).  One G step + one D step, ngf=ndf=8, 256x256, N=2."""
@@ -92,32 +104,42 @@ def style_trainer_fixture(args, syn):
             super().__init__(params, lr=lr, betas=(float(betas[0]), float(betas[1])), **kw)
     torch.optim.Adam = FloatAdam
     from trainers.pix2pix_trainer import Pix2PixTrainer
-    opt = ref_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, init_type='normal',
-                  lambda_l2=15.0, lambda_l1=2.0, lambda_style_w=0.5, lambda_style_feat=0.001, lambda_gram=10000.0)
+    opt = ref_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, init_type='normal', **opt_kw)
     opt.checkpoints_dir = '/tmp/s2e_golden_ckpt'
     trainer = Pix2PixTrainer(opt)
     model = trainer.pix2pix_model
     mG, mD, mE = load_filled(model.netG), load_filled(model.netD), load_filled(model.netE)
-    batch = syn.make_batch(2, 256, 256, seed=23)
+    batch = syn.make_batch(2, 256, 256, seed=seed)
 
     def tdata():
         return {'label': torch.from_numpy(batch['label'].astype(np.int64)),
                 'style_image': torch.from_numpy(batch['style_image']),
                 'target': torch.from_numpy(batch['target']), 'filename': batch['filename']}
     rec = {}
+    if with_w:
+        # the aggregated style codes BEFORE any step (train mode: each netE call advances its power iteration, as in the steps);
+        # u, v are put back so that the steps below start from the filled state
+        sdE = {k: v.clone() for k, v in model.netE.state_dict().items()}
+        with torch.no_grad():
+            rec['w'] = model(tdata(), mode='encode_only').numpy()
+        model.netE.load_state_dict(sdE)
     trainer.run_generator_one_step(tdata())
     for k, v in trainer.g_losses.items():
         rec['it0_%s' % k.replace('/', '_')] = v.detach().numpy().reshape(-1)
     rec['it0_fake_sub'] = trainer.generated.detach()[:, :, ::8, ::8].numpy()
+    for tag in grads:
+        for k, q in getattr(model, 'net' + tag).named_parameters():
+            if q.grad is not None:
+                rec['it0_grad_%s.%s' % (tag, k)] = checksum(q.grad)
     trainer.run_discriminator_one_step(tdata())
     for k, v in trainer.d_losses.items():
         rec['it0_%s' % k.replace('/', '_')] = v.detach().numpy().reshape(-1)
     for tag, net in (('G', model.netG), ('D', model.netD), ('E', model.netE)):
         for k, v in net.state_dict().items():
             rec['it0_ck_%s.%s' % (tag, k)] = checksum(v)
-    np.savez_compressed(os.path.join(args.out, 'trainer_style_ngf8_256.npz'), **rec,
+    np.savez_compressed(os.path.join(args.out, fname), **rec,
                         **manifest_arrays('G', mG), **manifest_arrays('D', mD), **manifest_arrays('E', mE))
-    print('style trainer ok', {k: float(v.reshape(-1)[0]) for k, v in rec.items() if k.startswith('it0_') and v.size == 1})
+    print(fname, 'ok', {k: float(v.reshape(-1)[0]) for k, v in rec.items() if k.startswith('it0_') and v.size == 1})
 
 
 def bn_generator_fixture(args, syn, onehot, SPADESTYLEGenerator):
@@ -175,7 +197,14 @@ def openeds_fixture(args, syn):
     print('openeds_metric.npz', out['mse_tensors'], out['mse_images'], st)
 
 
-def full_train_fixture(args, syn):
+def cfg5_train_fixture(args, syn):
+    """T5 (config 5's per-GPU workload): one G step + one D step of the reference trainer at ngf=ndf=64, 640x384
+    (--crop_size 384 --aspect_ratio 0.6), N=4, encoder + feature matching on (they always are) -- what cfg3's fixture is for
+    256x256.  A few minutes of CPU."""
+    full_train_fixture(args, syn, fname='trainer_ngf64_640x384_n4.npz', crop=384, aspect=0.6, n=4, hw=(640, 384), seed=77)
+
+
+def full_train_fixture(args, syn, fname='trainer_ngf64_256_n8.npz', crop=256, aspect=1.0, n=8, hw=(256, 256), seed=1234):
     """T3 (config 3 AS BENCHED): one G step + one D step of the reference `Pix2PixTrainer`
     (trainers/pix2pix_trainer.py:26-45) at ngf=ndf=64, 256x256, N=8 -- the batch bench.py times (seed 1234).
     Stores the losses, a strided subsample of the generated image, a checksum of every ResBlk output of the G step's
@@ -186,12 +215,12 @@ def full_train_fixture(args, syn):
     torch.optim.Adam = FloatAdam
     from trainers.pix2pix_trainer import Pix2PixTrainer
     import time
-    opt = ref_opt(ngf=64, ndf=64, crop_size=256, aspect_ratio=1.0, batchSize=8, init_type='normal')
+    opt = ref_opt(ngf=64, ndf=64, crop_size=crop, aspect_ratio=aspect, batchSize=n, init_type='normal')
     opt.checkpoints_dir = '/tmp/s2e_golden_ckpt'
     trainer = Pix2PixTrainer(opt)
     model = trainer.pix2pix_model
     mG, mD, mE = load_filled(model.netG), load_filled(model.netD), load_filled(model.netE)
-    batch = syn.make_batch(8, 256, 256, seed=1234)
+    batch = syn.make_batch(n, hw[0], hw[1], seed=seed)
 
     def tdata():
         return {'label': torch.from_numpy(batch['label'].astype(np.int64)),
@@ -224,9 +253,9 @@ def full_train_fixture(args, syn):
         for k, v in net.state_dict().items():
             rec['it0_ck_%s.%s' % (tag, k)] = checksum(v)
     rec['seconds'] = np.array([t1 - t0, time.time() - t1, torch.get_num_threads()])
-    np.savez_compressed(os.path.join(args.out, 'trainer_ngf64_256_n8.npz'), **rec,
+    np.savez_compressed(os.path.join(args.out, fname), **rec,
                         **manifest_arrays('G', mG), **manifest_arrays('D', mD), **manifest_arrays('E', mE))
-    print('full train ok (G step %.0f s, D step %.0f s)' % (t1 - t0, time.time() - t1),
+    print(fname, 'ok (G step %.0f s, D step %.0f s)' % (t1 - t0, time.time() - t1),
           {k: float(v.reshape(-1)[0]) for k, v in rec.items() if k.startswith('it0_') and v.size == 1})
 
 
@@ -365,7 +394,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=HERE)
     ap.add_argument('--full', action='store_true', help='also the ngf=64 256x256 N=8 pin (slow)')
-    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture); 'options': only reference_option_defaults.json; 'bn': only g_bn_ngf8_64.npz; 'openeds': only openeds_metric.npz; 'full-train': only trainer_ngf64_256_n8.npz (config 3 as benched, minutes); 'cfg5': only cfg5_ngf64_640x384_n4.npz; 'more': only g_more_ngf8_128.npz")
+    ap.add_argument('--only', default='', help="'style': write only trainer_style_ngf8_256.npz (the optional-loss fixture); 'options': only reference_option_defaults.json; 'bn': only g_bn_ngf8_64.npz; 'openeds': only openeds_metric.npz; 'full-train': only trainer_ngf64_256_n8.npz (config 3 as benched, minutes); 'cfg5': only cfg5_ngf64_640x384_n4.npz; 'more': only g_more_ngf8_128.npz; 'cfg5-train': only trainer_ngf64_640x384_n4.npz (one reference G+D step at 640x384, N=4: minutes); 'max': only trainer_max_ngf8_256.npz (--style_aggr_method max)")
     args = ap.parse_args()
     install_stubs()
     sys.path.insert(0, REF)
@@ -398,6 +427,12 @@ def main():
         return
     if args.only == 'full-train':
         full_train_fixture(args, syn)
+        return
+    if args.only == 'cfg5-train':
+        cfg5_train_fixture(args, syn)
+        return
+    if args.only == 'max':
+        max_aggr_fixture(args, syn)
         return
     if args.only == 'cfg5':
         cfg5_fixture(args, syn, onehot, SPADESTYLEGenerator, MultiscaleDiscriminator)

@@ -173,6 +173,43 @@ def test_trainer_optional_losses():
             assert_checksum_close(v, z['it0_ck_%s.%s' % (tag, k)], 1e-4, '%s.%s' % (tag, k))
 
 
+def test_trainer_max_aggregation():
+    """T4: --style_aggr_method max (pix2pix_model.py:271-278): the style codes, one G step + one D step, and netE's parameter
+    gradients (which reach only the arg-max style image per component) against the real reference."""
+    z = load_golden('trainer_max_ngf8_256')
+    opt = default_opt(ngf=8, ndf=8, crop_size=256, aspect_ratio=1.0, batchSize=2, style_aggr_method='max')
+    m = O.OracleModel(filled_state(z, 'G'), filled_state(z, 'D'), filled_state(z, 'E'), opt, 8, 8)
+    b = syn.make_batch(2, 256, 256, seed=29)
+    data = {'label': torch.from_numpy(b['label'].astype(np.int64)),
+            'style_image': torch.from_numpy(b['style_image']), 'target': torch.from_numpy(b['target'])}
+    with torch.no_grad():
+        w = O.encode_w(dict(m.E), data['style_image'], 'max', training=True)
+    np.testing.assert_allclose(w.numpy(), z['w'], atol=2e-5, rtol=1e-4)
+    w_mean = O.encode_w(dict(m.E), data['style_image'], 'mean', training=True)
+    assert float((w - w_mean).abs().max()) > 1e-3                       # (the fixture does tell the two aggregations apart)
+    # netE's gradients of the G step (what run_generator_one_step differentiates, before its Adam update)
+    G, D, E = m._leaf(m.G), m._leaf(m.D), m._leaf(m.E)
+    losses, _ = m.generator_losses(G, D, E, data, True, ({}, {}, {}))
+    names = [k for k in E if m.is_param(k)]
+    grads = torch.autograd.grad(sum(losses.values()).mean(), [E[k] for k in names], allow_unused=True)
+    seen = 0
+    for k, g in zip(names, grads):
+        key = 'it0_grad_E.' + k
+        assert (g is not None) == (key in z.files), k
+        if g is not None:
+            assert_checksum_close(g, z[key], 5e-4, 'grad E.' + k)
+            seen += 1
+    assert seen >= 8
+    gl, fake = m.run_generator_one_step(data)
+    dl = m.run_discriminator_one_step(data)
+    for k, v in list(gl.items()) + list(dl.items()):
+        np.testing.assert_allclose(v.numpy().reshape(-1), z['it0_%s' % k.replace('/', '_')], rtol=2e-4, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(fake[:, :, ::8, ::8].numpy(), z['it0_fake_sub'], atol=1e-4, rtol=0)
+    for tag, sd in (('G', m.G), ('D', m.D), ('E', m.E)):
+        for k, v in sd.items():
+            assert_checksum_close(v, z['it0_ck_%s.%s' % (tag, k)], 1e-4, '%s.%s' % (tag, k))
+
+
 def test_generator_batchnorm_spade():
     """G3: the reference's default --norm_G spectralspadebatch3x3: train-mode forward (batch statistics), every parameter
     gradient, the updated BatchNorm running buffers and u/v, then eval mode on the updated buffers."""
