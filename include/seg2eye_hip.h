@@ -111,6 +111,15 @@ int s2e_conv2d_wgrad_kernel_kind(int dtype, const s2e_conv_desc* d);
 int s2e_conv2d(int dtype, const void* x, const void* w_packed, const float* bias, const void* residual,
                const void* aux, void* y, const s2e_conv_desc* d, void* workspace, size_t workspace_bytes,
                void* stream);
+/* The forward convolution TOGETHER with the InstanceNorm partial sums of its output y (round 4; SURVEY 7 step 5: the statistics of
+ * a large map -- normalization.py:94 of the reference, nn.InstanceNorm2d on the tensor the previous conv produced,
+ * architecture.py:53-60 -- come out of the producer's epilogue instead of a pass over y).  s2e_conv2d_stats_slots: the partial-sum
+ * slots per sample the launch writes, or 0 when this shape's kernel has no such epilogue (then: s2e_conv2d + s2e_in_stats).
+ * part: (N, slots, Cout, 2) floats {sum y, sum y^2} over the slot's pixels, of the values as stored (rounded to the compute
+ * dtype); uninitialised on entry.  Feed it to s2e_in_stats_from_partials.  residual as in s2e_conv2d; no mask operand. */
+int s2e_conv2d_stats_slots(int dtype, const s2e_conv_desc* d);
+int s2e_conv2d_stats(int dtype, const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
+                     const s2e_conv_desc* d, float* part, void* stream);
 /* Weight gradient of the forward conv described by d (d->transposed must be 0):
  * dw[co][(ky*KW+kx)*Cin + ci] += sum_{n,oy,ox} gy[n,oy,ox,co] * in_act(x)[n, oy*s-p+ky, ox*s-p+kx, ci]
  * dw: fp32 (Cout x KH*KW*Cin), row-major, ACCUMULATED into (caller zeroes it); split over pixels:
@@ -211,6 +220,11 @@ size_t s2e_in_stats_workspace_bytes(int dtype, int N, int HW, int C);
 int s2e_in_stats_counters(int dtype, int N, int HW, int C);
 int s2e_in_stats(int dtype, const void* x, int N, int HW, int C, float eps, double* ws, float* stats, unsigned* counters,
                  void* stream);
+
+/* {mean, rstd} (and, in ws, the fp64 {sum x, sum x^2}) from P partial-sum slots per sample written by another kernel
+ * (s2e_conv2d_stats): part (N, P, C, 2) floats, ws N*C*2 doubles, stats (N, C, 2) floats; HW = pixels per sample.  The slots of a
+ * (sample, channel) are added in a fixed order in fp64: bit-reproducible. */
+int s2e_in_stats_from_partials(const float* part, int N, int P, int C, int HW, float eps, double* ws, float* stats, void* stream);
 
 /* ------------------------------------------------------------------ SPADE+Style modulation / IN+LeakyReLU
  * mode S2E_NORM_SPADE_STYLE (SPADE_STYLE_Block.forward normalization.py:184-192 + SPADE.forward :91-105

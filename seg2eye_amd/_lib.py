@@ -93,6 +93,9 @@ SIGNATURES = {
     's2e_conv2d_kernel_kind': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_wgrad_kernel_kind': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
+    's2e_conv2d_stats_slots': [_i, C.POINTER(ConvDesc)],
+    's2e_conv2d_stats': [_i, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, _vp],
+    's2e_in_stats_from_partials': [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     's2e_conv2d_wgrad_workspace_bytes': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_in_stats_workspace_bytes': [_i, _i, _i, _i],

@@ -53,6 +53,10 @@ struct DuoParams {
     // FUSE
     const void* mx; const float* mstats; const float* mstyle; int msld; void* mgamma; int mC, mlrelu, mup;
     const int* rect_list; const int* rect_count;
+    // InstanceNorm partial sums of the OUTPUT (plain launches; NULL = none): per wave and tile, {sum y, sum y^2} of its 64 channels
+    // over its rows -> spart[((n * sP + slot) * Cout + c) * 2], slot = rectangle-in-sample * waves-rows-per-tile + wave row;
+    // s2e_in_stats_from_partials adds the sP slots of a (sample, channel) in a fixed order (normalization.py:94 of the reference)
+    float* spart; int sP;
     long* dbg;                        // -DS2E_DUO_STAMPS builds only (tools/duo_stamps.py): per-tile phase time stamps
 };
 
@@ -61,15 +65,19 @@ constexpr int DU_P_BYTES = DU_PPX * 64;               // 25,600
 constexpr int DU_B_BYTES = 128 * 64;                  // one weight K-step
 constexpr int DU_NBS = 3, DU_PD = 2;
 
-template <bool FUSE>
+// BN = output channels per tile: 128 (waves 2 x 2, wave tile 128 x 64), or 64 for the 64-channel layers (waves 4 x 1, wave tile
+// 64 x 64: half the accumulators, one weight piece per wave and K-step)
+template <bool FUSE, int BN = 128>
 __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
+    static_assert(BN == 128 || (BN == 64 && !FUSE), "tile widths");
     typedef bf16_t T;
     constexpr int NW = 4, TAPS = 9;
-    constexpr int TM = 4, TN = 2;
+    constexpr int TM = BN / 32, TN = 2;               // wave tile TM * 32 pixels x 64 channels
+    constexpr int WROWS = TM * 32, NPASS = 2 * TM;    // tile rows per wave; 16-row epilogue passes per wave
     constexpr int P_BYTES = DU_P_BYTES, B_BYTES = DU_B_BYTES, NBS = DU_NBS, PD = DU_PD;
     constexpr int NPIECE = P_BYTES / 1024;             // 25 pieces of 16 pixels
     constexpr int NR = (NPIECE + NW - 1) / NW;         // 7 per wave
-    constexpr int NBJ = 8 / NW;                        // 2 weight pieces (16 rows each) per wave per K-step
+    constexpr int NBJ = BN / 64;                       // weight pieces (16 rows each) per wave per K-step
     static_assert(NR <= TAPS, "one patch piece per tap must cover the patch");
     static_assert(NW * 4096 <= P_BYTES, "the waves' staging slices must fit one patch buffer");
     __shared__ __attribute__((aligned(16))) char smem[2 * P_BYTES + NBS * B_BYTES];
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
     const int h = lane >> 5, l31 = lane & 31;
     const int TW = p.tw, TH = p.th, PW = TW + 2, PH = TH + 2, SH = p.sh;
     T* __restrict__ yg = (T*)p.y;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
 #pragma unroll
         for (int j = 0; j < NBJ; ++j) {
             const int trow = 16 * (wave + NW * j) + (lane >> 2);
-            const int grow = FUSE ? (trow < 64 ? q.tn * 64 + trow : p.mC + q.tn * 64 + (trow - 64)) : q.tn * 128 + trow;
+            const int grow = FUSE ? (trow < 64 ? q.tn * 64 + trow : p.mC + q.tn * 64 + (trow - 64)) : q.tn * BN + trow;
             woff[j] = 2u * (unsigned)(grow * p.Kpad) + (unsigned)(((lane & 3) ^ ((trow >> 2) & 3)) << 4);
         }
     };
@@ -165,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
             else s0p = (const char*)(sty + c0 + i4);
             if (lane < 32) s1p = (const char*)(p.mstats + ((size_t)q.n * p.mC + c0) * 2 + lane * 4);
         } else {
-            const int c = q.tn * 128 + lane * 4;
-            if (lane < 32 && p.bias && c < p.Cout) s0p = (const char*)(p.bias + c);
+            const int c = q.tn * BN + lane * 4;
+            if (lane * 4 < BN && p.bias && c < p.Cout) s0p = (const char*)(p.bias + c);
         }
         __builtin_amdgcn_global_load_lds((gptr_t)(const void*)s0p, (lptr_t)&kcst[cbuf][0], 16, 0, 0);
         if constexpr (FUSE) __builtin_amdgcn_global_load_lds((gptr_t)(const void*)s1p, (lptr_t)&kcst[cbuf][256], 16, 0, 0);
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
     uint32_t a_dx[TM][3];
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
-        const int r = wm * 128 + mi * 32 + l31;
+        const int r = wm * WROWS + mi * 32 + l31;
         const int ty = r / TW, tx = r - ty * TW;
         const bool in = r < TW * TH;                  // (rows past the rectangle read patch pixel 0 and are never stored)
         const int pp = in ? ty * PW + tx : 0, px = in ? tx : 0;
@@ -230,9 +238,16 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
         for (int ni = 0; ni < TN; ++ni)
             asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][ni]) : "v"(b_addr[ni] ^ (uint32_t)(sstep << 5)) : "memory");
     };
+    // wait until only the NEWEST set of reads (TM + TN of them) is outstanding, or none; the fragments are operands of the wait so
+    // that no MFMA consuming them can be scheduled above it
     auto frags_ready = [&](int set, bool all) __attribute__((always_inline)) {
-        if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1]) :: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1]) :: "memory");
+        if constexpr (TM == 4) {
+            if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1]) :: "memory");
+        } else {
+            if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fb[set][0]), "+v"(fb[set][1]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fb[set][0]), "+v"(fb[set][1]) :: "memory");
+        }
     };
     auto mfmas = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
@@ -284,34 +299,40 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
     // before the first pass (64 registers: the fragment registers are dead and the accumulators free up pass by pass), so that no
     // load is ever queued behind a store.  Both at once (no layer of the network has it) is not taken by the plan.
     int st_issued = 0;                                 // stores this wave issued in the epilogue (wave-uniform; see the loop top)
-    auto epilogue = [&](const Item& q, int sbuf, auto MODE) __attribute__((always_inline)) {
+    auto epilogue = [&](const Item& q, int sbuf, auto MODE, auto STATS) __attribute__((always_inline)) {
         constexpr int mode = decltype(MODE)::value;
+        constexpr bool stats = decltype(STATS)::value;
+        f32x2_t ssum[stats ? 4 : 1], ssq[stats ? 4 : 1];          // this lane's 8 channels over its 2 * NPASS rows
+        if constexpr (stats) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ssum[j] = f32x2_t{0.f, 0.f}; ssq[j] = f32x2_t{0.f, 0.f}; }
+        }
         const uint32_t wslice = lds0 + (uint32_t)(sbuf * P_BYTES + wave * 4096);
         const float neg = (p.aux_mode == S2E_AUX_RELU_MASK) ? 0.f : 0.2f;
-        const int cw0 = q.tn * 128 + wn * 64;          // first output channel of this wave (wave-uniform)
+        const int cw0 = q.tn * BN + wn * 64;           // first output channel of this wave (wave-uniform)
         st_issued = 0;
         if (cw0 >= p.Cout) return;                     // (a Cout tile past the end: nothing to write)
         const int tile_base = ((q.n * p.Ho + q.y0) * p.Wo + q.x0) * p.Cout + cw0;
         const T* __restrict__ opg = mode == 1 ? resg : auxg;
-        u32x4_t opr[mode ? 16 : 1];
+        u32x4_t opr[mode ? 2 * NPASS : 1];
         auto request = [&](auto Q) __attribute__((always_inline)) {      // the operand rows of pass qq
             constexpr int qq = decltype(Q)::value;
             int ty, tx;
-            pass_yx(wm * 128 + (qq >> 1) * 32 + (qq & 1) * 16, ty, tx);
+            pass_yx(wm * WROWS + (qq >> 1) * 32 + (qq & 1) * 16, ty, tx);
             const int so = tile_base + (ty * p.Wo + tx) * p.Cout;
             const int lo = (lane >> 3) * p.Cout + (lane & 7) * 8;
             opr[2 * qq] = *(const u32x4_t*)(opg + so + lo);
             opr[2 * qq + 1] = *(const u32x4_t*)(opg + so + 8 * p.Cout + lo);
         };
         // passes 0-3 before the first pass; passes 4-7 once the accumulators of passes 0-1 are out of their registers
-        if constexpr (mode != 0) static_for<0, 4>(request);
-        static_for<0, 8>([&](auto Q) {
+        if constexpr (mode != 0) static_for<0, NPASS / 2>(request);
+        static_for<0, NPASS>([&](auto Q) {
             constexpr int qq = decltype(Q)::value;
             int l = lane;
             asm volatile("" : "+v"(l));                   // (opaque per pass: nothing of a pass is hoisted above it)
             const int r0 = l >> 3, cg = l & 7;
             int ty, tx;
-            pass_yx(wm * 128 + (qq >> 1) * 32 + (qq & 1) * 16, ty, tx);
+            pass_yx(wm * WROWS + (qq >> 1) * 32 + (qq & 1) * 16, ty, tx);
             const int so = tile_base + (ty * p.Wo + tx) * p.Cout;       // scalar
             const int lo = r0 * p.Cout + cg * 8;
             stage_pass(Q, wslice);
@@ -336,12 +357,43 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
                     for (int j = 0; j < 4; ++j)
                         v[j] *= f32x2_t{bf16_bits_to_f32(t[j] & 0xffffu) > 0.f ? 1.f : neg, __builtin_bit_cast(float, t[j] & 0xffff0000u) > 0.f ? 1.f : neg};
                 }
-                *(u32x4_t*)(yg + so + k * 8 * p.Cout + lo) = u32x4_t{pack2_bf16(v[0][0], v[0][1]), pack2_bf16(v[1][0], v[1][1]),
-                                                                       pack2_bf16(v[2][0], v[2][1]), pack2_bf16(v[3][0], v[3][1])};
+                const u32x4_t packed = u32x4_t{pack2_bf16(v[0][0], v[0][1]), pack2_bf16(v[1][0], v[1][1]),
+                                               pack2_bf16(v[2][0], v[2][1]), pack2_bf16(v[3][0], v[3][1])};
+                *(u32x4_t*)(yg + so + k * 8 * p.Cout + lo) = packed;
+                if constexpr (stats) {                    // of the ROUNDED values: what a pass over the stored tensor would see
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2_t f = {bf16_bits_to_f32(packed[j] & 0xffffu), __builtin_bit_cast(float, packed[j] & 0xffff0000u)};
+                        ssum[j] += f; ssq[j] += f * f;
+                    }
+                }
             }
-            if constexpr (mode != 0 && qq == 1) { static_for<4, 8>(request); }
+            if constexpr (mode != 0 && qq == NPASS / 4 - 1) { static_for<NPASS / 2, NPASS>(request); }
         });
-        st_issued = 16;
+        st_issued = 2 * NPASS;
+        if constexpr (stats) {
+            // fold the 8 row-lanes of a channel group through the wave's staging slice (fixed order: bit-reproducible), one
+            // 8-byte store per channel: lane L = channel L of the wave's 64
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint32_t la = wslice + (uint32_t)(lane * 64);          // [lane][{sum x 8 | sq x 8}]
+            asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32\n\tds_write_b128 %0, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                         :: "v"(la), "v"(f32x4_t{ssum[0][0], ssum[0][1], ssum[1][0], ssum[1][1]}), "v"(f32x4_t{ssum[2][0], ssum[2][1], ssum[3][0], ssum[3][1]}),
+                            "v"(f32x4_t{ssq[0][0], ssq[0][1], ssq[1][0], ssq[1][1]}), "v"(f32x4_t{ssq[2][0], ssq[2][1], ssq[3][0], ssq[3][1]}) : "memory");
+            // channel L = group cg = L >> 3, element e = L & 7: rows r0 = 0..7 are lanes r0 * 8 + cg
+            const uint32_t ra = wslice + (uint32_t)(((lane >> 3) * 64) + (lane & 7) * 4);
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int r0 = 0; r0 < 8; ++r0) {
+                float t0, t1;
+                asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1) : "v"(ra), "n"(r0 * 8 * 64), "n"(r0 * 8 * 64 + 32) : "memory");
+                a += t0; b += t1;
+            }
+            const int rect = (q.y0 / TH) * p.tiles_x + q.x0 / TW;
+            const int slot = rect * (256 / WROWS) + wm;
+            *(f32x2_t*)(p.spart + (((size_t)q.n * p.sP + slot) * p.Cout + cw0 + lane) * 2) = f32x2_t{a, b};
+            st_issued += 1;
+        }
     };
 
     // ---- FUSE epilogue (normalization.py:91-105,163-169,184-192 of the reference in one pass, see conv_patch.hip): a lane owns 8
@@ -380,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
         static_for<0, 8>([&](auto Q) {
             constexpr int qq = decltype(Q)::value;
             int ty, tx;
-            pass_yx(wm * 128 + (qq >> 1) * 32 + (qq & 1) * 16, ty, tx);
+            pass_yx(wm * WROWS + (qq >> 1) * 32 + (qq & 1) * 16, ty, tx);
             const int row = lane >> 2, cg = lane & 3;
             const int so = p.mup ? xbase + ((ty >> 1) * (p.Wo >> 1) + (tx >> 1)) * p.mC : xbase + (ty * p.Wo + tx) * p.mC;
             const int lo = (p.mup ? (row >> 1) : row) * p.mC + cg * 8;
@@ -392,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
             asm volatile("" : "+v"(l));
             const int row = l >> 2, cg = l & 3;
             int ty, tx;
-            pass_yx(wm * 128 + (qq >> 1) * 32 + (qq & 1) * 16, ty, tx);
+            pass_yx(wm * WROWS + (qq >> 1) * 32 + (qq & 1) * 16, ty, tx);
             const int so = tile_base + (ty * p.Wo + tx) * p.mC;         // scalar
             const int lo = row * p.mC + cg * 8;
             stage_pass(Q, wslice);
@@ -520,9 +572,13 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
         if (has_next) { nxt = decode(next_id, nf); aim(nxt); prologue(nxt, pbn, cb ^ 1); }
         stamp(3);
         if constexpr (FUSE) epilogue_fused(cur, pbn ^ 1);
-        else if (resg) epilogue(cur, pbn ^ 1, std::integral_constant<int, 1>{});
-        else if (p.aux_mode != S2E_AUX_NONE) epilogue(cur, pbn ^ 1, std::integral_constant<int, 2>{});
-        else epilogue(cur, pbn ^ 1, std::integral_constant<int, 0>{});
+        else if (p.spart) {
+            if (resg) epilogue(cur, pbn ^ 1, std::integral_constant<int, 1>{}, std::true_type{});
+            else epilogue(cur, pbn ^ 1, std::integral_constant<int, 0>{}, std::true_type{});
+        }
+        else if (resg) epilogue(cur, pbn ^ 1, std::integral_constant<int, 1>{}, std::false_type{});
+        else if (p.aux_mode != S2E_AUX_NONE) epilogue(cur, pbn ^ 1, std::integral_constant<int, 2>{}, std::false_type{});
+        else epilogue(cur, pbn ^ 1, std::integral_constant<int, 0>{}, std::false_type{});
         stamp(4);
 #ifdef S2E_DUO_STAMPS
         ++dbg_i;
@@ -544,7 +600,7 @@ int duo_cu_count() {
 // S2E_CONV_DUO = the work items (rectangle x 128-channel tile) a launch must have for this kernel to take it (default 512: one per
 // workgroup of the 2-per-CU grid); 0 = never (conv_patch.hip runs everything, for A/B runs).
 int duo_min_items() {
-    static const int n = [] { const char* e = getenv("S2E_CONV_DUO"); return e ? atoi(e) : 512; }();
+    static const int n = [] { const char* e = getenv("S2E_CONV_DUO"); return e ? atoi(e) : 256; }();
     return n;
 }
 
@@ -557,7 +613,8 @@ int duo_launch(DuoParams& p, long rects_upper, hipStream_t st) {
     static long* const dbg_ptr = [] { const char* e = getenv("S2E_DUO_DBG_PTR"); return e ? (long*)strtoull(e, nullptr, 0) : (long*)nullptr; }();
     p.dbg = dbg_ptr;
 #endif
-    conv_duo_kernel<FUSE><<<grid, 256, 0, st>>>(p);
+    if (!FUSE && p.Cout <= 64) conv_duo_kernel<false, 64><<<grid, 256, 0, st>>>(p);
+    else conv_duo_kernel<FUSE><<<grid, 256, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_duo_kernel");
     return S2E_OK;
 }
@@ -571,7 +628,7 @@ static bool duo_rect_ok(int tw, int th, int H, int W) {
 }
 
 // Shapes the duo kernel takes: bf16, 3x3, stride 1 (forward or data-gradient), no fused input activation, Cin a multiple of 32,
-// Cout a multiple of 8 and > 64 (one 128-channel tile at least; the 64-channel tiles stay in conv_patch.hip), the rectangle plan of
+// Cout a multiple of 64 (128-channel tiles; a 64-channel layer runs the 64-wide instantiation), the rectangle plan of
 // conv_patch.hip, no tanh, tensors under 2 GB, and at least S2E_CONV_DUO work items (long-K layers with few tiles -- split over
 // channel chunks -- stay in conv_patch.hip too); Cout a multiple of 64; rectangles as duo_rect_ok; the caller keeps launches with a
 // residual AND a mask (no layer of the network has both) in conv_patch.hip.
@@ -580,7 +637,7 @@ int s2e_conv_duo_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan) {
     if (!plan) plan = &local;
     if (duo_min_items() <= 0 || dtype != S2E_BF16) return 0;
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->in_act != S2E_ACT_NONE || d->out_act == S2E_ACT_TANH) return 0;
-    if (d->Cin % 32 != 0 || d->Cout % 8 != 0 || d->Cout <= 64) return 0;
+    if (d->Cin % 32 != 0 || d->Cout % 8 != 0 || d->Cout < 64) return 0;
     const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;
     if (d->Ho != d->Hi + grow || d->Wo != d->Wi + grow) return 0;
     if ((long)d->N * d->Hi * d->Wi * d->Cin * 2 >= (1L << 31) || (long)d->N * d->Ho * d->Wo * d->Cout * 2 >= (1L << 31)) return 0;
@@ -589,7 +646,7 @@ int s2e_conv_duo_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan) {
     plan->splits = 1;
     if (s2e_patch_rectangle(d, 3, &plan->tw, &plan->th) < 0.8 || !duo_rect_ok(plan->tw, plan->th, d->Ho, d->Wo)) return 0;
     const long rects = (long)d->N * (d->Ho / plan->th) * (d->Wo / plan->tw);
-    return rects * ceil_div(d->Cout, 128) >= duo_min_items();
+    return rects * (d->Cout <= 64 ? 1 : ceil_div(d->Cout, 128)) >= duo_min_items();
 }
 
 static void duo_fill(DuoParams* p, const s2e_conv_desc* d, const s2e_patch_plan* plan, int kpad) {
@@ -604,12 +661,19 @@ static void duo_fill(DuoParams* p, const s2e_conv_desc* d, const s2e_patch_plan*
     p->x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Cin * 2);
 }
 
+// InstanceNorm partial-sum slots per sample a launch of this shape writes (s2e_conv_duo_launch with stats_part): rectangles per
+// sample x wave rows per tile.
+int s2e_conv_duo_stats_slots(const s2e_conv_desc* d, const s2e_patch_plan* plan) {
+    return (d->Ho / plan->th) * (d->Wo / plan->tw) * (d->Cout <= 64 ? 4 : 2);
+}
+
 int s2e_conv_duo_launch(const s2e_patch_plan* plan, const void* x, const void* w, const float* bias, const void* res,
-                        const void* aux, void* y, const s2e_conv_desc* d, int kpad, hipStream_t st) {
+                        const void* aux, void* y, const s2e_conv_desc* d, int kpad, float* stats_part, hipStream_t st) {
     DuoParams p{};
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
+    p.spart = stats_part; p.sP = stats_part ? s2e_conv_duo_stats_slots(d, plan) : 0;
     duo_fill(&p, d, plan, kpad);
-    p.tiles_n = ceil_div(d->Cout, 128);
+    p.tiles_n = d->Cout <= 64 ? 1 : ceil_div(d->Cout, 128);
     p.w_bytes = (unsigned)((long)s2e_conv_cout_pad(d->Cout) * kpad * 2);
     return duo_launch<false>(p, p.rects, st);
 }

@@ -638,6 +638,25 @@ extern "C" int s2e_conv2d_kernel_kind(int dtype, const s2e_conv_desc* d) {
     return (s2e_conv_duo_plan(dtype, d, nullptr) || s2e_conv_patch_plan(dtype, d, nullptr)) ? S2E_KERNEL_PATCH : S2E_KERNEL_GENERIC;
 }
 
+// The convolution WITH the InstanceNorm partial sums of its output (the statistics pass over a large map is
+// the producer's epilogue): s2e_conv2d_stats_slots = the slots per sample the launch writes (0: this shape's kernel has no such
+// epilogue -- run s2e_conv2d + s2e_in_stats), part = (N, slots, Cout, 2) floats {sum y, sum y^2}, to s2e_in_stats_from_partials.
+extern "C" int s2e_conv2d_stats_slots(int dtype, const s2e_conv_desc* d) {
+    s2e_patch_plan pplan;
+    if (!d || d->transposed || d->aux_mode != S2E_AUX_NONE || s2e_small_conv_kind(dtype, d) != SMALL_NONE) return 0;
+    if (!s2e_conv_duo_plan(dtype, d, &pplan)) return 0;
+    return s2e_conv_duo_stats_slots(d, &pplan);
+}
+
+extern "C" int s2e_conv2d_stats(int dtype, const void* x, const void* w, const float* bias, const void* res, void* y,
+                                const s2e_conv_desc* d, float* part, void* stream) {
+    if (!x || !w || !y || !d || !part) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_stats: null pointer");
+    s2e_patch_plan pplan;
+    if (!s2e_conv2d_stats_slots(dtype, d) || !s2e_conv_duo_plan(dtype, d, &pplan))
+        S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_stats: this shape's kernel writes no statistics (s2e_conv2d_stats_slots == 0)");
+    return s2e_conv_duo_launch(&pplan, x, w, bias, res, nullptr, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), part, (hipStream_t)stream);
+}
+
 extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* bias, const void* res,
                           const void* aux, void* y, const s2e_conv_desc* d, void* workspace, size_t workspace_bytes,
                           void* stream) {
@@ -660,7 +679,7 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
     }
     s2e_patch_plan pplan;
     if (!(res && d->aux_mode != S2E_AUX_NONE) && s2e_conv_duo_plan(dtype, d, &pplan))       // the big bf16 3x3 layers with >= 128 output channels: two staggered workgroups per CU (conv_duo.hip)
-        return s2e_conv_duo_launch(&pplan, x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), (hipStream_t)stream);
+        return s2e_conv_duo_launch(&pplan, x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), nullptr, (hipStream_t)stream);
     if (s2e_conv_patch_plan(dtype, d, &pplan)) {      // big 3x3 / 4x4 stride-1 layers: patch-resident kernel
         const int patch_splits = pplan.splits;
         const size_t need = s2e_conv_patch_workspace_bytes(dtype, d);

@@ -328,6 +328,51 @@ __global__ void in_stats_finalize_kernel(const float* __restrict__ part, double*
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// {mean, rstd} from partial sums another kernel wrote (s2e_conv2d_stats: P slots per sample, hundreds): one block per (sample, 16
+// channels); its 256 threads split the slots sixteen ways (each a fixed-order fp64 sum over its share, eight independent loads in
+// flight), the sixteen shares are added in a fixed order: bit-reproducible.  (A thread per (sample, channel) walking all P slots
+// -- in_stats_finalize_kernel's form, made for P ~ 32 -- took ~30 us at P = 512: eight blocks of serial strided loads.)
+__global__ __launch_bounds__(256) void in_stats_from_partials_kernel(const float* __restrict__ part, double* __restrict__ ws,
+                                                                     float* __restrict__ stats, int C, int P, int HW, float eps) {
+    __shared__ double red[16][16][2];
+    const int n = blockIdx.y, cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, sl = threadIdx.x >> 4;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const int per = (P + 15) / 16, b0 = sl * per, b1 = min(P, b0 + per);
+        const f32x2_t* base = (const f32x2_t*)(part + ((size_t)n * P * C + c) * 2);
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            f32x2_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = base[(size_t)(b + k) * C];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s += (double)w[k][0]; q += (double)w[k][1]; }
+        }
+        for (; b < b1; ++b) { const f32x2_t w = base[(size_t)b * C]; s += (double)w[0]; q += (double)w[1]; }
+    }
+    red[sl][cl][0] = s; red[sl][cl][1] = q;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    s = 0.0; q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s += red[k][cl][0]; q += red[k][cl][1]; }
+    const size_t i = (size_t)n * C + c;
+    ws[2 * i] = s; ws[2 * i + 1] = q;
+    const double mean = s / HW;
+    double var = q / HW - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" int s2e_in_stats_from_partials(const float* part, int N, int P, int C, int HW, float eps, double* ws, float* stats,
+                                          void* stream) {
+    if (!part || !ws || !stats || N <= 0 || P <= 0 || C <= 0 || HW <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_in_stats_from_partials: bad argument");
+    in_stats_from_partials_kernel<<<dim3(ceil_div(C, 16), N), 256, 0, (hipStream_t)stream>>>(part, ws, stats, C, P, HW, eps);
+    S2E_CHECK_LAUNCH("in_stats_from_partials_kernel");
+    return S2E_OK;
+}
+
 extern "C" size_t s2e_in_stats_workspace_bytes(int dtype, int N, int HW, int C) {
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (N <= 0 || HW <= 0 || C <= 0 || C % vec) return 0;

@@ -34,8 +34,25 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
 
     def input_stats(self, x, replication=1):
         """Statistics for norm_0 / norm_s of this block from x BEFORE the generator's nearest 2x upsampling
-        (replication=4): the same numbers from a quarter of the bytes.  Pass the result to forward(stats=...)."""
+        (replication=4): the same numbers from a quarter of the bytes.  Pass the result to forward(stats=...).
+        When x is the output of a block whose last conv produced the statistics in its epilogue (`_s2e_in_stats`, set by
+        forward below), they are taken from there: no pass over x at all."""
+        ready = getattr(x, '_s2e_in_stats', None)
+        if ready is not None and self.norm_0.spade.kind == 'instance':
+            return ready
         return spade_stats(x, [self.norm_0.spade] + ([self.norm_s.spade] if self.learned_shortcut else []), replication)
+
+    def _convs(self, h0, x_s, seg, latent_style):
+        """dx = conv_0(h0); out = conv_1(lrelu(SSB_1(dx))) + x_s.  With InstanceNorm SPADE the statistics norm_1 needs of dx,
+        and the statistics the NEXT block needs of out, come out of the two convs' epilogues when their kernel has that
+        epilogue (ops.conv2d_raw stats_out) -- otherwise norm_1 / the next block run the statistics pass."""
+        fused = self.norm_1.spade.kind == 'instance'
+        s_dx, s_out = ([], []) if fused else (None, None)
+        dx = ops.conv2d_m(h0, self.conv_0, None, 1, 1, stats_out=s_dx)
+        out = ops.conv2d_m(self.norm_1(dx, seg, latent_style, s_dx[0] if s_dx else None, lrelu=True), self.conv_1, x_s, 1, 1, stats_out=s_out)
+        if s_out:
+            out._s2e_in_stats = s_out[0]
+        return out
 
     def forward(self, x, seg, latent_style, stats=None, up=False):
         """up (not in the reference): x is the tensor BEFORE the generator's nearest 2x upsampling and `stats` were taken from
@@ -55,8 +72,7 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
             else:
                 h0 = self.norm_0(x, seg, latent_style, stats, lrelu=True, up=True)
             x_s = ops.conv2d_m(self.norm_s(x, seg, latent_style, stats, lrelu=False, up=True), self.conv_s)
-            dx = ops.conv2d_m(h0, self.conv_0, None, 1, 1)
-            return ops.conv2d_m(self.norm_1(dx, seg, latent_style, None, lrelu=True), self.conv_1, x_s, 1, 1)
+            return self._convs(h0, x_s, seg, latent_style)
         if stats is None:
             stats = self.input_stats(x)
         # x has two consumers (norm_0 and norm_s, or norm_0 and the residual).  With gradients on, the second one hangs off
@@ -70,6 +86,4 @@ class SPADE_STYLE_ResnetBlock(nn.Module):
             x_s = ops.conv2d_m(self.norm_s(x, seg, latent_style, stats, lrelu=False), self.conv_s)
         else:
             x_s = x
-        dx = ops.conv2d_m(h0, self.conv_0, None, 1, 1)
-        dx = ops.conv2d_m(self.norm_1(dx, seg, latent_style, None, lrelu=True), self.conv_1, x_s, 1, 1)
-        return dx
+        return self._convs(h0, x_s, seg, latent_style)

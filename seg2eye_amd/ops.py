@@ -462,8 +462,24 @@ def _conv_plan(wgrad, dt, *shape):
     return ent
 
 
+_CONV_STATS_OFF = os.environ.get('S2E_CONV_STATS', '1') == '0'      # A/B switch: 0 = InstanceNorm statistics always by a pass of their own
+_CONV_STATS_SLOTS = {}
+
+
+def _conv_stats_slots(dt, d, *shape):
+    """s2e_conv2d_stats_slots, memoised per shape."""
+    key = (dt,) + shape
+    v = _CONV_STATS_SLOTS.get(key)
+    if v is None:
+        v = _CONV_STATS_SLOTS[key] = int(L.lib().s2e_conv2d_stats_slots(dt, C.byref(d)))
+    return v
+
+
 def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transposed=False,
-               in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE, out=None):
+               in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE, out=None, stats_out=None):
+    """stats_out: None, or a list that receives the InstanceNorm statistics (N, Cout, 2) {mean, rstd} of the result when the
+    kernel this shape takes produces their partial sums in its epilogue (s2e_conv2d_stats; then the caller needs no pass over y);
+    left empty otherwise."""
     _need(x, wp, bias, residual, aux)
     n, hi, wi, cin = x.shape
     ho, wo, cout = out_hw_c
@@ -476,6 +492,21 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     # data-gradient executes 4x that on structural zeros; not counted)
     pix = hi * wi if transposed else ho * wo
     flops = 2.0 * n * pix * cin * cout * kh * kw
+    if stats_out is not None and aux is None and not transposed and not _CONV_STATS_OFF:
+        slots = _conv_stats_slots(dt, d, n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, in_act, out_act)
+        if slots:
+            part = torch.empty(n * slots * cout * 2, dtype=torch.float32, device=x.device)
+            LaunchProfiler.run('conv_patch', flops, lambda: L.check(
+                L.lib().s2e_conv2d_stats(dt, _p(x), _p(wp), _p(bias), _p(residual), _p(y), C.byref(d), _p(part), _stream()), 's2e_conv2d_stats'),
+                tag=lambda: 'F n%d %dx%d c%d->%d k%d s%d +stats' % (n, hi, wi, cin, cout, kh, stride),
+                nbytes=lambda: float((x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0)) * x.element_size()))
+            ws = torch.empty(n * cout * 2, dtype=torch.float64, device=x.device)
+            stats = torch.empty(n, cout, 2, dtype=torch.float32, device=x.device)
+            LaunchProfiler.run('in_stats', 0.0, lambda: L.check(
+                L.lib().s2e_in_stats_from_partials(_p(part), n, slots, cout, ho * wo, IN_EPS, _p(ws), _p(stats), _stream()),
+                's2e_in_stats_from_partials'), nbytes=float(part.numel() * 4))
+            stats_out.append(stats)
+            return y
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     LaunchProfiler.run(lambda: _CONV_FAMILY[L.lib().s2e_conv2d_kernel_kind(dt, C.byref(d))], flops, lambda: L.check(
         L.lib().s2e_conv2d(dt, _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _p(ws), wsb,
@@ -866,7 +897,7 @@ class Conv2dFn(torch.autograd.Function):
     `weight` is the one w.r.t. weight_orig, through sigma."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, pad, in_act, out_act, u, v, sigma):
+    def forward(ctx, x, weight, bias, residual, stride, pad, in_act, out_act, u, v, sigma, stats_out=None):
         n, hi, wi, cx = x.shape
         cout, cin, kh, kw = weight.shape
         if cx < cin:
@@ -877,7 +908,7 @@ class Conv2dFn(torch.autograd.Function):
         wp = packed_weight(weight, x.dtype, cx, False, sigma, plan)
         ctx.plan, ctx.plan_gen = plan, (plan.generation if plan is not None else None)
         b = None if bias is None else bias.detach().float().contiguous()
-        y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act)
+        y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act, stats_out=stats_out)
         ctx.cfg = (stride, pad, in_act, out_act, bias is not None, residual is not None)
         ctx.live = LivePrefix.n
         ctx.wdst = _grad_dst(weight)                       # direct accumulation targets (or None)
@@ -906,7 +937,7 @@ class Conv2dFn(torch.autograd.Function):
             wpt = packed_weight(weight, x.dtype, cx, True, sigma, ctx.plan, ctx.plan_gen)
             conv2d_raw(gl, wpt, None, None, x[:live] if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
                        True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE, out=gx[:live])
-            return gx, None, None, None, None, None, None, None, None, None, None
+            return gx, None, None, None, None, None, None, None, None, None, None, None
         if out_act == ACT_TANH:
             g2 = torch.empty_like(g)
             L.check(L.lib().s2e_tanh_bwd(_dt(g), _p(g), _p(y), _p(g2), g.numel(), _stream()), 's2e_tanh_bwd')
@@ -957,19 +988,20 @@ class Conv2dFn(torch.autograd.Function):
             gb = colsum(g)
         if has_res and ctx.needs_input_grad[3]:
             gres = g
-        return gx, gw, gb, gres, None, None, None, None, None, None, None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, residual=None, stride=1, pad=0, in_act=ACT_NONE, out_act=ACT_NONE, sn=None):
+def conv2d(x, weight, bias=None, residual=None, stride=1, pad=0, in_act=ACT_NONE, out_act=ACT_NONE, sn=None, stats_out=None):
+    """stats_out: see conv2d_raw -- a list that receives in_stats(result) when the conv kernel can produce it."""
     u, v, sigma = sn if sn is not None else (None, None, None)
-    return Conv2dFn.apply(x, weight, bias, residual, stride, pad, in_act, out_act, u, v, sigma)
+    return Conv2dFn.apply(x, weight, bias, residual, stride, pad, in_act, out_act, u, v, sigma, stats_out)
 
 
-def conv2d_m(x, conv, residual=None, stride=1, pad=0, in_act=ACT_NONE, out_act=ACT_NONE):
+def conv2d_m(x, conv, residual=None, stride=1, pad=0, in_act=ACT_NONE, out_act=ACT_NONE, stats_out=None):
     """conv2d on an nn.Conv2d parameter container (spectral-normed or not)."""
     from .spectral import conv_params
     weight, bias, sn = conv_params(conv)
-    return conv2d(x, weight, bias, residual, stride, pad, in_act, out_act, sn)
+    return conv2d(x, weight, bias, residual, stride, pad, in_act, out_act, sn, stats_out)
 
 
 # ------------------------------------------------------------------------------ the encoder's head

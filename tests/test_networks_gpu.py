@@ -778,11 +778,12 @@ def _bench_shape_kernels(dt):
     }
 
 
-def _cfg3_run(dt, graphs, z, steps=1, hooks=True):
-    """One (or more) G+D iterations of Pix2PixTrainer at the benchmarked configuration on the fixture's weights and batch.
+def _cfg3_run(dt, graphs, z, steps=1, hooks=True, crop=256, aspect=1.0, n=8, hw=(256, 256), seed=1234):
+    """One (or more) G+D iterations of Pix2PixTrainer at the benchmarked configuration (or, with the keywords, config 5's per-GPU
+    workload) on the fixture's weights and batch.
     -> dict(losses, fake, acts {block: NCHW fp32 cpu}, grads {name: fp32 gpu clone}, trainer)"""
     from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
-    opt = _opt(ngf=64, ndf=64, crop_size=256, aspect_ratio=1.0, batchSize=8, compute_dtype=dt, hip_graphs=graphs)
+    opt = _opt(ngf=64, ndf=64, crop_size=crop, aspect_ratio=aspect, batchSize=n, compute_dtype=dt, hip_graphs=graphs)
     tr = Pix2PixTrainer(opt)
     m = tr.pix2pix_model
     for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
@@ -790,7 +791,7 @@ def _cfg3_run(dt, graphs, z, steps=1, hooks=True):
         with torch.no_grad():
             for k, v in net.state_dict().items():
                 v.copy_(sd[k])
-    data = _batch(8, 256, 256, 1234)
+    data = _batch(n, hw[0], hw[1], seed)
     acts, hs = {}, []
     if hooks:
         for name in _BLOCKS:
@@ -820,27 +821,9 @@ def _relrms(a, b):
     return float(((a - b) ** 2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
 
 
-def test_cfg3_as_benched_matches_reference():
-    """BASELINE.json configs[2] exactly as bench.py runs it -- ngf = ndf = 64, 256x256, batch 8, the bench's seed-1234 batch --
-    against ONE G step + ONE D step of the real reference's Pix2PixTrainer (trainers/pix2pix_trainer.py:26-45; fixture
-    trainer_ngf64_256_n8.npz, `make_golden.py --only full-train`):
-      (a) fp32 eager: losses 2e-3, generated image < 1e-3, every ResBlk output, every G / E / D parameter gradient and every
-          parameter / buffer after the iteration, by checksum;
-      (b) bf16 eager against the fp32 run: every ResBlk output, losses, the weight gradients of the five largest layers;
-      (c) bf16 with hipGraphs ON (what the bench times): the replayed step against (b) and against the reference's losses.
-    The shapes take the patch-resident / split / fused kernels at batch 8 (they take the generic one at batch 1): asserted."""
-    z = load_golden('trainer_ngf64_256_n8')
-    from seg2eye_amd import _lib as L
-    for dt in ('fp32', 'bf16'):
-        kinds = _bench_shape_kernels(dt)
-        for name in ('up_3 conv_0 fwd', 'up_2 conv_0 fwd', 'mid conv split fwd', 'gb dgrad 32^2', 'D m3 4x4 s1'):
-            assert kinds[name][0] == 2, (dt, name, kinds[name])                       # S2E_KERNEL_PATCH
-        assert kinds['mid conv split fwd'][1] > 0, kinds['mid conv split fwd']          # ... split over channel chunks
-        assert kinds['fused 256^2 C=128'] == 1 and kinds['fused 16^2 C=1024'] == 1, kinds
-        if dt == 'bf16':
-            assert kinds['gb wgrad 256^2'] == 2 and kinds['up_1 wgrad'] == 2, kinds     # patch-resident weight gradient
-    # ---- (a) fp32 eager vs the reference
-    a = _cfg3_run('fp32', False, z)
+def _check_fp32_step_against_reference(a, z):
+    """`a` = _cfg3_run('fp32', False, z, ...): losses 2e-3, generated image < 1e-3, every ResBlk output, every G / E / D parameter
+    gradient and every parameter / buffer after the iteration against the reference trainer's fixture `z`, by checksum."""
     errs = []
     for k, v in a['losses'].items():
         ref = float(z['it0_%s' % k.replace('/', '_')].reshape(-1)[0])
@@ -878,8 +861,32 @@ def test_cfg3_as_benched_matches_reference():
         for k, v in net.state_dict().items():
             flip = 2 * lr if v.dtype.is_floating_point and not k.endswith(('_u', '_v')) else 0.0
             assert_checksum_close(v, z['it0_ck_%s.%s' % (tag, k)], 2e-3, 'after it0 %s.%s' % (tag, k), flip=flip)
+
+
+def test_cfg3_as_benched_matches_reference():
+    """BASELINE.json configs[2] exactly as bench.py runs it -- ngf = ndf = 64, 256x256, batch 8, the bench's seed-1234 batch --
+    against ONE G step + ONE D step of the real reference's Pix2PixTrainer (trainers/pix2pix_trainer.py:26-45; fixture
+    trainer_ngf64_256_n8.npz, `make_golden.py --only full-train`):
+      (a) fp32 eager: losses 2e-3, generated image < 1e-3, every ResBlk output, every G / E / D parameter gradient and every
+          parameter / buffer after the iteration, by checksum;
+      (b) bf16 eager against the fp32 run: every ResBlk output, losses, the weight gradients of the five largest layers;
+      (c) bf16 with hipGraphs ON (what the bench times): the replayed step against (b) and against the reference's losses.
+    The shapes take the patch-resident / split / fused kernels at batch 8 (they take the generic one at batch 1): asserted."""
+    z = load_golden('trainer_ngf64_256_n8')
+    from seg2eye_amd import _lib as L
+    for dt in ('fp32', 'bf16'):
+        kinds = _bench_shape_kernels(dt)
+        for name in ('up_3 conv_0 fwd', 'up_2 conv_0 fwd', 'mid conv split fwd', 'gb dgrad 32^2', 'D m3 4x4 s1'):
+            assert kinds[name][0] == 2, (dt, name, kinds[name])                       # S2E_KERNEL_PATCH
+        assert kinds['mid conv split fwd'][1] > 0, kinds['mid conv split fwd']          # ... split over channel chunks
+        assert kinds['fused 256^2 C=128'] == 1 and kinds['fused 16^2 C=1024'] == 1, kinds
+        if dt == 'bf16':
+            assert kinds['gb wgrad 256^2'] == 2 and kinds['up_1 wgrad'] == 2, kinds     # patch-resident weight gradient
+    # ---- (a) fp32 eager vs the reference
+    a = _cfg3_run('fp32', False, z)
+    _check_fp32_step_against_reference(a, z)
     fp32 = {k: a[k] for k in ('losses', 'fake', 'acts', 'grads_G', 'grads_D')}
-    del a, m
+    del a
     torch.cuda.empty_cache()
     # ---- (b) bf16 eager vs fp32
     b = _cfg3_run('bf16', False, z)
@@ -912,6 +919,34 @@ def test_cfg3_as_benched_matches_reference():
     assert _relrms(c['fake'], fp32['fake']) < 3e-2
     g5 = {k: _relrms(c['grads_G'][k], fp32['grads_G'][k]) for k in big}
     print('cfg3 bf16 hipGraph vs fp32: wgrad rel-RMS', {k: round(v, 4) for k, v in g5.items()})
+    assert max(g5.values()) < 8e-2, g5
+
+
+def test_cfg5_train_step_matches_reference():
+    """BASELINE.json configs[4]'s per-GPU workload -- ngf = ndf = 64, 640x384 (--crop_size 384 --aspect_ratio 0.6), batch 4,
+    encoder + feature matching on -- against ONE G step + ONE D step of the real reference's Pix2PixTrainer
+    (trainers/pix2pix_trainer.py:26-45; fixture trainer_ngf64_640x384_n4.npz, `make_golden.py --only cfg5-train`), as cfg3 is
+    (the 640x384 backward / optimizer path was pinned only to itself):
+      (a) fp32 eager: losses, generated image < 1e-3, every ResBlk output, all G / E / D parameter gradients and every parameter /
+          buffer after the iteration, by checksum;
+      (b) bf16 with hipGraphs ON against (a) and against the reference's losses."""
+    z = load_golden('trainer_ngf64_640x384_n4')
+    cfg = dict(crop=384, aspect=0.6, n=4, hw=(640, 384), seed=77)
+    a = _cfg3_run('fp32', False, z, **cfg)
+    _check_fp32_step_against_reference(a, z)
+    fp32 = {k: a[k] for k in ('losses', 'fake', 'grads_G')}
+    del a
+    torch.cuda.empty_cache()
+    c = _cfg3_run('bf16', True, z, steps=1, hooks=False, **cfg)
+    assert c['tr'].use_graphs and c['tr'].graph_G is not None, 'the step did not run as a hipGraph replay'
+    for k, v in c['losses'].items():
+        ref = float(z['it0_%s' % k.replace('/', '_')].reshape(-1)[0])
+        assert abs(v - fp32['losses'][k]) <= 2e-2 * max(1.0, abs(fp32['losses'][k])), ('bf16 graphs vs fp32', k, v, fp32['losses'][k])
+        assert abs(v - ref) <= 2e-2 * max(1.0, abs(ref)), ('bf16 graphs vs reference', k, v, ref)
+    assert _relrms(c['fake'], fp32['fake']) < 3e-2
+    big = sorted(fp32['grads_G'], key=lambda k: -fp32['grads_G'][k].numel())[:5]
+    g5 = {k: _relrms(c['grads_G'][k], fp32['grads_G'][k]) for k in big}
+    print('cfg5 bf16 (graphs) vs fp32: image rel-RMS %.4f, wgrad rel-RMS %s' % (_relrms(c['fake'], fp32['fake']), {k: round(v, 4) for k, v in g5.items()}))
     assert max(g5.values()) < 8e-2, g5
 
 

@@ -741,6 +741,39 @@ def test_patch_conv_kernels_match_torch_at_bench_shapes(duo):
     assert 'worst relative error' in out.stdout
 
 
+@pytest.mark.parametrize('cfg', [(4, 128, 128, 256, 128, True), (2, 256, 256, 128, 64, False), (8, 64, 64, 512, 256, True), (3, 48, 48, 64, 128, False)])
+def test_conv_epilogue_instance_norm_statistics(cfg):
+    """SURVEY 7 step 5 (round 4): the InstanceNorm statistics of a conv's output from the conv kernel's own epilogue
+    (s2e_conv2d_stats -> s2e_in_stats_from_partials) equal the statistics pass over the stored output (s2e_in_stats), with and
+    without a residual, for 128- and 64-channel tiles; a shape whose kernel has no such epilogue leaves the holder empty."""
+    from seg2eye_amd import ops
+    from seg2eye_amd import _lib as L
+    n, H, W, cin, cout, with_res = cfg
+    dev, dt = _dev(), torch.bfloat16
+    torch.manual_seed(5)
+    x = torch.randn(n, H, W, cin, device=dev).to(dt)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+    b = torch.randn(cout, device=dev)
+    res = (torch.randn(n, H, W, cout, device=dev) + 0.5).to(dt) if with_res else None
+    wp = ops.pack_weight(w, dt, cin, False)
+    holder = []
+    y = ops.conv2d_raw(x, wp, b, res, None, (H, W, cout), 3, 3, 1, 1, stats_out=holder)
+    y0 = ops.conv2d_raw(x, wp, b, res, None, (H, W, cout), 3, 3, 1, 1)
+    assert torch.equal(y, y0)                                           # the statistics epilogue changes no output bit
+    if H == 48:
+        assert not holder                                               # (ragged rectangles: conv_patch.hip's kernel, no statistics)
+        return
+    assert len(holder) == 1 and tuple(holder[0].shape) == (n, cout, 2)
+    ref = ops.in_stats(y)
+    mean_scale = float(ref[..., 0].abs().max()) + float(1.0 / ref[..., 1].min())
+    assert float((holder[0][..., 0] - ref[..., 0]).abs().max()) <= 2e-6 * mean_scale
+    assert float(((holder[0][..., 1] - ref[..., 1]) / ref[..., 1]).abs().max()) <= 1e-5
+    # and against fp64 torch on the stored values
+    yf = y.double().view(n, H * W, cout)
+    np.testing.assert_allclose(holder[0][..., 0].cpu().numpy(), yf.mean(1).cpu().numpy(), atol=2e-6 * mean_scale)
+    np.testing.assert_allclose(holder[0][..., 1].cpu().numpy(), (yf.var(1, unbiased=False) + 1e-5).rsqrt().cpu().numpy(), rtol=1e-5)
+
+
 def test_conv_stream_kernel_every_shape_matches_torch():
     """csrc/conv_stream.hip on EVERY shape it can run (S2E_CONV_STREAM=2; by default it takes the long-K tiles only): forward, the
     stride-2 data-gradients by parity class, split tiles + fix-up -- tools/bench_tail.py checks each against torch in fp32."""

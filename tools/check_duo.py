@@ -37,7 +37,7 @@ def main():
     torch.manual_seed(0)
     worst = 0.0
     # ---- plain conv: (N, H, Cin, Cout)
-    for n, H, cin, cout in ((8, 256, 128, 256), (8, 128, 256, 128), (8, 64, 512, 256), (8, 256, 64, 128), (8, 128, 128, 512), (3, 96, 96, 160)):
+    for n, H, cin, cout in ((8, 256, 128, 256), (8, 128, 256, 128), (8, 64, 512, 256), (8, 256, 64, 128), (8, 256, 128, 64), (8, 256, 64, 64), (8, 128, 128, 512), (3, 96, 96, 160)):
         x = torch.randn(n, H, H, cin, device=dev).to(dt)
         w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
         b = torch.randn(cout, device=dev)
