@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's measured evidence in one GPU call:  bash tools/collect_evidence.sh <out dir under gpurun_out> <file prefix>
 # (S2E_GIT_HEAD = the commit being measured; there is no .git on the GPU box).  Order matters: the PMC passes come first and
-# land in profiles/r03/pmc of the box's copy, so the bench line that follows quotes the traffic of THIS build.
+# land in profiles/r04/pmc of the box's copy, so the bench line that follows quotes the traffic of THIS build.
 set -u
 O=${1:-gpurun_out/evidence}; P=${2:-x}
 R=$(pwd); mkdir -p "$R/$O/pmc"
@@ -11,7 +11,7 @@ cd /tmp
 PMC="--steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events --no-extras"
 (cd "$R" && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py $PMC > /dev/null 2>&1)
 (cd "$R" && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py $PMC > /dev/null 2>&1)
-(cd "$R" && python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r03/pmc > /dev/null && cp profiles/r03/pmc/hbm_traffic* "$O/pmc/")
+(cd "$R" && python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r04/pmc > /dev/null && cp profiles/r04/pmc/hbm_traffic* "$O/pmc/")
 (cd "$R" && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \
     SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -o sq -- python3 bench.py $PMC > /dev/null 2>&1
  python3 tools/pmc_sq.py /tmp/pmc_sq "$O/pmc/sq_counters_patch_kernels.txt" > /dev/null)

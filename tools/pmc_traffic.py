@@ -4,7 +4,7 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
-    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r03/pmc [steps-profiled]
+    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r04/pmc [steps-profiled]
 
 Counters are in KB; FETCH_SIZE is doubled (gfx950 counts a 128-B request as 64 B: MI355X_MICROARCH.md, HBM section).
 Families are seg2eye_amd.ops.LaunchProfiler's -- one per C-ABI entry point (the conv entry points split by
@@ -21,6 +21,7 @@ from collections import defaultdict
 
 FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the family)
     'conv_patch_kernel': ('conv_patch', True),
+    'conv_duo_kernel': ('conv_patch', True),            # (round 4: the same s2e_conv2d / s2e_spade_conv_modulate launches, two workgroups per CU)
     'conv_igemm_kernel': ('conv_igemm', True),
     'conv_stream_kernel': ('conv_igemm', True), 'conv_stream_fixup_kernel': ('conv_igemm', False),   # (same profiler family: s2e_conv2d's generic shapes)
     'conv_finish_kernel': ('conv_igemm', False),          # (also finishes the patch kernel's channel-chunk splits)
@@ -33,6 +34,7 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'small_wgrad_reduce_kernel': ('conv_wgrad_small', False),
     # HBM-bound families
     'in_stats_partial_kernel': ('in_stats', True), 'in_stats_finalize_kernel': ('in_stats', False),
+    'in_stats_from_partials_kernel': ('in_stats', True),   # (round 4: the fold of partial sums a conv's epilogue wrote)
     # small maps, one launch per call: in_small_kernel<T, 0, G> = statistics only (s2e_in_stats), <T, 1, G> = the whole plain
     # InstanceNorm forward (s2e_instance_norm_fwd, family modulate_fwd).  rocprof prints the template arguments either as
     # '<..., 0, ...>' or mangled 'Li0E': both spellings are listed
