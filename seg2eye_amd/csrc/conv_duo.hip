@@ -67,9 +67,18 @@ constexpr int DU_NBS = 3, DU_PD = 2;
 
 // BN = output channels per tile: 128 (waves 2 x 2, wave tile 128 x 64), or 64 for the 64-channel layers (waves 4 x 1, wave tile
 // 64 x 64: half the accumulators, one weight piece per wave and K-step)
-template <bool FUSE, int BN = 128>
+// MF16 = the multiply loop on v_mfma_f32_16x16x32_bf16 instead of 32x32x16: the same FLOPs per cycle and the same LDS reads, but
+// the chip -- which lowers its clock under matrix load -- holds a higher one on this shape (MI355X_MICROARCH.md: 1.12-1.15 x the
+// FLOP/s at equal cycles).  A K-step is then ONE instruction per 16 x 16 accumulator (k = 32); the wave's 128 x 64 tile is 8 x 4 of
+// them.  16 x 16 rectangles only: a fragment is one rectangle row, so every fragment address is a lane base + an immediate.
+// EPI = which plain epilogue this instantiation carries: 0 none, 1 residual, 2 mask, 3 / 4 = 0 / 1 with the InstanceNorm partial
+// sums, -1 all of them behind run-time branches.  One epilogue per 128-channel kernel: with all five in one function the register
+// allocator spilled 33 values that live across them (the next tile's load offsets), and every reload in the tile turnaround is a
+// scratch load + vmcnt(0): 6-7 us per tile against 1.2 us without spills (in-kernel stamps, tools/duo_stamps.py).
+template <bool FUSE, int BN = 128, bool MF16 = false, int EPI = -1>
 __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
     static_assert(BN == 128 || (BN == 64 && !FUSE), "tile widths");
+    static_assert(!MF16 || BN == 128, "the 16x16x32 loop is written for 128-channel tiles");
     typedef bf16_t T;
     constexpr int NW = 4, TAPS = 9;
     constexpr int TM = BN / 32, TN = 2;               // wave tile TM * 32 pixels x 64 channels
@@ -139,7 +148,9 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
         for (int j = 0; j < NBJ; ++j) {
             const int trow = 16 * (wave + NW * j) + (lane >> 2);
             const int grow = FUSE ? (trow < 64 ? q.tn * 64 + trow : p.mC + q.tn * 64 + (trow - 64)) : q.tn * BN + trow;
-            woff[j] = 2u * (unsigned)(grow * p.Kpad) + (unsigned)(((lane & 3) ^ ((trow >> 2) & 3)) << 4);
+            // (swizzle of the weight rows: what makes the B fragment reads conflict-free -- 32 rows x 2 chunks per read in the
+            // 32x32x16 loop, 16 rows x 4 chunks in the 16x16x32 one)
+            woff[j] = 2u * (unsigned)(grow * p.Kpad) + (unsigned)(((lane & 3) ^ ((MF16 ? trow >> 1 : trow >> 2) & 3)) << 4);
         }
     };
     auto dma_patch = [&](auto R, int chunk, int buf) __attribute__((always_inline)) -> int {
@@ -258,6 +269,48 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
                                                                       __builtin_bit_cast(bf16x8_t, fb[set][ni]), acc[mi][ni], 0, 0, 0);
     };
 
+    // ---- the same for the 16x16x32 loop (MF16): lane (i = lane & 15, kq = lane >> 4) holds k = 8 kq .. + 7 of fragment row i.
+    // A fragment mi = rectangle row 8 wm + mi at tap (dy, dx): a16[dx] + patch buffer + ((mi + dy) * 18 * 64 as an immediate);
+    // B fragment ni = 16 weight rows: b16 + stage + an immediate.  The accumulators of rows 0-3 are multiplied while the A
+    // fragments of rows 4-7 arrive, those of rows 4-7 while the next K-step's rows 0-3 and B arrive (B in two register sets,
+    // alternating with the K-step's parity).
+    f32x4_t acc16[MF16 ? 8 : 1][4];
+    u32x4_t fal[4], fah[4], fbb[2][4];
+    uint32_t a16[3], b16 = 0;
+    if constexpr (MF16) {
+        const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+            a16[dx] = lds0 + (uint32_t)(((8 * wm) * 18 + i + dx) * 64 + ((kq ^ (((i + dx) >> 1) & 3)) << 4));
+        b16 = lds0 + 2 * P_BYTES + (uint32_t)((FUSE ? wn * 32 : wn * 64) * 64 + i * 64 + ((kq ^ ((i >> 1) & 3)) << 4));
+    }
+    // (plain lambdas with int arguments that are constants at every call site: an asm operand inside a GENERIC lambda does not
+    // capture -- clang -- and the offsets fold to immediates after inlining)
+    auto read_al = [&](uint32_t ab, int dy) __attribute__((always_inline)) {          // A rows 0-3 of a K-step
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fal[m]) : "v"(ab), "n"((m + dy) * 1152) : "memory");
+    };
+    auto read_ah = [&](uint32_t ab, int dy) __attribute__((always_inline)) {          // A rows 4-7
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fah[m]) : "v"(ab), "n"((4 + m + dy) * 1152) : "memory");
+    };
+    auto read_b = [&](uint32_t bb, int par) __attribute__((always_inline)) {
+        // FUSE: rows 32 wn + {0, 16} are gamma, 64 + 32 wn + {0, 16} the beta rows of the same channels
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbb[par][n]) : "v"(bb), "n"(FUSE ? (n & 1) * 1024 + (n >> 1) * 4096 : n * 1024) : "memory");
+    };
+    auto mfma16 = [&](int half, int par) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc16[MF16 ? half * 4 + m : 0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, half ? fah[m] : fal[m]), __builtin_bit_cast(bf16x8_t, fbb[par][n]), acc16[MF16 ? half * 4 + m : 0][n], 0, 0, 0);
+    };
+
     // ---- epilogue, wave-private.  Pass q = 0..7 handles the wave's accumulator rows 32 (q >> 1) + 16 (q & 1) .. + 15 (registers
     // r = 8 (q & 1) .. + 7 of acc[q >> 1][*]): staged as fp32 [16 rows][64 columns] (256-byte rows) in this wave's 4-KB slice of the
     // idle patch buffer, 16-byte chunk index XORed with g(row) -- plain: row & 1; FUSE: (row & 1) | ((row & 2) << 2) -- which makes
@@ -271,6 +324,26 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
         constexpr int q = decltype(Q)::value;          // compile time: a run-time pass index would turn the accumulators into scratch
         int l = lane;
         asm volatile("" : "+v"(l));                    // (opaque: recomputed per pass instead of living across the passes)
+        if constexpr (MF16) {
+            // accumulator (mi = q, ni) register r of lane (j = l & 15, qd = l >> 4) = staged row 4 qd + r, column 16 ni + j
+            const uint32_t c4 = (uint32_t)((l & 15) >> 2), w4 = (uint32_t)((l & 3) * 4);
+            const uint32_t rowb = wslice + (uint32_t)((4 * (l >> 4)) * 256);
+            const uint32_t base0 = rowb + c4 * 16 + w4, base1 = rowb + (c4 ^ 1u) * 16 + w4;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc16[MF16 ? q : 0][ni][r];
+                    if (r & 1)
+                        asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(base1), "v"(v),
+                                     "n"(r * 256 + (((ni * 4) ^ (FUSE ? ((r & 2) << 2) : 0)) * 16)) : "memory");
+                    else
+                        asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(base0), "v"(v),
+                                     "n"(r * 256 + (((ni * 4) ^ (FUSE ? ((r & 2) << 2) : 0)) * 16)) : "memory");
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            return;
+        }
         const uint32_t c4 = (uint32_t)((l & 31) >> 2), w4 = (uint32_t)((l & 3) * 4);
         const uint32_t rowb = wslice + (uint32_t)((4 * (l >> 5)) * 256);
         const uint32_t base0 = rowb + c4 * 16 + w4, base1 = rowb + (c4 ^ 1u) * 16 + w4;      // g & 1 = 0 / 1
@@ -513,52 +586,104 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
         // the accumulators start from the per-column constants of the epilogue (bias; FUSE: 1 + b_gamma | b_beta + s1)
         // (inline-asm reads: through a C++ access the compiler waits for vmcnt(0) first -- the constants arrived by LDS-DMA and it
         // cannot know they have landed -- which would drain the stores the wait above leaves in flight)
-        float cinit[TN];
-        {
-            const uint32_t ka = (uint32_t)(uintptr_t)(lptr_t)&kcst[cb][0] + (uint32_t)((FUSE ? wn * 32 + l31 : wn * 64 + l31) * 4);
-            float k0, k1, k2;
+        if constexpr (MF16) {
+            // lane (j = lane & 15)'s accumulator columns: plain 64 wn + 16 ni + j; FUSE gamma (ni 0, 1) / beta (ni 2, 3) of channel
+            // 32 wn + 16 (ni & 1) + j
+            const uint32_t ka = (uint32_t)(uintptr_t)(lptr_t)&kcst[cb][0] + (uint32_t)((FUSE ? wn * 32 + (lane & 15) : wn * 64 + (lane & 15)) * 4);
+            float ci[4];
             if constexpr (FUSE) {
-                asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:512\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(k0), "=&v"(k1), "=&v"(k2) : "v"(ka) : "memory");
-                cinit[0] = 1.f + k0; cinit[1] = k1 + k2;
+                float g0, g1, b0, b1, s0, s1;
+                asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:64\n\tds_read_b32 %2, %6 offset:256\n\tds_read_b32 %3, %6 offset:320\n\t"
+                             "ds_read_b32 %4, %6 offset:512\n\tds_read_b32 %5, %6 offset:576\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1), "=&v"(s0), "=&v"(s1) : "v"(ka) : "memory");
+                ci[0] = 1.f + g0; ci[1] = 1.f + g1; ci[2] = b0 + s0; ci[3] = b1 + s1;
             } else {
-                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(k0), "=&v"(k1) : "v"(ka) : "memory");
-                cinit[0] = k0; cinit[1] = k1;
+                asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\tds_read_b32 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(ci[0]), "=&v"(ci[1]), "=&v"(ci[2]), "=&v"(ci[3]) : "v"(ka) : "memory");
             }
-        }
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+            for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = cinit[ni];
-        int kt = 0, stage = 0;
-        aim_frags(0, 0, pb, 0);
-        read_frags(0, 0);
-        for (int c = 0; c < nch; ++c) {
-            const bool more = c + 1 < nch;
-            const int pcur = (pb + c) & 1;
-            static_for<0, TAPS>([&](auto TAP) {
-                constexpr int tap = decltype(TAP)::value;
-                constexpr int ntap = (tap + 1) % TAPS;
-                int issued = 0;
-                if constexpr (tap < NR) { if (more) issued += dma_patch(TAP, c + 1, pcur ^ 1); }
-                if (kt + PD < nk) { dma_w(kt + PD, stage == 0 ? NBS - 1 : stage - 1); issued += NBJ; }
-                read_frags(1, 1);
-                frags_ready(0, false);
-                mfmas(0);
-                // K-step kt+1 (and every older patch piece) has landed for this wave once all but this K-step's loads are back
-                wait_keep(issued);
-                frags_ready(1, true);
-                __builtin_amdgcn_s_barrier();
-                stage = stage == NBS - 1 ? 0 : stage + 1;
-                ++kt;
-                if (kt < nk) {
-                    aim_frags(ntap / 3, ntap % 3, ntap == 0 ? pcur ^ 1 : pcur, stage);
-                    read_frags(0, 0);
+                for (int ni = 0; ni < 4; ++ni) acc16[MF16 ? mi : 0][ni] = f32x4_t{ci[ni], ci[ni], ci[ni], ci[ni]};
+            int kt = 0, stage = 0;
+            read_al(a16[0] + (uint32_t)(pb * P_BYTES), 0);
+            read_b(b16, 0);
+            // two chunks (18 K-steps) per trip: the K-step's parity -- which B register set it multiplies -- is a compile-time fact
+            for (int c = 0; c < nch; c += 2) {
+                static_for<0, 2 * TAPS>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    constexpr int tap = t % TAPS, cc = t / TAPS, par = t & 1;
+                    constexpr int ntap = (tap + 1) % TAPS;
+                    if (kt >= nk) return;                                   // (odd chunk count: the second half of the last trip)
+                    const bool more = c + cc + 1 < nch;
+                    const int pcur = (pb + c + cc) & 1;
+                    int issued = 0;
+                    if constexpr (tap < NR) { if (more) issued += dma_patch(std::integral_constant<int, tap>{}, c + cc + 1, pcur ^ 1); }
+                    if (kt + PD < nk) { dma_w(kt + PD, stage == 0 ? NBS - 1 : stage - 1); issued += NBJ; }
+                    read_ah(a16[tap % 3] + (uint32_t)(pcur * P_BYTES), tap / 3);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fal[0]), "+v"(fal[1]), "+v"(fal[2]), "+v"(fal[3]), "+v"(fbb[par][0]), "+v"(fbb[par][1]),
+                                 "+v"(fbb[par][2]), "+v"(fbb[par][3]) :: "memory");
+                    mfma16(0, par);
+                    wait_keep(issued);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fah[0]), "+v"(fah[1]), "+v"(fah[2]), "+v"(fah[3]) :: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    stage = stage == NBS - 1 ? 0 : stage + 1;
+                    ++kt;
+                    if (kt < nk) {
+                        read_al(a16[ntap % 3] + (uint32_t)((ntap == 0 ? pcur ^ 1 : pcur) * P_BYTES), ntap / 3);
+                        read_b(b16 + (uint32_t)(stage * B_BYTES), par ^ 1);
+                    }
+                    mfma16(1, par);
+                });
+            }
+        } else {
+        float cinit[TN];
+            {
+                const uint32_t ka = (uint32_t)(uintptr_t)(lptr_t)&kcst[cb][0] + (uint32_t)((FUSE ? wn * 32 + l31 : wn * 64 + l31) * 4);
+                float k0, k1, k2;
+                if constexpr (FUSE) {
+                    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(k0), "=&v"(k1), "=&v"(k2) : "v"(ka) : "memory");
+                    cinit[0] = 1.f + k0; cinit[1] = k1 + k2;
+                } else {
+                    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(k0), "=&v"(k1) : "v"(ka) : "memory");
+                    cinit[0] = k0; cinit[1] = k1;
                 }
-                mfmas(1);
-            });
+            }
+    #pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+    #pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = cinit[ni];
+            int kt = 0, stage = 0;
+            aim_frags(0, 0, pb, 0);
+            read_frags(0, 0);
+            for (int c = 0; c < nch; ++c) {
+                const bool more = c + 1 < nch;
+                const int pcur = (pb + c) & 1;
+                static_for<0, TAPS>([&](auto TAP) {
+                    constexpr int tap = decltype(TAP)::value;
+                    constexpr int ntap = (tap + 1) % TAPS;
+                    int issued = 0;
+                    if constexpr (tap < NR) { if (more) issued += dma_patch(TAP, c + 1, pcur ^ 1); }
+                    if (kt + PD < nk) { dma_w(kt + PD, stage == 0 ? NBS - 1 : stage - 1); issued += NBJ; }
+                    read_frags(1, 1);
+                    frags_ready(0, false);
+                    mfmas(0);
+                    // K-step kt+1 (and every older patch piece) has landed for this wave once all but this K-step's loads are back
+                    wait_keep(issued);
+                    frags_ready(1, true);
+                    __builtin_amdgcn_s_barrier();
+                    stage = stage == NBS - 1 ? 0 : stage + 1;
+                    ++kt;
+                    if (kt < nk) {
+                        aim_frags(ntap / 3, ntap % 3, ntap == 0 ? pcur ^ 1 : pcur, stage);
+                        read_frags(0, 0);
+                    }
+                    mfmas(1);
+                });
+            }
         }
         // every buffer is free now (the last barrier is behind every LDS read): start the next item's loads, then write this one
         // out underneath them -- and, on this CU, underneath the partner workgroup's multiply loop
@@ -572,6 +697,11 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
         if (has_next) { nxt = decode(next_id, nf); aim(nxt); prologue(nxt, pbn, cb ^ 1); }
         stamp(3);
         if constexpr (FUSE) epilogue_fused(cur, pbn ^ 1);
+        else if constexpr (EPI == 0) epilogue(cur, pbn ^ 1, std::integral_constant<int, 0>{}, std::false_type{});
+        else if constexpr (EPI == 1) epilogue(cur, pbn ^ 1, std::integral_constant<int, 1>{}, std::false_type{});
+        else if constexpr (EPI == 2) epilogue(cur, pbn ^ 1, std::integral_constant<int, 2>{}, std::false_type{});
+        else if constexpr (EPI == 3) epilogue(cur, pbn ^ 1, std::integral_constant<int, 0>{}, std::true_type{});
+        else if constexpr (EPI == 4) epilogue(cur, pbn ^ 1, std::integral_constant<int, 1>{}, std::true_type{});
         else if (p.spart) {
             if (resg) epilogue(cur, pbn ^ 1, std::integral_constant<int, 1>{}, std::true_type{});
             else epilogue(cur, pbn ^ 1, std::integral_constant<int, 0>{}, std::true_type{});
@@ -613,18 +743,29 @@ int duo_launch(DuoParams& p, long rects_upper, hipStream_t st) {
     static long* const dbg_ptr = [] { const char* e = getenv("S2E_DUO_DBG_PTR"); return e ? (long*)strtoull(e, nullptr, 0) : (long*)nullptr; }();
     p.dbg = dbg_ptr;
 #endif
+    // S2E_DUO_MF16=0: the 32x32x16 loop everywhere (A/B switch)
+    static const bool mf16 = [] { const char* e = getenv("S2E_DUO_MF16"); return e ? atoi(e) != 0 : true; }();
     if (!FUSE && p.Cout <= 64) conv_duo_kernel<false, 64><<<grid, 256, 0, st>>>(p);
-    else conv_duo_kernel<FUSE><<<grid, 256, 0, st>>>(p);
+    else if (!mf16) conv_duo_kernel<FUSE><<<grid, 256, 0, st>>>(p);
+    else if (FUSE) conv_duo_kernel<true, 128, true><<<grid, 256, 0, st>>>(p);
+    else {
+        const int epi = p.aux_mode != S2E_AUX_NONE ? 2 : (p.res ? 1 : 0) + (p.spart ? 3 : 0);
+        if (epi == 0) conv_duo_kernel<false, 128, true, 0><<<grid, 256, 0, st>>>(p);
+        else if (epi == 1) conv_duo_kernel<false, 128, true, 1><<<grid, 256, 0, st>>>(p);
+        else if (epi == 2) conv_duo_kernel<false, 128, true, 2><<<grid, 256, 0, st>>>(p);
+        else if (epi == 3) conv_duo_kernel<false, 128, true, 3><<<grid, 256, 0, st>>>(p);
+        else conv_duo_kernel<false, 128, true, 4><<<grid, 256, 0, st>>>(p);
+    }
     S2E_CHECK_LAUNCH("conv_duo_kernel");
     return S2E_OK;
 }
 
 }  // namespace
 
-// interior-only rectangles: a power-of-two width >= 16, 256 pixels, tiling the map exactly (the epilogues address a pass's 16
-// rows as one scalar offset + a lane part and test no bounds)
+// interior-only 16 x 16 rectangles tiling the map exactly: the epilogues address a pass's 16 rows as one scalar offset + a lane
+// part and test no bounds, the 16x16x32 loop's fragments are one rectangle row each
 static bool duo_rect_ok(int tw, int th, int H, int W) {
-    return tw >= 16 && (tw & (tw - 1)) == 0 && tw * th == 256 && H % th == 0 && W % tw == 0;
+    return tw == 16 && th == 16 && H % 16 == 0 && W % 16 == 0;
 }
 
 // Shapes the duo kernel takes: bf16, 3x3, stride 1 (forward or data-gradient), no fused input activation, Cin a multiple of 32,
@@ -644,7 +785,9 @@ int s2e_conv_duo_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan) {
     if ((long)s2e_conv_cout_pad(d->Cout) * s2e_conv_k_pad(dtype, 9 * d->Cin) * 2 >= (1L << 31)) return 0;
     if (d->Cout % 64 != 0) return 0;
     plan->splits = 1;
-    if (s2e_patch_rectangle(d, 3, &plan->tw, &plan->th) < 0.8 || !duo_rect_ok(plan->tw, plan->th, d->Ho, d->Wo)) return 0;
+    if (s2e_patch_rectangle(d, 3, &plan->tw, &plan->th) < 0.8) return 0;
+    if (d->Ho % 16 == 0 && d->Wo % 16 == 0) plan->tw = plan->th = 16;       // the squarest rectangle: the smallest patch, and the 16x16x32 loop's
+    if (!duo_rect_ok(plan->tw, plan->th, d->Ho, d->Wo)) return 0;
     const long rects = (long)d->N * (d->Ho / plan->th) * (d->Wo / plan->tw);
     return rects * (d->Cout <= 64 ? 1 : ceil_div(d->Cout, 128)) >= duo_min_items();
 }
