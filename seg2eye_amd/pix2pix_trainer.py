@@ -59,6 +59,16 @@ class Pix2PixTrainer:
                 # step is `replay segment k; start group k's all-reduce` -- the collective runs on the backend's stream while the
                 # next segment replays.  (Rounds 1-3 had to choose: eager launches + overlap, or graphs + one exposed exchange.)
                 self.pix2pix_model.netG.__dict__['grad_ready'] = self._group_ready
+            if exchange_active() and 'batch' in str(getattr(opt, 'norm_G', '')) and getattr(opt, 'hip_graphs', False):
+                # BatchNorm SPADE under data parallelism exchanges its batch statistics between the replicas INSIDE every forward
+                # and backward (normalization.py::spade_stats): a collective cannot be captured into a hipGraph (gloo synchronises
+                # the stream on the host; attempting it took the process down), so these runs launch eagerly
+                from .distributed import get_rank
+                if get_rank() == 0:
+                    import sys
+                    print('seg2eye_amd: --norm_G %s with %d replicas exchanges batch statistics inside the step: the steps run '
+                          'as individual launches (no hipGraphs)' % (opt.norm_G, world_size()), file=sys.stderr)
+                self.opt.hip_graphs = False
             broadcast_flat(self.optimizer_G.flat_p)          # identical replicas at step 0: parameters ...
             broadcast_flat(self.optimizer_D.flat_p)
             self.sync_replica_buffers()                      # ... and spectral-norm u, v / BatchNorm running statistics
