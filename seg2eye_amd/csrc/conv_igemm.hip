@@ -608,7 +608,7 @@ static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tile
         return;
     }
     int s = 1;
-    static const int target = [] { const char* e = getenv("S2E_IGEMM_WG"); return e ? atoi(e) : 512; }();
+    const int target = 512;                          // (2 workgroups per CU; 256 ... 512 measured equal, 768 slower)
     if (*tiles < target && nk >= 8) {                // fewer than 2 workgroups per CU
         s = ceil_div(target, *tiles);
         // at least 4 K-tiles per split; a SHORT K (Cin = 128: 18 tiles) over >= 256 tiles is not worth splitting at all
@@ -715,11 +715,8 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
     // against ~25 MB of operands (the weight matrix arrives in all 8 L2s).  Walking the pixel tiles fastest instead
     // (S2E_IGEMM_TMFAST=1: one weight panel per XCD, the small activation replicated) was measured and changes
     // nothing on 1024->1024 @16^2 (577 vs 579 TFLOP/s) and costs 8 % on 128->2048: the re-reads are served by the
-    // Infinity Cache and are not what bounds these launches.  Kept as a switch, off.
-    {
-        static const int force = [] { const char* e = getenv("S2E_IGEMM_TMFAST"); return e ? atoi(e) : 0; }();
-        p.tm_fast = force > 0 && p.tiles_n > 1 && !s2;
-    }
+    // Infinity Cache and are not what bounds these launches.  Not used (the kernel keeps the code path; p.tm_fast = 0).
+    p.tm_fast = 0;                                   // (the pixel-tiles-fastest order: measured, no gain -- see above)
     p.partial = (float*)workspace;
     if (p.splits > 1 && (!workspace || workspace_bytes < s2e_conv2d_workspace_bytes(dtype, d)))
         S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: this shape needs %zu bytes of workspace (s2e_conv2d_workspace_bytes)",

@@ -483,7 +483,7 @@ static void generic_wgrad_plan(const s2e_conv_desc* d, WgradParams* p, int* spli
     p->tiles_k = ceil_div(p->Ktot, 128);
     p->tiles_co = ceil_div(d->Cout, 128);
     const int tiles = p->tiles_k * p->tiles_co;
-    static const int target_wg = [] { const char* e = getenv("S2E_WGRAD_WG"); return e ? atoi(e) : 2048; }();
+    const int target_wg = 2048;                      // (c128->256 @256^2: 476 / 497 / 558 TFLOP/s at 512 / 1024 / 2048 workgroups)
     int splits = ceil_div(target_wg, tiles);
     int max_splits = p->M / (tiles >= 64 ? 2048 : 1024);
     if (max_splits > 512) max_splits = 512;
@@ -566,7 +566,7 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
     generic_wgrad_plan(d, &p, &splits);
     const int tiles = p.tiles_k * p.tiles_co;
     hipStream_t st = (hipStream_t)stream;
-    static const int br = [] { const char* e = getenv("S2E_WGRAD_BR"); return e ? atoi(e) : 32; }();
+    const int br = 32;                               // pixels per chunk (64 measured no faster)
     static const bool glds = [] { const char* e = getenv("S2E_WGRAD_GLDS"); return e ? atoi(e) != 0 : false; }();
     const bool glds_path = dtype == S2E_BF16 && glds && d->in_act == S2E_ACT_NONE && d->Cin % 8 == 0 && d->Cout % 8 == 0;
     const int g = tiles * splits;

@@ -137,7 +137,7 @@ static long label_conv_blocks(int dtype, long npix, int Cout) {
     const int cgb_h = (cw + vec - 1) / vec;
     const int ppb = ((64 % cgb_h) == 0 && npix >= 65536) ? 256 : 256 / cgb_h;       // pixels per block per pass
     const long gx = (npix + ppb - 1) / ppb;
-    static const long cap = [] { const char* e = getenv("S2E_LABEL_GRID"); return e ? atol(e) : 1024L; }();
+    const long cap = 1024;                           // (the optimum of 256 ... 2048, measured)
     return gx > cap ? cap : gx;
 }
 

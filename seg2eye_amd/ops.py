@@ -610,9 +610,6 @@ def colsum(g):
     return out
 
 
-_IN_STATS_ONE_LAUNCH = os.environ.get('S2E_IN_STATS_ONE_LAUNCH', '0') == '1'      # experiment (slower: see include/seg2eye_hip.h)
-
-
 def in_stats(x, return_sums=False):
     """(N,H,W,C) -> (N,C,2) fp32 {mean, rstd}; not differentiated here (the IN backward lives in
     modulate_bwd, once per consumer of the statistics).
@@ -621,8 +618,7 @@ def in_stats(x, return_sums=False):
     n, h, w, c = x.shape
     ws = torch.empty(L.lib().s2e_in_stats_workspace_bytes(_dt(x), n, h * w, c) // 8, dtype=torch.float64, device=x.device)
     stats = torch.empty(n, c, 2, dtype=torch.float32, device=x.device)
-    ncnt = L.lib().s2e_in_stats_counters(_dt(x), n, h * w, c) if _IN_STATS_ONE_LAUNCH else 0
-    cnt = ZeroPool.take(ncnt, torch.int32, x.device) if ncnt else None     # zeroed block counters: the fold joins the row pass
+    cnt = None          # (the C ABI's one-launch form -- zeroed block counters -- measured slower: include/seg2eye_hip.h)
     LaunchProfiler.run('in_stats', 0.0, lambda: L.check(
         L.lib().s2e_in_stats(_dt(x), _p(x), n, h * w, c, IN_EPS, _p(ws), _p(stats), _p(cnt), _stream()), 's2e_in_stats'),
         nbytes=float(x.numel() * x.element_size()))                   # algorithmic: x read once
