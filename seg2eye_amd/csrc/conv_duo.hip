@@ -58,6 +58,7 @@ struct DuoParams {
     // s2e_in_stats_from_partials adds the sP slots of a (sample, channel) in a fixed order (normalization.py:94 of the reference)
     float* spart; int sP;
     long* dbg;                        // -DS2E_DUO_STAMPS builds only (tools/duo_stamps.py): per-tile phase time stamps
+    int abl;                          // ... and S2E_DUO_ABL, the timing ablation of the multiply loop
 };
 
 constexpr int DU_PPX = 400;                           // pixels per patch (with halo)
@@ -87,6 +88,8 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
     constexpr int NPIECE = P_BYTES / 1024;             // 25 pieces of 16 pixels
     constexpr int NR = (NPIECE + NW - 1) / NW;         // 7 per wave
     constexpr int NBJ = BN / 64;                       // weight pieces (16 rows each) per wave per K-step
+    constexpr int NR16 = 6;                            // MF16 (16 x 16 rectangles: an 18 x 18 patch = 20.25 pieces): six per wave, every wave
+                                                       // issues all six (pixels past the patch read zeros into the buffer's unused tail)
     static_assert(NR <= TAPS, "one patch piece per tap must cover the patch");
     static_assert(NW * 4096 <= P_BYTES, "the waves' staging slices must fit one patch buffer");
     __shared__ __attribute__((aligned(16))) char smem[2 * P_BYTES + NBS * B_BYTES];
@@ -155,7 +158,8 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
     };
     auto dma_patch = [&](auto R, int chunk, int buf) __attribute__((always_inline)) -> int {
         constexpr int r = decltype(R)::value;
-        if (r * NW + wave >= NPIECE) return 0;         // wave-uniform
+        if constexpr (MF16) { if (r >= NR16) return 0; }
+        else if (r * NW + wave >= NPIECE) return 0;    // wave-uniform
         const unsigned off = aoff[r] == OOB ? OOB : aoff[r] + 64u * (unsigned)chunk;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(smem + buf * P_BYTES + (r * NW + wave) * 1024), 16, (int)off, 0, 0, 0);
         return 1;
@@ -605,35 +609,73 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc16[MF16 ? mi : 0][ni] = f32x4_t{ci[ni], ci[ni], ci[ni], ci[ni]};
-            int kt = 0, stage = 0;
-            read_al(a16[0] + (uint32_t)(pb * P_BYTES), 0);
+            // ---- the multiply loop, straight-line.  Two chunks = 18 K-steps per trip, fully unrolled: tap, chunk-of-the-pair,
+            // weight stage ((t + 2) % 3: 18 is a multiple of 3) and B register set (t & 1) are compile-time facts of a K-step; what is
+            // left at run time is the trip's first chunk c, the patch-buffer parity of the tile and `last` (no chunk after this
+            // pair).  The round-4 stamps put the K-step's scalar skeleton -- ~60 instructions, a dozen branches: kt / 9, stage wrap,
+            // the wait selection -- at 350 cycles of a 1400-cycle K-step; here a K-step has at most two (uniform) branches.
+            const int tapb = 2 * p.Cin;                                     // bytes from one tap to the next in a weight row
+            const int fbase = p.flip ? 8 * tapb : 0, fstep = p.flip ? -tapb : tapb;
+            const uint32_t pbs0 = (uint32_t)(pb * P_BYTES), pbs1 = (uint32_t)((pb ^ 1) * P_BYTES);      // chunk c + cc lives in pbs[cc]
+            auto dma_patch16 = [&](int r, int chunk, uint32_t bufb) __attribute__((always_inline)) {
+                unsigned co = 64u * (unsigned)chunk;
+                asm volatile("" : "+s"(co));                                  // (opaque: see the K-step)
+                const unsigned off = aoff[r] == OOB ? OOB : aoff[r] + co;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(smem + bufb + (r * NW + wave) * 1024), 16, (int)off, 0, 0, 0);
+            };
+            auto dma_w16 = [&](int chunk, int tp, int stg) __attribute__((always_inline)) {
+                int koff = fbase + tp * fstep + 64 * chunk;
+                asm volatile("" : "+s"(koff));
+#pragma unroll
+                for (int j = 0; j < NBJ; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(smem + 2 * P_BYTES + stg * B_BYTES + (wave + NW * j) * 1024), 16,
+                                                             (int)(woff[j] + (unsigned)koff), 0, 0, 0);
+            };
+            read_al(a16[0] + pbs0, 0);
             read_b(b16, 0);
-            // two chunks (18 K-steps) per trip: the K-step's parity -- which B register set it multiplies -- is a compile-time fact
             for (int c = 0; c < nch; c += 2) {
+                const bool last = c + 2 >= nch;
                 static_for<0, 2 * TAPS>([&](auto T) {
                     constexpr int t = decltype(T)::value;
                     constexpr int tap = t % TAPS, cc = t / TAPS, par = t & 1;
-                    constexpr int ntap = (tap + 1) % TAPS;
-                    if (kt >= nk) return;                                   // (odd chunk count: the second half of the last trip)
-                    const bool more = c + cc + 1 < nch;
-                    const int pcur = (pb + c + cc) & 1;
-                    int issued = 0;
-                    if constexpr (tap < NR) { if (more) issued += dma_patch(std::integral_constant<int, tap>{}, c + cc + 1, pcur ^ 1); }
-                    if (kt + PD < nk) { dma_w(kt + PD, stage == 0 ? NBS - 1 : stage - 1); issued += NBJ; }
-                    read_ah(a16[tap % 3] + (uint32_t)(pcur * P_BYTES), tap / 3);
+                    constexpr int ntap = (tap + 1) % TAPS, u = t + PD;
+                    // (opaque per K-step: every address below is "loop-invariant + something" for the compiler, which would hoist
+                    // all 18 x 10 sums out of the loop -- a hundred registers beside 128 accumulators -- if it could)
+                    uint32_t pcb = cc ? pbs1 : pbs0, pnb = cc ? pbs0 : pbs1;                  // this chunk's / the next chunk's patch buffer
+                    uint32_t nsb = (uint32_t)(((t + 1) % NBS) * B_BYTES);
+                    int cs = c;
+                    asm volatile("" : "+s"(pcb), "+s"(pnb), "+s"(nsb), "+s"(cs));
+                    if (cs >= nch) return;                                  // (never taken; a block boundary per K-step: as ONE basic block of 576 MFMAs the
+                                                                            //  trip is register-allocated with renamed accumulators and 100 spills)
+#ifdef S2E_DUO_STAMPS
+                    const int abl = p.abl;                                  // timing ablation (results wrong): 1 no loads, 2 no MFMAs, 4 no fragment reads, 8 no barrier
+#else
+                    constexpr int abl = 0;
+#endif
+                    // loads: a patch piece of the NEXT chunk during taps 0-5 (24 pieces of 16 pixels cover the 18 x 18 patch),
+                    // the weights of K-step t + 2
+                    if (!(abl & 1)) {
+                        if constexpr (tap < NR16) { if (cc == 0 || !last) dma_patch16(tap, cs + cc + 1, pnb); }
+                        if (u < 2 * TAPS || !last) dma_w16(cs + u / TAPS, u % TAPS, u % NBS);
+                    }
+                    if (!(abl & 4)) read_ah(a16[tap % 3] + pcb, tap / 3);
                     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fal[0]), "+v"(fal[1]), "+v"(fal[2]), "+v"(fal[3]), "+v"(fbb[par][0]), "+v"(fbb[par][1]),
                                  "+v"(fbb[par][2]), "+v"(fbb[par][3]) :: "memory");
-                    mfma16(0, par);
-                    wait_keep(issued);
+                    if (!(abl & 2)) mfma16(0, par);
+                    // K-step t + 1 (and every older patch piece) has landed for this wave once all but THIS K-step's loads are back
+                    constexpr int now_p = tap < NR16 ? 1 : 0, now_w = NBJ;
+                    if constexpr (cc == 1 && (tap < NR16 || u >= 2 * TAPS)) {
+                        if (last) wait_keep(u < 2 * TAPS ? now_w : 0); else wait_keep(now_p + now_w);
+                    } else wait_keep(now_p + now_w);
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fah[0]), "+v"(fah[1]), "+v"(fah[2]), "+v"(fah[3]) :: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    stage = stage == NBS - 1 ? 0 : stage + 1;
-                    ++kt;
-                    if (kt < nk) {
-                        read_al(a16[ntap % 3] + (uint32_t)((ntap == 0 ? pcur ^ 1 : pcur) * P_BYTES), ntap / 3);
-                        read_b(b16 + (uint32_t)(stage * B_BYTES), par ^ 1);
+                    if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+                    if (!(abl & 4)) {
+                        if (t + 1 < 2 * TAPS || !last) {
+                            read_al(a16[ntap % 3] + (ntap == 0 ? pnb : pcb), ntap / 3);
+                            read_b(b16 + nsb, par ^ 1);
+                        }
                     }
-                    mfma16(1, par);
+                    if (!(abl & 2)) mfma16(1, par);
                 });
             }
         } else {
@@ -742,6 +784,8 @@ int duo_launch(DuoParams& p, long rects_upper, hipStream_t st) {
 #ifdef S2E_DUO_STAMPS
     static long* const dbg_ptr = [] { const char* e = getenv("S2E_DUO_DBG_PTR"); return e ? (long*)strtoull(e, nullptr, 0) : (long*)nullptr; }();
     p.dbg = dbg_ptr;
+    static const int abl_env = [] { const char* e = getenv("S2E_DUO_ABL"); return e ? atoi(e) : 0; }();
+    p.abl = abl_env;
 #endif
     // S2E_DUO_MF16=0: the 32x32x16 loop everywhere (A/B switch)
     static const bool mf16 = [] { const char* e = getenv("S2E_DUO_MF16"); return e ? atoi(e) != 0 : true; }();
