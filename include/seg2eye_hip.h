@@ -303,6 +303,40 @@ int s2e_wgrad_c8_batch(int dtype, int N, const s2e_wgrad_c8_job* jobs, int n_job
  * block in the generator (generator.py:77-92) is folded into the read of x, the upsampled tensor is never read (H, W even;
  * out and gamma_out are at full resolution). */
 int s2e_spade_conv_modulate_rect(int dtype, int N, int H, int W, int C, int nh, int flags, int* tw, int* th);
+/* Label-sparse BACKWARD of the SPADE branch (round 4; csrc/spade_sparse_bwd.hip has the algebra): in a 16 x 16 rectangle whose pixels and
+ * 2-pixel halo carry one class and lie inside the image, mlp_shared's gradients need only nine shifted sums of d[gamma | beta] and
+ * the [gamma | beta] conv's weight gradient is a rank-1 update per class; the branch's convolutions (normalization.py:97-103
+ * differentiated) run on the other rectangles only.
+ *   s2e_label_rect_lists_bwd : cls from s2e_label_rect_classify (16 x 16 rectangles) -> work_list (dense, or uniform on the image
+ *                              border), ui_list (uniform-interior), counts[2] (written).
+ *   s2e_conv2d_rects         : s2e_conv2d over the rectangles rect_list[0 .. *rect_count) only (the other pixels of y are not
+ *                              written); s2e_conv2d_rects_supported: does this shape's kernel take a list (16 x 16 rectangles)?
+ *   s2e_spade_uniform_sums   : R (S2E_UNI_REPLICAS, ncls, 9, 2C) fp32, ZEROED by the caller, += sum over the uniform-interior
+ *                              rectangles of class c of dgb[q - t + 1] (tap t = 3 ky + kx); fp32 atomics, spread over the replicas
+ *                              (a thousand rectangles add to four class slots); s2e_spade_uniform_grads folds the replicas.
+ *   s2e_spade_uniform_grads  : for up to 16 layers at once: A (ncls, nh) fp32 ZEROED scratch; dw_sh (nh, ncls, 3, 3) / db_sh (nh)
+ *                              ACCUMULATED; w_gb = the [gamma | beta] conv's fp32 weight (2C, nh, 3, 3) with element strides
+ *                              (w_sc, w_sk, w_st) for (co, k, tap); dw_gb / db_gb: NULL, or the same-strided weight gradient and
+ *                              the bias gradient, ACCUMULATED with the uniform rectangles' rank-1 part.  act_bf16: the hidden
+ *                              activation is stored in bf16 (its ReLU mask is taken from the rounded value). */
+#define S2E_UNI_REPLICAS 16
+typedef struct s2e_spade_uni_job {
+    const float* R; float* A; const float* w_gb; long w_sc, w_sk, w_st;
+    const float* w_sh; const float* b_sh; float* dw_sh; float* db_sh; float* dw_gb; float* db_gb;
+    int C2, nh, ncls, act_bf16;
+} s2e_spade_uni_job;
+int s2e_label_rect_lists_bwd(const uint8_t* cls, int N, int tiles_y, int tiles_x, int* work_list, int* ui_list, int* counts, void* stream);
+int s2e_conv2d_rects_supported(int dtype, const s2e_conv_desc* d);
+int s2e_conv2d_rects(int dtype, const void* x, const void* w_packed, const float* bias, const void* residual, const void* aux, void* y,
+                     const s2e_conv_desc* d, const int* rect_list, const int* rect_count, void* stream);
+/* s2e_conv2d_wgrad restricted to the pixels of rect_list[0 .. *rect_count) (16 x 16 rectangles): the [gamma | beta] conv's weight
+ * gradient on the rectangles that cross a label boundary; s2e_conv2d_wgrad_rects_workspace_bytes = 0: this shape takes no list. */
+size_t s2e_conv2d_wgrad_rects_workspace_bytes(int dtype, const s2e_conv_desc* d);
+int s2e_conv2d_wgrad_rects(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
+                           const int* rect_list, const int* rect_count, void* workspace, size_t workspace_bytes, void* stream);
+int s2e_spade_uniform_sums(int dtype, const void* dgb, int N, int H, int W, int C2, int ncls, const uint8_t* cls, const int* ui_list,
+                           const int* counts, float* R, void* stream);
+int s2e_spade_uniform_grads(const s2e_spade_uni_job* jobs_host, int n_jobs, void* stream);
 int s2e_label_rect_classify(const uint8_t* label, int N, int H, int W, int h, int w, int tw, int th,
                             uint8_t* cls, int* dense_list, int* uni_list, int* counts, void* stream);
 int s2e_spade_conv_modulate_sparse(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('S2E_LIB_PATH') or os.path.join(_HERE, 'lib', 'libseg2eye_hip.so')
 
 S2E_F32, S2E_BF16 = 0, 1
+UNI_REPLICAS = 16           # S2E_UNI_REPLICAS of include/seg2eye_hip.h
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 AUX_NONE, AUX_RELU_MASK, AUX_LRELU_GRAD = 0, 1, 2
 NORM_SPADE_STYLE, NORM_PLAIN_IN, NORM_SPADE_STYLE_BATCH = 0, 1, 2
@@ -62,6 +63,13 @@ class GradJob(C.Structure):
                 ('dot_index', C.c_int), ('reserved', C.c_int)]
 
 
+class SpadeUniJob(C.Structure):
+    """s2e_spade_uni_job"""
+    _fields_ = [('R', C.c_void_p), ('A', C.c_void_p), ('w_gb', C.c_void_p), ('w_sc', C.c_long), ('w_sk', C.c_long), ('w_st', C.c_long),
+                ('w_sh', C.c_void_p), ('b_sh', C.c_void_p), ('dw_sh', C.c_void_p), ('db_sh', C.c_void_p), ('dw_gb', C.c_void_p),
+                ('db_gb', C.c_void_p), ('C2', C.c_int), ('nh', C.c_int), ('ncls', C.c_int), ('act_bf16', C.c_int)]
+
+
 class SnGradJob(C.Structure):
     """s2e_sngrad_job"""
     _fields_ = [('g', C.c_void_p), ('w', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p), ('sigma', C.c_void_p),
@@ -96,6 +104,13 @@ SIGNATURES = {
     's2e_conv2d_stats_slots': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_stats': [_i, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, _vp],
     's2e_in_stats_from_partials': [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    's2e_label_rect_lists_bwd': [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    's2e_conv2d_rects_supported': [_i, C.POINTER(ConvDesc)],
+    's2e_conv2d_rects': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, _vp, _vp],
+    's2e_conv2d_wgrad_rects_workspace_bytes': [_i, C.POINTER(ConvDesc)],
+    's2e_conv2d_wgrad_rects': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, _vp, _vp, C.c_size_t, _vp],
+    's2e_spade_uniform_sums': [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    's2e_spade_uniform_grads': [_vp, _i, _vp],
     's2e_conv2d_wgrad_workspace_bytes': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_in_stats_workspace_bytes': [_i, _i, _i, _i],

@@ -50,9 +50,9 @@ struct DuoParams {
     int tiles_x, tiles_y, tiles_n;
     int rects;                        // rectangles of a dense launch (N * tiles_y * tiles_x)
     unsigned x_bytes, w_bytes;        // (< 2^31: the plan checks)
+    const int* rect_list; const int* rect_count;      // NULL, or the rectangles to compute (rect_count on the device)
     // FUSE
     const void* mx; const float* mstats; const float* mstyle; int msld; void* mgamma; int mC, mlrelu, mup;
-    const int* rect_list; const int* rect_count;
     // InstanceNorm partial sums of the OUTPUT (plain launches; NULL = none): per wave and tile, {sum y, sum y^2} of its 64 channels
     // over its rows -> spart[((n * sP + slot) * Cout + c) * 2], slot = rectangle-in-sample * waves-rows-per-tile + wave row;
     // s2e_in_stats_from_partials adds the sP slots of a (sample, channel) in a fixed order (normalization.py:94 of the reference)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
     // ---- work items: (rectangle, Cout tile); persistent grid, XCD-contiguous ranges
     struct Item { int tn, n, y0, x0; };
     int n_rects = p.rects;
-    if constexpr (FUSE) { if (p.rect_count) n_rects = *p.rect_count; }
+    if (p.rect_count) n_rects = *p.rect_count;              // a rectangle list (label-sparse launches): the count lives on the device
     const int n_items = n_rects * p.tiles_n;
     const int G = gridDim.x;
     int item_id = xcd_remap(blockIdx.x, G);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
         Item q;
         q.tn = id % p.tiles_n;
         int r = id / p.tiles_n;
-        if constexpr (FUSE) { if (p.rect_list) r = fetched >= 0 ? fetched : p.rect_list[r]; }
+        if (p.rect_list) r = fetched >= 0 ? fetched : p.rect_list[r];
         q.x0 = (r % p.tiles_x) * TW; r /= p.tiles_x;
         q.y0 = (r % p.tiles_y) * TH;
         q.n = r / p.tiles_y;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
     };
 
     auto fetch_rect = [&](int id) __attribute__((always_inline)) -> int {
-        if constexpr (FUSE) { if (p.rect_list && id < n_items) return p.rect_list[id / p.tiles_n]; }
+        if (p.rect_list && id < n_items) return p.rect_list[id / p.tiles_n];
         return -1;
     };
 
@@ -855,9 +855,11 @@ int s2e_conv_duo_stats_slots(const s2e_conv_desc* d, const s2e_patch_plan* plan)
 }
 
 int s2e_conv_duo_launch(const s2e_patch_plan* plan, const void* x, const void* w, const float* bias, const void* res,
-                        const void* aux, void* y, const s2e_conv_desc* d, int kpad, float* stats_part, hipStream_t st) {
+                        const void* aux, void* y, const s2e_conv_desc* d, int kpad, float* stats_part, const int* rect_list,
+                        const int* rect_count, hipStream_t st) {
     DuoParams p{};
     p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
+    p.rect_list = rect_list; p.rect_count = rect_count;
     p.spart = stats_part; p.sP = stats_part ? s2e_conv_duo_stats_slots(d, plan) : 0;
     duo_fill(&p, d, plan, kpad);
     p.tiles_n = d->Cout <= 64 ? 1 : ceil_div(d->Cout, 128);

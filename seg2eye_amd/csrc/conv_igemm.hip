@@ -654,7 +654,24 @@ extern "C" int s2e_conv2d_stats(int dtype, const void* x, const void* w, const f
     s2e_patch_plan pplan;
     if (!s2e_conv2d_stats_slots(dtype, d) || !s2e_conv_duo_plan(dtype, d, &pplan))
         S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_stats: this shape's kernel writes no statistics (s2e_conv2d_stats_slots == 0)");
-    return s2e_conv_duo_launch(&pplan, x, w, bias, res, nullptr, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), part, (hipStream_t)stream);
+    return s2e_conv_duo_launch(&pplan, x, w, bias, res, nullptr, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), part, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// s2e_conv2d over a device-side list of 16 x 16 rectangles (label-sparse backward of the SPADE branch): the duo kernel's shapes only.
+extern "C" int s2e_conv2d_rects_supported(int dtype, const s2e_conv_desc* d) {
+    s2e_patch_plan pplan;
+    return d && s2e_small_conv_kind(dtype, d) == SMALL_NONE && s2e_conv_duo_plan(dtype, d, &pplan) ? 1 : 0;
+}
+
+extern "C" int s2e_conv2d_rects(int dtype, const void* x, const void* w, const float* bias, const void* res, const void* aux, void* y,
+                                const s2e_conv_desc* d, const int* rect_list, const int* rect_count, void* stream) {
+    if (!x || !w || !y || !d || !rect_list || !rect_count) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_rects: null pointer");
+    if (d->aux_mode != S2E_AUX_NONE && !aux) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_rects: aux_mode without aux");
+    s2e_patch_plan pplan;
+    if ((res && d->aux_mode != S2E_AUX_NONE) || !s2e_conv2d_rects_supported(dtype, d) || !s2e_conv_duo_plan(dtype, d, &pplan))
+        S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_rects: this shape's kernel takes no rectangle list (s2e_conv2d_rects_supported)");
+    return s2e_conv_duo_launch(&pplan, x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), nullptr, rect_list, rect_count,
+                               (hipStream_t)stream);
 }
 
 extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* bias, const void* res,
@@ -679,7 +696,7 @@ extern "C" int s2e_conv2d(int dtype, const void* x, const void* w, const float* 
     }
     s2e_patch_plan pplan;
     if (!(res && d->aux_mode != S2E_AUX_NONE) && s2e_conv_duo_plan(dtype, d, &pplan))       // the big bf16 3x3 layers with >= 128 output channels: two staggered workgroups per CU (conv_duo.hip)
-        return s2e_conv_duo_launch(&pplan, x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), nullptr, (hipStream_t)stream);
+        return s2e_conv_duo_launch(&pplan, x, w, bias, res, aux, y, d, s2e_conv_k_pad(dtype, d->KH * d->KW * d->Cin), nullptr, nullptr, nullptr, (hipStream_t)stream);
     if (s2e_conv_patch_plan(dtype, d, &pplan)) {      // big 3x3 / 4x4 stride-1 layers: patch-resident kernel
         const int patch_splits = pplan.splits;
         const size_t need = s2e_conv_patch_workspace_bytes(dtype, d);

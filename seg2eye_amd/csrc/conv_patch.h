@@ -20,7 +20,8 @@ double s2e_patch_rectangle(const s2e_conv_desc* d, int ks, int* tw_out, int* th_
 // workgroup, 32-channel K-steps, wave-private epilogue; bf16 3x3.
 int s2e_conv_duo_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan);
 int s2e_conv_duo_launch(const s2e_patch_plan* plan, const void* x, const void* w, const float* bias, const void* res,
-                        const void* aux, void* y, const s2e_conv_desc* d, int kpad, float* stats_part, hipStream_t st);
+                        const void* aux, void* y, const s2e_conv_desc* d, int kpad, float* stats_part, const int* rect_list,
+                        const int* rect_count, hipStream_t st);
 int s2e_conv_duo_stats_slots(const s2e_conv_desc* d, const s2e_patch_plan* plan);
 int s2e_spade_conv_modulate_duo(int dtype, const void* actv, const void* w_packed, const float* bias, const void* x,
                                 const float* stats, const float* style, int style_ld, void* out, void* gamma_out,

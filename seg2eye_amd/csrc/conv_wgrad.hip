@@ -537,6 +537,22 @@ extern "C" int s2e_conv2d_wgrad_kernel_kind(int dtype, const s2e_conv_desc* d) {
     return (s2e_wgrad_patch_plan(dtype, d) || s2e_wgrad_c8_plan(dtype, d)) ? S2E_KERNEL_PATCH : S2E_KERNEL_GENERIC;
 }
 
+// s2e_conv2d_wgrad over the pixels of a device-side list of 16 x 16 rectangles only (label-sparse backward of the SPADE branch): the
+// patch-resident kernel with 8 x 16 slabs.  workspace: s2e_conv2d_wgrad_rects_workspace_bytes (0 = not this shape).
+extern "C" size_t s2e_conv2d_wgrad_rects_workspace_bytes(int dtype, const s2e_conv_desc* d) {
+    if (!d || d->transposed || s2e_small_wgrad_kind(dtype, d) || !s2e_wgrad_patch_plan(dtype, d) || (d->Hi & 15) || (d->Wi & 15)) return 0;
+    const size_t b = s2e_wgrad_patch_workspace_bytes(16, d);
+    return b ? b : 16;                                    // (non-zero = supported; few-split shapes need no tiles)
+}
+
+extern "C" int s2e_conv2d_wgrad_rects(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
+                                      const int* rect_list, const int* rect_count, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !gy || !dw || !d || !rect_list || !rect_count) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad_rects: null pointer");
+    if (!s2e_conv2d_wgrad_rects_workspace_bytes(dtype, d))
+        S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad_rects: this shape's kernel takes no rectangle list");
+    return s2e_wgrad_patch_launch(16, x, gy, dw, dbias, d, workspace, workspace_bytes, rect_list, rect_count, (hipStream_t)stream);
+}
+
 extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
                                 void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !gy || !dw || !d) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad: null pointer");
@@ -554,7 +570,7 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
         return S2E_OK;
     }
     if (const int slab_w = s2e_wgrad_patch_plan(dtype, d))          // big 3x3 stride-1 layers: patch-resident kernel
-        return s2e_wgrad_patch_launch(slab_w, x, gy, dw, dbias, d, workspace, workspace_bytes, (hipStream_t)stream);
+        return s2e_wgrad_patch_launch(slab_w, x, gy, dw, dbias, d, workspace, workspace_bytes, nullptr, nullptr, (hipStream_t)stream);
     if (const int slab_w = s2e_wgrad_c8_plan(dtype, d))             // 8-channel (label-map) input: B operand built from a 16-B/pixel patch
         if (workspace && workspace_bytes >= s2e_wgrad_c8_workspace_bytes(slab_w, d))
             return s2e_wgrad_c8_launch(slab_w, x, gy, dw, dbias, d, workspace, (hipStream_t)stream);

@@ -36,6 +36,8 @@ struct WpParams {
     int N, H, W, Cin, Cout, Ktot;
     int sx, sy, nslabs;           // slabs per image in x and y; N * sy * sx
     int per_split, tiles_co, tiles_ci;
+    // label-sparse launches (TWS = 4 only): the slabs are the two 8 x 16 halves of the 16 x 16 rectangles rect_list[0 .. *rect_count)
+    const int* rect_list; const int* rect_count; int splits;
 };
 
 // One MFMA operand = rows r and r+4 of a 4x16 transpose block (lane roles: conv_wgrad.hip).  The reads are inline asm with
@@ -82,8 +84,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
     const int tci = bid % p.tiles_ci; bid /= p.tiles_ci;
     const int tco = bid % p.tiles_co;
     const int split = bid / p.tiles_co;
-    const int s0 = split * p.per_split, s1 = min(p.nslabs, s0 + p.per_split);
-    if (s0 >= s1) return;
+    int nslabs = p.nslabs, per_split = p.per_split;
+    if (p.rect_count) {                               // the count lives on the device (hipGraph replays follow changing label maps)
+        nslabs = 2 * *p.rect_count;
+        per_split = (nslabs + p.splits - 1) / p.splits;
+    }
+    const int s0 = split * per_split, s1 = min(nslabs, s0 + per_split);
+    // (a workgroup without slabs -- possible with a list -- still writes its zero partial tile: the reduction reads every slot)
+    if (s0 >= s1 && !p.rect_count) return;
     constexpr int TW = 1 << TWS, TH = 128 >> TWS, PW = TW + 2, PH = TH + 2;
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ gg = (const T*)p.gy;
@@ -114,6 +122,15 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
         q.x0 = (s % p.sx) << TWS; s /= p.sx;
         q.y0 = (s % p.sy) * TH;
         q.n = s / p.sy;
+        return q;
+    };
+    // with a list: slab s = half (s & 1) of rectangle r = rect_list[s >> 1] of the (H / 16) x (W / 16) rectangle grid
+    auto decode_rect = [&](int r, int half) __attribute__((always_inline)) -> Slab {
+        Slab q;
+        const int tx = p.W >> 4, ty = p.H >> 4;
+        q.x0 = (r % tx) << 4; r /= tx;
+        q.y0 = ((r % ty) << 4) + 8 * half;
+        q.n = r / ty;
         return q;
     };
     auto dma_piece = [&](auto I, const Slab& q, int buf) __attribute__((always_inline)) {
@@ -163,15 +180,24 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams
     asm volatile("" : "+v"(ones));                  // kept in registers (else rebuilt with three moves in front of every use)
     const bool want_bias = p.dbias != nullptr;
 
-    Slab cur = decode(s0);
-    static_for<0, NPI>([&](auto I) { dma_piece(I, cur, 0); });
+    const int* __restrict__ rl = p.rect_list;
+    Slab cur = {0, 0, 0};
+    int r_ahead = 0;                                  // list launches: the rectangle of slab s + 2, requested a slab ahead of its use
+    if (s0 < s1) {
+        cur = rl ? decode_rect(rl[s0 >> 1], s0 & 1) : decode(s0);
+        if (rl && s0 + 1 < s1) r_ahead = rl[(s0 + 1) >> 1];
+        static_for<0, NPI>([&](auto I) { dma_piece(I, cur, 0); });
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int s = s0; s < s1; ++s) {
         const int buf = (s - s0) & 1;
         const bool has_next = s + 1 < s1;
         Slab nxt = cur;
-        if (has_next) nxt = decode(s + 1);
+        if (has_next) {
+            if (rl) { nxt = decode_rect(r_ahead, (s + 1) & 1); if (s + 2 < s1) r_ahead = rl[(s + 2) >> 1]; }
+            else nxt = decode(s + 1);
+        }
         const bool bias_slab = want_bias && (s % p.tiles_ci) == tci;
         const uint32_t a_stage = a_base + buf * STAGE;
         // 72 MFMA steps per slab (u = 9 g + t).  The x fragment of step u + FD and, at group boundaries, the gy fragment of
@@ -582,10 +608,13 @@ size_t s2e_wgrad_patch_workspace_bytes(int slab_w, const s2e_conv_desc* d) {
 }
 
 int s2e_wgrad_patch_launch(int slab_w, const void* x, const void* gy, float* dw, float* dbias, const s2e_conv_desc* d,
-                           void* workspace, size_t workspace_bytes, hipStream_t st) {
+                           void* workspace, size_t workspace_bytes, const int* rect_list, const int* rect_count, hipStream_t st) {
     WpParams p{}; int splits;
     wp_plan(slab_w, d, p, splits);
     p.x = x; p.gy = gy; p.dw = dw; p.dbias = dbias;
+    p.rect_list = rect_list; p.rect_count = rect_count; p.splits = splits;
+    if (rect_list && (slab_w != 16 || (d->Hi & 15) || (d->Wi & 15)))
+        S2E_FAIL(S2E_ERR_UNSUPPORTED, "conv_wgrad_patch: a rectangle list needs 16-wide slabs on a map made of 16 x 16 rectangles");
     const size_t need = s2e_wgrad_patch_workspace_bytes(slab_w, d);
     const int nwg = p.tiles_co * p.tiles_ci * splits;
     const bool have = need && workspace && workspace_bytes >= need;

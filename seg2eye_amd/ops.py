@@ -238,6 +238,7 @@ class _ZeroScope:
             else:
                 self.pool.sink.jobs = []
                 self.pool.sink.c8 = []
+                self.pool.sink.uni = []
         finally:
             self.pool._end()
         return False
@@ -257,6 +258,7 @@ class GradSink:
         self.c8 = []               # deferred 8-channel weight gradients (mlp_shared): (onehot, d actv, dw, db, ncls)
         self.inplace = []          # deferred in-place spectral-norm chain rules (channels-last masters): push_inplace
         self.inplace_done = set()  # gradient slices whose chain rule has already RUN in the open scope (see inplace_allowed)
+        self.uni = []              # deferred label-sparse SPADE backward jobs (uniform rectangles' closed-form gradients): push_uniform
         self.tables = {}
         self.keepalive = None
         self.keep_c8 = None
@@ -358,7 +360,31 @@ class GradSink:
         if rest:
             self._flush_c8()
 
+    def _flush_uniform(self):
+        """All queued SPADE layers' uniform-rectangle gradients (s2e_spade_uniform_grads): two launches per 16 layers."""
+        jobs, self.uni = self.uni, []
+        for i in range(0, len(jobs), 16):
+            chunk = jobs[i:i + 16]
+            arr = (L.SpadeUniJob * len(chunk))()
+            for a, j in zip(arr, chunk):
+                R, A, w_gb, w_sh, b_sh, dw_sh, db_sh, dw_gb, db_gb, c2, nh, ncls, act_bf16 = j
+                a.R, a.A, a.w_gb = R.data_ptr(), A.data_ptr(), w_gb.data_ptr()
+                a.w_sc, a.w_sk = w_gb.stride(0), w_gb.stride(1)
+                a.w_st = w_gb.stride(3)                          # tap t = 3 ky + kx: stride(2) == 3 * stride(3) in both layouts
+                a.w_sh, a.b_sh = w_sh.data_ptr(), b_sh.data_ptr()
+                a.dw_sh = dw_sh.data_ptr() if dw_sh is not None else None
+                a.db_sh = db_sh.data_ptr() if db_sh is not None else None
+                a.dw_gb = dw_gb.data_ptr() if dw_gb is not None else None
+                a.db_gb = db_gb.data_ptr() if db_gb is not None else None
+                a.C2, a.nh, a.ncls, a.act_bf16 = c2, nh, ncls, act_bf16
+            LaunchProfiler.run('spade_uniform_bwd', 0.0, lambda: L.check(
+                L.lib().s2e_spade_uniform_grads(C.byref(arr), len(chunk), _stream()), 's2e_spade_uniform_grads'),
+                nbytes=float(sum(j[2].numel() * 4 for j in chunk)))
+        self.keep_uni = jobs                                 # the tensors stay referenced until the next flush
+
     def flush(self):
+        if self.uni:
+            self._flush_uniform()
         if self.c8:
             self._flush_c8()
         if self.inplace:
@@ -1140,6 +1166,76 @@ def _gb_grad_targets(ctx, fused, w_sh, b_sh, w_g, b_g, w_b, b_b, nh):
     ctx.sh_dst = (_grad_dst(w_sh), _grad_dst(b_sh))
 
 
+_SPARSE_BWD_OFF = os.environ.get('S2E_SPADE_SPARSE_BWD', '1') == '0' or os.environ.get('S2E_DETERMINISTIC', '0') == '1'
+_byref = C.byref          # (functions below use C for a channel count)
+
+
+def _sparse_bwd_lists(ctx, g, h, w, cch, nh, ncls):
+    """(cls, work_list, ui_list, counts) for the label-sparse backward of this SPADE layer, or None: the forward ran label-sparse
+    on 16 x 16 rectangles (ctx.rects), a trainer step is open (zeroed scratch, deferred flush), mlp_shared's gradients go straight
+    to the arena, and the data-gradient's kernel takes a rectangle list.  S2E_SPADE_SPARSE_BWD=0 / S2E_DETERMINISTIC=1 (the sums
+    use float atomics): off."""
+    rects = getattr(ctx, 'rects', None)
+    pool = ZeroPool.active()
+    if _SPARSE_BWD_OFF or rects is None or pool is None or g.dtype != torch.bfloat16 or ncls > 4 or nh > 128:
+        return None
+    cls, _, _, _, tw, th = rects
+    wdst, bdst = ctx.sh_dst
+    if tw != 16 or th != 16 or h < 48 or w < 48 or 2 * cch not in (128, 256, 512, 1024) or wdst is None or bdst is None or not wdst.is_contiguous():
+        return None
+    n = g.shape[0]
+    d, _ = _conv_plan(False, _dt(g), n, h, w, 2 * cch, h, w, nh, 3, 3, 1, 1, 1, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
+    key = ('rects_supported', n, h, w, cch, nh)
+    ok = _CONV_STATS_SLOTS.get(key)
+    if ok is None:
+        ok = _CONV_STATS_SLOTS[key] = bool(L.lib().s2e_conv2d_rects_supported(_dt(g), _byref(d)))
+    if not ok:
+        return None
+    ck = ('rects_bwd', cls.data_ptr(), h, w)
+    ent = pool.step_cache.get(ck)
+    if ent is None:
+        lists = torch.empty(2, cls.numel(), dtype=torch.int32, device=g.device)
+        counts = torch.empty(2, dtype=torch.int32, device=g.device)
+        L.check(L.lib().s2e_label_rect_lists_bwd(_p(cls), n, h // 16, w // 16, _p(lists[0]), _p(lists[1]), _p(counts), _stream()),
+                's2e_label_rect_lists_bwd')
+        ent = pool.step_cache[ck] = (cls, lists[0], lists[1], counts)
+    return ent
+
+
+def _sparse_wgrad(g, actv, gb_dst, sp):
+    """The [gamma | beta] conv's weight (and bias) gradient over the backward's work rectangles only (s2e_conv2d_wgrad_rects),
+    accumulated straight into the channels-last arena slice; the uniform-interior rectangles' part -- rank one per class -- is
+    added by s2e_spade_uniform_grads at the flush.  False: this shape's kernel takes no list (the caller runs the dense one)."""
+    n, h, w, nh = actv.shape
+    c2 = g.shape[-1]
+    d, _ = _conv_plan(True, _dt(g), n, h, w, nh, h, w, c2, 3, 3, 1, 1, 0, ACT_NONE, ACT_NONE, AUX_NONE)
+    key = ('wgrad_rects_ws', n, h, w, nh, c2)
+    wsb = _CONV_STATS_SLOTS.get(key)
+    if wsb is None:
+        wsb = _CONV_STATS_SLOTS[key] = int(L.lib().s2e_conv2d_wgrad_rects_workspace_bytes(_dt(g), _byref(d)))
+    dw, db = gb_dst
+    if not wsb or db is None or w_strides_differ(dw):
+        return False
+    cls, work_list, ui_list, counts = sp
+    ws = torch.empty(max(wsb // 4, 4), dtype=torch.float32, device=g.device)
+    flops = 2.0 * n * h * w * nh * c2 * 9
+    frac = 1.0
+    if LaunchProfiler.active():
+        frac = float(int(counts[0])) / max(cls.numel(), 1)
+    LaunchProfiler.run('conv_wgrad_patch', flops, lambda: L.check(
+        L.lib().s2e_conv2d_wgrad_rects(_dt(g), _p(actv), _p(g), _p(_cl_rows(dw)), _p(db), _byref(d), _p(work_list), _p(counts),
+                                       _p(ws), wsb, _stream()), 's2e_conv2d_wgrad_rects'),
+        tag=lambda: 'W n%d %dx%d c%d->%d k3 s1 sparse' % (n, h, w, nh, c2),
+        nbytes=lambda: float((actv.numel() + g.numel()) * frac * g.element_size()), executed=flops * frac)
+    return True
+
+
+def w_strides_differ(dw):
+    """The rank-1 update walks dW with the weight's strides: both must be the dense channels-last (co, ky, kx, ci) layout."""
+    co, ci, kh, kw = dw.shape
+    return tuple(dw.stride()) != (kh * kw * ci, 1, kw * ci, ci)
+
+
 def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
     """Backward of gb = conv3x3(ReLU(conv3x3(one_hot(label)))) given g = d/d[gamma | beta] (N,h,w,2C):
     -> (gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b), None where the gradient went straight into the arena.
@@ -1149,7 +1245,11 @@ def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
     c2, nh = w_gb.shape[0], w_gb.shape[1]
     ncls = w_sh.shape[1]
     gw_g = gb_g = gw_b = gb_b = gw_sh = gb_sh = None
-    if ctx.gb_dst is not None and _cl_dense(ctx.gb_dst[0]):       # channels-last arena: straight into [dW_gamma; dW_beta]
+    sp = _sparse_bwd_lists(ctx, g, h, w, C, nh, ncls)
+    uni_gb = None                                            # (dW, db) of [gamma | beta] that take the uniform rectangles' rank-1 part
+    if sp is not None and ctx.gb_dst is not None and _cl_dense(ctx.gb_dst[0]) and _sparse_wgrad(g, actv, ctx.gb_dst, sp):
+        uni_gb = ctx.gb_dst
+    elif ctx.gb_dst is not None and _cl_dense(ctx.gb_dst[0]):     # channels-last arena: straight into [dW_gamma; dW_beta]
         conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1], dw_out=_cl_rows(ctx.gb_dst[0]))
     elif ctx.gb_dst is not None:
         dwp, _ = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1])
@@ -1159,7 +1259,34 @@ def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
         gw_gb = _unpack_dw(dwp, c2, nh, 3, 3, nh)
         gw_g, gw_b, gb_g, gb_b = gw_gb[:C], gw_gb[C:], gb_gb[:C], gb_gb[C:]
     wpt = packed_weight(w_gb, g.dtype, nh, True, None, ctx.plan, ctx.plan_gen, stable=ctx.fused)
-    dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
+    if sp is not None:
+        # label-sparse backward (csrc/spade_sparse_bwd.hip): the data gradient -- only ever used for mlp_shared's gradients -- on the
+        # rectangles that cross a label boundary (or touch the image border); the uniform-interior ones contribute through nine
+        # shifted sums of dgb per class, folded into mlp_shared's gradients when the step's sink flushes
+        cls, work_list, ui_list, counts = sp
+        n = g.shape[0]
+        dactv = ZeroPool.take(n * h * w * nh, g.dtype, g.device).view(n, h, w, nh)       # (zero where no conv runs)
+        d, _ = _conv_plan(False, _dt(g), n, h, w, c2, h, w, nh, 3, 3, 1, 1, 1, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
+        flops = 2.0 * n * h * w * c2 * nh * 9
+        frac = 1.0
+        if LaunchProfiler.active():
+            frac = float(int(counts[0])) / max(cls.numel(), 1)
+        LaunchProfiler.run('conv_patch', flops, lambda: L.check(
+            L.lib().s2e_conv2d_rects(_dt(g), _p(g), _p(wpt), None, None, _p(actv), _p(dactv), _byref(d), _p(work_list), _p(counts), _stream()),
+            's2e_conv2d_rects'), tag=lambda: 'D n%d %dx%d c%d->%d k3 s1 sparse' % (n, h, w, nh, c2),
+            nbytes=lambda: float((g.numel() + 2 * dactv.numel()) * frac * g.element_size() + wpt.numel() * g.element_size()), executed=flops * frac)
+        R = ZeroPool.take(L.UNI_REPLICAS * ncls * 9 * c2, torch.float32, g.device)
+        A = ZeroPool.take(ncls * nh, torch.float32, g.device)
+        LaunchProfiler.run('spade_uniform_bwd', 0.0, lambda: L.check(
+            L.lib().s2e_spade_uniform_sums(_dt(g), _p(g), n, h, w, c2, ncls, _p(cls), _p(ui_list), _p(counts), _p(R), _stream()),
+            's2e_spade_uniform_sums'), nbytes=float(g.numel() * g.element_size() * (1.0 - frac) * 1.27))
+        wdst, bdst = ctx.sh_dst
+        assert uni_gb is None or tuple(w_gb.stride()) == tuple(uni_gb[0].stride()), 'weight and gradient arenas are laid out alike'
+        ZeroPool.active().sink.uni.append((R, A, w_gb.detach(), w_sh.detach(), ctx.b_sh_f, wdst, bdst,
+                                           uni_gb[0] if uni_gb is not None else None, uni_gb[1] if uni_gb is not None else None, c2, nh, ncls,
+                                           int(g.dtype == torch.bfloat16)))
+    else:
+        dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
     # (a streaming class-bucket kernel for this gradient was tried twice -- LDS float atomics, then per-wave
     # queues of boundary pixels -- and lost to the MFMA wgrad against the 8-channel one-hot map: 1.7 vs 0.75 ms
     # per step; see DESIGN.md "tried and dropped")
@@ -1376,6 +1503,8 @@ class SpadeFusedFn(torch.autograd.Function):
         ctx.lrelu, ctx.off, ctx.dbig, ctx.batch, ctx.relay = lrelu, off, dbig, bool(batch), bool(relay)
         if train:
             _gb_grad_targets(ctx, fused, w_sh, b_sh, w_g, b_g, w_b, b_b, nh)
+            ctx.rects = sparse                                   # (the label-sparse backward reuses the forward's classification)
+            ctx.b_sh_f = b_sh.detach().float().contiguous()
             ctx.x_up_w = w if up else 0
             ctx.save_for_backward(xr, label, w_sh, w_gb, actv, gamma, out, style, stats)
         if relay:

@@ -359,6 +359,68 @@ def test_spade_conv_modulate_fused(cfg, sparse, dtype):
     _close(y, y2, dtype, what='fused vs two-launch')
 
 
+@pytest.mark.parametrize('cfg', [(4, 128, 128, 64), (2, 256, 256, 128), (4, 128, 256, 256)])
+def test_spade_label_sparse_backward(cfg):
+    """The label-sparse BACKWARD of the SPADE branch (csrc/spade_sparse_bwd.hip): with parameters in an
+    optimizer arena and a trainer-step scope open, the [gamma | beta] conv's data gradient runs on the rectangles that cross a label
+    boundary (or touch the border) only, and the uniform-interior ones reach mlp_shared's gradients through nine shifted sums of
+    d[gamma | beta] per class.  Every parameter gradient against the fp64 reference of normalization.py:91-105 differentiated, with
+    the sparse backward on and off (the two must also agree with each other), on nested-ellipse label maps."""
+    from seg2eye_amd import ops
+    from seg2eye_amd.optim import FlatAdam
+    from seg2eye_amd.synthetic import ellipse_labels
+    N, H, W, C = cfg
+    dev, dtype = _dev(), torch.bfloat16
+    lab = torch.from_numpy(ellipse_labels(N, H, W, 7)[:, 0])
+    onehot = torch.zeros(N, 4, H, W).scatter_(1, lab.long().unsqueeze(1), 1.0).double()
+    x = _rnd((N, C, H, W), 51, dtype) * 1.3 + 0.2
+    style = _rnd((N, 2 * C), 52, torch.float32, 0.5)
+    gy = _rnd((N, C, H, W), 53, dtype)
+    w_sh = _rnd((128, 4, 3, 3), 54, torch.float32, 0.3)
+    b_sh = _rnd((128,), 55, torch.float32, 0.1)
+    w_gb = _rnd((2 * C, 128, 3, 3), 56, torch.float32, 0.03)
+    b_gb = _rnd((2 * C,), 57, torch.float32, 0.1)
+    refs = [t.double().requires_grad_(True) for t in (w_sh, b_sh, w_gb.to(dtype), b_gb)]
+    xr = x.double()
+    actv = F.relu(F.conv2d(onehot, refs[0], refs[1], padding=1))
+    actv = actv + (actv.detach().to(dtype).double() - actv.detach())          # the kernel stores actv in bf16
+    gbr = F.conv2d(actv, refs[2], refs[3], padding=1)
+    s0, s1 = style.double()[:, :C, None, None], style.double()[:, C:, None, None]
+    yr = F.leaky_relu(0.5 * (F.instance_norm(xr, eps=1e-5) * (1 + gbr[:, :C]) + gbr[:, C:] + xr * (1 + s0) + s1), 0.2)
+    yr.backward(gy.double())
+    got = {}
+    for off in (True, False):
+        ops._SPARSE_BWD_OFF = off
+        try:
+            prm = [torch.nn.Parameter(t.to(dev)) for t in (w_sh, b_sh, w_gb[:C].clone(), b_gb[:C].clone(), w_gb[C:].clone(), b_gb[C:].clone())]
+            fa = FlatAdam([prm[0], prm[1], prm[2], prm[4], prm[3], prm[5]], lr=1e-3)         # gamma / beta weights (and biases) adjacent
+            fa.zero_grad()
+            xg = nhwc(x).to(dev).requires_grad_(True)
+            st = ops.in_stats(xg.detach())
+            pool = ops.ZeroPool(dev)
+            with pool.scope('t'):
+                y = ops.spade_style_fused(xg, lab.to(dev), *prm, style.to(dev), st, True)
+                rc = ops.label_rects(lab.to(dev), H, W, dtype, C, 128, 0)
+                assert rc is not None and rc[4] == 16 and rc[5] == 16
+                y.backward(nhwc(gy).to(dev))
+                queued = len(pool.sink.uni)
+            assert queued == (0 if off else 1), queued                             # the sparse backward really ran (or really did not)
+            if not off:
+                sp = pool.step_cache                                              # (cleared at scope exit: counts were read inside)
+            got[off] = [q.grad.detach().clone() for q in prm]
+        finally:
+            ops._SPARSE_BWD_OFF = False
+    for off in (True, False):
+        g = got[off]
+        tag = 'dense' if off else 'sparse'
+        _close(g[0], refs[0].grad, dtype, what='dw_sh (%s backward)' % tag)
+        _close(g[1], refs[1].grad, dtype, what='db_sh (%s backward)' % tag)
+        _close(torch.cat([g[2], g[4]]), refs[2].grad, dtype, what='dw_gb (%s backward)' % tag)
+        _close(torch.cat([g[3], g[5]]), refs[3].grad, dtype, what='db_gb (%s backward)' % tag)
+    for a, b in zip(got[True], got[False]):
+        assert float((a - b).abs().max()) <= 6e-3 * float(a.abs().max()) + 1e-6, float((a - b).abs().max()) / float(a.abs().max())
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_resampling_and_concat(dtype):
     from seg2eye_amd import ops
