@@ -104,7 +104,8 @@ int s2e_pack_conv_weights(int dtype, const s2e_pack_job* jobs, const int* block_
 size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d);
 /* Which kernel s2e_conv2d / s2e_conv2d_wgrad run for this shape (for profilers and tests; the choice is made inside the
  * library from the shape alone): S2E_KERNEL_GENERIC = implicit GEMM (conv_igemm.hip / conv_wgrad.hip),
- * S2E_KERNEL_SMALL = the 1-channel streaming kernels, S2E_KERNEL_PATCH = the patch-resident 3x3 stride-1 kernels. */
+ * S2E_KERNEL_SMALL = the 1-channel streaming kernels, S2E_KERNEL_PATCH = the patch-resident kernels (3x3 / 4x4 stride 1, and the
+ * 4x4 stride-2 pad-2 layers through the space-to-depth view). */
 enum { S2E_KERNEL_GENERIC = 0, S2E_KERNEL_SMALL = 1, S2E_KERNEL_PATCH = 2 };
 int s2e_conv2d_kernel_kind(int dtype, const s2e_conv_desc* d);
 int s2e_conv2d_wgrad_kernel_kind(int dtype, const s2e_conv_desc* d);

@@ -827,7 +827,9 @@ int s2e_conv_duo_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan) {
     if (d->Ho != d->Hi + grow || d->Wo != d->Wi + grow) return 0;
     if ((long)d->N * d->Hi * d->Wi * d->Cin * 2 >= (1L << 31) || (long)d->N * d->Ho * d->Wo * d->Cout * 2 >= (1L << 31)) return 0;
     if ((long)s2e_conv_cout_pad(d->Cout) * s2e_conv_k_pad(dtype, 9 * d->Cin) * 2 >= (1L << 31)) return 0;
-    if (d->Cout % 64 != 0) return 0;
+    // whole tiles only: the loop runs 64 input channels (two 32-channel K-steps x 9 taps) per trip and a tile's 128 (or 64) weight
+    // rows are all live -- the network has no other widths (96 -> 192 went wrong here: tools/bench_tail.py's odd layer)
+    if (d->Cin % 64 != 0 || (d->Cout != 64 && d->Cout % 128 != 0)) return 0;
     plan->splits = 1;
     if (s2e_patch_rectangle(d, 3, &plan->tw, &plan->th) < 0.8) return 0;
     if (d->Ho % 16 == 0 && d->Wo % 16 == 0) plan->tw = plan->th = 16;       // the squarest rectangle: the smallest patch, and the 16x16x32 loop's

@@ -1,4 +1,4 @@
-// Patch-resident stride-1 convolution, 3x3 and 4x4 (forward and data-gradient) for gfx950.
+// Patch-resident convolution: 3x3 and 4x4 stride 1, and 4x4 stride 2 through a space-to-depth view (forward and data-gradient) for gfx950.
 //
 // Why a second conv kernel.  The generic implicit GEMM (conv_igemm.hip) re-gathers the im2col panel from L2 for every
 // tap: a 128 x 128 x 64 K-step moves 32 KB through the CU's vector-memory path for 2.1 MFLOP.  That path -- not the
@@ -56,6 +56,8 @@ struct PatchParams {
     // FUSE, label-sparse launches: only the rectangles listed in rect_list[0 .. *rect_count) are computed (the others are
     // label-uniform and take gamma / beta from a per-class table: s2e_spade_modulate_uniform); NULL = every rectangle
     const int* rect_list; const int* rect_count;
+    // S2D (stride-2 4x4 pad-2 layers as a 2x2 stride-1 conv over the space-to-depth VIEW of the full-resolution tensor):
+    int c_shift;                      // log2 of the full-resolution tensor's channel count C (a power of two >= 64)
 };
 
 template <typename T> struct PMfma;
@@ -80,9 +82,20 @@ template <> struct PMfma<float> {           // same k permutation on both operan
 //     out = [lrelu] 0.5 * ((x - mean) * rstd * (1 + gamma) + beta + x * (1 + s0) + s1)         (C channels)
 // (normalization.py:91-105,163-169,184-192 of the reference in one pass); gamma itself is stored only when the backward
 // pass will need it.  gamma and beta stay fp32 from the accumulators to the result.
-template <typename T, int BN, int KS, bool FUSE = false>
+//
+// S2D: a 4x4 stride-2 pad-2 convolution (the PatchGAN discriminators' downsampling layers, discriminator.py:84-96) is a 2x2
+// stride-1 convolution over the space-to-depth view X'[n][Y][X][(py, px, c)] = X[n][2Y + py][2X + px][c] of its input, and that
+// view needs no copy: in NHWC memory the (px, c) half of an X' pixel is 2C contiguous elements of row 2Y + py.  A 64-channel
+// chunk of X' (C a power of two >= 64) therefore lies inside ONE phase (py, px): the patch DMA only adds a per-chunk offset
+// and checks that phase's bounds, the weight K-step of (chunk, 2x2 tap) is the original tap (2 ky' + py, 2 kx' + px) of the
+// ordinary packed matrix.  S2D = 1: forward (patch origin -1, 17 x 17 X' pixels for a 16 x 16 rectangle: every input byte once
+// per chunk instead of once per tap).  S2D = 2: the data gradient -- a 2x2 conv from gy to the space-to-depth view of dx,
+// 4C output "channels" whose tile columns are scattered to their full-resolution pixels by the epilogue; the rows of the
+// transposed packed matrix a tile needs are C-row blocks, one phase per 64-row weight piece.
+template <typename T, int BN, int KS, bool FUSE = false, int S2D = 0>
 __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p) {
     static_assert(!FUSE || (BN == 128 && KS == 3), "fused modulation: 3x3, 64 gamma + 64 beta columns per tile");
+    static_assert(S2D == 0 || (KS == 2 && !FUSE && (S2D == 1 || BN == 128)), "space-to-depth forms: 2x2 taps");
     constexpr int BM = 256, NW = 8, NT = 512;
     constexpr int VEC = Vec<T>::N, BK = 8 * VEC;      // one 128-byte row of K per pixel / weight row
     constexpr int TAPS = KS * KS;
@@ -96,7 +109,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     constexpr int PD = NBS - 1;
     constexpr int P_BYTES = PPX * 128, B_BYTES = BN * 128;
     constexpr int EP_ROWS = WTM;                      // epilogue staging: one wave row (64 pixels) per pass
-    static_assert(NR <= TAPS, "one patch piece per tap must cover the patch");
+    // The next chunk's patch pieces go out during taps 0 .. TAPS-2 of this one: a piece issued in the LAST tap would still be in
+    // flight (the tap's closing wait keeps its own loads outstanding) when the next chunk's first fragments are read.
+    constexpr int PPT = (NR + TAPS - 2) / (TAPS - 1); // pieces per tap: 1 (3x3, 4x4), 3 for the 2x2 forms
     static_assert(EP_ROWS * BN * 4 <= P_BYTES, "epilogue staging must fit one patch buffer");
     static_assert(2 * P_BYTES + NBS * B_BYTES <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char smem[2 * P_BYTES + NBS * B_BYTES];
@@ -151,8 +166,27 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         ppyx[r] = (py << 16) | px;
         pcol[r] = ((lane & 7) ^ ((pp >> 1) & 7)) * VEC;
     });
+    int aval[NR];                                     // S2D = 1: bit (py << 1 | px) = that phase of the X' pixel lies inside the image
+    int chunk0 = 0;                                   // S2D = 1: first chunk of this work item's split
+    const T* wrow2[NBJ];                              // S2D = 2: weight row of each 64-row piece (row c of the transposed matrix)
+    int wq2[NBJ];                                     //          and the phase (py << 1 | px) its output channels belong to
     auto aim = [&](const Tile& q) __attribute__((always_inline)) {
         const int iy0 = q.oy0 + p.org, ix0 = q.ox0 + p.org;
+        if constexpr (S2D == 1) {
+            chunk0 = q.split * p.cps;
+            static_for<0, NR>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                const int py = ppyx[r] >> 16, px = ppyx[r] & 0xffff;
+                const int iy = 2 * (iy0 + py), ix = 2 * (ix0 + px);
+                const bool in = py < PH;
+                const int vy0 = in && (unsigned)iy < (unsigned)p.Hi, vy1 = in && (unsigned)(iy + 1) < (unsigned)p.Hi;
+                const int vx0 = (unsigned)ix < (unsigned)p.Wi, vx1 = (unsigned)(ix + 1) < (unsigned)p.Wi;
+                aval[r] = (vy0 & vx0) | ((vy0 & vx1) << 1) | ((vy1 & vx0) << 2) | ((vy1 & vx1) << 3);
+                aoff[r] = ((long)(q.n * p.Hi + iy) * p.Wi + ix) * p.Cin + pcol[r];
+            });
+            wrow = wgt + (size_t)(q.tn * BN + brow) * p.Kpad + ((lane & 7) ^ ((brow >> 1) & 7)) * VEC;
+            return;
+        }
         const long cbase = (long)q.split * p.cps * BK;
         static_for<0, NR>([&](auto R) {
             constexpr int r = decltype(R)::value;
@@ -161,6 +195,15 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
             const bool ok = py < PH && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             aoff[r] = ok ? ((long)(q.n * p.Hi + iy) * p.Wi + ix) * p.Cin + cbase + pcol[r] : -1L;
         });
+        if constexpr (S2D == 2) {
+            static_for<0, NBJ>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const int row = q.tn * BN + 64 * j + brow;                    // output channel of the X' view: (phase, c)
+                wq2[j] = row >> p.c_shift;
+                wrow2[j] = wgt + (size_t)(row & ((1 << p.c_shift) - 1)) * p.Kpad + q.split * p.cps * BK + ((lane & 7) ^ ((brow >> 1) & 7)) * VEC;
+            });
+            return;
+        }
         // FUSE: tile rows 0..63 = gamma rows 64 tn .. 64 tn + 63 of the packed [gamma | beta] matrix, rows 64..127 = the beta
         // rows of the same channels (mC rows further down): piece j = 1 of dma_w is mC rows away instead of 64
         wrow = wgt + (size_t)(q.tn * (FUSE ? 64 : BN) + brow) * p.Kpad + q.split * p.cps * BK + ((lane & 7) ^ ((brow >> 1) & 7)) * VEC;
@@ -168,13 +211,36 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
     auto dma_patch = [&](auto R, int chunk, int buf) __attribute__((always_inline)) -> int {
         constexpr int r = decltype(R)::value;
         if (r * NW + wave >= NPIECE) return 0;        // wave-uniform
-        const void* src = aoff[r] >= 0 ? (const void*)(xg + aoff[r] + chunk * BK) : (const void*)pz_zero16;
+        const void* src;
+        if constexpr (S2D == 1) {
+            const int k0 = (chunk0 + chunk) * BK, qq = k0 >> p.c_shift, c0 = k0 & (p.Cin - 1);
+            const long off = (long)((qq >> 1) * p.Wi + (qq & 1)) * p.Cin + c0;
+            src = ((aval[r] >> qq) & 1) ? (const void*)(xg + aoff[r] + off) : (const void*)pz_zero16;
+        } else {
+            src = aoff[r] >= 0 ? (const void*)(xg + aoff[r] + chunk * BK) : (const void*)pz_zero16;
+        }
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * P_BYTES + (r * NW + wave) * 1024), 16, 0, 0);
         return 1;
     };
     auto dma_w = [&](int kt, int stage) __attribute__((always_inline)) {     // K-step kt = chunk * TAPS + patch offset
         const int chunk = kt / TAPS, tp = kt - chunk * TAPS;
-        const T* src = wrow + (p.flip ? TAPS - 1 - tp : tp) * p.Cin + chunk * BK;
+        if constexpr (S2D == 2) {                     // patch offset (dy, dx) pairs with the 2x2 tap (1 - dy, 1 - dx) of each piece's phase
+            const int ky = 2 * (1 - (tp >> 1)), kx = 2 * (1 - (tp & 1));
+            static_for<0, NBJ>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const int tap_o = (ky + (wq2[j] >> 1)) * 4 + kx + (wq2[j] & 1);
+                __builtin_amdgcn_global_load_lds((gptr_t)(const void*)(wrow2[j] + (size_t)tap_o * p.Cin + chunk * BK),
+                                                 (lptr_t)(smem + 2 * P_BYTES + stage * B_BYTES + (8 * wave + 64 * j) * 128), 16, 0, 0);
+            });
+            return;
+        }
+        const T* src;
+        if constexpr (S2D == 1) {
+            const int k0 = (chunk0 + chunk) * BK, qq = k0 >> p.c_shift, c0 = k0 & (p.Cin - 1);
+            src = wrow + (size_t)((2 * (tp >> 1) + (qq >> 1)) * 4 + 2 * (tp & 1) + (qq & 1)) * p.Cin + c0;
+        } else {
+            src = wrow + (p.flip ? TAPS - 1 - tp : tp) * p.Cin + chunk * BK;
+        }
         static_for<0, NBJ>([&](auto J) {
             constexpr int j = decltype(J)::value;
             __builtin_amdgcn_global_load_lds((gptr_t)(const void*)(src + (size_t)((FUSE ? p.mC : 64) * j) * p.Kpad),
@@ -190,9 +256,11 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
         if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     };
-    static_assert(NBJ + 1 <= 3, "wait_keep covers up to 3 loads per tap");
+    static_assert(NBJ + PPT <= 5, "wait_keep covers up to 5 loads per tap");
 
     // patch pixel of this lane's fragment row at offset (0,0): 32 lanes = 32 consecutive tx of one tile row
     int pp0[TM];
@@ -308,9 +376,15 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                 // (a 32-bit division is ~40 VALU instructions; the epilogue's index arithmetic, not its stores, was the largest
                 // part of its time in the round-3 ablation: DESIGN 3.1f)
                 const int ty = p.tw_shift >= 0 ? tr >> p.tw_shift : tr / TW;
-                const int oy = q.oy0 + ty, ox = q.ox0 + (tr - ty * TW);
+                int oy = q.oy0 + ty, ox = q.ox0 + (tr - ty * TW);
+                if constexpr (S2D == 2) {             // column co of the X' view = (phase, c): full-resolution pixel (2Y + py, 2X + px)
+                    const int qq = co >> p.c_shift;
+                    oy = 2 * oy + (qq >> 1); ox = 2 * ox + (qq & 1);
+                    o[sw] = (((size_t)(q.n * p.Ho + oy) * p.Wo + ox) << p.c_shift) + (co & ((1 << p.c_shift) - 1));
+                } else {
+                    o[sw] = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
+                }
                 live[sw] = cok && tr < TW * TH && oy < p.Ho && ox < p.Wo;
-                o[sw] = ((size_t)(q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + co;
                 rr[sw] = u32x4_t{0u, 0u, 0u, 0u}; aa[sw] = rr[sw];
                 if (live[sw] && resg && p.splits == 1) rr[sw] = *(const u32x4_t*)(resg + o[sw]);
                 if (live[sw] && p.aux_mode != S2E_AUX_NONE && p.splits == 1) aa[sw] = *(const u32x4_t*)(auxg + o[sw]);
@@ -319,7 +393,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
             stage_acc(ep, cs0);
             lds_barrier();
             if (p.splits > 1) {                       // split-K: raw fp32 partial tile -> this split's slab
-                float* slab = p.partial + (size_t)q.split * p.M * p.Cout;
+                float* slab = p.partial + (size_t)q.split * (S2D == 2 ? ((size_t)p.M << p.c_shift) : (size_t)p.M * p.Cout);   // (S2D = 2: M = N Ho Wo of dx)
 #pragma unroll
                 for (int sw = 0; sw < SWEEPS; ++sw) {
                     if (!live[sw]) continue;
@@ -469,7 +543,10 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const PatchParams p)
                 constexpr int tap = decltype(TAP)::value;
                 constexpr int ntap = (tap + 1) % TAPS;
                 int issued = 0;
-                if constexpr (tap < NR) { if (more) issued += dma_patch(TAP, c + 1, pcur ^ 1); }
+                static_for<0, PPT>([&](auto PJ) {
+                    constexpr int r = tap + decltype(PJ)::value * (TAPS - 1);
+                    if constexpr (tap < TAPS - 1 && r < NR) { if (more) issued += dma_patch(std::integral_constant<int, r>{}, c + 1, pcur ^ 1); }
+                });
                 if (kt + PD < nk) { dma_w(kt + PD, stage == 0 ? NBS - 1 : stage - 1); issued += NBJ; }
                 read_frags(1, 1); frags_ready(0, false); mfmas(0);
                 read_frags(0, 2); frags_ready(1, false); mfmas(1);
@@ -535,6 +612,25 @@ int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan)
     if (min_tiles <= 0) return 0;
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     const int ks = d->KH;
+    plan->s2d = 0;
+    if (dtype == S2E_BF16 && ks == 4 && d->KW == 4 && d->stride == 2 && d->pad == 2 && d->in_act == S2E_ACT_NONE) {
+        // the PatchGAN's 4x4 stride-2 pad-2 layers through the space-to-depth view (S2D, see the kernel)
+        static const bool allow_s2d = [] { const char* e = getenv("S2E_CONV_PATCH_S2D"); return e ? atoi(e) != 0 : true; }();
+        const int C = d->transposed ? d->Cout : d->Cin;          // channels of the full-resolution tensor
+        const int Hf = d->transposed ? d->Ho : d->Hi, Wf = d->transposed ? d->Wo : d->Wi;
+        const int Hh = d->transposed ? d->Hi : d->Ho, Wh = d->transposed ? d->Wi : d->Wo;
+        const int Cg = d->transposed ? d->Cin : d->Cout;          // channels of the half-resolution tensor
+        if (!allow_s2d || C < 64 || (C & (C - 1)) || Hh != Hf / 2 + 1 || Wh != Wf / 2 + 1) return 0;
+        if (d->transposed ? (Cg % 64 != 0) : (Cg % vec != 0 || Cg <= 32)) return 0;
+        s2e_conv_desc grid = *d;                                 // the rectangles tile the half-resolution grid (of y, or of dx's X' view)
+        grid.Ho = d->transposed ? (Hf + 1) / 2 : Hh; grid.Wo = d->transposed ? (Wf + 1) / 2 : Wh;
+        if (s2e_patch_rectangle(&grid, 2, &plan->tw, &plan->th) < 0.8) return 0;
+        const int ncol = d->transposed ? 4 * C : Cg;
+        const long tiles = (long)d->N * ceil_div(grid.Ho, plan->th) * ceil_div(grid.Wo, plan->tw) * ceil_div(ncol, ncol > 64 ? 128 : 64);
+        if (tiles < 128) return 0;                               // (a half-filled chip still beats the generic gather: K = 16 C)
+        plan->s2d = d->transposed ? 2 : 1;
+        return 1;
+    }
     if (d->KW != ks || (ks != 3 && !(ks == 4 && allow_k4)) || d->stride != 1 || d->in_act != S2E_ACT_NONE) return 0;
     if (d->Cin % (8 * vec) != 0 || d->Cout % vec != 0 || d->Cout <= 32) return 0;
     const int grow = d->transposed ? (ks - 1) - 2 * d->pad : 2 * d->pad - (ks - 1);
@@ -571,8 +667,13 @@ static int cu_count() {
 }
 
 template <typename T, int BN>
-static int launch_patch(const PatchParams& p, int ks, hipStream_t st) {
+static int launch_patch(const PatchParams& p, int ks, hipStream_t st, int s2d = 0) {
     const int grid = p.tiles < cu_count() ? p.tiles : cu_count();      // persistent: one 127-154 KB workgroup per CU
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (s2d == 1) conv_patch_kernel<T, BN, 2, false, 1><<<grid, 512, 0, st>>>(p);
+        else if (s2d == 2) { if constexpr (BN == 128) conv_patch_kernel<T, 128, 2, false, 2><<<grid, 512, 0, st>>>(p); }
+    }
+    if (s2d) { S2E_CHECK_LAUNCH("conv_patch_kernel (space-to-depth)"); return S2E_OK; }
     if (ks == 3) conv_patch_kernel<T, BN, 3><<<grid, 512, 0, st>>>(p);
     else conv_patch_kernel<T, BN, 4><<<grid, 512, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_patch_kernel");
@@ -595,6 +696,22 @@ int s2e_conv_patch_launch(int dtype, const s2e_patch_plan* plan, const void* x, 
     p.splits = plan->splits; p.cps = d->Cin / (dtype == S2E_BF16 ? 64 : 32) / plan->splits;
     p.tiles = p.tiles_out * plan->splits;
     p.M = d->N * d->Ho * d->Wo; p.partial = partial;
+    if (plan->s2d) {
+        if (dtype != S2E_BF16 || plan->splits != 1) S2E_FAIL(S2E_ERR_UNSUPPORTED, "conv_patch: the space-to-depth forms are bf16, unsplit");
+        const int C = plan->s2d == 2 ? d->Cout : d->Cin;
+        p.c_shift = __builtin_ctz(C);
+        if (plan->s2d == 1) {                         // forward: 2x2 taps over X' (4C channels), patch origin one X' pixel up / left
+            p.org = -1; p.flip = 0;
+            p.cps = 4 * C / 64;
+            return bn == 128 ? launch_patch<bf16_t, 128>(p, 2, st, 1) : launch_patch<bf16_t, 64>(p, 2, st, 1);
+        }
+        // data gradient: rectangles over the X' grid of dx, 4C columns; the patch (gy) starts at the rectangle's origin
+        p.org = 0; p.flip = 1;
+        p.Cout = 4 * C;
+        p.tiles_x = ceil_div((d->Wo + 1) / 2, p.tw); p.tiles_y = ceil_div((d->Ho + 1) / 2, p.th); p.tiles_n = 4 * C / 128;
+        p.tiles_out = p.N * p.tiles_y * p.tiles_x * p.tiles_n; p.tiles = p.tiles_out;
+        return launch_patch<bf16_t, 128>(p, 2, st, 2);
+    }
     if (dtype == S2E_BF16) return bn == 128 ? launch_patch<bf16_t, 128>(p, d->KH, st) : launch_patch<bf16_t, 64>(p, d->KH, st);
     if (dtype == S2E_F32) return bn == 128 ? launch_patch<float, 128>(p, d->KH, st) : launch_patch<float, 64>(p, d->KH, st);
     S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d: bad dtype %d", dtype);

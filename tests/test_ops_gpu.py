@@ -803,6 +803,45 @@ def test_patch_conv_kernels_match_torch_at_bench_shapes(duo):
     assert 'worst relative error' in out.stdout
 
 
+@pytest.mark.parametrize('cfg', [(16, 129, 129, 64, 128, False), (16, 65, 65, 128, 256, True), (8, 129, 129, 64, 128, True), (16, 130, 134, 256, 64, False),
+                                 (12, 130, 127, 64, 40, True)])
+def test_stride2_patch_conv_matches_torch(cfg):
+    """The PatchGAN's 4x4 stride-2 pad-2 layers (discriminator.py:84-96) through the space-to-depth view (csrc/conv_patch.hip, S2D):
+    forward with bias + LeakyReLU and the data gradient with the LeakyReLU mask, against torch's convolution on the same bf16
+    operands in fp32, on odd and even maps, 64- and 128-column tiles; the plan must route these shapes to the patch kernel."""
+    import torch.nn.functional as F
+    from seg2eye_amd import ops
+    from seg2eye_amd import _lib as L
+    import ctypes as C
+    n, H, W, cin, cout, masked = cfg
+    dev, dt = _dev(), torch.bfloat16
+    torch.manual_seed(11)
+    ho, wo = H // 2 + 1, W // 2 + 1
+    x = torch.randn(n, H, W, cin, device=dev).to(dt)
+    w = torch.randn(cout, cin, 4, 4, device=dev) / (cin * 16) ** 0.5
+    b = torch.randn(cout, device=dev)
+    gy = torch.randn(n, ho, wo, cout, device=dev).to(dt)
+    d = L.ConvDesc(n, H, W, cin, ho, wo, cout, 4, 4, 2, 2, 0, ops.ACT_NONE, ops.ACT_LRELU, ops.AUX_NONE)
+    assert L.lib().s2e_conv2d_kernel_kind(L.S2E_BF16, C.byref(d)) == 2                  # S2E_KERNEL_PATCH
+    dt_ = L.ConvDesc(n, ho, wo, cout, H, W, cin, 4, 4, 2, 2, 1, ops.ACT_NONE, ops.ACT_NONE, ops.AUX_LRELU_GRAD if masked else ops.AUX_NONE)
+    assert L.lib().s2e_conv2d_kernel_kind(L.S2E_BF16, C.byref(dt_)) == (2 if cin >= 64 and cout % 64 == 0 else 0)
+    wb = w.to(dt).float()
+    y = ops.conv2d_raw(x, ops.pack_weight(w, dt, cin, False), b, None, None, (ho, wo, cout), 4, 4, 2, 2, False, ops.ACT_NONE, ops.ACT_LRELU)
+    ref = F.leaky_relu(F.conv2d(x.float().permute(0, 3, 1, 2), wb, b, stride=2, padding=2), 0.2).permute(0, 2, 3, 1)
+    err = float((y.float() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 6e-3, err                                                            # (one bf16 rounding of the result)
+    gx = ops.conv2d_raw(gy, ops.pack_weight(w, dt, cin, True), None, None, x if masked else None, (H, W, cin), 4, 4, 2, 2, True,
+                        ops.ACT_NONE, ops.ACT_NONE, ops.AUX_LRELU_GRAD if masked else ops.AUX_NONE)
+    xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.conv2d(xr, wb, None, stride=2, padding=2).backward(gy.float().permute(0, 3, 1, 2))
+    gref = xr.grad.permute(0, 2, 3, 1)
+    assert bool(torch.isfinite(gx.float()).all()) and bool(torch.isfinite(gref).all())
+    if masked:
+        gref = gref * torch.where(x.float() > 0, 1.0, 0.2)
+    gerr = float((gx.float() - gref).abs().max()) / float(gref.abs().max())
+    assert gerr <= 6e-3, gerr
+
+
 @pytest.mark.parametrize('cfg', [(4, 128, 128, 256, 128, True), (2, 256, 256, 128, 64, False), (8, 64, 64, 512, 256, True), (3, 48, 48, 64, 128, False)])
 def test_conv_epilogue_instance_norm_statistics(cfg):
     """SURVEY 7 step 5 (round 4): the InstanceNorm statistics of a conv's output from the conv kernel's own epilogue
