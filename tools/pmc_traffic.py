@@ -46,6 +46,9 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'spade_modulate_uniform_kernel': ('modulate_fwd', True),   # label-uniform rectangles of a label-sparse SPADE forward
     'label_rect_classify_kernel': ('label_rects', True), 'label_rect_compact_kernel': ('label_rects', False),
     'spade_class_table_kernel': ('class_table', True),
+    # label-sparse SPADE backward (round 4): nine shifted sums per uniform rectangle, then the closed-form gradients at the flush
+    'spade_uniform_sums_kernel': ('spade_uniform_bwd', True), 'spade_uni_gemv_kernel': ('spade_uniform_bwd', True),
+    'spade_uni_apply_kernel': ('spade_uniform_bwd', False), 'rect_lists_bwd_kernel': ('label_rects', False),
     'modulate_bwd_reduce_kernel': ('modulate_bwd', True), 'modulate_bwd_coef_kernel': ('modulate_bwd', False),
     'modulate_bwd_apply_kernel': ('modulate_bwd', False),
     'label_conv3x3_kernel': ('label_conv', True),
