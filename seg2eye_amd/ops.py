@@ -1170,6 +1170,11 @@ _SPARSE_BWD_OFF = os.environ.get('S2E_SPADE_SPARSE_BWD', '1') == '0' or os.envir
 _byref = C.byref          # (functions below use C for a channel count)
 
 
+# smallest map side the label-sparse backward takes: at 64 x 64 only the 2 x 2 inner rectangles of 16 can be uniform-interior at all (none
+# is, on the bench's maps) and the lists + sums are pure overhead; 96 / 192 measured 18.43-18.48 / 18.40-18.44 ms against 18.44-18.60 at 48
+_SPARSE_BWD_MIN = int(os.environ.get('S2E_SPARSE_BWD_MIN', '96'))
+
+
 def _sparse_bwd_lists(ctx, g, h, w, cch, nh, ncls):
     """(cls, work_list, ui_list, counts) for the label-sparse backward of this SPADE layer, or None: the forward ran label-sparse
     on 16 x 16 rectangles (ctx.rects), a trainer step is open (zeroed scratch, deferred flush), mlp_shared's gradients go straight
@@ -1181,7 +1186,7 @@ def _sparse_bwd_lists(ctx, g, h, w, cch, nh, ncls):
         return None
     cls, _, _, _, tw, th = rects
     wdst, bdst = ctx.sh_dst
-    if tw != 16 or th != 16 or h < 48 or w < 48 or 2 * cch not in (128, 256, 512, 1024) or wdst is None or bdst is None or not wdst.is_contiguous():
+    if tw != 16 or th != 16 or h < _SPARSE_BWD_MIN or w < _SPARSE_BWD_MIN or 2 * cch not in (128, 256, 512, 1024) or wdst is None or bdst is None or not wdst.is_contiguous():
         return None
     n = g.shape[0]
     d, _ = _conv_plan(False, _dt(g), n, h, w, 2 * cch, h, w, nh, 3, 3, 1, 1, 1, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
