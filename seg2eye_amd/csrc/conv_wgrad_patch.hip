@@ -602,7 +602,10 @@ size_t s2e_wgrad_patch_workspace_bytes(int slab_w, const s2e_conv_desc* d) {
     const bool on = true;                            // (partial tiles through the workspace: 30 us against 58 us as atomics)
     WpParams p{}; int splits;
     wp_plan(slab_w, d, p, splits);
-    const int min_splits = s2e_deterministic() ? 2 : 4;   // (one split: every dW element has a single writer already)
+    // (one split: every dW element has a single writer already.  Two or three -- the 1024-channel layers at 16^2: 128 tiles x 2 -- were
+    //  combined with atomics until round 4: 75 MB of fp32 atomics at ~1.3 TB/s; through the workspace the family is 2.69 against
+    //  2.76-2.83 ms per step, same box, alternating)
+    const int min_splits = 2;
     if (!on || splits < min_splits) return s2e_deterministic() ? (size_t)p.tiles_co * p.tiles_ci * splits * 128 * sizeof(float) : 0;
     return (size_t)p.tiles_co * p.tiles_ci * splits * (9 * 128 * 64 + (s2e_deterministic() ? 128 : 0)) * sizeof(float);
 }
