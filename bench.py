@@ -211,10 +211,13 @@ def secondary_metrics(args, dev_index, data):
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) as
-    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` in a CHILD process and hand its exit status
-    back.  This process has not touched the GPU (counting devices does not initialise HIP) and never does -- a process that
-    has must not be replaced by, or fork into, another GPU program.  More ranks than GPUs are refused unless
-    S2E_DIST_BACKEND=gloo asks for the dry run in which the ranks share a device (RCCL refuses two ranks on one GPU)."""
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` in a CHILD process (subprocess.run) and hand
+    its exit status back.  The parent only ever SPAWNS a child -- never `os.exec*` from here: `torch.cuda.device_count()` may
+    initialise the HIP runtime in this process (it falls back to hipGetDeviceCount when amdsmi is not importable), and a
+    process that has touched the GPU must not be replaced by another GPU program on this pool.  More ranks than GPUs are
+    refused unless S2E_DIST_BACKEND=gloo asks for the dry run in which the ranks share a device (RCCL refuses two ranks on one
+    GPU).  The rendezvous port is probed by bind-then-close: on a shared box another process can take it before the ranks
+    bind it (the launch then fails with EADDRINUSE and is simply re-run; MASTER_PORT in the environment overrides the probe)."""
     import socket
     import subprocess
     have = torch.cuda.device_count()
@@ -222,9 +225,12 @@ def spawn_ranks(n):
         print('bench.py: --gpus %d but %d GPU(s) visible (S2E_DIST_BACKEND=gloo runs the ranks on shared devices as a dry run)'
               % (n, have), file=sys.stderr)
         return 2
-    with socket.socket() as sk:                         # a free rendezvous port on the loopback interface
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
+    if os.environ.get('MASTER_PORT'):
+        port = int(os.environ['MASTER_PORT'])
+    else:
+        with socket.socket() as sk:                     # a free rendezvous port on the loopback interface
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: what this pool's driver supports (RCCL across processes)
     env.setdefault('OMP_NUM_THREADS', '8')
@@ -291,6 +297,9 @@ def main():
                     help='--gpus > 1: all-reduce each gradient group of the G arena as soon as the backward has finished it (the '
                          'G step replays as one hipGraph segment per group, the collective of group k runs beside segment k+1; '
                          'the default) or all-reduce the whole arena after the backward (one graph, one exposed exchange)')
+    ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='--gpus > 1: payload of the gradient exchange')
+    ap.add_argument('--grad-exchange', default='allreduce', choices=['allreduce', 'direct'],
+                    help="--gpus > 1: the backend's all-reduce, or all-to-all + owner sum + all-gather (distributed.FlatGradSync)")
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
@@ -307,13 +316,16 @@ def main():
 
     opt_kwargs = dict(ngf=args.ngf, ndf=args.ngf, crop_size=args.size, aspect_ratio=1.0, batchSize=args.batch,
                       compute_dtype=args.dtype, gpu_ids=[dev_index], hip_graphs=not args.no_graphs,
-                      no_overlap_allreduce=(args.exchange == 'after_backward'))
+                      no_overlap_allreduce=(args.exchange == 'after_backward'),
+                      grad_dtype=args.grad_dtype, grad_exchange=args.grad_exchange)
     opt = default_opt(**opt_kwargs)
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         trainer = Pix2PixTrainer(opt)
     fill_weights(trainer.pix2pix_model)
     data = make_data(args.batch, args.size, 1234 + rank, dev)          # resident in HBM before timing
+
+    exchange_desc = trainer.sync_G.describe()
 
     def step():
         trainer.run_generator_one_step(dict(data))
@@ -468,6 +480,8 @@ def main():
             out['secondary'] = secondary_metrics(args, dev_index, data)
         if world > 1:
             out['rccl_ranks'] = world
+        if sdist.exchange_active():
+            out['config']['exchange'] = exchange_desc        # payload, algorithm, bucket size, NCCL_ALGO / NCCL_PROTO as set
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(opt_kwargs, args.size, args.batch, extras=args.cpu_baseline_extras)
         print(json.dumps(out), flush=True)

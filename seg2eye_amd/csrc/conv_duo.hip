@@ -351,6 +351,9 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(const DuoParams p) {
         const uint32_t c4 = (uint32_t)((l & 31) >> 2), w4 = (uint32_t)((l & 3) * 4);
         const uint32_t rowb = wslice + (uint32_t)((4 * (l >> 5)) * 256);
         const uint32_t base0 = rowb + c4 * 16 + w4, base1 = rowb + (c4 ^ 1u) * 16 + w4;      // g & 1 = 0 / 1
+        // (a pass index past this instantiation's NPASS is only ever named by the fused epilogue, which the 64-channel instantiation
+        //  compiles but never runs)
+        if constexpr (q < NPASS)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll

@@ -90,11 +90,26 @@ class FlatGradSync:
     the all-reduces of group i right away -- asynchronously: the collective is ordered after the kernels already enqueued on
     the current stream and runs on the backend's own stream while the rest of the backward keeps the compute stream busy --
     and `all_reduce()` starts whatever was not launched yet and waits for everything (buckets launched as they
-    become ready).  Without groups, or on one process, `all_reduce()` is the whole exchange."""
+    become ready).  Without groups, or on one process, `all_reduce()` is the whole exchange.
 
-    def __init__(self, flat_grad, bucket_bytes=64 << 20, group=None, groups=None):
+    payload ('fp32' | 'bf16', --grad_dtype): what travels.  bf16 halves the bytes on the links (G + E: 198 instead of 396 MB per
+        step): a bucket is rounded to bf16 into a staging buffer, summed across the replicas in bf16, and written back to the
+        fp32 arena.  Every replica receives the same bits, so the replicas stay bit-identical (tested); the gradient itself
+        carries bf16's 8 significant bits, like every activation gradient of the bf16 step already does.
+    algorithm ('allreduce' | 'direct', --grad_exchange): 'allreduce' hands each bucket to the backend's all-reduce (RCCL chooses
+        ring / tree and the protocol; NCCL_ALGO / NCCL_PROTO select them explicitly and are recorded in the bench line);
+        'direct' spells the exchange out for the fully connected xGMI mesh of one node (a ring pushes 2 (P-1)/P S
+        over ONE link, point-to-point pieces use all seven): all-to-all of the P bucket shards, each replica adds the P copies
+        of ITS shard in rank order, all-gather of the sums -- one owner per element, so bit-identical replicas here too.
+    S2E_DEBUG_SYNC=1: `launch(i)` only records a copy of the group's slice; `all_reduce()` checks that the slice still holds those
+        bits when the backward has ended -- i.e. that nothing wrote a group after it was declared final -- and then exchanges."""
+
+    def __init__(self, flat_grad, bucket_bytes=64 << 20, group=None, groups=None, payload='fp32', algorithm='allreduce'):
+        if payload not in ('fp32', 'bf16') or algorithm not in ('allreduce', 'direct'):
+            raise ValueError('FlatGradSync: payload %r / algorithm %r' % (payload, algorithm))
         self.flat = flat_grad
         self.group = group
+        self.payload, self.algorithm = payload, algorithm
         self.per = max(1, bucket_bytes // flat_grad.element_size())
         n = flat_grad.numel()
         self.groups = [(int(a), int(b)) for a, b in groups] if groups else [(0, n)]
@@ -103,36 +118,122 @@ class FlatGradSync:
             raise ValueError('FlatGradSync: groups must tile the arena exactly: %s vs %d elements' % (covered, n))
         self.buckets = [(s, min(b, s + self.per)) for a, b in self.groups for s in range(a, b, self.per)]
         self._launched, self._handles = set(), []
+        self._pending = []                                   # second halves of buckets in flight: callables run by all_reduce()
+        self._stage = {}                                     # bucket start -> staging buffers (kept: no allocation per step)
+        self._poisoned = False
+        self._debug = os.environ.get('S2E_DEBUG_SYNC', '0') == '1'
+        self._final = {}                                     # S2E_DEBUG_SYNC: group -> copy of its slice when it was declared final
+
+    # ---- one bucket ---------------------------------------------------------------------------------
+    def _buffers(self, s, e):
+        st = self._stage.get(s)
+        if st is None:
+            world = dist.get_world_size(self.group)
+            dt = torch.bfloat16 if self.payload == 'bf16' else self.flat.dtype
+            n = e - s
+            st = {}
+            if self.algorithm == 'direct':
+                shard = (n + world - 1) // world
+                st['send'] = torch.zeros(shard * world, dtype=dt, device=self.flat.device)       # (zero tail: padding adds nothing)
+                st['recv'] = torch.empty(shard * world, dtype=dt, device=self.flat.device)
+                st['sum'] = torch.empty(shard, dtype=dt, device=self.flat.device)
+                st['shard'] = shard
+            elif self.payload == 'bf16':
+                st['send'] = torch.empty(n, dtype=dt, device=self.flat.device)
+            self._stage[s] = st
+        return st
+
+    def _start_bucket(self, s, e):
+        sl = self.flat[s:e]
+        st = self._buffers(s, e)
+        if self.algorithm == 'allreduce':
+            if self.payload == 'fp32':
+                self._handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                return
+            st['send'].copy_(sl)                             # round to bf16 on the compute stream, behind the kernels that wrote sl
+            self._handles.append(dist.all_reduce(st['send'], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._pending.append(lambda: sl.copy_(st['send']))
+            return
+        # direct: shard r of every replica's bucket goes to replica r ...
+        n, shard = e - s, st['shard']
+        st['send'][:n].copy_(sl)
+        h = dist.all_to_all_single(st['recv'], st['send'], group=self.group, async_op=True)
+
+        def finish():
+            h.wait()                                         # (device-side dependency on RCCL's stream; a host wait under gloo)
+            world = dist.get_world_size(self.group)
+            # ... which adds the P copies in rank order (fp32 accumulation, one rounding for a bf16 payload) ...
+            acc = st['recv'].view(world, shard).to(torch.float32).sum(dim=0) if self.payload == 'bf16' else \
+                st['recv'].view(world, shard).sum(dim=0)
+            st['sum'].copy_(acc)
+            # ... and hands the sums to everybody
+            dist.all_gather_into_tensor(st['send'], st['sum'], group=self.group)
+            sl.copy_(st['send'][:n])
+        self._pending.append(finish)
 
     def _start(self, i):
         a, b = self.groups[i]
+        if self._debug:
+            self._final[i] = self.flat[a:b].clone()
+            self._launched.add(i)
+            return
         for s in range(a, b, self.per):
-            self._handles.append(dist.all_reduce(self.flat[s:min(b, s + self.per)], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._start_bucket(s, min(b, s + self.per))
         self._launched.add(i)
+
+    def _check_poison(self):
+        if self._poisoned:
+            raise RuntimeError('FlatGradSync: the previous step was aborted with collectives in flight (reset() dropped their '
+                               'handles): they may still write this gradient arena and the backend\'s stream holds them in front '
+                               'of every later collective.  Tear the process group down and restart the job.')
 
     def launch(self, i):
         """Group i's gradients are final: start their exchange now (no-op on one process / when already started)."""
         if exchange_active() and i not in self._launched:
+            self._check_poison()
             self._start(i)
 
     def reset(self):
-        """Forget launches whose step did not complete (a backward that raised after `launch(0)`), so that the next step starts
-        its own exchange instead of treating the groups as already launched.  The handles are DROPPED, not waited for: when the
-        failure is local to this rank the peers never issue the matching collective, and a wait here would hold the real
-        exception back until the process group's timeout.  A job whose ranks have diverged is over either way; the
-        caller re-raises."""
-        self._launched, self._handles = set(), []
+        """Forget launches whose step did not complete (a backward that raised after `launch(0)`).  The handles are DROPPED, not
+        waited for: when the failure is local to this rank the peers never issue the matching collective, and a wait here would
+        hold the real exception back until the process group's timeout.  If any collective was in flight the sync is
+        POISONED: the stale collectives still write the arena on the backend's stream and sit in front of every later
+        one, so a caller that survives the exception must not run another step through it -- `launch` / `all_reduce` raise.
+        Nothing in flight (the failure came before the first group completed): the object stays usable."""
+        if self._handles or self._pending:
+            self._poisoned = True
+        self._launched, self._handles, self._pending, self._final = set(), [], [], {}
 
     def all_reduce(self):
         if not exchange_active():
             return 1.0
+        self._check_poison()
+        if self._debug:
+            stale = [i for i, snap in self._final.items() if not torch.equal(self.flat[self.groups[i][0]:self.groups[i][1]], snap)]
+            self._final, self._launched = {}, set()
+            if stale:
+                raise AssertionError('FlatGradSync (S2E_DEBUG_SYNC): gradient group(s) %s were written after they had been '
+                                     'declared final -- an early all-reduce would have exchanged stale values' % stale)
+            self._debug = False
+            try:
+                return self.all_reduce()
+            finally:
+                self._debug = True
         for i in range(len(self.groups)):
             if i not in self._launched:
                 self._start(i)
         for h in self._handles:
             h.wait()
-        self._launched, self._handles = set(), []
+        for fin in self._pending:
+            fin()
+        self._launched, self._handles, self._pending = set(), [], []
         return 1.0 / world_size()
+
+    def describe(self):
+        """What the bench line records about the exchange."""
+        return {'payload': self.payload, 'algorithm': self.algorithm, 'bucket_MB': self.per * self.flat.element_size() / 2 ** 20,
+                'groups': len(self.groups), 'NCCL_ALGO': os.environ.get('NCCL_ALGO', 'backend default'),
+                'NCCL_PROTO': os.environ.get('NCCL_PROTO', 'backend default')}
 
 
 def broadcast_flat(flat, src=0):

@@ -116,26 +116,63 @@ class FlatAdam:
         ops.adam_flat_step(self.flat_p[:k], self.flat_g[:k], self.flat_m[:k], self.flat_v[:k], self.hyper)
 
     def _layout(self):
-        """What the flat moment arrays mean: element i belongs to which parameter, in which memory order."""
-        return {'offsets': list(self.offsets), 'channels_last': [bool(c) for c in self.cl]}
+        """What the flat moment arrays mean: element i belongs to which parameter, in which memory order.  `shapes` is the
+        per-parameter signature in arena order: a state is only ever loaded into an arena whose parameters have the same
+        shapes in the same order (a length check alone accepts a permuted parameter list)."""
+        return {'offsets': list(self.offsets), 'channels_last': [bool(c) for c in self.cl],
+                'shapes': [tuple(int(d) for d in p.shape) for p in self.params]}
 
     def state_dict(self):
         return {'step': self.step_count, 'm': self.flat_m, 'v': self.flat_v, 'lr': self.param_groups[0]['lr'], 'layout': self._layout()}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, trust_param_order=False):
+        """Moments saved by another FlatAdam.  With a `layout` that carries `shapes` the parameter signature must match; the
+        memory order (channels-last flags, alignment gaps) may differ and is converted per parameter by logical index.  A state
+        WITHOUT a signature (saved before round 5) is loaded only into the identical arena; a state without any layout (saved
+        before channels-last masters / with S2E_WEIGHTS_CL=0) only with `trust_param_order=True`: nothing in it says which
+        parameter a moment belongs to, and this build orders the generator's arena differently from the builds that wrote such
+        states (pix2pix_model.create_optimizers), so a positional load would attach moments to the wrong weights silently."""
         lay = sd.get('layout')
-        if (lay is None and any(self.cl)) or (lay is not None and lay != self._layout()):
-            if lay is None and len(sd['m']) == sum((p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN for p in self.params):
-                return self._load_torch_order(sd)            # saved before channels-last masters: convert per parameter
-            raise ValueError('FlatAdam.load_state_dict: the saved moments were laid out for another arena (parameter order / '
-                             'channels-last weights differ); they cannot be loaded element by element (a state saved with '
-                             'S2E_WEIGHTS_CL=0 -- every parameter in torch order, no alignment gaps -- is converted)')
+        mine = self._layout()
+        if lay is not None:
+            lay = {k: ([tuple(x) for x in v] if k == 'shapes' else list(v)) for k, v in lay.items()}
+        if lay is not None and 'shapes' in lay:
+            if lay['shapes'] != mine['shapes']:
+                raise ValueError('FlatAdam.load_state_dict: the saved moments belong to another parameter list (shapes / order '
+                                 'differ from this optimizer\'s): refusing a positional load')
+            if lay['offsets'] != mine['offsets'] or lay['channels_last'] != mine['channels_last']:
+                return self._load_converted(sd, lay['offsets'], lay['channels_last'])
+        elif lay is not None:
+            if lay != {k: v for k, v in mine.items() if k != 'shapes'}:
+                raise ValueError('FlatAdam.load_state_dict: the saved moments were laid out for another arena (parameter order / '
+                                 'channels-last weights differ) and carry no parameter signature')
+        else:
+            if not trust_param_order:
+                raise ValueError('FlatAdam.load_state_dict: the state has no layout / parameter signature (saved before '
+                                 'channels-last masters or with S2E_WEIGHTS_CL=0); pass trust_param_order=True only if the '
+                                 'parameter ORDER of the optimizer that wrote it is known to equal this one\'s')
+            if len(sd['m']) != sum((p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN for p in self.params):
+                raise ValueError('FlatAdam.load_state_dict: layout-less state of another total length')
+            return self._load_torch_order(sd)
         self.step_count = int(sd['step'])
         self.flat_m.copy_(sd['m'])
         self.flat_v.copy_(sd['v'])
+        self._finish_load(sd)
+
+    def _finish_load(self, sd):
+        self.step_count = int(sd['step'])
         self.param_groups[0]['lr'] = float(sd['lr'])
         self.hyper[4:5].fill_(float(self.step_count))
         self.sync_hyper(self._hyper_host[1])
+
+    def _load_converted(self, sd, offsets, cl_flags):
+        """Same parameters (signature checked by the caller), other memory order: copied per parameter through views."""
+        with torch.no_grad():
+            for i, p in enumerate(self.params):
+                for flat, key in ((self.flat_m, 'm'), (self.flat_v, 'v')):
+                    src = _arena_view(sd[key].to(flat.device), offsets[i], p, cl_flags[i])
+                    _arena_view(flat, self.offsets[i], p, self.cl[i]).copy_(src)
+        self._finish_load(sd)
 
     def _load_torch_order(self, sd):
         """A state dict without 'layout': moments saved when every parameter lay in torch's order, back to back (4-element
@@ -148,7 +185,4 @@ class FlatAdam:
                 for flat, key in ((self.flat_m, 'm'), (self.flat_v, 'v')):
                     _arena_view(flat, self.offsets[i], p, self.cl[i]).copy_(sd[key][off:off + n].view(p.shape))
                 off += (n + _ALIGN - 1) // _ALIGN * _ALIGN
-        self.step_count = int(sd['step'])
-        self.param_groups[0]['lr'] = float(sd['lr'])
-        self.hyper[4:5].fill_(float(self.step_count))
-        self.sync_hyper(self._hyper_host[1])
+        self._finish_load(sd)

@@ -30,6 +30,8 @@ _DEFAULTS = dict(
     compute_dtype='bf16',      # 'bf16' | 'fp32': storage + MFMA input type of the HIP path
     hip_graphs=False,          # capture zero_grad+forward+backward of each step into a hipGraph (fixed shapes)
     no_overlap_allreduce=False,  # data parallel: exchange all gradients after the backward instead of group by group during it
+    grad_dtype='fp32',         # data parallel: what travels in the gradient exchange ('fp32' | 'bf16': half the bytes, distributed.FlatGradSync)
+    grad_exchange='allreduce',  # 'allreduce' (the backend's all-reduce) | 'direct' (all-to-all + owner sum + all-gather over the xGMI mesh)
 )
 
 
@@ -102,6 +104,7 @@ _CLI = [  # (name, type or 'flag', default, choices)
     # build-only
     ('compute_dtype', _S, 'bf16', ['bf16', 'fp32']), ('hip_graphs', 'flag', False, None), ('no_hip_graphs', 'flag', False, None),
     ('no_overlap_allreduce', 'flag', False, None),
+    ('grad_dtype', _S, 'fp32', ['fp32', 'bf16']), ('grad_exchange', _S, 'allreduce', ['allreduce', 'direct']),
     ('synthetic_size', _I, 64, None),        # samples per epoch of the synthetic dataset
 ]
 _CLI_TRAIN = [

@@ -47,8 +47,9 @@ class Pix2PixTrainer:
         if opt.isTrain:
             self.optimizer_G, self.optimizer_D = self.pix2pix_model_on_one_gpu.create_optimizers(opt)
             self.old_lr = opt.lr
-            self.sync_G = FlatGradSync(self.optimizer_G.flat_g, groups=self.pix2pix_model.grad_groups_G)
-            self.sync_D = FlatGradSync(self.optimizer_D.flat_g)
+            how = dict(payload=getattr(opt, 'grad_dtype', 'fp32'), algorithm=getattr(opt, 'grad_exchange', 'allreduce'))
+            self.sync_G = FlatGradSync(self.optimizer_G.flat_g, groups=self.pix2pix_model.grad_groups_G, **how)
+            self.sync_D = FlatGradSync(self.optimizer_D.flat_g, **how)
             self._segments = None                            # while the G step is being captured in segments: (graphs, groups, mode)
             self._quiet_hooks = False                        # capture warm-up passes: hooks flush but exchange nothing
             if exchange_active() and not getattr(opt, 'no_overlap_allreduce', False):
@@ -106,7 +107,8 @@ class Pix2PixTrainer:
         SPADE block: spectral norm's power iteration and BatchNorm's running statistics stop there).  Reading ~260 flags costs
         ~15 us; re-setting them every step cost 2 ms of host time per eager step."""
         mods = self.__dict__.get('_all_modules')
-        if mods is None:
+        n = sum(1 for _ in self.pix2pix_model.modules())     # (a module added or replaced later must be seen: ADVICE r4)
+        if mods is None or len(mods) != n or any(a is not b for a, b in zip(mods, self.pix2pix_model.modules())):
             mods = self.__dict__['_all_modules'] = list(self.pix2pix_model.modules())
         if not all(x.training for x in mods):
             self.pix2pix_model.train()
@@ -269,9 +271,15 @@ class Pix2PixTrainer:
             self._segments = (segs, groups, mode)
             try:
                 body(self._static)
-            finally:
+            except BaseException:
                 self._segments = None
-                segs[-1].capture_end()
+                try:
+                    segs[-1].capture_end()                   # (an already invalidated capture raises here: keep the FIRST error)
+                except Exception:                            # noqa: BLE001
+                    pass
+                raise
+            self._segments = None
+            segs[-1].capture_end()
         torch.cuda.current_stream().wait_stream(stream)
         return _StepGraph(segs, groups)
 

@@ -185,6 +185,7 @@ def test_flat_adam_channels_last_arena_layout():
     """Conv weights with Cin % 8 == 0 are stored [Cout][KH][KW][Cin] in the arenas, 256-byte aligned, and exposed as
     (Cout,Cin,KH,KW) views: same values, state_dict unchanged; the moments' layout is tagged and a mismatching load refused."""
     from seg2eye_amd.optim import FlatAdam
+    from seg2eye_amd import optim as optim_mod
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3), torch.nn.Conv2d(16, 24, 3), torch.nn.Conv2d(4, 8, 3), torch.nn.Linear(5, 3))
     before = {k: v.detach().clone() for k, v in net.state_dict().items()}
@@ -209,10 +210,40 @@ def test_flat_adam_channels_last_arena_layout():
     sd = opt.state_dict()
     assert sd['layout']['channels_last'] == opt.cl
     opt.load_state_dict(sd)
-    other = FlatAdam(list(torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3), torch.nn.Conv2d(16, 24, 3), torch.nn.Conv2d(4, 8, 3),
-                                              torch.nn.Linear(5, 3)).parameters()), lr=1e-3, channels_last=False)
-    with pytest.raises(ValueError):
-        other.load_state_dict(sd)
+    #  a state carries its parameter signature: the same parameters in another MEMORY order are converted by logical
+    # index, a permuted parameter list is refused, a state without any signature is refused unless the caller vouches for its order
+    opt.flat_m.copy_(torch.arange(opt.numel, dtype=torch.float32))
+    opt.flat_v.copy_(torch.arange(opt.numel, dtype=torch.float32) * 0.5)
+    opt.step_count = 7
+    sd = opt.state_dict()
+    mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3), torch.nn.Conv2d(16, 24, 3), torch.nn.Conv2d(4, 8, 3), torch.nn.Linear(5, 3))
+    other = FlatAdam(list(mk().parameters()), lr=1e-3, channels_last=False)
+    other.load_state_dict(sd)
+    assert other.step_count == 7
+    def same_moments(a, b):
+        for i, (pa, pb) in enumerate(zip(a.params, b.params)):
+            for fa, fb in ((a.flat_m, b.flat_m), (a.flat_v, b.flat_v)):
+                if not torch.equal(optim_mod._arena_view(fa, a.offsets[i], pa, a.cl[i]), optim_mod._arena_view(fb, b.offsets[i], pb, b.cl[i])):
+                    return False                                                          # (same moment for the same logical weight element)
+        return True
+    assert same_moments(opt, other)
+    back = FlatAdam(list(mk().parameters()), lr=1e-3, channels_last=True)
+    back.load_state_dict(other.state_dict())                                              # torch order -> channels-last
+    assert same_moments(opt, back)
+    prm = list(mk().parameters())
+    permuted = FlatAdam([prm[2], prm[3], prm[0], prm[1]] + prm[4:], lr=1e-3, channels_last=False)
+    with pytest.raises(ValueError, match='another parameter list'):
+        permuted.load_state_dict(other.state_dict())
+    legacy = {k: v for k, v in other.state_dict().items() if k != 'layout'}               # what S2E_WEIGHTS_CL=0 builds before round 5 wrote
+    with pytest.raises(ValueError, match='no layout'):
+        back.load_state_dict(legacy)
+    back.flat_m.zero_()
+    back.load_state_dict(legacy, trust_param_order=True)
+    assert same_moments(opt, back)
+    unsigned = dict(sd, layout={k: v for k, v in sd['layout'].items() if k != 'shapes'})  # round 3/4 states: layout without signature
+    opt.load_state_dict(unsigned)
+    with pytest.raises(ValueError, match='no parameter signature'):
+        other.load_state_dict(unsigned)
 
 
 def test_channels_last_pack_and_inplace_gradient_maps_are_host_only():

@@ -57,17 +57,54 @@ def _worker(rank, world, port, out):
             assert sdist.sync_world_size() == 1
         assert sdist.sync_world_size() == 1
     assert sdist.sync_world_size() == world
-    # a step that failed after its first group was launched must not leave the sync thinking that group is in flight
-    opt.flat_g.copy_(local)
-    gsync.launch(0)
-    in_flight = list(gsync._handles)
-    gsync.reset()                                        # drops the handles WITHOUT waiting (a peer may never issue its half: ADVICE r3)
-    assert not gsync._handles and not gsync._launched
-    for h in in_flight:                                  # (here both ranks did launch: let the collectives finish before reusing the arena)
-        h.wait()
+    # a step that failed BEFORE anything was launched leaves the sync usable ...
+    gsync.reset()
     opt.flat_g.copy_(local)
     assert abs(gsync.all_reduce() - 1.0 / world) < 1e-12 and torch.equal(opt.flat_g, grouped)
-    out[rank] = (p0, local, grouped, opt.flat_g.clone())
+    # ... one that failed with collectives in flight POISONS it: the handles are dropped without waiting (a peer may
+    # never issue its half: ADVICE r3), so the stale collectives may still write the arena -- the next step must not run through it
+    psync = sdist.FlatGradSync(opt.flat_g, bucket_bytes=64, groups=[(cut, n), (0, cut)])
+    opt.flat_g.copy_(local)
+    psync.launch(0)
+    in_flight = list(psync._handles)
+    psync.reset()
+    assert not psync._handles and not psync._launched and psync._poisoned
+    for h in in_flight:                                  # (here both ranks did launch: let the collectives finish before reusing the arena)
+        h.wait()
+    for call in (lambda: psync.launch(1), psync.all_reduce):
+        try:
+            call()
+            raise AssertionError('a poisoned FlatGradSync must refuse to exchange')
+        except RuntimeError as e:
+            assert 'collectives in flight' in str(e)
+    # the bf16 payload and the spelled-out direct exchange: same sums (to the payload's rounding), replicas bit-identical
+    variants = {}
+    for payload, algo in (('bf16', 'allreduce'), ('fp32', 'direct'), ('bf16', 'direct')):
+        vs = sdist.FlatGradSync(opt.flat_g, bucket_bytes=64, groups=[(cut, n), (0, cut)], payload=payload, algorithm=algo)
+        for early in (False, True):                      # everything at the end / group 0 launched early (twice: staging buffers reused)
+            opt.flat_g.copy_(local)
+            if early:
+                vs.launch(0)
+            assert abs(vs.all_reduce() - 1.0 / world) < 1e-12 and not vs._pending and not vs._handles
+            variants[(payload, algo, early)] = opt.flat_g.clone()
+        d = vs.describe()
+        assert d['payload'] == payload and d['algorithm'] == algo and d['groups'] == 2
+    # S2E_DEBUG_SYNC: a group written after it was declared final is caught; an untouched one passes and is exchanged
+    os.environ['S2E_DEBUG_SYNC'] = '1'
+    dsync = sdist.FlatGradSync(opt.flat_g, bucket_bytes=64, groups=[(cut, n), (0, cut)])
+    del os.environ['S2E_DEBUG_SYNC']
+    opt.flat_g.copy_(local)
+    dsync.launch(0)
+    assert abs(dsync.all_reduce() - 1.0 / world) < 1e-12 and torch.equal(opt.flat_g, grouped)
+    opt.flat_g.copy_(local)
+    dsync.launch(0)
+    opt.flat_g[cut] += 1.0                               # "a later segment" writes the group that was reported final
+    try:
+        dsync.all_reduce()
+        raise AssertionError('S2E_DEBUG_SYNC must catch a write after launch')
+    except AssertionError as e:
+        assert 'declared final' in str(e)
+    out[rank] = (p0, local, grouped, grouped.clone(), variants)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -77,11 +114,18 @@ def test_flat_grad_allreduce_world2():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    (p_a, l_a, g_a, s_a), (p_b, l_b, g_b, s_b) = out[0], out[1]
+    (p_a, l_a, g_a, s_a, var_a), (p_b, l_b, g_b, s_b, var_b) = out[0], out[1]
     assert torch.equal(g_a, s_a) and torch.equal(g_b, s_b)          # grouped / early-launched exchange == plain exchange
     assert torch.equal(p_a, p_b)                                   # broadcast made replicas identical
     assert torch.allclose(s_a, l_a + l_b) and torch.equal(s_a, s_b)  # sum all-reduce, same on both ranks
     assert not torch.equal(l_a, l_b)
+    for key, got in var_a.items():
+        assert torch.equal(got, var_b[key]), key                    # every replica holds the same bits, whatever travelled
+        if key[0] == 'fp32':
+            assert torch.allclose(got, s_a, rtol=1e-6, atol=1e-7), key   # direct: the owner adds in rank order (fp32)
+        else:
+            assert torch.allclose(got, s_a, rtol=2 ** -7, atol=1e-6) and not torch.equal(got, s_a), key    # bf16 payload: 8 bits
+    assert torch.equal(var_a[('bf16', 'direct', False)], var_a[('bf16', 'direct', True)])
 
 
 def test_single_process_is_a_noop():
