@@ -286,6 +286,27 @@ int s2e_wgrad_c8_batch_supported(int dtype, int H, int W, int cout);
 size_t s2e_wgrad_c8_batch_workspace_bytes(int N, const s2e_wgrad_c8_job* jobs, int n_jobs);
 int s2e_wgrad_c8_batch(int dtype, int N, const s2e_wgrad_c8_job* jobs, int n_jobs, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* The patch-resident 3x3 stride-1 pad-1 weight gradients of MANY layers as ONE persistent launch (csrc/conv_wgrad_batch.hip; the
+ * weight-gradient half of architecture.py:24-25 / normalization.py:88-89's convolutions, which torch's autograd runs layer by layer).
+ * Job: x (N,H,W,Cin) and gy (N,H,W,Cout) bf16; dw fp32 (Cout, 9*Cin) row-major in (tap, ci) order -- a channels-last parameter
+ * gradient -- and dbias fp32 (Cout) or NULL are ACCUMULATED into.  rect_list / rect_count (both or neither): restrict the job to the
+ * pixels of the 16 x 16 rectangles rect_list[0 .. *rect_count) (device memory, read by the kernel: label-sparse SPADE backward).
+ * All jobs' (tile, 128-pixel slab) units are dealt evenly to one workgroup per CU; a dW tile with a single owner is added without
+ * atomics or workspace, the others through <= 2 partial tiles per workgroup and a fix-up launch.  No two jobs of a call may share
+ * dw.  jobs is a HOST array.  _supported: bf16, H % 8 == 0, W % 16 == 0 (16 with a list), Cin % 64 == 0, Cout % 8 == 0, Cout >= 64.
+ * flags & S2E_WGRAD_BATCH_DW_ZERO: the caller vouches that dw holds zeros (a gradient arena cleared at the start of the step, no other
+ * contribution yet): a tile with a single owner is then STORED instead of read, added and stored.
+ * workspace: s2e_wgrad_batch_workspace_bytes() (independent of the jobs), uninitialised. */
+#define S2E_WGRAD_BATCH_DW_ZERO 1
+typedef struct s2e_wgrad_batch_job {
+    const void* x; const void* gy; float* dw; float* dbias;
+    const int* rect_list; const int* rect_count;
+    int N, H, W, Cin, Cout;
+    int flags;                                         /* S2E_WGRAD_BATCH_DW_ZERO */
+} s2e_wgrad_batch_job;
+int s2e_wgrad_batch_supported(int dtype, int N, int H, int W, int Cin, int Cout);
+size_t s2e_wgrad_batch_workspace_bytes(void);
+int s2e_wgrad_batch(int dtype, const s2e_wgrad_batch_job* jobs, int n_jobs, void* workspace, size_t workspace_bytes, void* stream);
 /* Label-sparse form of the fused launch.  gamma / beta at a pixel depend only on the labels of its 5x5 neighbourhood, so a
  * rectangle of the fused launch's tiling (s2e_spade_conv_modulate_rect: tw x th pixels) whose pixels and in-image 2-pixel halo
  * all carry ONE class takes them from a per-class table instead of the convolution -- exact up to fp32 summation order, and

@@ -34,6 +34,13 @@ class WgradC8Job(C.Structure):
                 ('H', C.c_int), ('W', C.c_int), ('ncls', C.c_int)]
 
 
+class WgradBatchJob(C.Structure):
+    """s2e_wgrad_batch_job"""
+    _fields_ = [('x', C.c_void_p), ('gy', C.c_void_p), ('dw', C.c_void_p), ('dbias', C.c_void_p),
+                ('rect_list', C.c_void_p), ('rect_count', C.c_void_p),
+                ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('flags', C.c_int)]
+
+
 class LabelConvJob(C.Structure):
     _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('out_off', C.c_long), ('h', C.c_int), ('w', C.c_int),
                 ('cout', C.c_int), ('relu', C.c_int)]
@@ -134,6 +141,9 @@ SIGNATURES = {
     's2e_wgrad_c8_batch_supported': [_i, _i, _i, _i],
     's2e_wgrad_c8_batch_workspace_bytes': [_i, _vp, _i],
     's2e_wgrad_c8_batch': [_i, _i, _vp, _i, _vp, C.c_size_t, _vp],
+    's2e_wgrad_batch_supported': [_i, _i, _i, _i, _i, _i],
+    's2e_wgrad_batch_workspace_bytes': [],
+    's2e_wgrad_batch': [_i, _vp, _i, _vp, C.c_size_t, _vp],
     's2e_label_conv_block_map': [_i, _vp, _i, _i, _vp],
     's2e_label_conv3x3_batch': [_i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     's2e_class_table_block_map': [_vp, _i, _vp],

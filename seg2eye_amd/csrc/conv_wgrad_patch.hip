@@ -23,6 +23,7 @@
 //                shared between the two ci waves (alternate groups) and between the ci-tile workgroups (alternate slabs).
 //   combine    : fp32 atomics in 128-B row segments, one per accumulator register, into the caller's dW.
 #include "conv_wgrad_patch.h"
+#include "wgrad_tr_frag.h"
 #include <stdlib.h>
 
 namespace {
@@ -39,31 +40,6 @@ struct WpParams {
     // label-sparse launches (TWS = 4 only): the slabs are the two 8 x 16 halves of the 16 x 16 rectangles rect_list[0 .. *rect_count)
     const int* rect_list; const int* rect_count; int splits;
 };
-
-// One MFMA operand = rows r and r+4 of a 4x16 transpose block (lane roles: conv_wgrad.hip).  The reads are inline asm with
-// hand-counted waits: through the builtin the compiler puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 that
-// follows an LDS-DMA (it cannot tell the DMA's destination stage from the stage being read), which serialises the next
-// slab's loads with this slab's MFMAs.
-struct TrFrag { u32x2_t lo, hi; };
-template <int HI_OFF>
-__device__ __forceinline__ void tr_issue(TrFrag& f, uint32_t addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(addr) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(HI_OFF) : "memory");
-}
-// all but the newest KEEP LDS reads are back; the fragments are operands so no MFMA on them can move above the wait
-template <int KEEP>
-__device__ __forceinline__ void tr_ready(TrFrag& b) {
-    static_assert(KEEP >= 0 && KEEP <= 15, "lgkmcnt is a 4-bit counter");
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b.lo), "+v"(b.hi) : "n"(KEEP) : "memory");
-}
-template <int KEEP>
-__device__ __forceinline__ void tr_ready(TrFrag& a, TrFrag& b) {
-    static_assert(KEEP >= 0 && KEEP <= 15, "lgkmcnt is a 4-bit counter");
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : "n"(KEEP) : "memory");
-}
-__device__ __forceinline__ bf16x8_t tr_operand(const TrFrag& f) {
-    return __builtin_bit_cast(bf16x8_t, u32x4_t{f.lo.x, f.lo.y, f.hi.x, f.hi.y});
-}
 
 template <int TWS>                                // slab width 1 << TWS (64, 32 or 16)
 __global__ __launch_bounds__(512, 1) void conv_wgrad_patch_kernel(const WpParams p) {

@@ -127,8 +127,14 @@ class ZeroPool:
 
     @classmethod
     def arena_zeroed(cls, flat_g):
-        """optim.FlatAdam.zero_grad reports here: this gradient arena is all zeros as of now."""
-        cls._zeroed[flat_g.data_ptr()] = (flat_g.numel() * flat_g.element_size(), cls.serial)
+        """optim.FlatAdam.zero_grad reports here: this gradient arena is all zeros as of now.  Entries of arenas that no longer
+        exist -- their memory now (partly) belongs to this one -- are dropped: a lookup by address must find THIS arena's entry, not
+        a dead optimizer's (found in round 5 as a test-order-dependent failure: `arena_touched` marked the stale entry, the live
+        arena stayed "fresh" and a chain-ruled gradient was rewritten in place)."""
+        base, nbytes = flat_g.data_ptr(), flat_g.numel() * flat_g.element_size()
+        for b in [b for b, (nb, _) in cls._zeroed.items() if b != base and b < base + nbytes and base < b + nb]:
+            del cls._zeroed[b]
+        cls._zeroed[base] = (nbytes, cls.serial)
 
     @classmethod
     def arena_touched(cls, g):
@@ -197,6 +203,7 @@ class ZeroPool:
         self.key, self.bump, self.tail_i = key, 0, 0
         self.step_cache = {}
         self.sink.inplace_done = set()
+        self.sink.wg_done = set()
         ZeroPool._active = self
         ZeroPool.serial += 1
 
@@ -239,6 +246,7 @@ class _ZeroScope:
                 self.pool.sink.jobs = []
                 self.pool.sink.c8 = []
                 self.pool.sink.uni = []
+                self.pool.sink.wg = []
         finally:
             self.pool._end()
         return False
@@ -259,6 +267,8 @@ class GradSink:
         self.inplace = []          # deferred in-place spectral-norm chain rules (channels-last masters): push_inplace
         self.inplace_done = set()  # gradient slices whose chain rule has already RUN in the open scope (see inplace_allowed)
         self.uni = []              # deferred label-sparse SPADE backward jobs (uniform rectangles' closed-form gradients): push_uniform
+        self.wg = []               # deferred patch-resident 3x3 weight gradients (one persistent launch per flush): push_wgrad
+        self.wg_done = set()       # dW slices a wgrad flush of the open scope has already written (a later job must ADD to them)
         self.tables = {}
         self.keepalive = None
         self.keep_c8 = None
@@ -325,6 +335,68 @@ class GradSink:
             's2e_sn_grads_inplace'), nbytes=nbytes)
 
     @staticmethod
+    def push_wgrad(x, gy, dw_rows, dbias, rects=None, tag=None, gy_shared=False):
+        """Queue the weight (and bias) gradient of a 3x3 stride-1 pad-1 conv -- x (N,H,W,Cin), gy (N,H,W,Cout) bf16 -- to be ACCUMULATED
+        into dw_rows (Cout, 9*Cin) fp32 row-major / dbias (Cout) at the next flush: all queued layers as ONE persistent launch
+        (s2e_wgrad_batch, csrc/conv_wgrad_batch.hip) instead of a launch + a 75-MB partial-tile round trip per layer.  rects =
+        (rect_list, counts): the label-sparse form.  x, gy (and the list) stay referenced until the next flush.  False: not
+        queued -- no trainer step open, a shape the batch does not take, a dW already queued in this flush (single-owner tiles are
+        added without atomics), or S2E_WGRAD_BATCH=0 / S2E_DETERMINISTIC=1.
+        gy_shared: the caller hands the SAME tensor on as somebody's gradient (a conv with a residual input returns it as the
+        residual's gradient, and the block's first SPADE then adds its own dx into it IN PLACE -- ModulateFn's relay): the queue
+        keeps a copy, the deferred launch must not see that sum."""
+        pool = ZeroPool.active()
+        if pool is None or _WGRAD_BATCH_OFF or x.dtype != torch.bfloat16 or gy.dtype != torch.bfloat16:
+            return False
+        n, h, w, cin = x.shape
+        cout = gy.shape[-1]
+        key = (n, h, w, cin, cout, rects is not None)
+        ok = _WGRAD_BATCH_OK.get(key)
+        if ok is None:
+            ok = _WGRAD_BATCH_OK[key] = bool(L.lib().s2e_wgrad_batch_supported(L.S2E_BF16, n, h, w, cin, cout)) and \
+                (rects is None or (h % 16 == 0 and w % 16 == 0))
+        if not ok:
+            return False
+        for j in pool.sink.wg:
+            if j[2].data_ptr() == dw_rows.data_ptr():
+                j[6] = False                                 # (that dW receives another contribution before the flush: add, do not store)
+                return False
+        _need(x, gy, dw_rows, dbias)
+        # a gradient arena that zero_grad cleared right before this step, and nothing queued for it yet: single-owner tiles are stored
+        fresh = ZeroPool.grad_is_fresh(dw_rows) and dw_rows.data_ptr() not in pool.sink.wg_done
+        pool.sink.wg.append([x, gy.clone() if gy_shared else gy, dw_rows, dbias, rects, tag, fresh])
+        return True
+
+    def _flush_wgrad(self):
+        jobs, self.wg = self.wg, []
+        self.wg_done.update(j[2].data_ptr() for j in jobs)
+        dev = jobs[0][0].device
+        arr = (L.WgradBatchJob * len(jobs))()
+        flops = executed = nbytes = 0.0
+        for a, (x, gy, dw, db, rects, _, fresh) in zip(arr, jobs):
+            a.flags = 1 if fresh else 0                      # S2E_WGRAD_BATCH_DW_ZERO
+            n, h, w, cin = x.shape
+            cout = gy.shape[-1]
+            a.x, a.gy, a.dw, a.dbias = x.data_ptr(), gy.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+            a.N, a.H, a.W, a.Cin, a.Cout = n, h, w, cin, cout
+            f, frac = 2.0 * n * h * w * cin * cout * 9, 1.0
+            if rects is not None:
+                a.rect_list, a.rect_count = rects[0].data_ptr(), rects[1].data_ptr()
+                if LaunchProfiler.active():
+                    frac = float(int(rects[1][0])) / max(n * (h // 16) * (w // 16), 1)
+            flops += f
+            executed += f * frac
+            nbytes += (x.numel() + gy.numel()) * 2.0 * frac + dw.numel() * 4.0
+        ws = self.__dict__.get('_wg_ws')
+        wsb = L.lib().s2e_wgrad_batch_workspace_bytes()
+        if ws is None or ws.device != dev or ws.numel() * 4 < wsb:
+            ws = self._wg_ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)     # (kept: the same 151 MB every flush)
+        LaunchProfiler.run('conv_wgrad_patch', flops, lambda: L.check(
+            L.lib().s2e_wgrad_batch(L.S2E_BF16, C.byref(arr), len(jobs), _p(ws), wsb, _stream()), 's2e_wgrad_batch'),
+            tag='W k3 s1 x%d batched' % len(jobs), nbytes=nbytes, executed=executed)
+        self.keep_wg = jobs                                  # the tensors stay referenced until the next flush (stream order covers the rest)
+
+    @staticmethod
     def push_c8(oh, dactv, dw, db, ncls):
         """Queue the weight / bias gradient of a 3x3 conv on the 8-channel one-hot map `oh` (N,h,w,8) with output gradient
         `dactv` (N,h,w,128), accumulated straight into dw (128,ncls,3,3) / db (128) fp32 at the next flush -- all queued layers
@@ -383,6 +455,8 @@ class GradSink:
         self.keep_uni = jobs                                 # the tensors stay referenced until the next flush
 
     def flush(self):
+        if self.wg:
+            self._flush_wgrad()                              # first: the re-layout / chain-rule / rank-1 jobs below read or add to its results
         if self.uni:
             self._flush_uniform()
         if self.c8:
@@ -488,6 +562,9 @@ def _conv_plan(wgrad, dt, *shape):
     return ent
 
 
+# A/B switch: 0 = every patch-resident weight gradient as its own launch (round 4); S2E_DETERMINISTIC keeps the fixed-order per-layer path
+_WGRAD_BATCH_OFF = os.environ.get('S2E_WGRAD_BATCH', '1') == '0' or os.environ.get('S2E_DETERMINISTIC', '0') == '1'
+_WGRAD_BATCH_OK = {}
 _CONV_STATS_OFF = os.environ.get('S2E_CONV_STATS', '1') == '0'      # A/B switch: 0 = InstanceNorm statistics always by a pass of their own
 _CONV_STATS_SLOTS = {}
 
@@ -544,12 +621,14 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     return y
 
 
-def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False, dbias_out=None, dw_out=None):
+def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False, dbias_out=None, dw_out=None, gy_shared=False):
     """-> (dw, db): dw (Cout, KH*KW*Cin) fp32 in packed order; db (Cout) fp32 or None.  Both live in one
     zero-filled buffer (ZeroPool scratch when the bias gradient is not returned).  dbias_out: an fp32 (Cout) tensor to ACCUMULATE the bias
     gradient into instead (e.g. the parameter's slice of the gradient arena); then db is None.
     dw_out: an fp32 (Cout, KH*KW*Cin) row-major tensor to ACCUMULATE the weight gradient into instead of a fresh zeroed buffer
-    (the gradient of a parameter stored channels-last: _cl_rows(p.grad)); returned as dw."""
+    (the gradient of a parameter stored channels-last: _cl_rows(p.grad)); returned as dw.
+    Inside a trainer step the patch-resident 3x3 shapes are QUEUED (GradSink.push_wgrad): dw / dbias_out then receive the sums at
+    the step's next flush.  gy_shared: gy is also handed on as another tensor's gradient (see push_wgrad)."""
     _need(x, gy, dbias_out, dw_out)
     n, hi, wi, cin = x.shape
     _, ho, wo, cout = gy.shape
@@ -565,6 +644,9 @@ def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=Fals
     else:
         dw, db = ZeroPool.take(cout * k, torch.float32, x.device).view(cout, k), None
     dbp = db if own_b else dbias_out
+    if (kh == 3 and kw == 3 and stride == 1 and pad == 1 and in_act == ACT_NONE and not own_b and ho == hi and wo == wi
+            and GradSink.push_wgrad(x, gy, dw, dbp, gy_shared=gy_shared)):
+        return dw, db                                        # accumulated at the step's next flush, with every other queued layer
     d, wsb = _conv_plan(True, _dt(x), n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     LaunchProfiler.run(lambda: _WGRAD_FAMILY[L.lib().s2e_conv2d_wgrad_kernel_kind(_dt(x), C.byref(d))],
@@ -975,6 +1057,7 @@ class Conv2dFn(torch.autograd.Function):
                             True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
         want_b = has_bias and ctx.needs_input_grad[2]
         wdst = ctx.wdst
+        shared = bool(has_res and ctx.needs_input_grad[3])   # g goes on as the residual's gradient (and may be added to in place there)
         direct = ctx.needs_input_grad[1] and wdst is not None and cx == cin and cin % 8 == 0 and _cl_dense(wdst)
         if direct and sigma is not None and not GradSink.inplace_allowed(wdst):
             direct = False                                   # (the chain rule must ACCUMULATE here: packed scratch, below)
@@ -984,12 +1067,13 @@ class Conv2dFn(torch.autograd.Function):
             # the parameter's gradient lies in the packed order (channels-last arena, or any 1x1 conv; Cin % 8 == 0 -- a 1-channel
             # weight is "channels-last" too, but the in-place kernels work on 16-byte groups of one tap): the kernel accumulates
             # straight into it; spectral norm's chain rule is then applied in place (queued: one launch pair per step)
-            _, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, ctx.bdst if want_b else None, dw_out=_cl_rows(wdst))
+            _, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, ctx.bdst if want_b else None, dw_out=_cl_rows(wdst),
+                                     gy_shared=shared)
             if sigma is not None:
                 GradSink.push_inplace(_cl_rows(wdst), weight, u, v, sigma, cout, cin, kh * kw)
         elif ctx.needs_input_grad[1]:
             bdst = ctx.bdst if want_b else None
-            dwp, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, bdst)
+            dwp, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, bdst, gy_shared=shared)
             if wdst is not None and not wdst.is_contiguous():
                 wdst = None                                  # (a channels-last .grad fed a channel-padded input: through autograd)
             w_oihw = weight.detach() if weight.is_contiguous() else weight.detach().contiguous()
@@ -1222,6 +1306,8 @@ def _sparse_wgrad(g, actv, gb_dst, sp):
     if not wsb or db is None or w_strides_differ(dw):
         return False
     cls, work_list, ui_list, counts = sp
+    if GradSink.push_wgrad(actv, g, _cl_rows(dw), db, rects=(work_list, counts)):
+        return True
     ws = torch.empty(max(wsb // 4, 4), dtype=torch.float32, device=g.device)
     flops = 2.0 * n * h * w * nh * c2 * 9
     frac = 1.0

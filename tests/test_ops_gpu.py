@@ -788,6 +788,55 @@ def test_wgrad_c8_batch_matches_per_layer_launches():
             assert float((db - rb).abs().max()) <= 1e-4 * float(rb.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize('wgs', ['', '5', '37'])
+def test_wgrad_batch_kernel_matches_fp64(wgs):
+    """s2e_wgrad_batch (csrc/conv_wgrad_batch.hip): 36 jobs -- single-owner tiles, tiles shared between workgroups, ragged Cout,
+    label-sparse rectangle lists (empty / odd / full), accumulation into non-zero dW, two launches -- against fp64 sums of the same
+    bf16 operands (tools/check_wgrad_batch.py).  One workgroup per CU (the default: nearly every tile of these small cases is
+    shared), 5 workgroups (long ranges: whole tiles and many segments per workgroup) and 37 (a mix)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if wgs:
+        env['S2E_WGRAD_BATCH_WGS'] = wgs
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_wgrad_batch.py')], env=env, capture_output=True, text=True,
+                         timeout=900, cwd=root)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    assert 'worst relative error' in out.stdout
+
+
+def test_wgrad_batch_through_the_sink():
+    """Inside a trainer-step scope ops.conv2d_wgrad_raw QUEUES the patch-resident 3x3 weight gradients (GradSink.push_wgrad) and the
+    scope's flush runs them as one launch; outside a scope -- and for shapes the batch does not take, or a dW queued twice -- the
+    per-layer launch runs at once.  Both must give the same gradients."""
+    from seg2eye_amd import ops
+    dev = _dev()
+    shapes = [(2, 32, 32, 64, 128), (2, 16, 16, 128, 256), (1, 64, 64, 64, 64), (2, 12, 20, 64, 64)]    # (the last: not made of 8 x 16 slabs)
+    ins = []
+    for i, (n, h, w, cin, cout) in enumerate(shapes):
+        ins.append((nhwc(_rnd((n, cin, h, w), 300 + i, torch.bfloat16)).to(dev), nhwc(_rnd((n, cout, h, w), 320 + i, torch.bfloat16)).to(dev)))
+    ref = []
+    for x, gy in ins:                                           # no scope: launched one by one
+        dw = torch.zeros(gy.shape[-1], 9 * x.shape[-1], device=dev)
+        db = torch.zeros(gy.shape[-1], device=dev)
+        ops.conv2d_wgrad_raw(x, gy, 3, 3, 1, 1, ops.ACT_NONE, True, db, dw_out=dw)
+        ref.append((dw, db))
+    pool = ops.ZeroPool(dev)
+    outs = [(torch.zeros_like(dw), torch.zeros_like(db)) for dw, db in ref]
+    with pool.scope('t'):
+        for (x, gy), (dw, db) in zip(ins, outs):
+            ops.conv2d_wgrad_raw(x, gy, 3, 3, 1, 1, ops.ACT_NONE, True, db, dw_out=dw)
+        assert len(pool.sink.wg) == 3                            # the 12 x 20 map ran at once
+        assert float(outs[0][0].abs().max()) == 0.0 and float(outs[3][0].abs().max()) > 0.0
+        ops.conv2d_wgrad_raw(ins[0][0], ins[0][1], 3, 3, 1, 1, ops.ACT_NONE, True, outs[0][1], dw_out=outs[0][0])   # same dW again: at once
+        assert len(pool.sink.wg) == 3 and float(outs[0][0].abs().max()) > 0.0
+    torch.cuda.synchronize()
+    for i, ((dw, db), (rw, rb)) in enumerate(zip(outs, ref)):
+        k = 2.0 if i == 0 else 1.0
+        assert float((dw - k * rw).abs().max()) <= 2e-5 * float(rw.abs().max()) * k + 1e-6, i
+        assert float((db - k * rb).abs().max()) <= 2e-5 * float(rb.abs().max()) * k + 1e-6, i
+
+
 @pytest.mark.parametrize('duo', ['512', '0'])
 def test_patch_conv_kernels_match_torch_at_bench_shapes(duo):
     """The two patch-resident 3x3 kernels at the bench's shapes against torch's own convolution in fp32 (tools/check_duo.py):
