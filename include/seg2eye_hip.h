@@ -491,7 +491,9 @@ int s2e_fc_head_bwd(int dtype, const void* x, const float* W, const float* dy, v
  * p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), bc1 = 1-b1^t, bc2 = 1-b2^t, t = steps+1.
  * hyper: 7 fp32 in DEVICE memory {lr, beta1, beta2, eps, completed steps, grad_scale, weight_decay}; the call
  * increments hyper[4].  Device-resident so a captured hipGraph replays with current values;
- * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ * With beta1 == 0 and weight_decay == 0 (the reference's TTUR default) m_t = g_t*grad_scale whatever m was: the kernel then neither
+ * reads nor writes m (same bits in p and v, 20 instead of 28 bytes per parameter); a caller that saves m forms it from g. */
 int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float* hyper, void* stream);
 
 /* ------------------------------------------------------------------ OpenEDS validation metric

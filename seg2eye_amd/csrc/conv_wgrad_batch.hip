@@ -16,18 +16,22 @@
 //               slab: every workgroup on its own HBM / Infinity-Cache stream).  So a long job's slabs are cut into nb = ceil(ns / Q*)
 //               equal blocks and workgroup wbase + b T + t runs block b of tile t: consecutive workgroups (one XCD under
 //               xcd_remap) in lockstep on the same slabs.
-//     SHORT jobs (everything else: many tiles, few slabs): their units, numbered (job, tile, slab), are dealt to the remaining
-//               workgroups stream-K fashion: workgroup w' owns units [w' U' / G', (w' + 1) U' / G'), cut into SEGMENTS at tile
-//               boundaries.
-//     Q*      = the smallest of 64 candidate quotas in [U / G, 2 U / G) for which both pools fit into G workgroups, found by
-//               every workgroup for itself from the device-side slab counts (one candidate per lane of wave 0).
+//     SHORT jobs (everything else: many tiles, few slabs): their units, numbered (job, tile, slab), are dealt stream-K fashion to
+//               ALL workgroups in proportion to what each has left of its quota -- Q* minus its block for the long jobs'
+//               workgroups (a 1024-slab job at Q* = 460 is three blocks of 342: 118 spare each), the whole Q* for the others --
+//               and a workgroup's unit range is cut into SEGMENTS at tile boundaries.  (First version: long jobs' workgroups
+//               did nothing else; the quota then had to grow to 512 until the blocks of the 4096- and 1024-slab jobs fit.)
+//     Q*      = the smallest of 64 candidate quotas in [U / G, 2 U / G) for which the long jobs' blocks fit into G workgroups and
+//               the total capacity G Q* covers the work, found by every workgroup for itself from the device-side slab counts
+//               (one candidate per lane of wave 0).
 //   results   = a segment that covers a whole tile has a single owner: its accumulators are added straight into dW (plain
-//               read-modify-write: no atomics, no workspace).  Any other segment -- a long job's block when nb > 1, the first and
-//               the last segment of a stream-K range -- writes a partial tile ("fragment") to workspace slot 2w / 2w + 1.
+//               read-modify-write: no atomics, no workspace; a plain store when the caller vouches that dW holds zeros).  Any other
+//               segment -- a long job's block when nb > 1, the first and the last segment of a stream-K range -- writes a partial
+//               tile ("fragment") to workspace slot 3w / 3w + 1 / 3w + 2.
 //   fix-up    = a second, small launch: for every tile with more than one owner, add its fragments in workgroup order into dW.
 //               Which workgroups, and which slots, follows from the plan workgroup 0 leaves in the workspace.
 //
-// So a launch writes at most 2 G fragments in total (typically < G: 75 MB per BATCH instead of per layer), the many-tile layers at
+// So a launch writes at most 3 G fragments in total (typically ~G: 75 MB per BATCH instead of per layer), the many-tile layers at
 // small maps (1024 -> 1024 at 16 x 16: 128 tiles of 16 slabs) get one owner per tile, and ramp / tail are paid once.
 // Label-sparse jobs (a device-side list of 16 x 16 rectangles, two slabs each) take part with their device-side counts: every
 // workgroup derives the unit ranges itself from the counts, so hipGraph replays follow label maps that change between replays.
@@ -48,23 +52,39 @@ struct WbJob {
     int flags, pad_;                                  // S2E_WGRAD_BATCH_DW_ZERO: dW holds zeros (a single-owner tile is stored, not added)
 };
 constexpr int WB_MAX_JOBS = 32;
-struct WbBatch { int n, G; WbJob j[WB_MAX_JOBS]; };
+struct WbBatch { int n, G, spare_min, pad_; WbJob j[WB_MAX_JOBS]; };      // spare_min: see wb_make_plan
 constexpr int WB_TILE = 9 * 128 * 64;                  // floats per (partial) tile: [tap][co % 128][ci % 64]
-constexpr int WB_FIX_PARTS = 18;                       // fix-up blocks per tile: 1024 float4 each
+constexpr int WB_SLOTS = 3;                           // fragment slots per workgroup: a long job's block, the first and the last stream-K segment
+constexpr int WB_FIX_LIST = 512;                       // most workgroups one stream-K tile can be shared by (the fix-up's slot list)
+constexpr int WB_FIX_PARTS = 6;                        // fix-up blocks per tile: 3072 float4 each (18 432 per tile)
 struct WbFix { int first_block[WB_MAX_JOBS + 1]; };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// first unit of stream-K workgroup w of G over U units (both kernels must agree on this to the bit)
-__device__ __forceinline__ int wb_u0(int w, int U, int G) { return (int)(((long)w * (long)U) / (long)G); }
-
 // The launch's plan (LDS of every workgroup; workgroup 0 copies it behind the fragments for the fix-up launch).
 struct WbPlan {
-    int w_long, g_short, u_short, n;                  // workgroups of the long jobs, of the stream-K pool, its units, jobs
+    int w_long, q, u_short, n;                        // workgroups that start with a long job's block; the quota; stream-K units; jobs
+    long s_total, s_long;                             // spare capacity of all workgroups (>= u_short); of the long jobs' alone
     int ns[WB_MAX_JOBS];                              // slabs per tile
     int nb[WB_MAX_JOBS];                              // long job: blocks per tile (>= 1); short job: 0
     int wbase[WB_MAX_JOBS];                           // long job: its first workgroup
+    int cap[WB_MAX_JOBS];                             // long job: what its workgroups have left for stream-K units (q - block size)
+    long sbase[WB_MAX_JOBS];                          // long job: spare capacity of all workgroups before wbase
     int pre[WB_MAX_JOBS + 1];                         // first stream-K unit of job k (long jobs contribute none)
 };
+
+// Spare capacity of the workgroups before w: long job k's workgroups have cap[k] each, the ones behind w_long the whole quota.
+__device__ __forceinline__ long wb_spare_before(const WbPlan* P, const WbBatch& b, int w) {
+    if (w >= P->w_long) return P->s_long + (long)(w - P->w_long) * P->q;
+    int k = 0;                                        // (the long jobs' workgroup ranges are NOT in job order: see wb_make_plan)
+    while (!(P->nb[k] > 0 && w >= P->wbase[k] && w < P->wbase[k] + P->nb[k] * b.j[k].tiles_co * b.j[k].tiles_ci)) ++k;
+    return P->sbase[k] + (long)(w - P->wbase[k]) * P->cap[k];
+}
+// first stream-K unit of workgroup w: the units are dealt in proportion to the spare capacities (both kernels must agree on this
+// to the bit)
+__device__ __forceinline__ int wb_first_unit(const WbPlan* P, const WbBatch& b, int w) {
+    if (P->s_total <= 0) return 0;
+    return (int)((wb_spare_before(P, b, w) * (long)P->u_short) / P->s_total);
+}
 
 // all 512 threads of a workgroup; P in LDS
 __device__ __forceinline__ void wb_make_plan(const WbBatch& b, int G, WbPlan* P) {
@@ -76,26 +96,54 @@ __device__ __forceinline__ void wb_make_plan(const WbBatch& b, int G, WbPlan* P)
         for (int k = 0; k < b.n; ++k) U += (long)P->ns[k] * (b.j[k].tiles_co * b.j[k].tiles_ci);
         const int q0 = (int)((U + G - 1) / G) > 0 ? (int)((U + G - 1) / G) : 1;
         const int qc = q0 + (int)(((long)q0 * tid) >> 6);                 // this lane's candidate quota
-        long cost = 0, us = 0;
+        // long jobs (ns > qc) take nb = ceil(ns / qc) blocks of ceil(ns / nb) slabs per tile, one workgroup each; what such a
+        // workgroup's quota has left is filled with the short jobs' units -- when it is worth a segment of its own (>= spare_min
+        // units: a segment costs a pipeline fill and a 288-KB write-out, about two slabs' time; a 4096-slab job at quota 460 leaves
+        // 4 units per workgroup, and dealing those out made 117 fragments for 468 slabs of work) -- the others' whole quota is
+        long wgs = 0, room = 0, us = 0;
         for (int k = 0; k < b.n; ++k) {
-            const int ns = P->ns[k], T = b.j[k].tiles_co * b.j[k].tiles_ci;
-            if (ns > qc) cost += (long)((ns + qc - 1) / qc) * T;
-            else us += (long)ns * T;
+            const int ns = P->ns[k], Tn = b.j[k].tiles_co * b.j[k].tiles_ci;
+            if (ns > qc) {
+                const int nb = (ns + qc - 1) / qc, spare = qc - (ns + nb - 1) / nb;
+                wgs += (long)nb * Tn;
+                if (spare >= b.spare_min) room += (long)nb * Tn * spare;
+            } else {
+                us += (long)ns * Tn;
+            }
         }
-        cost += (us + qc - 1) / qc;
-        const unsigned long long ok = __ballot(cost <= (long)G);
+        room += ((long)G - wgs) * qc;
+        const unsigned long long ok = __ballot(wgs <= (long)G && us <= room);
         const int pick = ok ? __builtin_ctzll(ok) : -1;                   // the smallest feasible quota (none: everything stream-K)
         const int qstar = pick >= 0 ? __shfl(qc, pick, 64) : 0x7fffffff;
         if (tid == 0) {
             int w = 0, a = 0;
+            long sp = 0;
             for (int k = 0; k < b.n; ++k) {
-                const int ns = P->ns[k], T = b.j[k].tiles_co * b.j[k].tiles_ci;
+                const int ns = P->ns[k], Tn = b.j[k].tiles_co * b.j[k].tiles_ci;
                 P->pre[k] = a;
-                if (ns > qstar) { P->nb[k] = (ns + qstar - 1) / qstar; P->wbase[k] = w; w += P->nb[k] * T; }
-                else { P->nb[k] = 0; P->wbase[k] = 0; a += ns * T; }
+                P->nb[k] = 0; P->wbase[k] = 0; P->cap[k] = 0; P->sbase[k] = 0;
+                if (ns <= qstar) a += ns * Tn;
             }
             P->pre[b.n] = a;
-            P->w_long = w; P->g_short = G - w; P->u_short = a; P->n = b.n;
+            // The long jobs' workgroups, jobs with MORE tiles first: the T workgroups that walk one block together must share an
+            // XCD (one L2), and xcd_remap gives an XCD 32 consecutive workgroups -- with the tile counts in descending powers of
+            // two every group starts on a multiple of its own size and never straddles two XCDs.  (In job order the dense bench mix
+            // at 9 + 3 blocks put the 8-tile groups of the 128^2 layers at 117, 125, ...: half of them straddled, streamed from the
+            // Infinity Cache at the slow rate, and the launch took 3.0 instead of 2.5 ms.)
+            for (int tt = 64; tt >= 1; tt >>= 1)               // (64: that many tiles or more)
+                for (int k = 0; k < b.n; ++k) {
+                    const int ns = P->ns[k], Tn = b.j[k].tiles_co * b.j[k].tiles_ci;
+                    if (ns <= qstar || Tn < tt || (tt < 64 && Tn >= 2 * tt)) continue;
+                    const int nb = (ns + qstar - 1) / qstar, spare = qstar - (ns + nb - 1) / nb;
+                    P->nb[k] = nb; P->wbase[k] = w; P->cap[k] = spare >= b.spare_min ? spare : 0; P->sbase[k] = sp;
+                    w += nb * Tn;
+                    sp += (long)nb * Tn * P->cap[k];
+                }
+            P->w_long = w; P->u_short = a; P->n = b.n;
+            // (no feasible quota: one block of units, dealt evenly)
+            P->q = pick >= 0 ? qstar : (a + G - 1) / G + 1;
+            P->s_long = sp;
+            P->s_total = sp + (long)(G - w) * P->q;
         }
     }
     __syncthreads();
@@ -108,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
     constexpr int X_BYTES = XPIECES * 1024, G_BYTES = 128 * 256, STAGE = X_BYTES + G_BYTES;
     constexpr int NPI = 7;                            // pieces per thread per slab: 4 gy, 3 x
     constexpr int RED_OFF = 2 * STAGE, PLAN_OFF = RED_OFF + 1024;
-    __shared__ __attribute__((aligned(16))) char smem[PLAN_OFF + ((sizeof(WbPlan) + 15) & ~15)];
+    __shared__ __attribute__((aligned(1024))) char smem[PLAN_OFF + ((sizeof(WbPlan) + 15) & ~15)];
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -120,18 +168,16 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
     const int G = (int)gridDim.x;
     wb_make_plan(b, G, P);
     const int wg = xcd_remap(blockIdx.x, G);          // consecutive workgroups share an XCD's L2
-    if (wg == 0 && tid < (int)(sizeof(WbPlan) / 4)) ((int*)(ws + (size_t)2 * G * WB_TILE))[tid] = ((const int*)P)[tid];
+    if (wg == 0 && tid < (int)(sizeof(WbPlan) / 4)) ((int*)(ws + (size_t)WB_SLOTS * G * WB_TILE))[tid] = ((const int*)P)[tid];
     const int w_long = rfl(P->w_long);
-    const bool is_long = wg < w_long;
-    // stream-K pool: this workgroup's units
-    const int g_short = rfl(P->g_short), u_short = rfl(P->u_short);
+    const bool is_long = wg < w_long;                 // this workgroup starts with a block of a long job ...
+    // ... and then, like the others, takes its share of the stream-K units
     int u = 0, u_last = 0;
-    if (!is_long) {
-        if (g_short <= 0 || u_short <= 0) return;
-        u = wb_u0(wg - w_long, u_short, g_short);
-        u_last = wb_u0(wg - w_long + 1, u_short, g_short);
-        if (u >= u_last) return;
+    if (rfl(P->u_short) > 0) {
+        u = rfl(wb_first_unit(P, b, wg));
+        u_last = rfl(wb_first_unit(P, b, wg + 1));
     }
+    if (!is_long && u >= u_last) return;
 
     // ---- LDS-DMA pieces of this thread (geometry only: the same for every slab of every job).  i < 4: gy piece q = 8 i + wave,
     // slab pixels 4q .. 4q+3, 16 lanes per 256-B row; i >= 4: x piece xq = 8 (i - 4) + wave, patch pixels 8 xq .. +7, 8 lanes per row.
@@ -157,32 +203,36 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     const uint32_t a_base = lds0 + X_BYTES + (8 * hh + q4) * 256 + (((cb * 4 + 2 * g2 + (pq >> 1)) ^ (q4 << 2)) << 4) + (pq & 1) * 8;
     const uint32_t x_const = ((cib * 4 + 2 * g2 + (pq >> 1)) << 4) + (pq & 1) * 8;
-    uint32_t x_tap[2][9];                             // [bit 1 of the group's first patch pixel]
+    // (conv_wgrad_patch.hip keeps a second table for groups whose first patch pixel has bit 1 set -- the same addresses with bit 6
+    //  flipped.  Here the flip is applied to the finished address instead: the wave-uniform part (LDS base, stage, R << 7) has its low
+    //  seven bits clear, so bit 6 of the sum is bit 6 of the lane part.  Nine registers instead of eighteen: the kernel carries
+    //  the segment loop's state on top of conv_wgrad_patch_kernel's and the allocator had begun to spill INTO the slab loop.)
+    uint32_t x_tap[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const uint32_t r = 8 * hh + q4 + (t / 3) * PW + t % 3;
-        x_tap[0][t] = ((r << 7) + x_const) ^ ((r & 2u) << 5);
-        x_tap[1][t] = x_tap[0][t] ^ 64u;
+        x_tap[t] = ((r << 7) + x_const) ^ ((r & 2u) << 5);
     }
-    u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};           // bf16 1.0 x 8
-    asm volatile("" : "+v"(ones));
 
     struct Slab { int n, y0, x0; };
     int k = 0;
-    bool first_seg = true;
-    while (is_long ? first_seg : u < u_last) {
-        int tile, s0, s1, seg_end = 0;
+    bool long_seg = is_long, first_short = true;
+    while (long_seg || u < u_last) {
+        int tile, s0, s1, seg_end = 0, slot;
         bool whole;
-        if (is_long) {
-            // block b of tile t of the long job whose workgroups hold this one
-            while (!(rfl(P->nb[k]) > 0 && wg < rfl(P->wbase[k]) + rfl(P->nb[k]) * b.j[k].tiles_co * b.j[k].tiles_ci)) ++k;
+        if (long_seg) {
+            // block blk of tile `tile` of the long job whose workgroups hold this one
+            k = 0;
+            while (!(rfl(P->nb[k]) > 0 && wg >= rfl(P->wbase[k]) && wg < rfl(P->wbase[k]) + rfl(P->nb[k]) * b.j[k].tiles_co * b.j[k].tiles_ci)) ++k;
             const int Tn = b.j[k].tiles_co * b.j[k].tiles_ci, nb = rfl(P->nb[k]), ns = rfl(P->ns[k]);
             const int i = wg - rfl(P->wbase[k]), blk = i / Tn;
             tile = i - blk * Tn;
             s0 = (int)(((long)blk * ns) / nb);
             s1 = (int)(((long)(blk + 1) * ns) / nb);
             whole = nb == 1;
+            slot = WB_SLOTS * wg;
         } else {
+            if (first_short) k = 0;
             while (u >= rfl(P->pre[k + 1])) ++k;      // (long jobs and jobs without slabs hold no stream-K unit: stepped over)
             const int ns = rfl(P->ns[k]), pre = rfl(P->pre[k]);
             tile = (u - pre) / ns;
@@ -190,6 +240,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
             seg_end = min(u_last, pre + (tile + 1) * ns);
             s1 = s0 + (seg_end - u);
             whole = s0 == 0 && s1 == ns;              // the tile has no other owner: straight into dW
+            slot = WB_SLOTS * wg + (first_short ? 1 : 2);
         }
         const WbJob& J = b.j[k];
         const T* __restrict__ xg = J.x;
@@ -237,13 +288,15 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
         };
 
-        f32x16_t acc[9], accb;
+        f32x16_t acc[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+        // bias gradient = column sums of gy.  The MFMA's A operand of a lane is 8 consecutive pixels of ONE output channel (row lane & 31,
+        // pixel half lane >> 5), so the sum is four v_dot2c_f32_bf16 against (1, 1) into ONE register per lane -- conv_wgrad_patch.hip
+        // spends an extra MFMA against an all-ones fragment and 16 + 4 registers on it, which this kernel does not have to spare.
+        float bsum = 0.f;
 
         Slab cur = rl ? decode_rect(rl[s0 >> 1], s0 & 1) : decode(s0);
         int r_ahead = 0;                              // list jobs: the rectangle of slab s + 2, requested a slab ahead of its use
@@ -269,7 +322,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
             auto x_addr = [&](auto Uq) __attribute__((always_inline)) -> uint32_t {
                 constexpr int uu = decltype(Uq)::value, g = uu / 9, t = uu % 9;
                 constexpr uint32_t R = g * PW;          // group g = slab row g: its first patch pixel
-                return x_tap[(R >> 1) & 1][t] + (x_stage + (R << 7));
+                const uint32_t ad = x_tap[t] + (x_stage + (R << 7));
+                return ((R >> 1) & 1) ? (ad ^ 64u) : ad;
             };
             tr_issue<1024>(Af[0], a_stage);
             static_for<0, FD>([&](auto Uq) { tr_issue<512>(Bf[decltype(Uq)::value % (FD + 1)], x_addr(Uq)); });
@@ -303,8 +357,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
                 else tr_ready<keep>(B);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(A), tr_operand(B), acc[t], 0, 0, 0);
                 if constexpr (t == 0) {
-                    if (bias_slab && (g & 1) == cib)
-                        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(A), __builtin_bit_cast(bf16x8_t, ones), accb, 0, 0, 0);
+                    if (bias_slab && (g & 1) == cib) {
+                        const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+                        // (by value and indexed with []: __builtin_bit_cast of .x / .y of an ext-vector behind a REFERENCE reads element 0
+                        //  for both on this compiler -- DESIGN 3.8; found here as a bias gradient that summed half the pixels twice)
+                        const u32x2_t alo = A.lo, ahi = A.hi;
+                        const uint32_t a0 = alo[0], a1 = alo[1], a2 = ahi[0], a3 = ahi[1];
+                        bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a0), one2, bsum, false);
+                        bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a1), one2, bsum, false);
+                        bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a2), one2, bsum, false);
+                        bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a3), one2, bsum, false);
+                    }
                 }
             });
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -323,23 +386,37 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
             asm volatile("" : "+v"(lane_off));
             float* dwt = J.dw + (size_t)tco * 128 * (9 * Cin) + tci * 64;        // uniform
             const bool dw_zero = (J.flags & S2E_WGRAD_BATCH_DW_ZERO) != 0;      // (uniform) nothing to add to: 4 instead of 8 bytes per element
-            static_for<0, 9>([&](auto Tq) {
-                constexpr int t = decltype(Tq)::value;
-                float old[16];
+            if (dw_zero) {
+                static_for<0, 9>([&](auto Tq) {
+                    constexpr int t = decltype(Tq)::value;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = (r & 3) + 8 * (r >> 2);
-                    old[r] = (!dw_zero && co0 + ro < Cout) ? dwt[lane_off + (uint32_t)(ro * 9 * Cin + t * Cin)] : 0.f;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        if (co0 + ro < Cout) dwt[lane_off + (uint32_t)(ro * 9 * Cin + t * Cin)] = acc[t][r];
+                    }
+                });
+            } else {
+                // read-modify-write, tap by tap with a compiler barrier between them: hoisted together the 144 loads need 144 more
+                // registers than the kernel has.  (Rare inside a trainer step -- the arenas are fresh; ~25 us per tile for one
+                // workgroup.  A two-tap pipeline of the loads was built and spilled INTO the slab loop: not kept.)
+                static_for<0, 9>([&](auto Tq) {
+                    constexpr int t = decltype(Tq)::value;
+                    float old[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = (r & 3) + 8 * (r >> 2);
-                    if (co0 + ro < Cout) dwt[lane_off + (uint32_t)(ro * 9 * Cin + t * Cin)] = old[r] + acc[t][r];
-                }
-                asm volatile("" ::: "memory");
-            });
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        old[r] = (co0 + ro < Cout) ? dwt[lane_off + (uint32_t)(ro * 9 * Cin + t * Cin)] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        if (co0 + ro < Cout) dwt[lane_off + (uint32_t)(ro * 9 * Cin + t * Cin)] = old[r] + acc[t][r];
+                    }
+                    asm volatile("" ::: "memory");
+                });
+            }
         } else {
-            float* __restrict__ tl = ws + (size_t)(2 * wg + (first_seg ? 0 : 1)) * WB_TILE;      // uniform
+            float* __restrict__ tl = ws + (size_t)slot * WB_TILE;      // uniform
             uint32_t lane_off = (uint32_t)((cb * 32 + 4 * hh) * 64 + cib * 32 + l31);
             asm volatile("" : "+v"(lane_off));
 #pragma unroll
@@ -348,14 +425,12 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
                 for (int r = 0; r < 16; ++r)
                     tl[lane_off + (uint32_t)((t * 128 + (r & 3) + 8 * (r >> 2)) * 64)] = acc[t][r];
         }
-        // bias gradient of the segment's slabs: every column of accb holds the same sums (lanes 0 and 32 carry a wave's 32 channels);
+        // bias gradient of the segment's slabs: lanes l and l + 32 hold the two pixel halves of channel cb * 32 + (l & 31); folded, then
         // gathered through LDS into one 128-lane atomic per segment
         if (want_bias) {                              // block-uniform
             float* red = (float*)(smem + RED_OFF);    // [2 ci waves][128 co]
-            if (l31 == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[cib * 128 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accb[r];
-            }
+            const float tot = bsum + __shfl_xor(bsum, 32, 64);
+            if (lane < 32) red[cib * 128 + cb * 32 + lane] = tot;
             __syncthreads();
             if (tid < 128) {
                 const int co = tco * 128 + tid;
@@ -363,8 +438,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
             }
             __syncthreads();                          // (red is rewritten by the next segment)
         }
-        u = seg_end;
-        first_seg = false;
+        if (long_seg) long_seg = false;
+        else { u = seg_end; first_short = false; }
     }
 }
 
@@ -376,55 +451,80 @@ __global__ __launch_bounds__(256) void wgrad_batch_fixup_kernel(const WbBatch b,
     const WbJob& J = b.j[k];
     const int rel = (int)blockIdx.x - f.first_block[k];
     const int tile = rel / WB_FIX_PARTS, part = rel - tile * WB_FIX_PARTS;
-    const WbPlan* __restrict__ P = (const WbPlan*)(ws + (size_t)2 * b.G * WB_TILE);
-    const int ns = P->ns[k], nb = P->nb[k];
-    if (ns == 0 || nb == 1) return;                   // nothing ran / a long job whose tiles have one owner each
-    const int Tn = J.tiles_co * J.tiles_ci;
-    // the fragment slots of this tile: long job -- 2 (wbase + blk Tn + tile) for every block; stream-K -- the workgroups w' whose
-    // ranges meet the tile's units [ua, ue): slot 2 (w_long + w') when the tile holds w's first unit (its first segment), + 1 else
-    int w_lo = 0, w_hi = 0, ua = 0;
-    const int w_long = P->w_long, G = P->g_short, U = P->u_short;
-    if (nb == 0) {
-        ua = P->pre[k] + tile * ns;
-        const int ue = ua + ns;
-        auto owner = [&](int u) {
-            int w = (int)(((long)u * (long)G) / (long)U);
-            if (w > G - 1) w = G - 1;
-            while (w + 1 < G && wb_u0(w + 1, U, G) <= u) ++w;
-            while (w > 0 && wb_u0(w, U, G) > u) --w;
-            return w;
-        };
-        w_lo = owner(ua); w_hi = owner(ue - 1);
-        if (w_lo == w_hi) return;                     // one owner: it added the tile itself
-    } else {
-        w_hi = nb - 1;
+    const int G = b.G;
+    // the plan into LDS first (one coalesced read): the owner search below evaluates the unit map a few dozen times, and from
+    // global memory every evaluation was a chain of dependent loads -- the fix-up took longer than the fragments it adds
+    __shared__ WbPlan Ps;
+    __shared__ int s_slots[WB_FIX_LIST], s_nslots;
+    {
+        const int* src = (const int*)(ws + (size_t)WB_SLOTS * G * WB_TILE);
+        for (int i = threadIdx.x; i < (int)(sizeof(WbPlan) / 4); i += blockDim.x) ((int*)&Ps)[i] = src[i];
     }
+    __syncthreads();
+    const WbPlan* P = &Ps;
+    const int ns = P->ns[k], nb = P->nb[k];
+    if (ns == 0 || nb == 1) return;                   // nothing ran / a long job whose tiles have one owner each (block-uniform)
+    const int Tn = J.tiles_co * J.tiles_ci;
+    // the fragment slots of this tile: long job -- 3 (wbase + blk Tn + tile) for every block; stream-K -- the workgroups w whose
+    // unit ranges meet the tile's units [ua, ue): slot 3 w + 1 when the tile holds w's first unit (its first segment), 3 w + 2 else
+    if (threadIdx.x == 0) {
+        int n = 0;
+        if (nb == 0) {
+            const int ua = P->pre[k] + tile * ns, ue = ua + ns;
+            auto owner = [&](int u) {                 // the last workgroup whose first unit is <= u (binary search: first units are monotone)
+                int lo = 0, hi = G - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (wb_first_unit(P, b, mid) <= u) lo = mid; else hi = mid - 1;
+                }
+                return lo;
+            };
+            const int w_lo = owner(ua), w_hi = owner(ue - 1);
+            if (w_lo != w_hi)                         // (one owner: it added the tile itself)
+                for (int w = w_lo; w <= w_hi && n < WB_FIX_LIST; ++w) {
+                    const int u0 = wb_first_unit(P, b, w), u1 = wb_first_unit(P, b, w + 1);
+                    if (u0 < u1) s_slots[n++] = WB_SLOTS * w + (u0 >= ua ? 1 : 2);      // (skipping workgroups without stream-K units)
+                }
+        } else {
+            n = nb;                                   // (a long job's slots follow from the block index: no list)
+        }
+        s_nslots = n;
+    }
+    __syncthreads();
+    const int nslots = s_nslots;
+    if (nslots == 0) return;
     const int tci = tile % J.tiles_ci, tco = tile / J.tiles_ci;
     const int Ktot = 9 * J.Cin;
+    const bool dw_zero = (J.flags & S2E_WGRAD_BATCH_DW_ZERO) != 0;        // nothing in dW yet: stored, not added
 #pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
-        const int idx4 = part * 1024 + i * 256 + (int)threadIdx.x;        // float4 index in the tile: [tap][co % 128][ci % 64 / 4]
+    for (int i = 0; i < 12; ++i) {
+        const int idx4 = part * 3072 + i * 256 + (int)threadIdx.x;        // float4 index in the tile: [tap][co % 128][ci % 64 / 4]
         const int c4 = idx4 & 15, row = (idx4 >> 4) & 127, t = idx4 >> 11;
         const int co = tco * 128 + row;
         if (co >= J.Cout) continue;
         f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-        for (int w = w_lo; w <= w_hi; ++w) {
-            int slot;
-            if (nb == 0) {
-                const int u0 = wb_u0(w, U, G), u1 = wb_u0(w + 1, U, G);
-                if (u0 >= u1) continue;               // (a workgroup without units)
-                slot = 2 * (w_long + w) + (u0 >= ua ? 0 : 1);
-            } else {
-                slot = 2 * (P->wbase[k] + w * Tn + tile);
-            }
+        for (int q = 0; q < nslots; ++q) {
+            const int slot = nb > 0 ? WB_SLOTS * (P->wbase[k] + q * Tn + tile) : s_slots[q];
             const f32x4_t v = *(const f32x4_t*)(ws + (size_t)slot * WB_TILE + (size_t)idx4 * 4);
             a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
         }
         float* dst = J.dw + (size_t)co * Ktot + t * J.Cin + tci * 64 + c4 * 4;
-        f32x4_t o = *(f32x4_t*)dst;
-        o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3];
-        *(f32x4_t*)dst = o;
+        if (!dw_zero) {
+            const f32x4_t o = *(f32x4_t*)dst;
+            a[0] += o[0]; a[1] += o[1]; a[2] += o[2]; a[3] += o[3];
+        }
+        *(f32x4_t*)dst = a;
     }
+}
+
+// experiment switch S2E_WGRAD_BATCH_SPARE: the least spare capacity (units) of a long job's workgroup that is filled with stream-K
+// units.  Default: never -- long jobs' workgroups do nothing else.  Measured with 48 (same box, tools/check_wgrad_batch.py --bench /
+// the replayed step): the quota drops from 517 to 467 slabs, and the launch takes 2.8 instead of 2.2 ms, the step 17.44 instead of
+// 17.30 ms: a unit of a many-tile job is dearer than a long job's slab (every 16-slab tile ends with a 288-KB write-out by ONE
+// workgroup), so equal unit counts leave the stream-K workgroups, now fewer, on the critical path.
+int wb_spare_min() {
+    static const int v = [] { const char* e = getenv("S2E_WGRAD_BATCH_SPARE"); return e && atoi(e) > 0 ? atoi(e) : (1 << 30); }();
+    return v;
 }
 
 int wb_workgroups() {
@@ -449,7 +549,7 @@ extern "C" int s2e_wgrad_batch_supported(int dtype, int N, int H, int W, int Cin
 }
 
 extern "C" size_t s2e_wgrad_batch_workspace_bytes(void) {
-    return (size_t)2 * wb_workgroups() * WB_TILE * sizeof(float) + ((sizeof(WbPlan) + 255) & ~(size_t)255);      // fragments + the plan
+    return (size_t)WB_SLOTS * wb_workgroups() * WB_TILE * sizeof(float) + ((sizeof(WbPlan) + 255) & ~(size_t)255);      // fragments + the plan
 }
 
 extern "C" int s2e_wgrad_batch(int dtype, const s2e_wgrad_batch_job* jobs, int n_jobs, void* workspace, size_t workspace_bytes, void* stream) {
@@ -460,7 +560,7 @@ extern "C" int s2e_wgrad_batch(int dtype, const s2e_wgrad_batch_job* jobs, int n
         const int cnt = n_jobs - base < WB_MAX_JOBS ? n_jobs - base : WB_MAX_JOBS;
         WbBatch B{};
         WbFix F{};
-        B.n = cnt; B.G = wb_workgroups();
+        B.n = cnt; B.G = wb_workgroups(); B.spare_min = wb_spare_min();
         int blocks = 0;
         for (int i = 0; i < cnt; ++i) {
             const s2e_wgrad_batch_job& h = jobs[base + i];

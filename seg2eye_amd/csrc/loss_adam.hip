@@ -132,6 +132,30 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
     const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
     const float lr_bc1 = lr / bc1, rsqrt_bc2 = 1.f / sqrtf(bc2);
     const long nv = n / 4;
+    // beta1 == 0 (the reference's TTUR setting, pix2pix_model.py:98-108) and no weight decay: m_t = g_t * grad_scale EXACTLY, whatever m_{t-1}
+    // was (0 * m + 1 * g), and bc1 = 1 -- so the first moment is neither read nor written: 20 instead of 28 bytes per parameter, the
+    // same bits in p and v.  (The caller can form m from g when it wants to save it: optim.FlatAdam.state_dict.)
+    if (beta1 == 0.f && wd == 0.f) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+            f32x4_t pp = ((f32x4_t*)p)[i], gg = ((const f32x4_t*)g)[i], vv = ((f32x4_t*)v)[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gr = gg[j] * grad_scale + wd * pp[j];
+                const float mj = beta1 * 0.f + (1.f - beta1) * gr;
+                vv[j] = beta2 * vv[j] + (1.f - beta2) * gr * gr;
+                pp[j] -= lr_bc1 * mj / (sqrtf(vv[j]) * rsqrt_bc2 + eps);
+            }
+            ((f32x4_t*)p)[i] = pp; ((f32x4_t*)v)[i] = vv;
+        }
+        if (blockIdx.x == 0)
+            for (long i = nv * 4 + threadIdx.x; i < n; i += blockDim.x) {
+                const float gr = g[i] * grad_scale + wd * p[i];
+                const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+                v[i] = vi;
+                p[i] -= lr_bc1 * ((1.f - beta1) * gr) / (sqrtf(vi) * rsqrt_bc2 + eps);
+            }
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
         f32x4_t pp = ((f32x4_t*)p)[i], gg = ((const f32x4_t*)g)[i], mm = ((f32x4_t*)m)[i], vv = ((f32x4_t*)v)[i];
 #pragma unroll

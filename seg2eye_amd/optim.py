@@ -86,6 +86,7 @@ class FlatAdam:
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
+        self._g_is_last_step = False
         ops.ZeroPool.arena_zeroed(self.flat_g)               # (lets the in-place spectral-norm chain rule know the arena is fresh)
 
     def rebind_grads(self):
@@ -114,6 +115,7 @@ class FlatAdam:
         self.step_count += 1
         k = self.numel_active
         ops.adam_flat_step(self.flat_p[:k], self.flat_g[:k], self.flat_m[:k], self.flat_v[:k], self.hyper)
+        self._g_is_last_step = True
 
     def _layout(self):
         """What the flat moment arrays mean: element i belongs to which parameter, in which memory order.  `shapes` is the
@@ -122,8 +124,20 @@ class FlatAdam:
         return {'offsets': list(self.offsets), 'channels_last': [bool(c) for c in self.cl],
                 'shapes': [tuple(int(d) for d in p.shape) for p in self.params]}
 
+    def _first_moment(self):
+        """The first-moment arena as torch.optim.Adam would hold it.  With beta1 == 0 and no weight decay (the reference's TTUR
+        setting) s2e_adam_flat does not touch flat_m -- m_t = g_t * grad_scale exactly, whatever m was -- so it is formed here from
+        the gradient arena when that still holds the gradients of the last step (between step() and the next zero_grad()).
+        (With beta1 == 0 the saved m never influences a resumed run: the next step overwrites it.)"""
+        if self.betas[0] == 0.0 and float(self.hyper[6]) == 0.0 and self.step_count > 0 and self.__dict__.get('_g_is_last_step', False):
+            k = self.numel_active
+            m = self.flat_m.clone()
+            m[:k] = self.flat_g[:k] * self._hyper_host[1]
+            return m
+        return self.flat_m
+
     def state_dict(self):
-        return {'step': self.step_count, 'm': self.flat_m, 'v': self.flat_v, 'lr': self.param_groups[0]['lr'], 'layout': self._layout()}
+        return {'step': self.step_count, 'm': self._first_moment(), 'v': self.flat_v, 'lr': self.param_groups[0]['lr'], 'layout': self._layout()}
 
     def load_state_dict(self, sd, trust_param_order=False):
         """Moments saved by another FlatAdam.  With a `layout` that carries `shapes` the parameter signature must match; the

@@ -922,6 +922,78 @@ def test_cfg3_as_benched_matches_reference():
     assert max(g5.values()) < 8e-2, g5
 
 
+def _trajectory(dt, graphs, z, iters, seeds):
+    """`iters` G+D iterations of Pix2PixTrainer at the benchmarked configuration from the fixture's weights, batch `seeds[it % len]`
+    at iteration it.  -> per-iteration losses, the last generated image, the G / D parameter arenas before and after."""
+    from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
+    opt = _opt(ngf=64, ndf=64, crop_size=256, aspect_ratio=1.0, batchSize=8, compute_dtype=dt, hip_graphs=graphs)
+    tr = Pix2PixTrainer(opt)
+    m = tr.pix2pix_model
+    for tag, net in (('G', m.netG), ('D', m.netD), ('E', m.netE)):
+        sd = filled_state(z, tag)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(sd[k])
+    batches = [_batch(8, 256, 256, sd) for sd in seeds]
+    p0 = (tr.optimizer_G.flat_p.clone(), tr.optimizer_D.flat_p.clone())
+    losses = []
+    for it in range(iters):
+        data = batches[it % len(batches)]
+        tr.run_generator_one_step(dict(data))
+        tr.run_discriminator_one_step(dict(data))
+        losses.append({k: float(v.detach().float().mean()) for k, v in tr.get_latest_losses().items()})
+    torch.cuda.synchronize()
+    out = {'losses': losses, 'fake': tr.get_latest_generated().detach().float().cpu(), 'p0': p0,
+           'p': (tr.optimizer_G.flat_p.clone(), tr.optimizer_D.flat_p.clone()), 'graphs': tr.use_graphs and tr.graph_G is not None}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
+def test_bf16_trajectory_tracks_fp32_over_20_iterations():
+    """the benchmarked dtype beyond ONE step.  20 G+D iterations of trainers/pix2pix_trainer.py:26-45 at the bench's
+    size (ngf = ndf = 64, 256x256, batch 8; four batches in rotation) from the same weights:
+      A, A' -- fp32, eager, twice: their difference is the trajectory's OWN run-to-run spread (weight-gradient partial sums are
+               combined with float atomics, and Adam with beta1 = 0 turns a 1e-7 difference of a near-zero gradient into a +-lr step);
+      B     -- bf16 with hipGraphs on (what bench.py times).
+    What can be asked of B is set by A': this GAN is chaotic at the fixture's weights -- measured (round 5), A' itself leaves A within
+    ~6 iterations: by iteration 20 its losses differ from A's by 0.06-0.40 (of max(1, |loss|)), its last generated image by rel-RMS
+    1.6 (decorrelated), its parameters by 0.83 (G) / 0.46 (D) of the distance training moved them.  So: (1) while the trajectories
+    still coincide -- the first 3 iterations -- B's losses are within 5 % of A's (measured 0.8 %); (2) over all 20 iterations B stays
+    as close to A as another fp32 run does, up to a stated factor: parameter distance and image rel-RMS <= 1.5 x A' 's (+ 0.05),
+    worst loss deviation <= 5 x A' 's (+ 0.05) (measured: 0.90 vs 0.83 and 0.52 vs 0.46; 1.44 vs 1.60; 0.84 vs 0.27)."""
+    z = load_golden('trainer_ngf64_256_n8')
+    iters, seeds = 20, (1234, 77, 2024, 5)
+    a = _trajectory('fp32', False, z, iters, seeds)
+    a2 = _trajectory('fp32', False, z, iters, seeds)
+    b = _trajectory('bf16', True, z, iters, seeds)
+    assert b['graphs'], 'the bf16 run did not replay hipGraphs'
+    # per loss: the largest deviation from A over the 20 iterations, in units of max(1, |loss|) -- for B and for A's own rerun
+    worst, spread = {}, {}
+    for it in range(iters):
+        for k, v in a['losses'][it].items():
+            worst[k] = max(worst.get(k, 0.0), abs(b['losses'][it][k] - v) / max(1.0, abs(v)))
+            spread[k] = max(spread.get(k, 0.0), abs(a2['losses'][it][k] - v) / max(1.0, abs(v)))
+    early = max(abs(b['losses'][it][k] - v) / max(1.0, abs(v)) for it in range(3) for k, v in a['losses'][it].items())
+    per_it = lambda r: [round(max(abs(r['losses'][it][k] - v) / max(1.0, abs(v)) for k, v in a['losses'][it].items()), 3) for it in range(iters)]
+    print('trajectory losses: worst deviation bf16 %s | fp32 rerun %s | bf16, first 3 iterations %.4f'
+          % ({k: round(v, 4) for k, v in worst.items()}, {k: round(v, 4) for k, v in spread.items()}, early))
+    print('trajectory losses, max deviation per iteration: bf16 %s | fp32 rerun %s' % (per_it(b), per_it(a2)))
+    img_b, img_a2 = _relrms(b['fake'], a['fake']), _relrms(a2['fake'], a['fake'])
+    rep = {}
+    for i, tag in enumerate(('G', 'D')):
+        moved = (a['p'][i] - a['p0'][i]).double().norm()                       # how far 20 iterations moved the parameters
+        rep[tag] = (float((b['p'][i] - a['p'][i]).double().norm() / moved), float((a2['p'][i] - a['p'][i]).double().norm() / moved))
+    print('trajectory (20 it): worst loss deviation %s | image rel-RMS bf16 %.4f, fp32 rerun %.4f | parameter distance / movement: %s'
+          % ({k: round(v, 4) for k, v in worst.items()}, img_b, img_a2, {k: (round(x, 4), round(y, 4)) for k, (x, y) in rep.items()}))
+    assert early < 5e-2, early
+    for k in worst:
+        assert worst[k] < 5.0 * spread[k] + 5e-2, (k, worst[k], spread[k])
+    assert img_b < 1.5 * img_a2 + 5e-2, (img_b, img_a2)
+    for tag, (db, da) in rep.items():
+        assert db < 1.5 * da + 5e-2, (tag, db, da)          # as far from A as another fp32 run, up to the stated factor
+
+
 def test_cfg5_train_step_matches_reference():
     """BASELINE.json configs[4]'s per-GPU workload -- ngf = ndf = 64, 640x384 (--crop_size 384 --aspect_ratio 0.6), batch 4,
     encoder + feature matching on -- against ONE G step + ONE D step of the real reference's Pix2PixTrainer
@@ -1249,8 +1321,8 @@ def test_label_sparse_forward_under_graph_replay_with_changing_labels():
     assert counts[0] < counts[1] < rc[0].numel(), counts
     res = {}
     for mode in ('eager', 'graph', 'dense'):
-        old = ops._SPARSE_OFF
-        ops._SPARSE_OFF = mode == 'dense'
+        old = ops.switches.SPARSE_OFF
+        ops.switches.SPARSE_OFF = mode == 'dense'
         try:
             opt = _opt(ngf=64, ndf=64, crop_size=256, aspect_ratio=1.0, batchSize=2, compute_dtype='bf16', hip_graphs=(mode == 'graph'))
             tr = Pix2PixTrainer(opt)
@@ -1270,7 +1342,7 @@ def test_label_sparse_forward_under_graph_replay_with_changing_labels():
             res[mode] = imgs
             del tr, m
         finally:
-            ops._SPARSE_OFF = old
+            ops.switches.SPARSE_OFF = old
         torch.cuda.empty_cache()
     assert torch.equal(res['eager'][0], res['graph'][0])                               # same weights, same labels: same bits
     # Iteration 1 is the check that matters: the first replay on a map whose rectangle classes differ from the captured one's

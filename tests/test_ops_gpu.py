@@ -390,7 +390,7 @@ def test_spade_label_sparse_backward(cfg):
     yr.backward(gy.double())
     got = {}
     for off in (True, False):
-        ops._SPARSE_BWD_OFF = off
+        ops.switches.SPARSE_BWD_OFF = off
         try:
             prm = [torch.nn.Parameter(t.to(dev)) for t in (w_sh, b_sh, w_gb[:C].clone(), b_gb[:C].clone(), w_gb[C:].clone(), b_gb[C:].clone())]
             fa = FlatAdam([prm[0], prm[1], prm[2], prm[4], prm[3], prm[5]], lr=1e-3)         # gamma / beta weights (and biases) adjacent
@@ -409,7 +409,7 @@ def test_spade_label_sparse_backward(cfg):
                 sp = pool.step_cache                                              # (cleared at scope exit: counts were read inside)
             got[off] = [q.grad.detach().clone() for q in prm]
         finally:
-            ops._SPARSE_BWD_OFF = False
+            ops.switches.SPARSE_BWD_OFF = False
     for off in (True, False):
         g = got[off]
         tag = 'dense' if off else 'sparse'
@@ -480,16 +480,20 @@ def test_losses(dtype, n):
         _close(ag.grad, ar.grad, dtype, what='loss grad %d' % mode)
 
 
+@pytest.mark.parametrize('beta1', [0.0, 0.5])
 @pytest.mark.parametrize('wd', [0.0, 0.05])
-def test_adam_flat_matches_torch(wd):
+def test_adam_flat_matches_torch(wd, beta1):
+    """s2e_adam_flat against torch.optim.Adam: parameters AND both moments after four steps.  beta1 = 0, wd = 0 is the reference's
+    TTUR setting (pix2pix_model.py:98-108): there the kernel skips the first moment altogether (m_t = g_t exactly) and
+    FlatAdam.state_dict forms it from the gradient arena."""
     from seg2eye_amd.optim import FlatAdam
     dev = _dev()
     n = 10007
     p0 = _rnd((n,), 51, torch.float32)
     ref = torch.nn.Parameter(p0.clone())
-    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.0, 0.9), eps=1e-8, weight_decay=wd)
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(beta1, 0.9), eps=1e-8, weight_decay=wd)
     mine = torch.nn.Parameter(p0.to(dev).clone())
-    fa = FlatAdam([mine], lr=1e-3, betas=(0, 0.9), weight_decay=wd)
+    fa = FlatAdam([mine], lr=1e-3, betas=(beta1, 0.9), weight_decay=wd)
     for step in range(1, 5):
         g = _rnd((n,), 60 + step, torch.float32)
         if step == 3:
@@ -501,6 +505,11 @@ def test_adam_flat_matches_torch(wd):
         fa.step(grad_scale=0.5)                          # ... averaged inside the kernel
     assert float(fa.hyper[4]) == 4.0
     np.testing.assert_allclose(mine.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    sd, st = fa.state_dict(), opt.state[ref]
+    np.testing.assert_allclose(sd['v'][:n].cpu().numpy(), st['exp_avg_sq'].numpy(), rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(sd['m'][:n].cpu().numpy(), st['exp_avg'].numpy(), rtol=1e-5, atol=1e-7)
+    if beta1 == 0.0 and wd == 0.0:
+        assert float(fa.flat_m.abs().max()) == 0.0      # never touched by the kernel
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -138,8 +138,10 @@ def main():
             for x, gy, dw, db, _, _ in bj:
                 ops.conv2d_wgrad_raw(x, gy, 3, 3, 1, 1, ops.ACT_NONE, True, db, dw_out=dw)
 
+        last = {}
+
         def batched():
-            run_batch(bj, dev)
+            last['ws'] = run_batch(bj, dev)
         for name, fn in (('per-layer launches', per_layer), ('one batched launch', batched), ('per-layer launches', per_layer), ('one batched launch', batched)):
             for _ in range(2):
                 fn()
@@ -164,6 +166,16 @@ def main():
             eb = float((j[3] - db).abs().max()) / float(db.abs().max())
             assert e < 1e-4 and eb < 1e-4, (hw, cin, cout, e, eb)
         print('batched == per-layer on the bench mix')
+        # the plan workgroup 0 left behind the fragment slots (csrc/conv_wgrad_batch.hip: WbPlan)
+        ws = last['ws']
+        nwg = (ws.numel() * 4 - 1024) // (3 * 9 * 128 * 64 * 4)
+        plan = ws[3 * nwg * 9 * 128 * 64:].view(torch.int32).cpu().numpy()
+        w_long, q, u_short, n = [int(v) for v in plan[:4]]
+        nb = [int(v) for v in plan[8 + 32:8 + 64][:n]]
+        cap = [int(v) for v in plan[8 + 96:8 + 128][:n]]
+        wbase = [int(v) for v in plan[8 + 64:8 + 96][:n]]
+        print('plan: %d workgroups, quota %d, %d start with a long block, %d stream-K units; blocks per tile %s; first workgroup %s; spare %s'
+              % (nwg, q, w_long, u_short, nb, wbase, cap))
 
 
 if __name__ == '__main__':

@@ -4,7 +4,7 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
-    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r04/pmc [steps-profiled]
+    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r05/pmc [steps-profiled]
 
 Counters are in KB; FETCH_SIZE is doubled (gfx950 counts a 128-B request as 64 B: MI355X_MICROARCH.md, HBM section).
 Families are seg2eye_amd.ops.LaunchProfiler's -- one per C-ABI entry point (the conv entry points split by
@@ -27,6 +27,8 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'conv_finish_kernel': ('conv_igemm', False),          # (also finishes the patch kernel's channel-chunk splits)
     'fwd_cout1_kernel': ('conv_small', True), 'fwd_cin1_kernel': ('conv_small', True), 'dgrad_cout1_kernel': ('conv_small', True),
     'conv_wgrad_patch_kernel': ('conv_wgrad_patch', True),
+    # (round 5: the queued patch-resident weight gradients of a backward as ONE launch + a fix-up: csrc/conv_wgrad_batch.hip)
+    'conv_wgrad_batch_kernel': ('conv_wgrad_patch', True), 'wgrad_batch_fixup_kernel': ('conv_wgrad_patch', False),
     'wgrad_patch_reduce_kernel': ('conv_wgrad_patch', False),
     'conv_wgrad_c8_kernel': ('conv_wgrad_patch', True), 'wgrad_c8_reduce_kernel': ('conv_wgrad_patch', False),
     'conv_wgrad_kernel': ('conv_wgrad', True), 'conv_wgrad_glds_kernel': ('conv_wgrad', True),
