@@ -52,7 +52,7 @@ struct WbJob {
     int flags, pad_;                                  // S2E_WGRAD_BATCH_DW_ZERO: dW holds zeros (a single-owner tile is stored, not added)
 };
 constexpr int WB_MAX_JOBS = 32;
-struct WbBatch { int n, G, spare_min, pad_; WbJob j[WB_MAX_JOBS]; };      // spare_min: see wb_make_plan
+struct WbBatch { int n, G, spare_min, ov; WbJob j[WB_MAX_JOBS]; };      // spare_min, ov: see wb_make_plan
 constexpr int WB_TILE = 9 * 128 * 64;                  // floats per (partial) tile: [tap][co % 128][ci % 64]
 constexpr int WB_SLOTS = 3;                           // fragment slots per workgroup: a long job's block, the first and the last stream-K segment
 constexpr int WB_FIX_LIST = 512;                       // most workgroups one stream-K tile can be shared by (the fix-up's slot list)
@@ -92,23 +92,27 @@ __device__ __forceinline__ void wb_make_plan(const WbBatch& b, int G, WbPlan* P)
     if (tid < b.n) P->ns[tid] = b.j[tid].rect_count ? 2 * *b.j[tid].rect_count : b.j[tid].nslabs;
     __syncthreads();
     if (tid < 64) {
+        // Cost model: a slab is one unit; every SEGMENT (a visit of a tile: pipeline fill, 288-KB write-out by one workgroup, bias
+        // fold) costs `ov` units on top -- measured ~4 (a plain store of the tile) to ~7 (read-modify-write) slabs' time.  Without it
+        // equal unit counts left the workgroups that walk many 16-slab tiles 15-25 % behind the ones on one long block.  A stream-K
+        // tile therefore has ns + ov VIRTUAL units, the first ov of them standing for no slab (whoever gets only those does nothing).
+        const int ov = b.ov;
         long U = 0;
-        for (int k = 0; k < b.n; ++k) U += (long)P->ns[k] * (b.j[k].tiles_co * b.j[k].tiles_ci);
-        const int q0 = (int)((U + G - 1) / G) > 0 ? (int)((U + G - 1) / G) : 1;
+        for (int k = 0; k < b.n; ++k) U += (long)(P->ns[k] > 0 ? P->ns[k] + ov : 0) * (b.j[k].tiles_co * b.j[k].tiles_ci);
+        const int q0 = (int)((U + G - 1) / G) > ov + 1 ? (int)((U + G - 1) / G) : ov + 2;
         const int qc = q0 + (int)(((long)q0 * tid) >> 6);                 // this lane's candidate quota
-        // long jobs (ns > qc) take nb = ceil(ns / qc) blocks of ceil(ns / nb) slabs per tile, one workgroup each; what such a
-        // workgroup's quota has left is filled with the short jobs' units -- when it is worth a segment of its own (>= spare_min
-        // units: a segment costs a pipeline fill and a 288-KB write-out, about two slabs' time; a 4096-slab job at quota 460 leaves
-        // 4 units per workgroup, and dealing those out made 117 fragments for 468 slabs of work) -- the others' whole quota is
+        // long jobs (a tile does not fit a quota: ns + ov > qc) take nb = ceil(ns / (qc - ov)) blocks of ceil(ns / nb) slabs per tile,
+        // one workgroup each; what such a workgroup's quota has left is filled with the short jobs' units when it is worth a segment
+        // of its own (>= spare_min units) -- the others' whole quota is
         long wgs = 0, room = 0, us = 0;
         for (int k = 0; k < b.n; ++k) {
             const int ns = P->ns[k], Tn = b.j[k].tiles_co * b.j[k].tiles_ci;
-            if (ns > qc) {
-                const int nb = (ns + qc - 1) / qc, spare = qc - (ns + nb - 1) / nb;
+            if (ns + ov > qc) {
+                const int nb = (ns + (qc - ov) - 1) / (qc - ov), spare = qc - ov - (ns + nb - 1) / nb;
                 wgs += (long)nb * Tn;
                 if (spare >= b.spare_min) room += (long)nb * Tn * spare;
-            } else {
-                us += (long)ns * Tn;
+            } else if (ns > 0) {
+                us += (long)(ns + ov) * Tn;
             }
         }
         room += ((long)G - wgs) * qc;
@@ -122,7 +126,7 @@ __device__ __forceinline__ void wb_make_plan(const WbBatch& b, int G, WbPlan* P)
                 const int ns = P->ns[k], Tn = b.j[k].tiles_co * b.j[k].tiles_ci;
                 P->pre[k] = a;
                 P->nb[k] = 0; P->wbase[k] = 0; P->cap[k] = 0; P->sbase[k] = 0;
-                if (ns <= qstar) a += ns * Tn;
+                if (ns > 0 && ns + ov <= qstar) a += (ns + ov) * Tn;
             }
             P->pre[b.n] = a;
             // The long jobs' workgroups, jobs with MORE tiles first: the T workgroups that walk one block together must share an
@@ -133,8 +137,8 @@ __device__ __forceinline__ void wb_make_plan(const WbBatch& b, int G, WbPlan* P)
             for (int tt = 64; tt >= 1; tt >>= 1)               // (64: that many tiles or more)
                 for (int k = 0; k < b.n; ++k) {
                     const int ns = P->ns[k], Tn = b.j[k].tiles_co * b.j[k].tiles_ci;
-                    if (ns <= qstar || Tn < tt || (tt < 64 && Tn >= 2 * tt)) continue;
-                    const int nb = (ns + qstar - 1) / qstar, spare = qstar - (ns + nb - 1) / nb;
+                    if (ns + ov <= qstar || Tn < tt || (tt < 64 && Tn >= 2 * tt)) continue;
+                    const int nb = (ns + (qstar - ov) - 1) / (qstar - ov), spare = qstar - ov - (ns + nb - 1) / nb;
                     P->nb[k] = nb; P->wbase[k] = w; P->cap[k] = spare >= b.spare_min ? spare : 0; P->sbase[k] = sp;
                     w += nb * Tn;
                     sp += (long)nb * Tn * P->cap[k];
@@ -234,11 +238,13 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_batch_kernel(const WbBatch 
         } else {
             if (first_short) k = 0;
             while (u >= rfl(P->pre[k + 1])) ++k;      // (long jobs and jobs without slabs hold no stream-K unit: stepped over)
-            const int ns = rfl(P->ns[k]), pre = rfl(P->pre[k]);
-            tile = (u - pre) / ns;
-            s0 = (u - pre) - tile * ns;
-            seg_end = min(u_last, pre + (tile + 1) * ns);
-            s1 = s0 + (seg_end - u);
+            const int ns = rfl(P->ns[k]), pre = rfl(P->pre[k]), nsv = ns + b.ov;       // (virtual units per tile: wb_make_plan)
+            tile = (u - pre) / nsv;
+            const int va = (u - pre) - tile * nsv;
+            seg_end = min(u_last, pre + (tile + 1) * nsv);
+            s0 = max(va - b.ov, 0);
+            s1 = max(va + (seg_end - u) - b.ov, 0);
+            if (s0 >= s1) { u = seg_end; continue; }  // only overhead units of this tile: nothing to do for it
             whole = s0 == 0 && s1 == ns;              // the tile has no other owner: straight into dW
             slot = WB_SLOTS * wg + (first_short ? 1 : 2);
         }
@@ -470,7 +476,8 @@ __global__ __launch_bounds__(256) void wgrad_batch_fixup_kernel(const WbBatch b,
     if (threadIdx.x == 0) {
         int n = 0;
         if (nb == 0) {
-            const int ua = P->pre[k] + tile * ns, ue = ua + ns;
+            const int ov = b.ov, nsv = ns + ov;
+            const int ua = P->pre[k] + tile * nsv, ue = ua + nsv;        // the tile's VIRTUAL units (wb_make_plan)
             auto owner = [&](int u) {                 // the last workgroup whose first unit is <= u (binary search: first units are monotone)
                 int lo = 0, hi = G - 1;
                 while (lo < hi) {
@@ -480,11 +487,13 @@ __global__ __launch_bounds__(256) void wgrad_batch_fixup_kernel(const WbBatch b,
                 return lo;
             };
             const int w_lo = owner(ua), w_hi = owner(ue - 1);
-            if (w_lo != w_hi)                         // (one owner: it added the tile itself)
-                for (int w = w_lo; w <= w_hi && n < WB_FIX_LIST; ++w) {
-                    const int u0 = wb_first_unit(P, b, w), u1 = wb_first_unit(P, b, w + 1);
-                    if (u0 < u1) s_slots[n++] = WB_SLOTS * w + (u0 >= ua ? 1 : 2);      // (skipping workgroups without stream-K units)
-                }
+            for (int w = w_lo; w <= w_hi && n < WB_FIX_LIST; ++w) {
+                const int u0 = wb_first_unit(P, b, w), u1 = wb_first_unit(P, b, w + 1);
+                const int va = max(u0, ua) - ua, vb = min(u1, ue) - ua;
+                if (max(vb - ov, 0) > max(va - ov, 0))                   // (it holds slabs of the tile, not just overhead units)
+                    s_slots[n++] = WB_SLOTS * w + (u0 >= ua ? 1 : 2);
+            }
+            if (n == 1) n = 0;                        // one owner of all its slabs: it added the tile itself
         } else {
             n = nb;                                   // (a long job's slots follow from the block index: no list)
         }
@@ -518,12 +527,17 @@ __global__ __launch_bounds__(256) void wgrad_batch_fixup_kernel(const WbBatch b,
 }
 
 // experiment switch S2E_WGRAD_BATCH_SPARE: the least spare capacity (units) of a long job's workgroup that is filled with stream-K
-// units.  Default: never -- long jobs' workgroups do nothing else.  Measured with 48 (same box, tools/check_wgrad_batch.py --bench /
-// the replayed step): the quota drops from 517 to 467 slabs, and the launch takes 2.8 instead of 2.2 ms, the step 17.44 instead of
-// 17.30 ms: a unit of a many-tile job is dearer than a long job's slab (every 16-slab tile ends with a 288-KB write-out by ONE
-// workgroup), so equal unit counts leave the stream-K workgroups, now fewer, on the critical path.
+// units; a huge value = long jobs' workgroups do nothing else (the round's first version).  Measured, same box, the replayed step /
+// the dense 28-layer mix of tools/check_wgrad_batch.py --bench (spare, ov): (never, 0) 17.39 ms / 2.22 ms; (48, 0) -- equal unit
+// counts, no overhead term -- 17.44 / 2.78; (48, 4) 17.27 / 2.36; (24, 4) 17.26 / 2.19; (24, 6) 17.27.  Default 24 with ov = 4.
 int wb_spare_min() {
-    static const int v = [] { const char* e = getenv("S2E_WGRAD_BATCH_SPARE"); return e && atoi(e) > 0 ? atoi(e) : (1 << 30); }();
+    static const int v = [] { const char* e = getenv("S2E_WGRAD_BATCH_SPARE"); return e && atoi(e) > 0 ? atoi(e) : 24; }();
+    return v;
+}
+
+// experiment switch S2E_WGRAD_BATCH_OV: what a segment costs beside its slabs, in slabs (wb_make_plan's cost model)
+int wb_overhead() {
+    static const int v = [] { const char* e = getenv("S2E_WGRAD_BATCH_OV"); return e && atoi(e) >= 0 ? atoi(e) : 4; }();
     return v;
 }
 
@@ -560,7 +574,7 @@ extern "C" int s2e_wgrad_batch(int dtype, const s2e_wgrad_batch_job* jobs, int n
         const int cnt = n_jobs - base < WB_MAX_JOBS ? n_jobs - base : WB_MAX_JOBS;
         WbBatch B{};
         WbFix F{};
-        B.n = cnt; B.G = wb_workgroups(); B.spare_min = wb_spare_min();
+        B.n = cnt; B.G = wb_workgroups(); B.spare_min = wb_spare_min(); B.ov = wb_overhead();
         int blocks = 0;
         for (int i = 0; i < cnt; ++i) {
             const s2e_wgrad_batch_job& h = jobs[base + i];

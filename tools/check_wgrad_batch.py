@@ -61,6 +61,8 @@ def run_batch(jobs, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bench', action='store_true', help='also time the G step\'s job mix against the per-layer launches')
+    ap.add_argument('--mix', default='all', choices=['all', 'long', 'short'], help='--bench: all 28 layers, the 256^2 / 128^2 ones, or the rest')
+    ap.add_argument('--only-batched', action='store_true', help='--bench: time the batched launch only (for profiler runs)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     torch.manual_seed(3)
@@ -127,6 +129,12 @@ def main():
                (32, 128, 2048), (32, 128, 2048), (32, 128, 1024), (32, 1024, 512), (32, 512, 512),
                (16, 128, 2048), (16, 128, 2048), (16, 128, 2048), (16, 128, 2048),
                (16, 1024, 1024), (16, 1024, 1024), (16, 1024, 1024), (16, 1024, 1024)]
+        if args.mix != 'all':
+            mix = [m for m in mix if (m[0] >= 128) == (args.mix == 'long')]
+        units = sum(((cout + 127) // 128) * (cin // 64) * 8 * (hw // 8) * (hw // 16) for hw, cin, cout in mix)
+        print('mix %s: %d jobs, %d (tile, slab) units = %.1f per workgroup at 256; operands %.0f MB, dW %.0f MB'
+              % (args.mix, len(mix), units, units / 256.0, sum(8 * hw * hw * (cin + cout) * 2 for hw, cin, cout in mix) / 1e6,
+                 sum(9 * cin * cout * 4 for hw, cin, cout in mix) / 1e6))
         bj = []
         for hw, cin, cout in mix:
             x = torch.randn(8, hw, hw, cin, device=dev).to(torch.bfloat16)
@@ -142,7 +150,10 @@ def main():
 
         def batched():
             last['ws'] = run_batch(bj, dev)
-        for name, fn in (('per-layer launches', per_layer), ('one batched launch', batched), ('per-layer launches', per_layer), ('one batched launch', batched)):
+        runs = (('per-layer launches', per_layer), ('one batched launch', batched), ('per-layer launches', per_layer), ('one batched launch', batched))
+        if args.only_batched:
+            runs = (('one batched launch', batched),)
+        for name, fn in runs:
             for _ in range(2):
                 fn()
             torch.cuda.synchronize()
