@@ -169,13 +169,15 @@ def feat_tap(h, scale, pooled=False):
 
 # ------------------------------------------------------------------------------ optimizer
 
-def adam_flat_step(p, g, m, v, hyper):
+def adam_flat_step(p, g, m, v, hyper, skips_m=False):
     """One torch.optim.Adam step over flat fp32 arenas (pix2pix_model.py:92-110 semantics).
-    hyper: 6-float DEVICE tensor {lr, beta1, beta2, eps, completed steps, grad_scale}."""
+    hyper: 7-float DEVICE tensor {lr, beta1, beta2, eps, completed steps, grad_scale, weight_decay}.
+    skips_m: the caller knows beta1 == 0 and weight_decay == 0 (the kernel then leaves m alone): only the profiler's byte count uses it."""
     _need(p, g, m, v, hyper)
     LaunchProfiler.run('adam', 0.0, lambda: L.check(
         L.lib().s2e_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _stream()), 's2e_adam_flat'),
-        nbytes=float(7 * 4 * p.numel()))                              # SURVEY 8(d): read p, g, m, v + write p, m, v
+        # SURVEY 8(d): read p, g, m, v + write p, m, v = 28 B per parameter; without the first moment 20 B
+        nbytes=float((5 if skips_m else 7) * 4 * p.numel()))
 
 
 def openeds_error(produced, target):

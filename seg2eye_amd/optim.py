@@ -80,6 +80,7 @@ class FlatAdam:
         self.step_count = 0
         self.param_groups = [{'params': plist, 'lr': float(lr)}]         # update_learning_rate writes ['lr']
         # device-resident hyper-parameters {lr, beta1, beta2, eps, completed steps, grad_scale, weight_decay}
+        self._wd = float(weight_decay)
         self.hyper = torch.tensor([float(lr), self.betas[0], self.betas[1], self.eps, 0.0, 1.0, float(weight_decay)],
                                   dtype=torch.float32, device=dev)
         self._hyper_host = (float(lr), 1.0)
@@ -114,7 +115,8 @@ class FlatAdam:
         self.sync_hyper(grad_scale)
         self.step_count += 1
         k = self.numel_active
-        ops.adam_flat_step(self.flat_p[:k], self.flat_g[:k], self.flat_m[:k], self.flat_v[:k], self.hyper)
+        ops.adam_flat_step(self.flat_p[:k], self.flat_g[:k], self.flat_m[:k], self.flat_v[:k], self.hyper,
+                           skips_m=self.betas[0] == 0.0 and self._wd == 0.0)
         self._g_is_last_step = True
 
     def _layout(self):
@@ -129,7 +131,7 @@ class FlatAdam:
         setting) s2e_adam_flat does not touch flat_m -- m_t = g_t * grad_scale exactly, whatever m was -- so it is formed here from
         the gradient arena when that still holds the gradients of the last step (between step() and the next zero_grad()).
         (With beta1 == 0 the saved m never influences a resumed run: the next step overwrites it.)"""
-        if self.betas[0] == 0.0 and float(self.hyper[6]) == 0.0 and self.step_count > 0 and self.__dict__.get('_g_is_last_step', False):
+        if self.betas[0] == 0.0 and self._wd == 0.0 and self.step_count > 0 and self.__dict__.get('_g_is_last_step', False):
             k = self.numel_active
             m = self.flat_m.clone()
             m[:k] = self.flat_g[:k] * self._hyper_host[1]

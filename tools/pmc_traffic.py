@@ -53,7 +53,16 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'spade_uni_apply_kernel': ('spade_uniform_bwd', False), 'rect_lists_bwd_kernel': ('label_rects', False),
     'modulate_bwd_reduce_kernel': ('modulate_bwd', True), 'modulate_bwd_coef_kernel': ('modulate_bwd', False),
     'modulate_bwd_apply_kernel': ('modulate_bwd', False),
-    'label_conv3x3_kernel': ('label_conv', True),
+    'label_conv3x3_kernel': ('label_conv', True), 'label_conv3x3_batch_kernel': ('label_conv', True),
+    'spade_class_table_batch_kernel': ('class_table', True),
+    'modulate_bwd_apply_quad_kernel': ('modulate_bwd', False),
+    'conv_wgrad_c8_batch_kernel': ('conv_wgrad_patch', False), 'wgrad_c8_batch_reduce_kernel': ('conv_wgrad_patch', False),
+    'fc_head_fwd_kernel': ('fc_head', True), 'fc_head_bwd_kernel': ('fc_head', True),
+    'lrelu_bwd_kernel': ('activation_bwd', True), 'tanh_bwd_kernel': ('activation_bwd', True),
+    'pack_tr_cl_kernel': ('weight_pack', False), 'pack_fwd_cl_kernel': ('weight_pack', False), 'colsum_scalar_kernel': ('colsum', True), 'colsum_kernel': ('colsum', True),
+    'adam_tick_kernel': ('adam', False),
+    # stock torch / runtime (fills, copies, loss-scalar arithmetic)
+    'at::native': ('torch', True), '__amd_rocclr': ('torch', True),
     'adam_flat_kernel': ('adam', True),
     'pack_batch_kernel': ('weight_pack', True),
     'grad_unpack_batch_kernel': ('weight_grad_relayout', True), 'grad_dot_batch_kernel': ('weight_grad_relayout', False),

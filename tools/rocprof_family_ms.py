@@ -4,7 +4,9 @@ bench line quotes it beside its own HIP-event figure -- the events of an eager r
 
     python3 tools/rocprof_family_ms.py <..._kernel_stats.csv> profiles/r05/kernel_ms_per_step.json
 
-Families are tools/pmc_traffic.py's (= seg2eye_amd.ops.LaunchProfiler's); steps profiled = adam_flat_kernel calls / 2."""
+Families are tools/pmc_traffic.py's (= seg2eye_amd.ops.LaunchProfiler's).  Step BODIES profiled = adam_flat_kernel calls / 2 (every
+timed, warm-up and per-step-timed G+D step ends with two Adam launches) + 2: the two eager G+D bodies the trainer runs before
+capturing its hipGraphs launch every kernel of a step but no Adam (pix2pix_trainer._capture)."""
 import csv
 import json
 import os
@@ -19,7 +21,7 @@ def main():
     src, dst = sys.argv[1:3]
     rows = list(csv.DictReader(open(src)))
     adam = [int(r['Calls']) for r in rows if 'adam_flat_kernel' in r['Name']]
-    steps = max(1, adam[0] // 2) if adam else 1
+    steps = (max(1, adam[0] // 2) if adam else 1) + (int(sys.argv[3]) if len(sys.argv) > 3 else 2)
     fams, other, total = defaultdict(lambda: [0, 0.0]), 0.0, 0.0
     for r in rows:
         ns = float(r['TotalDurationNs'])
