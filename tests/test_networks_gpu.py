@@ -712,7 +712,7 @@ def test_full_size_train_step_matches_oracle():
     assert float(d.mean()) < 3e-2 and float(d.max()) < 0.5, (float(d.mean()), float(d.max()))
 
 
-@pytest.mark.parametrize('exchange', ['after_backward', 'overlap'])
+@pytest.mark.parametrize('exchange', ['after_backward', 'overlap', 'overlap+bf16+direct', 'overlap+debug_sync'])
 def test_bench_two_ranks_dry_run(exchange):
     """`python bench.py --gpus 2` with NO launcher: bench.py starts its own two ranks in a child process; here
     they share this box's GPU over gloo (S2E_DIST_BACKEND=gloo: RCCL refuses two ranks on one device; the collective calls
@@ -724,8 +724,17 @@ def test_bench_two_ranks_dry_run(exchange):
     env = dict(os.environ, S2E_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
+    # round 5: the bf16 payload through the spelled-out direct exchange (all-to-all + owner sum + all-gather), and the
+    # overlapped exchange under S2E_DEBUG_SYNC -- every group's slice must still hold the bits it had when its hook declared it final
+    # (i.e. no later graph segment, deferred weight-gradient batch or chain rule writes a group that has been handed to the exchange)
+    extra = []
+    exchange, _, opts = exchange.partition('+')
+    if 'bf16' in opts:
+        extra = ['--grad-dtype', 'bf16', '--grad-exchange', 'direct']
+    if 'debug_sync' in opts:
+        env['S2E_DEBUG_SYNC'] = '1'
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--ngf', '16',
-                          '--batch', '2', '--exchange', exchange], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+                          '--batch', '2', '--exchange', exchange] + extra, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 prints ONE line
@@ -734,6 +743,8 @@ def test_bench_two_ranks_dry_run(exchange):
     assert d['value'] > 0 and 'roofline' in d and 'cpu_baseline' not in d
     assert d['config']['gradient_exchange'] == exchange and d['hip_graphs'] is True, d['config']
     assert d['config']['graph_segments_G'] == (6 if exchange == 'overlap' else 1), d['config']
+    ex = d['config']['exchange']
+    assert ex['payload'] == ('bf16' if extra else 'fp32') and ex['algorithm'] == ('direct' if extra else 'allreduce') and ex['groups'] == 6, ex
 
 
 def test_bench_refuses_more_ranks_than_gpus():
