@@ -424,8 +424,19 @@ class GradSink:
     def _flush_uniform(self):
         """All queued SPADE layers' uniform-rectangle gradients (s2e_spade_uniform_grads): two launches per 16 layers."""
         jobs, self.uni = self.uni, []
-        for i in range(0, len(jobs), 16):
-            chunk = jobs[i:i + 16]
+        # launches of <= 16 jobs; two jobs that add into the SAME parameter gradients (a SPADE module applied twice before a flush)
+        # never share one: the apply kernel adds with plain read-modify-writes, one job per blockIdx.y (ADVICE r4)
+        chunks, cur, seen = [], [], set()
+        for j in jobs:
+            keys = {t.data_ptr() for t in (j[5], j[6], j[7], j[8]) if t is not None}
+            if len(cur) == 16 or (keys & seen):
+                chunks.append(cur)
+                cur, seen = [], set()
+            cur.append(j)
+            seen |= keys
+        if cur:
+            chunks.append(cur)
+        for chunk in chunks:
             arr = (L.SpadeUniJob * len(chunk))()
             for a, j in zip(arr, chunk):
                 R, A, w_gb, w_sh, b_sh, dw_sh, db_sh, dw_gb, db_gb, c2, nh, ncls, act_bf16 = j
