@@ -480,8 +480,11 @@ int s2e_style_fc_bwd(const float* dbig, const float* gbig, const float* big, con
  * x (M, P, C) in `dtype`; W (N x C*P), b, y (M x N), dy: fp32.  M <= 64, N <= 32 (s2e_fc_head_supported).  Backward, one pass:
  * dx (M, P, C) in `dtype` is WRITTEN (NULL: skipped), dW (N x C*P) and db (N) are ACCUMULATED into (NULL: skipped). */
 int s2e_fc_head_supported(int M, int N);
+size_t s2e_fc_head_fwd_workspace_bytes(int M, int P, int C, int N);
+/* workspace (uninitialised, s2e_fc_head_fwd_workspace_bytes) given: two small launches -- 256 columns of W x 8 samples per block, the
+ * partial (8, N) tiles added in a fixed order -- instead of one block per sample (NULL): 128 instead of 32 blocks, W read 4x not 32x. */
 int s2e_fc_head_fwd(int dtype, const void* x, const float* W, const float* b, float* y, int M, int P, int C, int N, float slope,
-                    void* stream);
+                    void* workspace, size_t workspace_bytes, void* stream);
 int s2e_fc_head_bwd(int dtype, const void* x, const float* W, const float* dy, void* dx, float* dW, float* db, int M, int P, int C,
                     int N, float slope, void* stream);
 

@@ -168,7 +168,8 @@ SIGNATURES = {
     's2e_style_fc_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     's2e_style_fc_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _i, _i, _i, _f, _vp],
     's2e_fc_head_supported': [_i, _i],
-    's2e_fc_head_fwd': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    's2e_fc_head_fwd_workspace_bytes': [_i, _i, _i, _i],
+    's2e_fc_head_fwd': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, C.c_size_t, _vp],
     's2e_fc_head_bwd': [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     's2e_adam_flat': [_vp, _vp, _vp, _vp, _l, _vp, _vp],
 }

@@ -210,6 +210,60 @@ __global__ __launch_bounds__(FH_FWD_THREADS) void fc_head_fwd_kernel(const T* __
     }
 }
 
+// Forward in two small launches (round 5).  The one-block-per-sample kernel above keeps 32 of 256 CUs busy, each pulling the whole
+// 1-MB weight matrix through one L1: 57 us per call for 17 MFLOP.  Here a block owns 256 columns kw of W for EIGHT samples: W is read
+// 4 times instead of 32, by 128 blocks; each thread forms its 8 x N products and folds them over the wave with DPP adds at once
+// (no per-thread accumulator array), the four waves' sums meet in LDS, and the block writes its partial (8, N) tile to the
+// workspace; fc_head_fin_kernel adds the K / 256 partial tiles in a fixed order (bit-reproducible) and the bias.
+template <typename T, int NMAX>
+__global__ __launch_bounds__(256) void fc_head_part_kernel(const T* __restrict__ x, const float* __restrict__ W, float* __restrict__ part,
+                                                           int M, int P, int C, int N, float slope) {
+    __shared__ float red[4][8][FH_MAXN];
+    const int K = P * C, kw = blockIdx.x * 256 + threadIdx.x, m0 = blockIdx.y * 8;
+    const bool in = kw < K;
+    const int c = in ? kw / P : 0, pp = in ? kw - c * P : 0;
+    float xv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = 0.f;
+        if (in && m0 + i < M) { v = load1<T>(x + (size_t)(m0 + i) * K + pp * C + c); v = v > 0.f ? v : slope * v; }
+        xv[i] = v;
+    }
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+        if (n < N) {                                         // (uniform)
+            const float w = in ? W[(size_t)n * K + kw] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float s = wave_sum_last(xv[i] * w);    // total in lane 63
+                if ((threadIdx.x & 63) == 63) red[wave][i][n] = s;
+            }
+        }
+    }
+    __syncthreads();
+    const int i = threadIdx.x >> 5, n = threadIdx.x & 31;
+    if (n < N && m0 + i < M)
+        part[((size_t)blockIdx.x * M + m0 + i) * FH_MAXN + n] = (red[0][i][n] + red[1][i][n]) + (red[2][i][n] + red[3][i][n]);
+}
+
+__global__ void fc_head_fin_kernel(const float* __restrict__ part, const float* __restrict__ b, float* __restrict__ y, int M, int N, int chunks) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * N) return;
+    const int m = idx / N, n = idx - m * N;
+    float s = b[n];
+    int q = 0;
+    for (; q + 8 <= chunks; q += 8) {                        // eight loads in flight, added in order (one by one each load waited for the last)
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[((size_t)(q + j) * M + m) * FH_MAXN + n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; q < chunks; ++q) s += part[((size_t)q * M + m) * FH_MAXN + n];
+    y[idx] = s;
+}
+
 template <typename T, int NMAX>
 __global__ __launch_bounds__(256) void fc_head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ W, const float* __restrict__ dy,
                                                           T* __restrict__ dx, float* __restrict__ dW, float* __restrict__ db,
@@ -258,8 +312,28 @@ __global__ __launch_bounds__(256) void fc_head_bwd_kernel(const T* __restrict__ 
 
 extern "C" int s2e_fc_head_supported(int M, int N) { return M >= 1 && M <= FH_MAXM && N >= 1 && N <= FH_MAXN; }
 
+extern "C" size_t s2e_fc_head_fwd_workspace_bytes(int M, int P, int C, int N) {
+    if (!s2e_fc_head_supported(M, N) || P <= 0 || C <= 0) return 0;
+    return (size_t)ceil_div((long)P * C, 256) * M * FH_MAXN * sizeof(float);
+}
+
+// workspace (s2e_fc_head_fwd_workspace_bytes, uninitialised) given: the two-launch form above; NULL: one block per sample
 extern "C" int s2e_fc_head_fwd(int dtype, const void* x, const float* W, const float* b, float* y, int M, int P, int C, int N, float slope,
-                               void* stream) {
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace && x && W && b && y && P > 0 && C > 0 && s2e_fc_head_supported(M, N) && workspace_bytes >= s2e_fc_head_fwd_workspace_bytes(M, P, C, N)) {
+        hipStream_t st2 = (hipStream_t)stream;
+        const int chunks = ceil_div((long)P * C, 256);
+        const dim3 grid(chunks, ceil_div(M, 8));
+#define S2E_FHP(TT, NM) fc_head_part_kernel<TT, NM><<<grid, 256, 0, st2>>>((const TT*)x, W, (float*)workspace, M, P, C, N, slope)
+        if (dtype == S2E_BF16) { if (N <= 16) S2E_FHP(bf16_t, 16); else S2E_FHP(bf16_t, 32); }
+        else if (dtype == S2E_F32) { if (N <= 16) S2E_FHP(float, 16); else S2E_FHP(float, 32); }
+#undef S2E_FHP
+        else S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_fwd: bad dtype %d", dtype);
+        S2E_CHECK_LAUNCH("fc_head_part_kernel");
+        fc_head_fin_kernel<<<ceil_div(M * N, 256), 256, 0, st2>>>((const float*)workspace, b, y, M, N, chunks);
+        S2E_CHECK_LAUNCH("fc_head_fin_kernel");
+        return S2E_OK;
+    }
     if (!x || !W || !b || !y || P <= 0 || C <= 0 || !s2e_fc_head_supported(M, N)) S2E_FAIL(S2E_ERR_ARG, "s2e_fc_head_fwd: bad argument (M=%d N=%d)", M, N);
     if ((size_t)P * C * sizeof(float) > 48 * 1024) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_fc_head_fwd: a sample row of %d x %d features does not fit the LDS stage", P, C);
     hipStream_t st = (hipStream_t)stream;

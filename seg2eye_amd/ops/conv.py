@@ -363,7 +363,10 @@ class FcHeadFn(torch.autograd.Function):
         m, h, w, c = x.shape
         n = weight.shape[0]
         y = torch.empty(m, n, dtype=torch.float32, device=x.device)
-        L.check(L.lib().s2e_fc_head_fwd(_dt(x), _p(x), _p(weight), _p(bias), _p(y), m, h * w, c, n, float(slope), _stream()), 's2e_fc_head_fwd')
+        wsb = L.lib().s2e_fc_head_fwd_workspace_bytes(m, h * w, c, n)
+        ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=x.device)
+        L.check(L.lib().s2e_fc_head_fwd(_dt(x), _p(x), _p(weight), _p(bias), _p(y), m, h * w, c, n, float(slope), _p(ws), wsb, _stream()),
+                's2e_fc_head_fwd')
         ctx.slope = float(slope)
         ctx.wdst, ctx.bdst = _grad_dst(weight), _grad_dst(bias)
         ctx.save_for_backward(x, weight)

@@ -1090,3 +1090,10 @@ def test_fc_head_matches_torch_linear_on_leaky_relu_of_nchw_flatten(cfg, dtype):
     _close(w.grad - 0.25, lin.weight.grad, torch.float32, what='fc head dW')
     _close(b.grad + 0.5, lin.bias.grad, torch.float32, what='fc head db')
     assert ops.fc_head(torch.zeros(65, so, so, C, device=dev, dtype=dtype), w, b) is None
+    # the one-block-per-sample form of the C ABI (no workspace) gives the same numbers as the two-launch form ops.fc_head uses
+    from seg2eye_amd import _lib as L
+    y1 = torch.empty(M, N, dtype=torch.float32, device=dev)
+    xd = nhwc(x).to(dev)
+    L.check(L.lib().s2e_fc_head_fwd(ops._dt(xd), xd.data_ptr(), w.data_ptr(), b.data_ptr(), y1.data_ptr(), M, so * so, C, N, 0.2, None, 0,
+                                    torch.cuda.current_stream().cuda_stream), 's2e_fc_head_fwd')
+    _close(y1, yr, torch.float32, what='fc head y (no workspace)')
