@@ -79,10 +79,27 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const T* __restrict__ 
 }
 
 template <typename T, int MODE>
-__global__ void loss_grad_kernel(const T* __restrict__ a, const T* __restrict__ b, long n, float scale,
+__global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ a, const T* __restrict__ b, long n, float scale,
                                  const float* __restrict__ gscale, T* __restrict__ da, int accumulate) {
+    constexpr int VEC = Vec<T>::N;
     if (gscale) scale *= *gscale;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    // 16-byte vectors when every pointer is 16-byte aligned (round 5: element by element -- 2-byte loads and stores -- the eight
+    // feature-matching gradients of a G step took 12 us each for 2 ... 17 MB)
+    const bool al = ((((uintptr_t)a) | ((uintptr_t)da) | (MODE == S2E_LOSS_L1 ? (uintptr_t)b : 0)) & 15) == 0;
+    const long nv = al ? n / VEC : 0;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+        float fa[VEC], fb[VEC], g[VEC];
+        unpack16<T>(*(const u32x4_t*)(a + v * VEC), fa);
+        if (MODE == S2E_LOSS_L1) unpack16<T>(*(const u32x4_t*)(b + v * VEC), fb);
+        if (accumulate) unpack16<T>(*(const u32x4_t*)(da + v * VEC), g);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float d = scale * loss_dterm<MODE>(fa[j], MODE == S2E_LOSS_L1 ? fb[j] : 0.f);
+            g[j] = accumulate ? d + g[j] : d;
+        }
+        *(u32x4_t*)(da + v * VEC) = pack16<T>(g);
+    }
+    for (long i = nv * VEC + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float g = scale * loss_dterm<MODE>(load1<T>(a + i), MODE == S2E_LOSS_L1 ? load1<T>(b + i) : 0.f);
         if (accumulate) g += load1<T>(da + i);
         store1<T>(da + i, g);
@@ -92,8 +109,12 @@ __global__ void loss_grad_kernel(const T* __restrict__ a, const T* __restrict__ 
 template <typename T>
 static int loss_dispatch(bool grad, int mode, const T* a, const T* b, long n, float scale, const float* gscale, void* out,
                          int accumulate, hipStream_t st) {
-    const long work = grad ? n : n / Vec<T>::N + 1;
-    const int grid = (int)((work + 255) / 256 < 1024 ? (work + 255) / 256 : 1024);
+    // one 16-byte vector per thread and trip.  The reduction ends with ONE float atomic per block on a single address, and
+    // same-address atomics serialise at ~12 ns each: 1024 blocks cost the feature-matching sums more (13 us) than their 2 ... 17 MB
+    // of reads -- at most 256 blocks
+    const long work = n / Vec<T>::N + 1;
+    const int cap = grad ? 2048 : 256;
+    const int grid = (int)((work + 255) / 256 < cap ? (work + 255) / 256 : cap);
 #define S2E_L(MM) do { if (grad) loss_grad_kernel<T, MM><<<grid, 256, 0, st>>>(a, b, n, scale, gscale, (T*)out, accumulate); \
                        else loss_reduce_kernel<T, MM><<<grid, 256, 0, st>>>(a, b, n, scale, (float*)out); } while (0)
     switch (mode) {
