@@ -208,14 +208,45 @@ __global__ void onehot_nhwc_kernel(const uint8_t* __restrict__ label, const T* _
     }
 }
 
+// cpad == 8 (every caller): one thread per PIXEL -- one label byte in, the 8 channels out as one (bf16) or two (fp32) 16-byte stores.
+// (The element-per-thread form above: eight 2-byte stores and three 64-bit divisions per pixel, ~10 us per call, ten calls per step.)
+template <typename T>
+__global__ __launch_bounds__(256) void onehot_nhwc8_kernel(const uint8_t* __restrict__ label, const T* __restrict__ img, T* __restrict__ out,
+                                                           int N, int H, int W, int h, int w, int ncls) {
+    const int sy = H / h, sx = W / w, total = N * h * w;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += gridDim.x * blockDim.x) {
+        const int n = pix / (h * w), rem = pix - n * h * w;
+        const int y = rem / w, x = rem - y * w;
+        const int cls = label[((size_t)n * H + (size_t)y * sy) * W + (size_t)x * sx];
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (c < ncls && c == cls) ? 1.f : 0.f;
+        if (img && ncls < 8) v[ncls] = load1<T>(img + pix);
+        if constexpr (Vec<T>::N == 8) {
+            *(u32x4_t*)(out + (size_t)pix * 8) = pack16<T>(v);
+        } else {
+            *(u32x4_t*)(out + (size_t)pix * 8) = pack16<T>(v);
+            *(u32x4_t*)(out + (size_t)pix * 8 + 4) = pack16<T>(v + 4);
+        }
+    }
+}
+
 extern "C" int s2e_onehot_nhwc(int dtype, const uint8_t* label, const void* img, void* out,
                                int N, int H, int W, int h, int w, int ncls, int cpad, void* stream) {
     if (!label || !out || N <= 0 || h <= 0 || w <= 0 || ncls <= 0 || cpad < ncls + (img ? 1 : 0))
         S2E_FAIL(S2E_ERR_ARG, "s2e_onehot_nhwc: bad argument");
     if (H % h || W % w) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_onehot_nhwc: non-integer downsampling ratio");
     const long total = (long)N * h * w * cpad;
-    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipStream_t st = (hipStream_t)stream;
+    if (cpad == 8 && ((uintptr_t)out & 15) == 0 && (long)N * h * w < (1L << 31) && (dtype == S2E_BF16 || dtype == S2E_F32)) {
+        const long px = (long)N * h * w;
+        const int gridp = (int)((px + 255) / 256 < 4096 ? (px + 255) / 256 : 4096);
+        if (dtype == S2E_BF16) onehot_nhwc8_kernel<bf16_t><<<gridp, 256, 0, st>>>(label, (const bf16_t*)img, (bf16_t*)out, N, H, W, h, w, ncls);
+        else onehot_nhwc8_kernel<float><<<gridp, 256, 0, st>>>(label, (const float*)img, (float*)out, N, H, W, h, w, ncls);
+        S2E_CHECK_LAUNCH("onehot_nhwc8_kernel");
+        return S2E_OK;
+    }
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype == S2E_BF16) onehot_nhwc_kernel<bf16_t><<<grid, 256, 0, st>>>(label, (const bf16_t*)img, (bf16_t*)out, N, H, W, h, w, ncls, cpad);
     else if (dtype == S2E_F32) onehot_nhwc_kernel<float><<<grid, 256, 0, st>>>(label, (const float*)img, (float*)out, N, H, W, h, w, ncls, cpad);
     else S2E_FAIL(S2E_ERR_ARG, "s2e_onehot_nhwc: bad dtype %d", dtype);

@@ -144,6 +144,9 @@ template <typename T, int G>
 __global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ stats,
                                                            T* __restrict__ dx, int HW, int C, int lrelu) {
     constexpr int VEC = Vec<T>::N, CH = G * VEC, RL = 256 / G;
+    // rows in flight per thread and tensor (round 5: four instead of two measured the same 19-20 us per call on the 33 x 33 maps --
+    // the trips are few; the fixed parts -- statistics loads, the fp64 fold of 64 row lanes through LDS, two passes -- are the time)
+    constexpr int UR = 2;
     __shared__ float red[RL][CH][2];
     __shared__ float mm[CH][2];
     const int tid = threadIdx.x, gx = tid % G, ry = tid / G;
@@ -158,15 +161,15 @@ __global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__
         s0[j] = 0.f; s1[j] = 0.f;
     }
     if (active)
-        for (int r = ry; r < HW; r += 2 * RL) {                  // two rows x two tensors in flight
-            u32x4_t rg[2], rx[2];
+        for (int r = ry; r < HW; r += UR * RL) {                 // UR rows x two tensors in flight
+            u32x4_t rg[UR], rx[UR];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < UR; ++k) {
                 const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
                 rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o);
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < UR; ++k) {
                 if (r + RL * k >= HW) continue;
                 float fg[VEC], fx[VEC];
                 unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx);
@@ -191,15 +194,15 @@ __global__ __launch_bounds__(256) void in_small_bwd_kernel(const T* __restrict__
     float m0[VEC], m1[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { m0[j] = mm[gx * VEC + j][0]; m1[j] = mm[gx * VEC + j][1]; }
-    for (int r = ry; r < HW; r += 2 * RL) {
-        u32x4_t rg[2], rx[2];
+    for (int r = ry; r < HW; r += UR * RL) {
+        u32x4_t rg[UR], rx[UR];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < UR; ++k) {
             const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
             rg[k] = *(const u32x4_t*)(g + o); rx[k] = *(const u32x4_t*)(x + o);
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < UR; ++k) {
             if (r + RL * k >= HW) continue;
             float fg[VEC], fx[VEC], o[VEC];
             unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx);
@@ -752,7 +755,17 @@ __global__ void modulate_bwd_coef_kernel(double* __restrict__ ws, const float* _
     const int n = i / C, c = i - n * C;
     if (part && !batch) {                                    // per-sample statistics: this thread's own (n, c) sums
         double s[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int b = 0; b < P; ++b) {
+        int b = 0;
+        for (; b + 8 <= P; b += 8) {                         // eight 16-byte slots in flight, added in slot order (one by one every
+            f32x4_t w[8];                                    //  load waited for the last: 11 us per call for 32 slots)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = *(const f32x4_t*)(part + (((size_t)n * P + b + j) * C + c) * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) s[k] += (double)w[j][k];
+        }
+        for (; b < P; ++b) {
             const float* w = part + (((size_t)n * P + b) * C + c) * 4;
 #pragma unroll
             for (int k = 0; k < NS; ++k) s[k] += (double)w[k];
@@ -893,6 +906,7 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
         const T* __restrict__ fout, const float* __restrict__ stats, const float* __restrict__ style, T* __restrict__ dx, T* __restrict__ dgb,
         float* __restrict__ dstyle, int HW, int C, int lrelu, int sld, int acc, int xw, float inv_xw, int quad) {
     constexpr int VEC = Vec<T>::N, CH = G * VEC, RL = 256 / G;
+    constexpr int UR = 2;                                    // rows in flight per thread and tensor (see in_small_bwd_kernel)
     __shared__ float red[RL][CH][4];
     __shared__ float mm[CH][2];
     const int tid = threadIdx.x, gx = tid % G, ry = tid / G;
@@ -909,17 +923,17 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
         for (int k = 0; k < 4; ++k) S[k][j] = 0.f;
     }
     if (active)
-        for (int r = ry; r < HW; r += 2 * RL) {
-            u32x4_t rg[2], rx[2], ra[2], ro[2];
+        for (int r = ry; r < HW; r += UR * RL) {
+            u32x4_t rg[UR], rx[UR], ra[UR], ro[UR];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < UR; ++k) {
                 const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
                 rg[k] = *(const u32x4_t*)(g + o); ra[k] = *(const u32x4_t*)(gamma + o);
                 rx[k] = *(const u32x4_t*)(x + mod_x_row(n, min(r + RL * k, HW - 1), HW, xw, inv_xw) * C + c0);
                 ro[k] = lrelu ? *(const u32x4_t*)(fout + o) : u32x4_t{0u, 0u, 0u, 0u};
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < UR; ++k) {
                 if (r + RL * k >= HW) continue;
                 float fg[VEC], fx[VEC], ga[VEC], fo[VEC], dga[VEC], dbe[VEC];
                 unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx); unpack16<T>(ra[k], ga); unpack16<T>(ro[k], fo);
@@ -999,10 +1013,10 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
         }
         return;
     }
-    for (int r = ry; r < HW; r += 2 * RL) {
-        u32x4_t rg[2], rx[2], ra[2], ro[2], rp[2];
+    for (int r = ry; r < HW; r += UR * RL) {
+        u32x4_t rg[UR], rx[UR], ra[UR], ro[UR], rp[UR];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < UR; ++k) {
             const size_t o = off + (size_t)min(r + RL * k, HW - 1) * C;
             rg[k] = *(const u32x4_t*)(g + o); ra[k] = *(const u32x4_t*)(gamma + o);
             rx[k] = *(const u32x4_t*)(x + mod_x_row(n, min(r + RL * k, HW - 1), HW, xw, inv_xw) * C + c0);
@@ -1010,7 +1024,7 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
             rp[k] = acc ? *(const u32x4_t*)(dx + o) : u32x4_t{0u, 0u, 0u, 0u};
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < UR; ++k) {
             if (r + RL * k >= HW) continue;
             float fg[VEC], fx[VEC], ga[VEC], fo[VEC], prev[VEC], o[VEC];
             unpack16<T>(rg[k], fg); unpack16<T>(rx[k], fx); unpack16<T>(ra[k], ga); unpack16<T>(ro[k], fo); unpack16<T>(rp[k], prev);
