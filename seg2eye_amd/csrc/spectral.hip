@@ -228,6 +228,12 @@ __global__ __launch_bounds__(256) void sn_gemvT_chain_kernel(const s2e_sn_layer*
     const int row0 = bm[1], col = bm[2] + threadIdx.x;
     const int nr = min(L.rows - row0, SN_T_BR);
     const long long* sp = sn_sb(L, (k - 1) & 1);
+    // the whole 32-row column strip is requested BEFORE |s| is summed: the chain is a string of dependent launches of ~10 us
+    // each, and the norm (a pass over s plus a block reduction) otherwise sits in front of the weight loads' latency
+    sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + min(col, L.cols - 1);
+    float w[SN_T_BR];
+#pragma unroll
+    for (int r = 0; r < SN_T_BR; ++r) w[r] = wp[(size_t)min(r, nr - 1) * L.cols];
     float inv = 1.f;
     if (k > 0) {                                             // u = s / max(|s|, eps), s of the previous iteration
         float q = 0.f;
@@ -235,19 +241,12 @@ __global__ __launch_bounds__(256) void sn_gemvT_chain_kernel(const s2e_sn_layer*
         inv = 1.f / fmaxf(sqrtf(sn_block_sum256(q, red)), eps);
     }
     if (col >= L.cols) return;
-    sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + col;
     float acc = 0.f;
 #pragma unroll
-    for (int b = 0; b < SN_T_BR; b += 16) {
-        float w[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) w[r] = wp[(size_t)min(b + r, nr - 1) * L.cols];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = row0 + min(b + r, nr - 1);
-            const float u = (k > 0 ? sn_unfix(sp[rr]) * inv : L.u[rr]) * (b + r < nr ? 1.f : 0.f);
-            acc += w[r] * u;
-        }
+    for (int r = 0; r < SN_T_BR; ++r) {
+        const int rr = row0 + min(r, nr - 1);
+        const float u = (k > 0 ? sn_unfix(sp[rr]) * inv : L.u[rr]) * (r < nr ? 1.f : 0.f);
+        acc += w[r] * u;
     }
     sn_fix_add(sn_tb(L, k & 1) + col, acc);
     if (k > 0 && row0 == 0) sn_tb(L, (k - 1) & 1)[col] = 0;       // (consumed by the previous W v pass)
@@ -263,8 +262,27 @@ __global__ __launch_bounds__(256) void sn_gemv_chain_kernel(const s2e_sn_layer* 
     const int nr = min(L.rows - row0, SN_BR);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long* tp = sn_tb(L, k & 1);
+    const bool vec = (L.cols & 3) == 0 && ((uintptr_t)L.w & 15) == 0;
+    const int cc = vec ? min(col, L.cols - 4) : col;         // a thread past the matrix re-reads its last columns, weighted with zero (vv = 0)
+    sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + cc;
+    f32x4_t w[SN_BR];                                        // all 32 rows requested before |t| is summed (see the W^T u kernel)
+    if (vec) {
+#pragma unroll
+        for (int r = 0; r < SN_BR; ++r) w[r] = *(sn_gptr4)(wp + (size_t)min(r, nr - 1) * L.cols);
+    } else {                                                 // (the encoder's first layer: 9 columns; row by row this path was the chain's longest block)
+#pragma unroll
+        for (int r = 0; r < SN_BR; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[r][j] = wp[(size_t)min(r, nr - 1) * L.cols + min(j, L.cols - 1 - col)];
+    }
     float q = 0.f;
-    for (int j = threadIdx.x; j < L.cols; j += 256) { const float v = sn_unfix(tp[j]); q += v * v; }
+    for (int j0 = threadIdx.x; j0 < L.cols; j0 += 256 * 8) {        // eight accumulator loads in flight (up to 4608 columns: 18 round trips one by one)
+        long long a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = tp[min(j0 + 256 * e, L.cols - 1)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = j0 + 256 * e < L.cols ? sn_unfix(a[e]) : 0.f; q += v * v; }
+    }
     const float inv = 1.f / fmaxf(sqrtf(sn_block_sum256(q, red4)), eps);
     float vv[4];
 #pragma unroll
@@ -273,27 +291,16 @@ __global__ __launch_bounds__(256) void sn_gemv_chain_kernel(const s2e_sn_layer* 
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (col + j < L.cols) L.v[sn_vidx(L, col + j)] = vv[j];
     }
-    const bool vec = (L.cols & 3) == 0 && ((uintptr_t)L.w & 15) == 0;
-    const int cc = vec ? min(col, L.cols - 4) : col;         // a thread past the matrix re-reads its last columns, weighted with zero (vv = 0)
-    sn_gptr wp = (sn_gptr)L.w + (size_t)row0 * L.cols + cc;
     if (vec) {
 #pragma unroll
-        for (int b = 0; b < SN_BR; b += 16) {
-            f32x4_t w[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) w[r] = *(sn_gptr4)(wp + (size_t)min(b + r, nr - 1) * L.cols);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = wave_sum_last((w[r][0] * vv[0] + w[r][1] * vv[1]) + (w[r][2] * vv[2] + w[r][3] * vv[3]));
-                if (lane == 63) red[b + r][wave] = p;
-            }
+        for (int r = 0; r < SN_BR; ++r) {
+            const float p = wave_sum_last((w[r][0] * vv[0] + w[r][1] * vv[1]) + (w[r][2] * vv[2] + w[r][3] * vv[3]));
+            if (lane == 63) red[r][wave] = p;
         }
     } else {
-        for (int r = 0; r < SN_BR; ++r) {
-            float p = 0.f;
-            if (r < nr)
-                for (int j = 0; j < 4; ++j) if (col + j < L.cols) p += wp[(size_t)r * L.cols + j] * vv[j];
-            p = wave_sum_last(p);
+#pragma unroll
+        for (int r = 0; r < SN_BR; ++r) {                    // columns past the matrix carry vv = 0 (their loads repeat the last column)
+            const float p = wave_sum_last(((w[r][0] * vv[0] + w[r][1] * vv[1]) + w[r][2] * vv[2]) + w[r][3] * vv[3]);
             if (lane == 63) red[r][wave] = p;
         }
     }
