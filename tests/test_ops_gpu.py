@@ -89,6 +89,10 @@ CONV_CASES = [
     (8, 64, 64, 8, 128, 3, 1, 1, True, False, 0, 0, None),       # 8-channel input (label-map convs): wgrad with the B operand built from a 16-B/pixel patch
     (10, 60, 90, 8, 256, 3, 1, 1, True, False, 0, 0, None),      # ... 32-wide slabs, ragged, two co tiles
     (3, 250, 256, 64, 64, 3, 1, 1, True, False, 0, 2, None),     # ... BN = 64 (wgrad: half-empty co tile), ragged in y, tanh epilogue
+    (1, 20, 300, 64, 1, 3, 1, 1, True, False, 1, 0, None),       # Cout = 1, wider than one 256-column segment of the band kernels (dgrad, wgrad); dot-then-stencil forward
+    (2, 40, 40, 128, 1, 3, 1, 1, True, True, 0, 0, None),        # ... 128 channels (8 K-steps a wave), residual
+    (2, 20, 21, 256, 1, 4, 1, 2, False, False, 1, 0, None),      # ... 256 channels: four channel quarters, one LDS slab each
+    (1, 12, 600, 1, 16, 3, 2, 1, True, False, 1, 0, None),       # Cin = 1, two column segments, LeakyReLU applied while the patch is staged
 ]
 
 
