@@ -76,7 +76,12 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'upsample2x_fwd_kernel': ('resample', True), 'upsample2x_bwd_kernel': ('resample', True),
     'avgpool_fwd_kernel': ('resample', True), 'avgpool_bwd_kernel': ('resample', True),
     'loss_reduce_kernel': ('loss', True), 'loss_grad_kernel': ('loss', True),
-    'onehot_nhwc_kernel': ('onehot', True),
+    'onehot_nhwc_kernel': ('onehot', True), 'onehot_nhwc8_kernel': ('onehot', True),
+    # round 5, after milestone a: the degenerate-channel convs on the matrix cores, the two-launch encoder head, vector pools
+    'tap_gemm_kernel': ('conv_small', True), 'fwd_cout1_mfma_kernel': ('conv_small', True),
+    'fc_head_part_kernel': ('fc_head', True), 'fc_head_fin_kernel': ('fc_head', False),
+    'avgpool_fwd_vec_kernel': ('resample', True), 'avgpool_bwd_vec_kernel': ('resample', True),
+    'pack_tr_kernel': ('weight_pack', False), 'pack_fwd_kernel': ('weight_pack', False),
 }
 
 
