@@ -608,12 +608,14 @@ static void plan_splits(int dtype, const s2e_conv_desc* d, int* tiles, int* tile
         return;
     }
     int s = 1;
-    const int target = 512;                          // (2 workgroups per CU; 256 ... 512 measured equal, 768 slower)
+    const int target = 512;                          // (2 workgroups per CU; 256 ... 512 measured equal, 768 and 1024 slower)
     if (*tiles < target && nk >= 8) {                // fewer than 2 workgroups per CU
         s = ceil_div(target, *tiles);
         // at least 4 K-tiles per split; a SHORT K (Cin = 128: 18 tiles) over >= 256 tiles is not worth splitting at all
-        // (128->2048 @16^2: 259 -> 302 TFLOP/s unsplit; the 64-tile 8x8 layer still is: it would leave 3/4 of the CUs idle)
-        const int min_per = (nk < 32 && *tiles >= 256) ? 16 : 4;
+        // (128->2048 @16^2: 259 -> 302 TFLOP/s unsplit; the 64-tile 8x8 layer still is: it would leave 3/4 of the CUs idle).
+        // <= 4 tiles (the 8x8 [gamma | beta] data gradient, 2048 -> 128: K = 288 tiles): 16 a split -- at 4 the 72 fp32 slabs were 19 MB
+        // beside 4.7 MB of weights, 43 -> 29 us; every other small-map shape measured equal or slower at 8, 16 and 32 (round 5)
+        const int min_per = ((nk < 32 && *tiles >= 256) || *tiles <= 4) ? 16 : 4;
         if (s > nk / min_per) s = nk / min_per;
         if (s < 1) s = 1;
     }
