@@ -833,7 +833,7 @@ int s2e_conv_duo_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan) {
     // whole tiles only: the loop runs 64 input channels (two 32-channel K-steps x 9 taps) per trip and a tile's 128 (or 64) weight
     // rows are all live -- the network has no other widths (96 -> 192 went wrong here: tools/bench_tail.py's odd layer)
     if (d->Cin % 64 != 0 || (d->Cout != 64 && d->Cout % 128 != 0)) return 0;
-    plan->splits = 1;
+    plan->splits = 1; plan->s2d = 0; plan->bn = 0;
     if (s2e_patch_rectangle(d, 3, &plan->tw, &plan->th) < 0.8) return 0;
     if (d->Ho % 16 == 0 && d->Wo % 16 == 0) plan->tw = plan->th = 16;       // the squarest rectangle: the smallest patch, and the 16x16x32 loop's
     if (!duo_rect_ok(plan->tw, plan->th, d->Ho, d->Wo)) return 0;
@@ -887,7 +887,7 @@ int s2e_spade_conv_modulate_duo(int dtype, const void* actv, const void* w_packe
     const int kpad = ceil_div(9 * nh, 64) * 64;
     if ((long)s2e_conv_cout_pad(2 * C) * kpad * 2 >= (1L << 31)) return 0;
     const s2e_conv_desc d{N, H, W, nh, H, W, 2 * C, 3, 3, 1, 1, 0, S2E_ACT_NONE, S2E_ACT_NONE, S2E_AUX_NONE};
-    const s2e_patch_plan plan{tw, th, 1};
+    const s2e_patch_plan plan{tw, th, 1, 0, 0};
     DuoParams p{};
     p.x = actv; p.w = w_packed; p.bias = bias; p.y = out;
     duo_fill(&p, &d, &plan, kpad);

@@ -6,6 +6,7 @@ struct s2e_patch_plan {
     int tw, th;       // rectangle of output pixels per tile: width <= 64, height; tw * th <= 256
     int splits;       // channel-chunk splits (> 1: fp32 partial slabs + conv_finish_kernel)
     int s2d;          // 0; 1 / 2: a 4x4 stride-2 pad-2 layer (forward / data gradient) as a 2x2 conv over the space-to-depth view
+    int bn;           // 0 = by Cout (128 above 64 channels); 64: split layers that fill the chip better with narrower tiles and fewer splits
 };
 // 0 = the generic implicit-GEMM kernel runs this shape; 1 = this kernel does, with *plan (may be NULL) filled in.
 int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan);

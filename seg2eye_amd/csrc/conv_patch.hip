@@ -608,7 +608,7 @@ int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan)
     static const bool allow_k4 = [] { const char* e = getenv("S2E_CONV_PATCH_K4"); return e ? atoi(e) != 0 : true; }();
     s2e_patch_plan local;
     if (!plan) plan = &local;
-    plan->tw = plan->th = 0; plan->splits = 1;
+    plan->tw = plan->th = 0; plan->splits = 1; plan->bn = 0;
     if (min_tiles <= 0) return 0;
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     const int ks = d->KH;
@@ -644,6 +644,14 @@ int s2e_conv_patch_plan(int dtype, const s2e_conv_desc* d, s2e_patch_plan* plan)
     // here against 0.31 ms in the generic kernel
     if (tiles >= 160 && tiles * 7 >= min_tiles * 5 && nch * ks * ks >= 64) return 1;
     if (!allow_split) return 0;
+    // 64-channel tiles first: twice the tiles, so half the splits fill the chip -- half the fp32 slab traffic of the finish pass
+    // (round 5: 512 -> 512 at 32^2 58 -> 50 us, 1024 -> 1024 at 16^2 53 -> 51 us, the other split layers 2-4 %)
+    if (bn == 128 && d->Cout % 64 == 0) {
+        int b2 = 0;
+        for (int s = 1; s <= nch / 2; ++s)
+            if (nch % s == 0 && 2 * tiles * s <= 256) b2 = s;
+        if (b2 && 2 * tiles * b2 >= 192) { plan->splits = b2; plan->bn = 64; return 1; }
+    }
     int best = 0;
     for (int s = 2; s <= nch / 2; ++s)               // a divisor of the chunk count, >= 2 chunks per split, <= ~one workgroup per CU
         if (nch % s == 0 && tiles * s <= 256) best = s;
@@ -690,7 +698,7 @@ int s2e_conv_patch_launch(int dtype, const s2e_patch_plan* plan, const void* x, 
     p.out_act = d->out_act; p.aux_mode = d->aux_mode;
     p.tw = plan->tw; p.th = plan->th;
     p.tw_shift = (plan->tw & (plan->tw - 1)) == 0 ? __builtin_ctz(plan->tw) : -1;
-    const int bn = d->Cout > 64 ? 128 : 64;
+    const int bn = plan->bn ? plan->bn : (d->Cout > 64 ? 128 : 64);
     p.tiles_x = ceil_div(d->Wo, p.tw); p.tiles_y = ceil_div(d->Ho, p.th); p.tiles_n = ceil_div(d->Cout, bn);
     p.tiles_out = p.N * p.tiles_y * p.tiles_x * p.tiles_n;
     p.splits = plan->splits; p.cps = d->Cin / (dtype == S2E_BF16 ? 64 : 32) / plan->splits;
