@@ -60,9 +60,9 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.s2e_conv2d_kernel_kind(_lib.S2E_BF16, ctypes.byref(d2)) == 0                      # 8x8: rectangles would be 25 % full
     d4 = _lib.ConvDesc(8, 256, 256, 64, 256, 256, 1, 3, 3, 1, 1, 0, 0, 0, 0)
     assert L.s2e_conv2d_kernel_kind(_lib.S2E_BF16, ctypes.byref(d4)) == 1                      # conv_img: Cout = 1
-    d5 = _lib.ConvDesc(8, 16, 16, 1024, 16, 16, 1024, 3, 3, 1, 1, 0, 0, 0, 0)                  # few tiles, long K: patch kernel split 4x
-    assert L.s2e_conv2d_kernel_kind(_lib.S2E_BF16, ctypes.byref(d5)) == 2
-    assert L.s2e_conv2d_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d5)) == 4 * 8 * 16 * 16 * 1024 * 4
+    d5 = _lib.ConvDesc(8, 16, 16, 1024, 16, 16, 1024, 3, 3, 1, 1, 0, 0, 0, 0)                  # few tiles, long K: patch kernel, 64-channel tiles split 2x
+    assert L.s2e_conv2d_kernel_kind(_lib.S2E_BF16, ctypes.byref(d5)) == 2                      # (round 5; 128-channel tiles split 4x before: twice the fp32 slabs)
+    assert L.s2e_conv2d_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d5)) == 2 * 8 * 16 * 16 * 1024 * 4
     d4 = _lib.ConvDesc(8, 256, 256, 64, 256, 256, 1, 3, 3, 1, 1, 0, 0, 0, 0)      # conv_img: 1-channel stream kernels
     assert L.s2e_conv2d_wgrad_workspace_bytes(_lib.S2E_BF16, ctypes.byref(d4)) == 1024 * 9 * 64 * 4
     assert L.s2e_conv2d_wgrad(_lib.S2E_BF16, 1, 1, 1, None, ctypes.byref(d4), None, 0, None) == -1        # workspace missing

@@ -93,6 +93,9 @@ CONV_CASES = [
     (2, 40, 40, 128, 1, 3, 1, 1, True, True, 0, 0, None),        # ... 128 channels (8 K-steps a wave), residual
     (2, 20, 21, 256, 1, 4, 1, 2, False, False, 1, 0, None),      # ... 256 channels: four channel quarters, one LDS slab each
     (1, 12, 600, 1, 16, 3, 2, 1, True, False, 1, 0, None),       # Cin = 1, two column segments, LeakyReLU applied while the patch is staged
+    (8, 256, 256, 64, 1, 3, 1, 1, False, False, 1, 2, None),     # the degenerate-channel layers AS BENCHED: the generator's image conv (32 x 32 rectangles),
+    (16, 34, 34, 512, 1, 4, 1, 2, False, False, 0, 0, None),     # ... a PatchGAN head (9 x 9 rectangles, four channel quarters),
+    (32, 256, 256, 1, 64, 3, 2, 1, False, False, 0, 0, None),    # ... the encoder's first layer (1024 bands of four output rows)
 ]
 
 
