@@ -32,4 +32,6 @@ python3 tools/trace_copies.py > "$O/${P}_torch_launches_per_step.log" 2>/dev/nul
 python3 tools/bench_pack.py > "$O/${P}_weight_pack_microbench.log" 2>/dev/null
 python3 tools/bench_mm.py > "$O/${P}_hipblaslt_same_gemm_shapes.log" 2>/dev/null
 python3 tools/check_wgrad_batch.py --bench 2>&1 | grep -v amdgpu.ids > "$O/${P}_wgrad_batch_microbench.log"
+python3 tools/bench_small.py 2>&1 | grep -v amdgpu.ids > "$O/${P}_degenerate_channel_convs_microbench.log"
+python3 tools/bench_sn.py 2>&1 | grep " bank " > "$O/${P}_spectral_norm_chain_microbench.log"
 tail -c 1500 "$O/${P}_bench.json"
