@@ -656,6 +656,61 @@ def test_spectral_norm_weight_gradient_accumulates(cfg, where):
         _close(conv.weight_orig.grad, want + ref.weight_orig.grad, torch.float32, what='stale arena (%s)' % where)
 
 
+def test_degenerate_channel_convs_random_shapes():
+    """csrc/conv_small.hip (round 5): 40 random 1-channel layers -- Cout = 1 (dot-then-stencil on the matrix cores for 64 / 128 /
+    256 / 512 input channels, the vector kernel for the others; data gradient with the taps as one MFMA K-step for whole 32-channel
+    blocks, the band kernel otherwise; weight gradient from an LDS copy of the gradient map) and Cin = 1 (the same, mirrored) --
+    3x3 and 4x4, any pad, stride 1 or 2 where the kind allows it, odd sizes, widths past one 256-column segment, bias / residual /
+    LeakyReLU-in / tanh-out, both dtypes; forward and all three gradients through ops.conv2d against fp64."""
+    from seg2eye_amd import ops
+    dev = _dev()
+    rng = np.random.RandomState(5)
+    for it in range(40):
+        dtype = torch.bfloat16 if it % 4 else torch.float32
+        vec = 8 if dtype == torch.bfloat16 else 4
+        k = int(rng.choice([3, 4]))
+        wide = int(rng.choice([8, 16, 32, 64, 128, 256, 512] if dtype == torch.bfloat16 else [4, 8, 16, 64, 128, 256]))
+        cout1 = bool(rng.randint(2))
+        Cin, Cout = (wide, 1) if cout1 else (1, wide)
+        s = 1 if cout1 else int(rng.choice([1, 2]))
+        p = int(rng.randint(0, k))
+        N = int(rng.randint(1, 4))
+        H = int(rng.randint(k + 1, 40))
+        W = int(rng.choice([rng.randint(k + 1, 40), rng.randint(257, 300) * s])) if it % 5 == 0 else int(rng.randint(k + 1, 40))
+        if wide >= 256:
+            H, W = min(H, 20), min(W, 24)
+        in_act = int(rng.choice([0, 1]))
+        out_act = int(rng.choice([0, 0, 2]))
+        has_b, has_r = bool(rng.randint(2)), bool(rng.randint(3) == 0)
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        x = _rnd((N, Cin, H, W), 100 + it, dtype)
+        w = _rnd((Cout, Cin, k, k), 200 + it, torch.float32, (1.0 / (Cin * k * k)) ** 0.5)
+        b = _rnd((Cout,), 300 + it, torch.float32, 0.1) if has_b else None
+        r = _rnd((N, Cout, Ho, Wo), 400 + it, dtype) if has_r else None
+        gy = _rnd((N, Cout, Ho, Wo), 500 + it, dtype, 1.0 / max(1.0, (N * Ho * Wo) ** 0.5))     # (keeps the bias sum well-conditioned)
+        xr = x.double().requires_grad_(True)
+        wr = w.to(dtype).double().requires_grad_(True)
+        br = b.double().requires_grad_(True) if has_b else None
+        yr = F.conv2d(F.leaky_relu(xr, 0.2) if in_act else xr, wr, br, stride=s, padding=p)
+        if has_r:
+            yr = yr + r.double()
+        if out_act == 2:
+            yr = torch.tanh(yr)
+        yr.backward(gy.double())
+        xg = nhwc(x).to(dev).requires_grad_(True)
+        wg = w.to(dev).requires_grad_(True)
+        bg = b.to(dev).requires_grad_(True) if has_b else None
+        rg = nhwc(r).to(dev) if has_r else None
+        y = ops.conv2d(xg, wg, bg, rg, s, p, in_act, out_act)
+        y.backward(nhwc(gy).to(dev))
+        tag = 'case %d: %s N%d %dx%d c%d->%d k%d s%d p%d in%d out%d b%d r%d' % (it, dtype, N, H, W, Cin, Cout, k, s, p, in_act, out_act, has_b, has_r)
+        _close(nchw(y), yr, dtype, what=tag + ' y')
+        (_close_kink if in_act else _close)(nchw(xg.grad), xr.grad, dtype, what=tag + ' dx')
+        _close(wg.grad, wr.grad, dtype, what=tag + ' dw')
+        if has_b:
+            _close(bg.grad, br.grad, dtype, scale=max(float(br.grad.abs().max()), float(gy.double().abs().sum()) * 1e-2), what=tag + ' db')
+
+
 @pytest.mark.parametrize('forced', [True, False])
 def test_conv2d_random_shapes(forced):
     """60 random 3x3 stride-1 shapes (odd sizes, ragged channels, 8-channel inputs, bias / residual / activations, both
