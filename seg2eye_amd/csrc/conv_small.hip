@@ -1,25 +1,22 @@
-// Degenerate-channel convolutions: Cout == 1 (conv_img 64->1, the PatchGAN heads 512->1) and Cin == 1
-// (encoder layer0 1->64).  A 128-wide MFMA tile does 1/32..1/128 useful work on these; they are pure
-// HBM-bound streams, so each gets a small vector kernel: one thread owns a 16-byte channel group of the
-// wide tensor and a handful of scalar loads of the 1-channel tensor.  Dispatched from s2e_conv2d /
-// s2e_conv2d_wgrad (conv_igemm.hip / conv_wgrad.hip); no separate ABI.
-//
-// What makes them stream instead of crawl (each was 5-15x off the HBM time when written naively):
-//   * the kernel size is a template parameter (3 or 4) and the tap loops are fully unrolled with CLAMPED
-//     addresses + a validity select, so all tap loads of a pixel are independent and issued together
-//     (a `continue` on the bounds test serialises them: one L2 round trip per tap);
-//   * weights live in registers (read once per thread), not in an LDS table rebuilt by every block;
-//   * pixel indices are 32-bit (the dispatch guarantees N*H*W < 2^31): no 64-bit divisions;
-//   * the weight-gradient kernels keep two pixels in flight per thread, reduce lanes -> waves -> block
-//     in registers/LDS and write ONE partial row per block to a workspace; a second tiny kernel sums the
-//     rows (same-address float atomics from ~1000 blocks serialise for longer than the whole stream).
+// Degenerate-channel convolutions: Cout == 1 (conv_img 64->1, the PatchGAN heads 512->1) and Cin == 1 (encoder layer0 1->64).
+// A 128-wide MFMA tile does 1/32..1/128 useful work on these as an implicit GEMM; they are HBM-bound streams of ONE wide tensor
+// (16 B a lane) beside a 1-channel one.  Dispatched from s2e_conv2d / s2e_conv2d_wgrad (conv_igemm.hip / conv_wgrad.hip); no separate
+// ABI.  Three generations live here (round 5 rewrote the hot ones; tools/bench_small.py times all of them at the step's sizes):
+//   * bf16, the sizes of the benchmark -- on the matrix cores after all, with the TAPS where an implicit GEMM has channels:
+//       forward Cout == 1 (Cin 64 / 128 / 256 / 512, stride 1)  : fwd_cout1_mfma_kernel, dot-then-stencil        71 -> 21 us
+//       forward Cin == 1, data gradient of Cout == 1 (C % 32 == 0): tap_gemm_kernel, the taps as one K-step   44 -> 23, 37 -> 18 us
+//   * any dtype / channel count -- "band" vector kernels: a work item's patch of the 1-channel tensor is copied to LDS once and a
+//     pixel's taps are LDS broadcasts (fwd_cin1_kernel, dgrad_cout1_kernel, and the two weight gradients, which have no MFMA form yet);
+//   * fwd_cout1_kernel, the original vector kernel, for the remaining Cout == 1 forwards (fp32, odd channel counts).
+// What the vector kernels keep from round 1: kernel size as a template parameter with fully unrolled tap loops (no `continue` on
+// the bounds test: that serialises the loads), weights in registers (16-B row loads), 32-bit pixel indices, weight gradients as
+// one partial row per block to a workspace + a tiny fixed-order reduce kernel (same-address float atomics from ~1000 blocks
+// serialise for longer than the whole stream).
 #include "common.h"
 #include "conv_small.h"
 
 static constexpr size_t SMALL_WS_CAP = 8u << 20;      // bytes of block partials at most
-#ifndef SMALL_INFLIGHT
-#define SMALL_INFLIGHT 2
-#endif
+static constexpr int SMALL_INFLIGHT = 2;               // pixels a weight-gradient thread has in flight (4 measured 10 % slower)
 
 __device__ __forceinline__ void decode_px(int o, int HW, int W, int& n, int& y, int& x) {
     n = o / HW;
