@@ -79,7 +79,8 @@ int s2e_conv_k_pad(int dtype, int k);            /* columns of a packed weight m
  * transposed = 1: packed[ci][(ky*kw+kx)*cout + co]              (cout_pad(cin_pad) x k_pad(kh*kw*cout))
  * transposed | 2: the SOURCE is stored channels-last, w[co][ky][kx][ci] (the fp32 masters of a trainer: DESIGN 3.4b); needs
  * cin_pad == cin and cin % 8 == 0.  Same outputs; the forward pack is then a streaming convert, the transposed one a tile
- * transpose per tap.  s2e_pack_job.transposed takes the same values. */
+ * transpose per tap.  transposed | 4 (bf16, cin_pad == cin, K dimension a multiple of 32): the PLANE layout of s2e_conv2d_plane
+ * (csrc/conv_plane.h), ceil(rows / 64) * 64 x taps * K elements.  s2e_pack_job.transposed takes the same values. */
 int s2e_pack_conv_weight(int dtype, const float* w_oihw, void* packed, const float* sigma, int cout, int cin,
                          int kh, int kw, int cin_pad, int transposed, void* stream);
 /* Batched weight pack: every conv of a network in ONE launch (a network packs 20-50 weight matrices per
@@ -112,6 +113,18 @@ int s2e_conv2d_wgrad_kernel_kind(int dtype, const s2e_conv_desc* d);
 int s2e_conv2d(int dtype, const void* x, const void* w_packed, const float* bias, const void* residual,
                const void* aux, void* y, const s2e_conv_desc* d, void* workspace, size_t workspace_bytes,
                void* stream);
+/* Plane-patch convolution (round 6; csrc/conv_plane.hip): netE's 3x3 stride-2 convs (reference models/networks/encoder.py:23-39)
+ * forward and data gradient, and the learned 1x1 shortcuts (architecture.py:26-27,53-56), patch-resident with the input patch of a
+ * stride-2 layer stored as four parity planes in LDS (9 taps executed, each a shifted view of one plane) and the weights streamed
+ * from L2 straight into registers.  s2e_conv2d_plane_supported: 0, or the mode (> 0) this kernel runs the shape in -- the caller
+ * then packs the weight in the PLANE layout (s2e_pack_conv_weight with transposed | 4: s2e_conv_plane_weight_elems(d) bf16 elements,
+ * for a 4-KB block per (64 rows, 32-channel chunk, tap) in MFMA fragment order) and calls s2e_conv2d_plane instead of s2e_conv2d;
+ * same operands and epilogue contract otherwise (bias, residual OR mask, LeakyReLU), no workspace.  S2E_CONV_PLANE (environment, bit
+ * mask of modes) = 0 disables it.  bf16 only. */
+int s2e_conv2d_plane_supported(int dtype, const s2e_conv_desc* d);
+size_t s2e_conv_plane_weight_elems(const s2e_conv_desc* d);
+int s2e_conv2d_plane(int dtype, const void* x, const void* w_plane, const float* bias, const void* residual, const void* aux,
+                     void* y, const s2e_conv_desc* d, void* stream);
 /* The forward convolution TOGETHER with the InstanceNorm partial sums of its output y (round 4; SURVEY 7 step 5: the statistics of
  * a large map -- normalization.py:94 of the reference, nn.InstanceNorm2d on the tensor the previous conv produced,
  * architecture.py:53-60 -- come out of the producer's epilogue instead of a pass over y).  s2e_conv2d_stats_slots: the partial-sum

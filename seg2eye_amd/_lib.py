@@ -108,6 +108,9 @@ SIGNATURES = {
     's2e_conv2d_kernel_kind': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_wgrad_kernel_kind': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
+    's2e_conv2d_plane_supported': [_i, C.POINTER(ConvDesc)],
+    's2e_conv_plane_weight_elems': [C.POINTER(ConvDesc)],
+    's2e_conv2d_plane': [_i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp],
     's2e_conv2d_stats_slots': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_stats': [_i, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, _vp],
     's2e_in_stats_from_partials': [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
@@ -194,7 +197,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = (C.c_char_p if name == 's2e_last_error' else
-                          C.c_size_t if name.endswith('_workspace_bytes') else
+                          C.c_size_t if (name.endswith('_workspace_bytes') or name == 's2e_conv_plane_weight_elems') else
                           C.c_long if name in ('s2e_pack_block_map', 's2e_grad_block_map', 's2e_sngrad_block_map', 's2e_sngrad_scratch_floats', 's2e_label_conv_block_map', 's2e_class_table_block_map') else C.c_int)
         _lib = L
     return _lib

@@ -1,0 +1,484 @@
+// Plane-patch convolution (bf16, gfx950): the layers the stride-1 3x3 patch kernels do not take -- netE's 3x3 stride-2 convs
+// (reference models/networks/encoder.py:23-39), the PatchGAN's 4x4 stride-2 / stride-1 convs (discriminator.py:84-96), the learned
+// 1x1 shortcuts (architecture.py:26-27,53-56) -- forward AND data gradient, patch-resident, VERDICT r5 #1.
+//
+// Until round 6 these ran in the generic implicit GEMM (conv_igemm.hip / conv_stream.hip), which re-gathers the im2col panel
+// from L2 once per tap and is paced by that gather (0.09-0.10 of the MFMA peak, PMC traffic 2.2x the operands).  Here:
+//
+//   tile        : an 8 x 16 rectangle of output pixels (of the "rectangle space": the output map; for a stride-2 data gradient the
+//                 half-resolution grid, each rectangle then serving ONE of the four output-parity classes) x 128 or 64 channels.
+//   patch       : per 32-channel chunk of the input, every input pixel the rectangle needs is brought into LDS ONCE, by range-checked
+//                 LDS-DMA (an offset past the tensor returns zeros: padding), as PARITY PLANES: a stride-2 layer's input pixels
+//                 (2Y + a, 2X + b) are stored plane by plane (a, b), so that each of its taps is a stride-1 shifted view of one
+//                 plane -- 9 taps executed for 3x3 stride 2 (16 for 4x4), no zero taps, no strided LDS reads.  64-byte rows,
+//                 16-byte chunk index XORed with (x >> 1) & 3 (x = the pixel's column inside its plane; applied on the source side
+//                 of the DMA): every ds_read_b128 of a fragment -- 16 consecutive columns of one plane row at any shift -- is
+//                 conflict-free whatever the plane width (brute-forced).
+//   weights     : NOT staged through LDS.  The packed weight is stored in PLANE layout (s2e_pack_conv_weight, transposed | 4): per
+//                 (64 rows, chunk, tap) one 4-KB block holding the four 16x16x32 fragments in register order, so a wave fetches a
+//                 K-step's weights for its 64 channels with four fully coalesced 16-byte-per-lane loads, one K-step ahead, from L2.
+//                 No weight LDS-DMA (78 % of conv_duo's LDS fill), no weight ds_reads, and the workgroup's barrier
+//                 moves from every K-step to every patch stage.
+//   MFMA        : v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand (rows = channels) and the pixels as B: a lane's four
+//                 accumulator registers are four consecutive channels of ONE pixel, and with the fragment rows permuted by the pack
+//                 (fragment pair (2m, 2m+1) interleaves 4-channel groups) a lane owns 8 consecutive channels of a pixel: the epilogue
+//                 is plain 16-byte stores from registers -- no LDS staging, no barrier.
+//   workgroups  : 256 threads = 4 waves, two per CU (<= 80 KB of LDS), persistent over work items.
+//   stages      : S chunks per patch stage (double-buffered); S > 1 for the short-K-step modes (1x1: S = 4) keeps 32 KB per workgroup
+//                 in flight: those launches are HBM-bound.
+#include "conv_plane.h"
+#include <stdlib.h>
+
+namespace {
+
+struct PlaneParams {
+    const void* x; const void* w; const float* bias; const void* res; const void* aux; void* y;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout;     // x: (N, Hi, Wi, Cin); y: (N, Ho, Wo, Cout)
+    int org, flip;                        // stride-1 modes: patch origin = tile origin + org; data gradient: taps mirrored
+    int out_act, aux_mode;
+    int tiles_x, tiles_y, tiles_n, rects; // rectangle grid over the rectangle space, Cout tiles of BN, N * tiles_y * tiles_x
+    int nch;                              // Cin / 32
+    unsigned x_bytes, w_bytes;
+};
+
+// ---------------------------------------------------------------- compile-time geometry of a mode
+constexpr bool m_s2f(int m) { return m == PLANE_K3S2F || m == PLANE_K4S2F; }
+constexpr bool m_s2d(int m) { return m == PLANE_K3S2D || m == PLANE_K4S2D; }
+constexpr int m_np(int m) { return m_s2f(m) ? 4 : 1; }
+constexpr int m_ks(int m) { return m == PLANE_K1 ? 1 : (m == PLANE_K3S1 || m == PLANE_K3S2F || m == PLANE_K3S2D) ? 3 : 4; }
+constexpr int m_si(int m) { return m_s2f(m) ? 2 : 1; }          // input stride
+constexpr int m_so(int m) { return m_s2d(m) ? 2 : 1; }          // output stride (classes)
+// extent of plane parity a along a dimension whose tile extent is E
+constexpr int m_ext(int m, int a, int E) {
+    return m == PLANE_K1 ? E : m == PLANE_K3S1 ? E + 2 : m == PLANE_K4S1 ? E + 3 : m == PLANE_K3S2F ? (a ? E + 1 : E) : E + 1;
+}
+// input coordinate of plane index i: si * (T0 + i) + off (+ the run-time org of the stride-1 modes)
+constexpr int m_off(int m, int a) { return m == PLANE_K3S2F ? (a ? -1 : 0) : m == PLANE_K4S2F ? (a ? -1 : -2) : 0; }
+// 1-D taps of output-parity class bit c (0 for the modes without classes): count, kernel index, plane parity, shift
+constexpr int m_ntd(int m, int c) { return m_s2d(m) ? (m == PLANE_K3S2D ? (c ? 2 : 1) : 2) : m_ks(m); }
+constexpr int m_tk(int m, int c, int i) { return m == PLANE_K3S2D ? (c ? 2 * i : 1) : m == PLANE_K4S2D ? c + 2 * i : i; }
+constexpr int m_ta(int m, int c, int i) { return m == PLANE_K3S2F ? (i == 1 ? 0 : 1) : m == PLANE_K4S2F ? (i & 1) : 0; }
+constexpr int m_td(int m, int c, int i) {
+    return m == PLANE_K3S2F ? (i == 2 ? 1 : 0) : m == PLANE_K4S2F ? (i >> 1) : m_s2d(m) ? (m == PLANE_K3S2D ? (c ? 1 - i : 0) : 1 - i) : i;
+}
+constexpr int m_slot_base(int m, int TH, int p) {
+    int b = 0;
+    for (int q = 0; q < p; ++q) b += m_ext(m, q >> 1, TH) * m_ext(m, q & 1, 16);
+    return b;
+}
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int MODE, int BN, int TH, int S>
+__global__ __launch_bounds__(256, 2) void conv_plane_kernel(const PlaneParams p) {
+    typedef bf16_t T;
+    constexpr int NW = 4, TW = 16;
+    constexpr int WN = BN / 64, WM = NW / WN, NPF = TH / WM;       // waves over channels / pixel rows; pixel fragments (rectangle rows) per wave
+    static_assert(BN == 64 || BN == 128, "tile widths");
+    static_assert(NPF >= 2 && NPF % 2 == 0, "two halves of pixel fragments per K-step");
+    constexpr int NP = m_np(MODE), TT = m_ks(MODE) * m_ks(MODE), SI = m_si(MODE), SO = m_so(MODE);
+    constexpr int SLOTS = m_slot_base(MODE, TH, NP);
+    constexpr int NPC = (SLOTS + 15) / 16;                         // 1-KiB pieces per chunk
+    constexpr int CH_BYTES = NPC * 1024, ST_BYTES = S * CH_BYTES;
+    constexpr int NR = (NPC + NW - 1) / NW;                        // pieces per wave per chunk
+    static_assert(2 * ST_BYTES <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) char smem[2 * ST_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int nch = p.nch, NS = nch / S;
+    T* __restrict__ yg = (T*)p.y;
+    const T* __restrict__ resg = (const T*)p.res;
+    const T* __restrict__ auxg = (const T*)p.aux;
+
+    // ---- work items, heavier classes first: id = class rank * R + rectangle * tiles_n + Cout tile
+    struct Item { int cls, tn, n, y0, x0; };
+    const int R = p.rects * p.tiles_n;
+    const int n_items = R * (SO == 2 ? 4 : 1);
+    const int G = gridDim.x;
+    int item_id = xcd_remap(blockIdx.x, G);
+    if (item_id >= n_items) return;
+    auto decode = [&](int id) __attribute__((always_inline)) -> Item {
+        Item q;
+        int rank = 0;
+        if constexpr (SO == 2) { rank = id / R; id -= rank * R; }
+        // (3x3 stride-2 data gradient: classes (1,1), (0,1), (1,0), (0,0) run 4, 2, 2, 1 taps)
+        q.cls = MODE == PLANE_K3S2D ? (rank == 0 ? 3 : rank == 3 ? 0 : rank) : rank;
+        q.tn = id % p.tiles_n;
+        int r = id / p.tiles_n;
+        q.x0 = (r % p.tiles_x) * TW; r /= p.tiles_x;
+        q.y0 = (r % p.tiles_y) * TH;
+        q.n = r / p.tiles_y;
+        return q;
+    };
+
+    // ---- patch pieces.  Piece q = r * 4 + wave of a chunk covers slots 16 q .. + 15; this lane brings the 16 bytes at physical chunk
+    // lane & 3 of slot 16 q + (lane >> 2); (plane, row, column) of that slot by constant divisions, once per tile.
+    unsigned aoff[NR];                                // byte offset in x of those 16 bytes at channel chunk 0; OOB: zeros
+    auto aim = [&](const Item& q) __attribute__((always_inline)) {
+        static_for<0, NR>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            const int slot = 16 * (r * NW + wave) + (lane >> 2);
+            int y = 0, x = 0, offy = p.org, offx = p.org;
+            bool in = false;
+            static_for<0, NP>([&](auto PP) {
+                constexpr int pl = decltype(PP)::value;
+                constexpr int b0 = m_slot_base(MODE, TH, pl), pw = m_ext(MODE, pl & 1, TW), ph = m_ext(MODE, pl >> 1, TH);
+                if (slot >= b0 && slot < b0 + ph * pw) {
+                    const int rel = slot - b0;
+                    y = rel / pw; x = rel - y * pw; in = true;
+                    if constexpr (NP == 4) { offy = m_off(MODE, pl >> 1); offx = m_off(MODE, pl & 1); }
+                }
+            });
+            const int iy = SI * (q.y0 + y) + offy, ix = SI * (q.x0 + x) + offx;
+            const bool ok = in && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            aoff[r] = ok ? 2u * (unsigned)(((q.n * p.Hi + iy) * p.Wi + ix) * p.Cin) + (unsigned)(((lane & 3) ^ ((x >> 1) & 3)) << 4) : OOB;
+        });
+    };
+    auto dma_piece = [&](auto NN, int stage, int buf) __attribute__((always_inline)) {      // piece n = u * NR + r of a wave's share of a stage
+        constexpr int n = decltype(NN)::value, u = n / NR, r = n % NR;
+        if (r * NW + wave >= NPC) return;             // wave-uniform
+        // (a pixel outside the image carries offset 2^31: with the chunk's offset added it is still past the tensor (< 2^31 bytes: the
+        //  plan checks), so the range check returns zeros -- no select)
+        const unsigned off = aoff[r] + 64u * (unsigned)(stage * S + u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(smem + buf * ST_BYTES + u * CH_BYTES + (r * NW + wave) * 1024), 16, (int)off, 0, 0, 0);
+    };
+
+    // ---- weights: K-step (chunk c, weight tap wt) of this wave's 64 rows = block ((tn64 * nch + c) * TT + wt) of 4 KB
+    // a ring of RING register sets: K-step j's weights are requested D = RING - 1 K-steps ahead (an L2 hit under load takes longer than
+    // one 16-MFMA K-step).  RING divides the K-steps of every stage (pair of stages when odd), so every stage starts on set 0.
+    constexpr int KS_MIN = S * (SO == 2 ? (MODE == PLANE_K3S2D ? 1 : 4) : TT);      // the shortest class's K-steps per stage
+    constexpr int RING = (KS_MIN & 1) ? 3 : (KS_MIN % 4 == 0 ? 4 : 2), D = RING - 1;
+    u32x4_t wf[RING][4];
+    const int wlane = lane * 16;
+    auto load_w = [&](int set, int tn64, int c, int wt) __attribute__((always_inline)) {
+        const int blk = ((tn64 * nch + c) * TT + wt) * 4096;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) wf[set][f] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, blk + f * 1024, 0);
+    };
+
+    // ---- pixel fragments: lane (li, kq) reads k = 8 kq .. + 7 of column li + dx of plane row (wm * NPF + np + dy)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    uint32_t a_lane[4];
+#pragma unroll
+    for (int dx = 0; dx < 4; ++dx) a_lane[dx] = lds0 + (uint32_t)((li + dx) * 64 + ((kq ^ (((li + dx) >> 1) & 3)) << 4));
+    u32x4_t xf[2][NPF];
+    f32x4_t acc[4][NPF];
+
+    // epilogue: a lane owns pixel (rectangle row wm * NPF + np, column li) and channels 32 m + 8 kq .. + 7 of the wave's 64 (m = 0, 1):
+    // accumulators (2m, np) and (2m + 1, np) -- 16 bytes per store, straight from registers
+    auto epilogue = [&](const Item& q) __attribute__((always_inline)) {
+        const int cy = SO == 2 ? q.cls >> 1 : 0, cx = SO == 2 ? q.cls & 1 : 0;
+        const int ox = SO * (q.x0 + li) + cx;
+        const int c0 = q.tn * BN + wn * 64 + 8 * kq;
+        const float neg = (p.aux_mode == S2E_AUX_RELU_MASK) ? 0.f : 0.2f;
+        const bool has_res = resg != nullptr, has_aux = p.aux_mode != S2E_AUX_NONE;
+        u32x4_t opr[NPF][2];
+        int off[NPF]; bool ok[NPF];
+        f32x4_t bv[4];                                  // bias of this lane's channels 32 m + 8 kq + 4 hf + r (f = 2 m + hf)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            bv[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv[f] = *(const f32x4_t*)(p.bias + c0 + 32 * (f >> 1) + 4 * (f & 1));
+        }
+#pragma unroll
+        for (int np = 0; np < NPF; ++np) {
+            const int oy = SO * (q.y0 + wm * NPF + np) + cy;
+            ok[np] = oy < p.Ho && ox < p.Wo;
+            off[np] = ((q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + c0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                opr[np][m] = u32x4_t{0u, 0u, 0u, 0u};
+                if (ok[np] && (has_res || has_aux)) opr[np][m] = *(const u32x4_t*)((has_res ? resg : auxg) + off[np] + 32 * m);
+            }
+        }
+#pragma unroll
+        for (int np = 0; np < NPF; ++np) {
+            if (!ok[np]) continue;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f32x4_t lo = acc[2 * m][np] + bv[2 * m], hi = acc[2 * m + 1][np] + bv[2 * m + 1];
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (has_res) {
+                    float t[8];
+                    unpack16<T>(opr[np][m], t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += t[j];
+                }
+                if (p.out_act == S2E_ACT_LRELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.2f * v[j]);
+                }
+                if (has_aux && !has_res) {
+                    float t[8];
+                    unpack16<T>(opr[np][m], t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= (t[j] > 0.f ? 1.f : neg);
+                }
+                *(u32x4_t*)(yg + off[np] + 32 * m) = u32x4_t{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+            }
+        }
+    };
+
+    // the weights of K-step jj (a constant at every call site) of item q, whose class is a run-time value: a tile's first D K-steps
+    // are requested from inside the previous tile
+    auto load_w_item = [&](int set, const Item& q, int jj) __attribute__((always_inline)) {
+        const int tn64q = q.tn * WN + wn;
+        if constexpr (SO == 2) {
+            static_for<0, 4>([&](auto CC) {
+                constexpr int c = decltype(CC)::value, cy = c >> 1, cx = c & 1;
+                constexpr int ntx = m_ntd(MODE, cx), taps = m_ntd(MODE, cy) * ntx;
+                if (q.cls == c) {
+                    const int t = jj % taps;
+                    load_w(set, tn64q, jj / taps, m_tk(MODE, cy, t / ntx) * m_ks(MODE) + m_tk(MODE, cx, t % ntx));
+                }
+            });
+        } else {
+            const int t = jj % TT;
+            load_w(set, tn64q, jj / TT, (SI == 1 && p.flip) ? TT - 1 - t : t);
+        }
+    };
+
+    Item cur = decode(item_id), nxt = cur;
+    aim(cur);
+    int pb = 0;                                       // patch buffer of the current tile's stage 0
+    bool has_next = false;
+    static_for<0, S * NR>([&](auto NN) { dma_piece(NN, 0, pb); });      // the first tile's stage 0 ...
+    static_for<0, D>([&](auto JJ) { load_w_item(decltype(JJ)::value, cur, decltype(JJ)::value); });      // ... and first weights
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // One tile of class CLS.  The stream of (tile, stage) pairs never stops: during a tile's LAST stage the next tile's stage 0 lands in
+    // the other patch buffer and its first weights in register set 0, so a tile boundary costs the epilogue's instructions only.
+    // On entry: stage 0 is in buffer pb (landed, barrier passed), the first K-step's weights are in flight to set 0.
+    auto tile = [&](auto CLSC) __attribute__((always_inline)) {
+        constexpr int CLS = decltype(CLSC)::value, CY = CLS >> 1, CX = CLS & 1;
+        constexpr int NTX = m_ntd(MODE, CX), TAPS = m_ntd(MODE, CY) * NTX;
+        constexpr int KSTEPS = S * TAPS;                                  // K-steps per stage
+        // the following stage's pieces go out at the START of a stage, PPK per K-step (never in its last K-step unless it is the only one):
+        // the longer they have to land, the better -- but a K-step's weight wait also waits for every older piece (in-order counter)
+        constexpr int KD = KSTEPS > 1 ? KSTEPS - 1 : 1;
+        constexpr int PPK = (S * NR + KD - 1) / KD > 3 ? (S * NR + KD - 1) / KD : (S * NR < 3 ? S * NR : 3);
+        constexpr int JP = (S * NR + PPK - 1) / PPK;                       // K-steps that carry pieces
+        static_assert(JP <= KD, "piece schedule");
+        static_assert(D <= KSTEPS, "weight ring deeper than a stage");
+        const int tn64 = cur.tn * WN + wn;
+        const int flipw = (SO == 1 && SI == 1 && p.flip) ? 1 : 0;
+        // (plain lambdas with int arguments that are constants at every call site: the asm offsets fold to immediates after inlining)
+        auto wtap = [&](int t) __attribute__((always_inline)) -> int {
+            const int w = m_tk(MODE, CY, t / NTX) * m_ks(MODE) + m_tk(MODE, CX, t % NTX);
+            return flipw ? TT - 1 - w : w;
+        };
+        auto read_x = [&](int set, int t, int u, int buf, int h0, int h1) __attribute__((always_inline)) {      // fragments h0 .. h1 - 1
+            const int ty = t / NTX, tx = t % NTX;
+            const int pl = m_ta(MODE, CY, ty) * 2 + m_ta(MODE, CX, tx), dy = m_td(MODE, CY, ty), dx = m_td(MODE, CX, tx);
+            const int pw = m_ext(MODE, pl & 1, TW);
+            int so = buf * ST_BYTES + (wm * NPF) * pw * 64;
+            asm volatile("" : "+s"(so));               // (opaque: one v_add per K-step instead of a table of hoisted sums)
+            const uint32_t ab = a_lane[dx] + (uint32_t)so;
+#pragma unroll
+            for (int np = h0; np < h1; ++np)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[set][np]) : "v"(ab), "n"(u * CH_BYTES + (m_slot_base(MODE, TH, pl) + (np + dy) * pw) * 64) : "memory");
+        };
+        auto mfmas = [&](int set, int wset, int h0, int h1) __attribute__((always_inline)) {
+#pragma unroll
+            for (int np = h0; np < h1; ++np)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    acc[f][np] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[wset][f]), __builtin_bit_cast(bf16x8_t, xf[set][np]),
+                                                                         acc[f][np], 0, 0, 0);
+        };
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int np = 0; np < NPF; ++np) acc[f][np] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        read_x(0, 0, 0, pb, 0, NPF);
+        // A stage whose first K-step runs on register set P.  With an odd number of K-steps per stage the sets swap roles from one stage
+        // to the next: the loop below then runs TWO stages per trip, straight-line (the plan guarantees an even number of stages, so
+        // every tile starts on set 0).
+        auto stage = [&](int s, auto PC) __attribute__((always_inline)) {
+            constexpr int P = decltype(PC)::value;
+            const bool last_stage = s + 1 >= NS;
+            const bool more = !last_stage || has_next;     // another stage follows in the stream
+            const int buf = (pb + s) & 1;
+            if (last_stage && has_next) aim(nxt);           // (this tile's last pieces went out during the previous stage)
+            const int nstage = last_stage ? 0 : s + 1;      // the following stage's index in ITS tile
+            static_for<0, KSTEPS>([&](auto JC) {
+                constexpr int j = decltype(JC)::value;
+                constexpr bool lastk = j == KSTEPS - 1;
+                constexpr int cs = (P + j) & 1, ns = cs ^ 1;                  // pixel-fragment register sets
+                constexpr int jg = P * KSTEPS + j, wcs = jg % RING, wns = (jg + D) % RING;      // weight ring
+                constexpr int jt = j + D;                                     // the K-step whose weights go out now
+                int sv = s;
+                asm volatile("" : "+s"(sv));               // (opaque per K-step: see conv_duo.hip)
+                if (sv >= NS) return;                      // (never taken: a block boundary per K-step keeps the accumulators in place)
+                // the following stage's pieces (never in a stage's last K-step unless it is the only one)
+                if (more)
+                    static_for<0, PPK>([&](auto QC) {
+                        constexpr int n = j * PPK + decltype(QC)::value;
+                        if constexpr (n < S * NR) dma_piece(std::integral_constant<int, n>{}, nstage, buf ^ 1);
+                    });
+                asm volatile("" ::: "memory");             // (pieces before weights: the stage-end wait counts what follows the last piece)
+                // the weights of K-step j + D
+                if constexpr (jt < KSTEPS) load_w(wns, tn64, sv * S + jt / TAPS, wtap(jt % TAPS));
+                else if (!last_stage) load_w(wns, tn64, (sv + 1) * S + (jt - KSTEPS) / TAPS, wtap((jt - KSTEPS) % TAPS));
+                else if (has_next) load_w_item(wns, nxt, jt - KSTEPS);
+                asm volatile("" ::: "memory");
+                if constexpr (!lastk) {
+                    read_x(ns, (j + 1) % TAPS, (j + 1) / TAPS, buf, 0, NPF);
+                    // all but the newest NPF reads are back: this K-step's fragments
+                    if constexpr (NPF == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xf[cs][0]), "+v"(xf[cs][1]), "+v"(xf[cs][2]), "+v"(xf[cs][3]) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xf[cs][0]), "+v"(xf[cs][1]) :: "memory");
+                    mfmas(cs, wcs, 0, NPF);
+                } else {
+                    if constexpr (NPF == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[cs][0]), "+v"(xf[cs][1]), "+v"(xf[cs][2]), "+v"(xf[cs][3]) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[cs][0]), "+v"(xf[cs][1]) :: "memory");
+                    mfmas(cs, wcs, 0, NPF / 2);
+                    if (more) {
+                        // this wave's pieces of the following stage have landed once only the weight loads issued after the last of them
+                        // are outstanding (four per K-step from the last piece-carrying K-step on); every read of this stage's buffer is
+                        // back (above); then the waves meet
+                        constexpr int after = 4 * (KSTEPS - JP + 1);
+                        static_assert(after <= 63, "vmcnt range");
+                        if constexpr (KSTEPS == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(after) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                        if (!last_stage) read_x(ns, 0, 0, buf ^ 1, 0, NPF);       // (a following TILE reads its own first fragments: its class may differ)
+                    }
+                    mfmas(cs, wcs, NPF / 2, NPF);
+                }
+            });
+        };
+        if constexpr (KSTEPS & 1) {
+            for (int s = 0; s < NS; s += 2) {
+                stage(s, std::integral_constant<int, 0>{});
+                stage(s + 1, std::integral_constant<int, 1>{});
+            }
+        } else {
+            for (int s = 0; s < NS; ++s) stage(s, std::integral_constant<int, 0>{});
+        }
+    };
+
+    for (;;) {
+        const int next_id = item_id + G;
+        has_next = next_id < n_items;
+        if (has_next) nxt = decode(next_id);
+        if constexpr (SO == 2) {
+            if (cur.cls == 3) tile(std::integral_constant<int, 3>{});
+            else if (cur.cls == 2) tile(std::integral_constant<int, 2>{});
+            else if (cur.cls == 1) tile(std::integral_constant<int, 1>{});
+            else tile(std::integral_constant<int, 0>{});
+        } else tile(std::integral_constant<int, 0>{});
+        epilogue(cur);
+        if (!has_next) break;
+        cur = nxt; item_id = next_id; pb = (pb + NS) & 1;
+    }
+}
+
+int plane_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+template <int MODE, int S>
+int plane_launch(const PlaneParams& p, hipStream_t st) {
+    const long items = (long)p.rects * p.tiles_n * (m_so(MODE) == 2 ? 4 : 1);
+    const int cap = 2 * plane_cu_count();
+    const int grid = items < cap ? (int)items : cap;
+    if (p.Cout % 128 == 0) conv_plane_kernel<MODE, 128, 8, S><<<grid, 256, 0, st>>>(p);
+    else conv_plane_kernel<MODE, 64, 8, S><<<grid, 256, 0, st>>>(p);
+    S2E_CHECK_LAUNCH("conv_plane_kernel");
+    return S2E_OK;
+}
+
+// chunks per patch stage of a mode (1x1: four, or two when the channel count has no four chunks: the 64-channel data gradient)
+constexpr int plane_stage_chunks(int mode, int nch = 4) { return mode == PLANE_K1 ? (nch % 4 == 0 ? 4 : 2) : mode == PLANE_K3S2D || mode == PLANE_K4S2D ? 2 : 1; }
+
+}  // namespace
+
+// S2E_CONV_PLANE: bit mask of the modes this kernel may take (default: 1x1 and the 3x3 stride-2 pair); 0 = never (A/B runs)
+static int plane_mask() {
+    static const int m = [] {
+        const char* e = getenv("S2E_CONV_PLANE");
+        return e ? atoi(e) : (1 << PLANE_K1) | (1 << PLANE_K3S2F) | (1 << PLANE_K3S2D);
+    }();
+    return m;
+}
+
+int s2e_conv_plane_mode(int dtype, const s2e_conv_desc* d) {
+    if (!d || dtype != S2E_BF16 || plane_mask() == 0) return PLANE_NONE;
+    if (d->in_act != S2E_ACT_NONE || d->out_act == S2E_ACT_TANH || d->KH != d->KW) return PLANE_NONE;
+    if (d->Cin % 32 != 0 || d->Cout % 64 != 0) return PLANE_NONE;
+    if ((long)d->N * d->Hi * d->Wi * d->Cin * 2 >= (1L << 31) || (long)d->N * d->Ho * d->Wo * d->Cout * 2 >= (1L << 31)) return PLANE_NONE;
+    if ((long)d->Cout * d->KH * d->KW * d->Cin * 2 >= (1L << 31)) return PLANE_NONE;
+    int mode = PLANE_NONE, rh = d->Ho, rw = d->Wo;
+    if (d->KH == 1 && d->stride == 1 && d->pad == 0 && d->Ho == d->Hi && d->Wo == d->Wi) mode = PLANE_K1;
+    else if (d->KH == 3 && d->stride == 2 && d->pad == 1 && !d->transposed && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo) mode = PLANE_K3S2F;
+    else if (d->KH == 3 && d->stride == 2 && d->pad == 1 && d->transposed && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi) { mode = PLANE_K3S2D; rh = d->Hi; rw = d->Wi; }
+    else if (d->KH == 3 && d->stride == 1) {
+        const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;
+        if (d->Ho == d->Hi + grow && d->Wo == d->Wi + grow) mode = PLANE_K3S1;
+    }
+    if (mode == PLANE_NONE || !((plane_mask() >> mode) & 1)) return PLANE_NONE;
+    if ((d->Cin / 32) % plane_stage_chunks(mode, d->Cin / 32) != 0) return PLANE_NONE;
+    // (a stage of an odd number of K-steps -- the 3x3 forward modes: 9 -- swaps the two register sets: the kernel runs such stages in pairs)
+    if ((mode == PLANE_K3S1 || mode == PLANE_K3S2F) && (d->Cin / 32 / plane_stage_chunks(mode)) % 2 != 0) return PLANE_NONE;
+    // rectangles of 8 x 16: the map must be at least one rectangle wide and tall, and the launch must give the chip something to do
+    if (rw < 16 || rh < 8) return PLANE_NONE;
+    const long items = (long)d->N * ceil_div(rh, 8) * ceil_div(rw, 16) * ceil_div(d->Cout, d->Cout % 128 == 0 ? 128 : 64) * (mode == PLANE_K3S2D ? 4 : 1);
+    static const int min_items = [] { const char* e = getenv("S2E_CONV_PLANE_MIN"); return e ? atoi(e) : 128; }();
+    if (items < min_items) return PLANE_NONE;
+    return mode;
+}
+
+int s2e_conv_plane_launch(int mode, const void* x, const void* w, const float* bias, const void* res, const void* aux, void* y,
+                          const s2e_conv_desc* d, hipStream_t st) {
+    if (res && d->aux_mode != S2E_AUX_NONE) S2E_FAIL(S2E_ERR_UNSUPPORTED, "conv_plane: residual and mask in one launch");
+    PlaneParams p{};
+    p.x = x; p.w = w; p.bias = bias; p.res = res; p.aux = aux; p.y = y;
+    p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.org = (mode == PLANE_K3S1 || mode == PLANE_K4S1) ? (d->transposed ? d->pad - (d->KH - 1) : -d->pad) : 0;      // (the other modes' planes carry their own offsets)
+    p.flip = d->transposed ? 1 : 0;
+    p.out_act = d->out_act; p.aux_mode = d->aux_mode;
+    const bool dg = mode == PLANE_K3S2D || mode == PLANE_K4S2D;
+    const int rh = dg ? d->Hi : d->Ho, rw = dg ? d->Wi : d->Wo;
+    p.tiles_x = ceil_div(rw, 16); p.tiles_y = ceil_div(rh, 8);
+    p.tiles_n = ceil_div(d->Cout, d->Cout % 128 == 0 ? 128 : 64);
+    p.rects = d->N * p.tiles_y * p.tiles_x;
+    p.nch = d->Cin / 32;
+    p.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Cin * 2);
+    p.w_bytes = (unsigned)((long)ceil_div(d->Cout, 64) * 64 * d->KH * d->KW * d->Cin * 2);
+    switch (mode) {
+    case PLANE_K1: return p.nch % 4 == 0 ? plane_launch<PLANE_K1, 4>(p, st) : plane_launch<PLANE_K1, 2>(p, st);
+    case PLANE_K3S1: return plane_launch<PLANE_K3S1, plane_stage_chunks(PLANE_K3S1)>(p, st);
+    case PLANE_K3S2F: return plane_launch<PLANE_K3S2F, plane_stage_chunks(PLANE_K3S2F)>(p, st);
+    case PLANE_K3S2D: return plane_launch<PLANE_K3S2D, plane_stage_chunks(PLANE_K3S2D)>(p, st);
+    default: break;
+    }
+    S2E_FAIL(S2E_ERR_UNSUPPORTED, "conv_plane: mode %d", mode);
+}
+
+// ---- C ABI (include/seg2eye_hip.h)
+extern "C" int s2e_conv2d_plane_supported(int dtype, const s2e_conv_desc* d) { return s2e_conv_plane_mode(dtype, d); }
+
+extern "C" size_t s2e_conv_plane_weight_elems(const s2e_conv_desc* d) {
+    if (!d) return 0;
+    return (size_t)ceil_div(d->Cout, 64) * 64 * d->KH * d->KW * d->Cin;
+}
+
+extern "C" int s2e_conv2d_plane(int dtype, const void* x, const void* w_plane, const float* bias, const void* res, const void* aux,
+                                void* y, const s2e_conv_desc* d, void* stream) {
+    if (!x || !w_plane || !y || !d) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_plane: null pointer");
+    if (d->aux_mode != S2E_AUX_NONE && !aux) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_plane: aux_mode without aux");
+    const int mode = s2e_conv_plane_mode(dtype, d);
+    if (mode == PLANE_NONE) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_plane: not a shape of this kernel (s2e_conv2d_plane_supported == 0): run s2e_conv2d");
+    return s2e_conv_plane_launch(mode, x, w_plane, bias, res, aux, y, d, (hipStream_t)stream);
+}

@@ -360,6 +360,7 @@ extern "C" int s2e_sn_power_iteration(const s2e_sn_layer* layers, int n_layers, 
 }
 
 // ------------------------------------------------------------------------------------ weight packers
+#include "conv_plane.h"
 // OIHW fp32 -> MFMA B-operand layout in the compute dtype, divided by *sigma when sigma != NULL.
 // Both directions go through LDS so that global reads AND writes are contiguous runs.
 // Every element of the padded matrix is written exactly once per call (padding rows / channels / K tail as
@@ -492,6 +493,11 @@ __global__ __launch_bounds__(256) void pack_tr_cl_kernel(const float* __restrict
     extern __shared__ float lds[];
     pack_tr_cl_block<T>(w, out, sigma, cout, cin, taps, rows_pad, kpad, blockIdx.x, blockIdx.y, lds);
 }
+// the PLANE layout (conv_plane.h): bf16 only
+__global__ __launch_bounds__(256) void pack_plane_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, const float* __restrict__ sigma,
+                                                         int cout, int cin, int taps, int transposed) {
+    pack_plane_block(w, out, sigma, cout, cin, taps, transposed, blockIdx.x);
+}
 // every conv of a network in one launch: block_map = {job, bx, by} per block (s2e_pack_block_map)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batch_kernel(const s2e_pack_job* __restrict__ jobs, const int* __restrict__ block_map,
@@ -500,7 +506,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const s2e_pack_job* __r
     const int* bm = block_map + 3 * blockIdx.x;
     const s2e_pack_job J = jobs[bm[0]];
     const float* sg = J.sigma_index >= 0 ? sigma_base + J.sigma_index : nullptr;
-    if (J.transposed == 2) {                                 // channels-last source (s2e_pack_job: transposed bit 1), forward
+    if (J.transposed & S2E_PACK_PLANE) {                     // the PLANE layout (conv_plane.hip's weights)
+        if constexpr (std::is_same<T, bf16_t>::value) pack_plane_block(J.w, (bf16_t*)J.out, sg, J.cout, J.cin, J.taps, J.transposed, bm[1]);
+    } else if (J.transposed == 2) {                                 // channels-last source (s2e_pack_job: transposed bit 1), forward
         const int kpad = (J.taps * J.cin + (dtype == S2E_BF16 ? 63 : 31)) / (dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
         const int rows = J.cout <= 32 ? 32 : (J.cout <= 64 ? 64 : (J.cout + 127) / 128 * 128);
         pack_fwd_cl_block<T>(J.w, (T*)J.out, sg, J.cout, J.taps * J.cin, rows, kpad, bm[1]);
@@ -526,6 +534,14 @@ extern "C" int s2e_pack_conv_weight(int dtype, const float* w, void* packed, con
     const int taps = kh * kw;
     if (taps > 64) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_pack_conv_weight: kernel %dx%d too large", kh, kw);
     const bool tr = (transposed & 1) != 0;
+    if (transposed & S2E_PACK_PLANE) {                       // the PLANE layout (conv_plane.h): bf16, no channel padding, K a multiple of 32
+        if (dtype != S2E_BF16 || cin_pad != cin || (tr ? cout : cin) % 32 != 0)
+            S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_pack_conv_weight: the plane layout needs bf16, cin_pad == cin and a K dimension that is a multiple of 32");
+        const long units = s2e_plane_pack_units(cout, cin, taps, transposed);
+        pack_plane_kernel<<<ceil_div(units, 256), 256, 0, (hipStream_t)stream>>>(w, (bf16_t*)packed, sigma, cout, cin, taps, transposed);
+        S2E_CHECK_LAUNCH("pack_plane_kernel");
+        return S2E_OK;
+    }
     const int rows = s2e_conv_cout_pad(tr ? cin_pad : cout);
     const int kpad = s2e_conv_k_pad(dtype, taps * (tr ? cout : cin_pad));
     hipStream_t st = (hipStream_t)stream;
@@ -566,7 +582,8 @@ extern "C" long s2e_pack_block_map(int dtype, const s2e_pack_job* jobs_host, int
     for (int j = 0; j < n_jobs; ++j) {
         const s2e_pack_job& J = jobs_host[j];
         int gx, gy;
-        if (J.transposed == 2)  { gx = ceil_div((long)s2e_conv_cout_pad(J.cout) * s2e_conv_k_pad(dtype, J.taps * J.cin), PACK_CL_ELEMS); gy = 1; }
+        if (J.transposed & S2E_PACK_PLANE) { gx = ceil_div(s2e_plane_pack_units(J.cout, J.cin, J.taps, J.transposed), 256); gy = 1; }
+        else if (J.transposed == 2)  { gx = ceil_div((long)s2e_conv_cout_pad(J.cout) * s2e_conv_k_pad(dtype, J.taps * J.cin), PACK_CL_ELEMS); gy = 1; }
         else if (J.transposed & 2) { gx = ceil_div(J.cout, 64);   gy = J.taps * ceil_div(s2e_conv_cout_pad(J.cin_pad), 64); }
         else if (!J.transposed) { gx = s2e_conv_cout_pad(J.cout) / 4; gy = ceil_div(J.cin_pad, 64); }
         else                    { gx = ceil_div(J.cout, 64);      gy = ceil_div(s2e_conv_cout_pad(J.cin_pad), 8); }

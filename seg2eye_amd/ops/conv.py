@@ -12,12 +12,27 @@ from .core import GradSink, IN_EPS, LaunchProfiler, ZeroPool, _cl_dense, _cl_row
 
 # ------------------------------------------------------------------------------ raw launchers
 
-def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False, sigma=None):
+PLANE_LAYOUT = 4            # S2E_PACK_PLANE: the weight layout of s2e_conv2d_plane (csrc/conv_plane.h)
+
+
+def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False, sigma=None, plane=False):
     """OIHW fp32 -> MFMA B-operand matrix in the compute dtype; divided by the device scalar `sigma`
-    (spectral norm) on the fly when given."""
+    (spectral norm) on the fly when given.  plane: the PLANE layout (the weight operand of s2e_conv2d_plane: plane_mode())."""
     w = w_oihw.detach()
     cout, cin, kh, kw = w.shape
     cin_pad = cin if cin_pad is None else cin_pad
+    if plane:
+        if dtype != torch.bfloat16 or cin_pad != cin:
+            raise ValueError('pack_weight: the plane layout is bf16 without channel padding')
+        cl = w.dtype == torch.float32 and not w.is_contiguous() and _cl_dense(w)
+        if not cl and (w.dtype != torch.float32 or not w.is_contiguous()):
+            w = w.float().contiguous()
+        _need(_cl_rows(w) if cl else w, sigma)
+        rows = cin if transposed else cout
+        out = torch.empty((rows + 63) // 64 * 64, kh * kw * (cout if transposed else cin), dtype=dtype, device=w.device)
+        L.check(L.lib().s2e_pack_conv_weight(L.S2E_BF16, _p(w), _p(out), _p(sigma), cout, cin, kh, kw, cin, int(bool(transposed)) | (2 if cl else 0) | PLANE_LAYOUT,
+                                             _stream()), 's2e_pack_conv_weight')
+        return out
     # a weight stored channels-last (optim.FlatAdam) is packed from where it lies: rows in, rows out
     cl = w.dtype == torch.float32 and not w.is_contiguous() and _cl_dense(w) and cin_pad == cin and cin % 8 == 0
     if not cl and (w.dtype != torch.float32 or not w.is_contiguous()):
@@ -34,17 +49,35 @@ def pack_weight(w_oihw, dtype, cin_pad=None, transposed=False, sigma=None):
     return out
 
 
-def packed_weight(w, dtype, cin_pad, transposed, sigma, plan, generation=None, stable=True):
+def packed_weight(w, dtype, cin_pad, transposed, sigma, plan, generation=None, stable=True, plane=False):
     """The packed matrix from the network's PackPlan (packing.py) when it has one for THIS forward, else an
     individual pack -- which also teaches the plan, so the next forward packs it in the batched launch.
-    stable=False: `w` is a temporary (its address means nothing next time): never recorded."""
+    stable=False: `w` is a temporary (its address means nothing next time): never recorded.
+    plane: the PLANE layout (the conv runs in s2e_conv2d_plane: plane_mode())."""
     if plan is not None and stable:
-        wp = plan.lookup(w, dtype, cin_pad, transposed, generation)
+        wp = plan.lookup(w, dtype, cin_pad, transposed, generation, plane)
         if wp is not None:
             return wp
         if generation is None or generation == plan.generation:
-            plan.record(w, dtype, cin_pad, transposed, sigma)
-    return pack_weight(w, dtype, cin_pad, transposed, sigma)
+            plan.record(w, dtype, cin_pad, transposed, sigma, plane)
+    return pack_weight(w, dtype, cin_pad, transposed, sigma, plane)
+
+
+_PLANE_MODES = {}
+
+
+def plane_mode(x_dtype, n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, transposed, in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE,
+               has_res=False):
+    """0, or the mode (> 0) in which the plane-patch kernel (s2e_conv2d_plane) runs this launch: its weight operand is then packed
+    in the PLANE layout (pack_weight(..., plane=True)) and conv2d_raw is called with plane=True.  Memoised per shape."""
+    if x_dtype != torch.bfloat16 or (has_res and aux_mode != AUX_NONE):
+        return 0
+    key = (n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, int(transposed), in_act, out_act, aux_mode)
+    v = _PLANE_MODES.get(key)
+    if v is None:
+        d = ConvDesc(*key)
+        v = _PLANE_MODES[key] = int(L.lib().s2e_conv2d_plane_supported(L.S2E_BF16, C.byref(d)))
+    return v
 
 
 # profiler families = the kernel s2e_conv2d / s2e_conv2d_wgrad choose for the shape (S2E_KERNEL_GENERIC / SMALL / PATCH)
@@ -80,8 +113,9 @@ def _conv_stats_slots(dt, d, *shape):
 
 
 def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transposed=False,
-               in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE, out=None, stats_out=None):
-    """stats_out: None, or a list that receives the InstanceNorm statistics (N, Cout, 2) {mean, rstd} of the result when the
+               in_act=ACT_NONE, out_act=ACT_NONE, aux_mode=AUX_NONE, out=None, stats_out=None, plane=False):
+    """plane: wp is in the PLANE layout and the launch goes to s2e_conv2d_plane (the caller asked plane_mode()).
+    stats_out: None, or a list that receives the InstanceNorm statistics (N, Cout, 2) {mean, rstd} of the result when the
     kernel this shape takes produces their partial sums in its epilogue (s2e_conv2d_stats; then the caller needs no pass over y);
     left empty otherwise."""
     _need(x, wp, bias, residual, aux)
@@ -96,6 +130,13 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     # data-gradient executes 4x that on structural zeros; not counted)
     pix = hi * wi if transposed else ho * wo
     flops = 2.0 * n * pix * cin * cout * kh * kw
+    if plane:
+        LaunchProfiler.run('conv_plane', flops, lambda: L.check(
+            L.lib().s2e_conv2d_plane(dt, _p(x), _p(wp), _p(bias), _p(residual), _p(aux), _p(y), C.byref(d), _stream()), 's2e_conv2d_plane'),
+            tag=lambda: '%s n%d %dx%d c%d->%d k%d s%d' % ('D' if transposed else 'F', n, hi, wi, cin, cout, kh, stride),
+            nbytes=lambda: float((x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0)
+                                  + (aux.numel() if aux is not None else 0)) * x.element_size()))
+        return y
     if stats_out is not None and aux is None and not transposed:
         slots = _conv_stats_slots(dt, d, n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, in_act, out_act)
         if slots:
@@ -250,10 +291,11 @@ class Conv2dFn(torch.autograd.Function):
         ho = (hi + 2 * pad - kh) // stride + 1
         wo = (wi + 2 * pad - kw) // stride + 1
         plan = packing.current()
-        wp = packed_weight(weight, x.dtype, cx, False, sigma, plan)
+        pm = plane_mode(x.dtype, n, hi, wi, cx, ho, wo, cout, kh, kw, stride, pad, False, in_act, out_act, AUX_NONE) if cx == cin else 0
+        wp = packed_weight(weight, x.dtype, cx, False, sigma, plan, plane=pm > 0)
         ctx.plan, ctx.plan_gen = plan, (plan.generation if plan is not None else None)
         b = None if bias is None else bias.detach().float().contiguous()
-        y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act, stats_out=stats_out)
+        y = conv2d_raw(x, wp, b, residual, None, (ho, wo, cout), kh, kw, stride, pad, False, in_act, out_act, stats_out=stats_out, plane=pm > 0)
         ctx.cfg = (stride, pad, in_act, out_act, bias is not None, residual is not None)
         ctx.live = LivePrefix.n
         ctx.wdst = _grad_dst(weight)                       # direct accumulation targets (or None)
@@ -279,9 +321,11 @@ class Conv2dFn(torch.autograd.Function):
                 L.check(L.lib().s2e_lrelu_bwd(_dt(gl), _p(gl), _p(y), _p(g2), gl.numel(), _stream()), 's2e_lrelu_bwd')
                 gl = g2
             gx = _live_tail_buffer(x, live)                    # (samples live.. are zero already)
-            wpt = packed_weight(weight, x.dtype, cx, True, sigma, ctx.plan, ctx.plan_gen)
+            am = AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE
+            pm = plane_mode(x.dtype, live, gl.shape[1], gl.shape[2], cout, hi, wi, cx, kh, kw, stride, pad, True, ACT_NONE, ACT_NONE, am) if cx == cin else 0
+            wpt = packed_weight(weight, x.dtype, cx, True, sigma, ctx.plan, ctx.plan_gen, plane=pm > 0)
             conv2d_raw(gl, wpt, None, None, x[:live] if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
-                       True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE, out=gx[:live])
+                       True, ACT_NONE, ACT_NONE, am, out=gx[:live], plane=pm > 0)
             return gx, None, None, None, None, None, None, None, None, None, None, None
         if out_act == ACT_TANH:
             g2 = torch.empty_like(g)
@@ -293,9 +337,11 @@ class Conv2dFn(torch.autograd.Function):
             g = g2
         gx = gw = gb = gres = None
         if ctx.needs_input_grad[0]:
-            wpt = packed_weight(weight, x.dtype, cx, True, sigma, ctx.plan, ctx.plan_gen)
+            am = AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE
+            pm = plane_mode(x.dtype, n, g.shape[1], g.shape[2], cout, hi, wi, cx, kh, kw, stride, pad, True, ACT_NONE, ACT_NONE, am) if cx == cin else 0
+            wpt = packed_weight(weight, x.dtype, cx, True, sigma, ctx.plan, ctx.plan_gen, plane=pm > 0)
             gx = conv2d_raw(g, wpt, None, None, x if in_act == ACT_LRELU else None, (hi, wi, cx), kh, kw, stride, pad,
-                            True, ACT_NONE, ACT_NONE, AUX_LRELU_GRAD if in_act == ACT_LRELU else AUX_NONE)
+                            True, ACT_NONE, ACT_NONE, am, plane=pm > 0)
         want_b = has_bias and ctx.needs_input_grad[2]
         wdst = ctx.wdst
         shared = bool(has_res and ctx.needs_input_grad[3])   # g goes on as the residual's gradient (and may be added to in place there)

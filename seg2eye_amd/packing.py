@@ -36,12 +36,12 @@ class PackPlan:
         self.hits = 0                # lookups served from the batched launch (tests)
 
     @staticmethod
-    def key(w, dtype, cin_pad, transposed):
-        return (w.data_ptr(), tuple(w.shape), tuple(w.stride()), dtype, int(cin_pad), bool(transposed))
+    def key(w, dtype, cin_pad, transposed, plane=False):
+        return (w.data_ptr(), tuple(w.shape), tuple(w.stride()), dtype, int(cin_pad), bool(transposed), bool(plane))
 
     # ---------------------------------------------------------------- learning
-    def record(self, w, dtype, cin_pad, transposed, sigma):
-        k = self.key(w, dtype, cin_pad, transposed)
+    def record(self, w, dtype, cin_pad, transposed, sigma, plane=False):
+        k = self.key(w, dtype, cin_pad, transposed, plane)
         if k in self.jobs:
             return
         sidx = -1 if sigma is None else int(sigma.storage_offset())
@@ -50,16 +50,17 @@ class PackPlan:
         cl = bool(wd.dtype == torch.float32 and not wd.is_contiguous() and _cl_dense(wd) and int(cin_pad) == wd.shape[1] and wd.shape[1] % 8 == 0)
         if not cl and (wd.dtype != torch.float32 or not wd.is_contiguous()):
             return                                           # (needs a converted copy: packed one by one, ops.pack_weight)
-        self.jobs[k] = dict(w=wd, dtype=dtype, cin_pad=int(cin_pad), transposed=bool(transposed), sigma_index=sidx, out=None, cl=cl)
+        self.jobs[k] = dict(w=wd, dtype=dtype, cin_pad=int(cin_pad), transposed=bool(transposed), sigma_index=sidx, out=None, cl=cl,
+                            plane=bool(plane))
         self.dirty = True
 
-    def lookup(self, w, dtype, cin_pad, transposed, generation=None):
+    def lookup(self, w, dtype, cin_pad, transposed, generation=None, plane=False):
         """The pre-packed matrix, or None (not learned yet / packed by an older or newer forward)."""
         if self.tables is None or (generation is not None and generation != self.generation):
             return None
         if transposed and not self.packed_tr:
             return None
-        j = self.jobs.get(self.key(w, dtype, cin_pad, transposed))
+        j = self.jobs.get(self.key(w, dtype, cin_pad, transposed, plane))
         if j is None or j.get('stale', True):
             return None
         self.hits += 1
@@ -81,12 +82,15 @@ class PackPlan:
                 cout, cin, kh, kw = j['w'].shape
                 rows = lib.s2e_conv_cout_pad(j['cin_pad'] if j['transposed'] else cout)
                 kpad = lib.s2e_conv_k_pad(dt, kh * kw * (cout if j['transposed'] else j['cin_pad']))
+                if j['plane']:                               # the PLANE layout (csrc/conv_plane.h): 64-row groups, no K padding
+                    rows = ((j['cin_pad'] if j['transposed'] else cout) + 63) // 64 * 64
+                    kpad = kh * kw * (cout if j['transposed'] else j['cin_pad'])
                 if j['out'] is None:
                     j['out'] = torch.empty(rows, kpad, dtype=dtype, device=dev)
                 j['stale'] = True
                 arr[i].w, arr[i].out, arr[i].sigma_index = j['w'].data_ptr(), j['out'].data_ptr(), j['sigma_index']
                 arr[i].cout, arr[i].cin, arr[i].taps, arr[i].cin_pad = cout, cin, kh * kw, j['cin_pad']
-                arr[i].transposed = int(j['transposed']) | (2 if j['cl'] else 0)      # bit 1: the source is stored channels-last
+                arr[i].transposed = int(j['transposed']) | (2 if j['cl'] else 0) | (4 if j['plane'] else 0)     # bit 1: the source is stored channels-last; bit 2: PLANE layout
             n_fwd = sum(1 for j in jobs if not j['transposed'])
             nb_fwd = lib.s2e_pack_block_map(dt, C.byref(arr), n_fwd, None) if n_fwd else 0
             nb_all = lib.s2e_pack_block_map(dt, C.byref(arr), len(jobs), None)

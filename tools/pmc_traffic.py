@@ -22,6 +22,7 @@ from collections import defaultdict
 FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the family)
     'conv_patch_kernel': ('conv_patch', True),
     'conv_duo_kernel': ('conv_patch', True),            # (round 4: the same s2e_conv2d / s2e_spade_conv_modulate launches, two workgroups per CU)
+    'conv_plane_kernel': ('conv_plane', True),            # (round 6: netE's stride-2 3x3 layers and the 1x1 shortcuts, csrc/conv_plane.hip)
     'conv_igemm_kernel': ('conv_igemm', True),
     'conv_stream_kernel': ('conv_igemm', True), 'conv_stream_fixup_kernel': ('conv_igemm', False),   # (same profiler family: s2e_conv2d's generic shapes)
     'conv_finish_kernel': ('conv_igemm', False),          # (also finishes the patch kernel's channel-chunk splits)
