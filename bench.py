@@ -23,6 +23,7 @@ import argparse
 import json
 import os
 import sys
+import subprocess
 import time
 
 import numpy as np
@@ -236,6 +237,14 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode     # the ranks inherit stdout: rank 0's JSON line passes through
 
 
+def _git_head():
+    try:
+        return subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, timeout=5).stdout.strip()
+    except Exception:                                    # noqa: BLE001 -- no git on the GPU box: S2E_GIT_HEAD names the commit there
+        return ''
+
+
+BATCH_SEEDS = (1234, 77, 2024, 5)          # the timed loop's batches (rank r: + r)
 TRAIN_GFLOP_PER_SAMPLE = {(256, 256): 1239.4, (640, 384): 4528.9}     # G step + D step, ngf = ndf = 64
 
 
@@ -320,13 +329,19 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         trainer = Pix2PixTrainer(opt)
     fill_weights(trainer.pix2pix_model)
-    data = make_data(args.batch, args.size, 1234 + rank, dev)          # resident in HBM before timing
+    # FOUR batches, resident in HBM before timing, taken in rotation (what train.py runs -- the label-sparse launches'
+    # rectangle lists, class tables and uniform fractions differ from batch to batch; the first one alone is `single_batch` below)
+    datas = [make_data(args.batch, args.size, seed + rank, dev) for seed in BATCH_SEEDS]
+    data = datas[0]
+    turn = [0]
 
     exchange_desc = trainer.sync_G.describe()
 
     def step():
-        trainer.run_generator_one_step(dict(data))
-        trainer.run_discriminator_one_step(dict(data))
+        d = datas[turn[0] % len(datas)]
+        turn[0] += 1
+        trainer.run_generator_one_step(dict(d))
+        trainer.run_discriminator_one_step(dict(d))
 
     for _ in range(args.warmup):
         step()
@@ -358,6 +373,12 @@ def main():
     # Beside the headline (rank 0's line only, one GPU only, never inside the timed region above):
     extras = {}
     if world == 1 and not args.no_extras:
+        def step_single():
+            trainer.run_generator_one_step(dict(data))
+            trainer.run_discriminator_one_step(dict(data))
+        sec = timed_steps(step_single, args.steps, 3)
+        extras['single_batch'] = {'value': args.batch / sec, 'unit': 'images/s', 'ms_per_step': sec * 1e3, 'hip_graphs': graphs_ran,
+                                  'what': 'the same G+D steps replayed on ONE batch (seed %d: what rounds 1-5 timed)' % BATCH_SEEDS[0]}
         dense = make_dense_label_data(data, 4321)
 
         def step_dense():
@@ -395,6 +416,29 @@ def main():
     losses = {k: float(v.detach().float().mean()) for k, v in trainer.get_latest_losses().items()}
     if not all(np.isfinite(list(losses.values()))):
         raise SystemExit('non-finite losses: %s' % losses)
+    #  what the gradient exchange costs the step: the same K steps with the collectives switched off (FlatGradSync.noop:
+    # the replicas' weights drift apart from here on -- nothing below depends on them), and each group's exchange on its own
+    exchange = None
+    if world > 1 and sdist.exchange_active():
+        trainer.opt.hip_graphs = not args.no_graphs
+        trainer.sync_G.noop = trainer.sync_D.noop = True
+        for _ in range(2):
+            step()
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        trainer.sync_G.noop = trainer.sync_D.noop = False
+        ms_noex = float(t.item()) / args.steps * 1e3
+        exchange = {'ms_per_step_without_exchange': ms_noex, 'exchange_ms_exposed': elapsed / args.steps * 1e3 - ms_noex,
+                    'allreduce_ms_per_group_standalone': {'G': trainer.sync_G.time_groups(), 'D': trainer.sync_D.time_groups()},
+                    'what': 'exposed = ms_per_step minus the same steps with the collectives off (max over ranks); per group: the '
+                            'exchange of that arena slice alone on an idle device, host-timed on rank 0'}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -405,7 +449,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'hip_graphs': graphs_ran,
             'config': {'workload': 'Seg2Eye G+D hinge-GAN train step (G step + D step, TTUR Adam, GAN + GAN_Feat), '
-                                   '%dx%d, batch %d per GPU, ngf=ndf=%d, 4 style images, synthetic ellipse labels'
+                                   '%dx%d, batch %d per GPU, ngf=ndf=%d, 4 style images, synthetic ellipse labels, 4 batches in rotation'
                                    % (args.size, args.size, args.batch, args.ngf),
                        'global_batch': global_batch, 'parallelism': 'dp%d' % world,
                        'gradient_exchange': (args.exchange if sdist.exchange_active() else 'none'),
@@ -455,8 +499,13 @@ def main():
                 kj = json.load(open(kms[-1]))
                 rp = kj.get('families', {}).get(fam, {}).get('ms_per_step')
                 if rp:
+                    #  the summary is of a committed run -- another commit and another box unless its git_head is the code
+                    # being measured now (S2E_GIT_HEAD on the GPU box, git HEAD here): say so instead of letting the figure pass as live
+                    here = os.environ.get('S2E_GIT_HEAD') or _git_head()
+                    same = bool(here) and str(kj.get('git_head', '?')).startswith(here[:7])
                     out['roofline'].update({'rocprof_ms_per_step': rp, 'rocprof_frac': d['executed_flops'] / prof_steps / (rp * 1e-3) / 1e12 / peak,
-                                            'rocprof_source': '%s @ %s' % (os.path.relpath(kms[-1], ROOT), kj.get('git_head', '?'))})
+                                            'rocprof_source': '%s @ %s' % (os.path.relpath(kms[-1], ROOT), kj.get('git_head', '?')),
+                                            'rocprof_stale': not same})
             if (args.size, args.size) in TRAIN_GFLOP_PER_SAMPLE and args.ngf == 64:
                 # the whole step against the dense MFMA peak: SURVEY 8(d)'s algorithmic FLOPs of a G+D step / the timed step
                 step_tf = TRAIN_GFLOP_PER_SAMPLE[(args.size, args.size)] * args.batch / 1e3
@@ -493,6 +542,8 @@ def main():
             out['rccl_ranks'] = world
         if sdist.exchange_active():
             out['config']['exchange'] = exchange_desc        # payload, algorithm, bucket size, NCCL_ALGO / NCCL_PROTO as set
+        if exchange is not None:
+            out['exchange'] = exchange
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(opt_kwargs, args.size, args.batch, extras=args.cpu_baseline_extras)
         print(json.dumps(out), flush=True)

@@ -305,7 +305,7 @@ int s2e_wgrad_c8_batch(int dtype, int N, const s2e_wgrad_c8_job* jobs, int n_job
  * gradient -- and dbias fp32 (Cout) or NULL are ACCUMULATED into.  rect_list / rect_count (both or neither): restrict the job to the
  * pixels of the 16 x 16 rectangles rect_list[0 .. *rect_count) (device memory, read by the kernel: label-sparse SPADE backward).
  * All jobs' (tile, 128-pixel slab) units are dealt evenly to one workgroup per CU; a dW tile with a single owner is added without
- * atomics or workspace, the others through <= 2 partial tiles per workgroup and a fix-up launch.  No two jobs of a call may share
+ * atomics or workspace, the others through <= 3 partial tiles per workgroup (WB_SLOTS) and a fix-up launch.  No two jobs of a call may share
  * dw.  jobs is a HOST array.  _supported: bf16, H % 8 == 0, W % 16 == 0 (16 with a list), Cin % 64 == 0, Cout % 8 == 0, Cout >= 64.
  * flags & S2E_WGRAD_BATCH_DW_ZERO: the caller vouches that dw holds zeros (a gradient arena cleared at the start of the step, no other
  * contribution yet): a tile with a single owner is then STORED instead of read, added and stored.
@@ -511,6 +511,13 @@ int s2e_fc_head_bwd(int dtype, const void* x, const float* W, const float* dy, v
  * With beta1 == 0 and weight_decay == 0 (the reference's TTUR default) m_t = g_t*grad_scale whatever m was: the kernel then neither
  * reads nor writes m (same bits in p and v, 20 instead of 28 bytes per parameter); a caller that saves m forms it from g. */
 int s2e_adam_flat(float* p, const float* g, float* m, float* v, long n, float* hyper, void* stream);
+
+/* ------------------------------------------------------------------ data-parallel gradient exchange (new: the reference is single-GPU;
+ * its only multi-GPU hook is the nn.DataParallel wrap of models/networks/__init__.py:46-47)
+ * The 'direct' exchange of seg2eye_amd/distributed.py (all-to-all of the bucket shards, owner sum, all-gather): the owner's sum of the
+ * `world` copies of its shard -- recv[r][i], r in rank order, fp32 accumulation, one rounding to dtype -- as ONE launch (round 5 did
+ * it with view().sum() and three staging copies).  shard * sizeof(dtype) must be a multiple of 16. */
+int s2e_shard_sum(int dtype, const void* recv, void* out, int world, long shard, void* stream);
 
 /* ------------------------------------------------------------------ OpenEDS validation metric
  * What the reference's Tester and its --lambda_openeds loss compute on the host (util/tester.py:44-47,93-97;

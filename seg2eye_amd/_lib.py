@@ -175,6 +175,7 @@ SIGNATURES = {
     's2e_fc_head_fwd': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, C.c_size_t, _vp],
     's2e_fc_head_bwd': [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     's2e_adam_flat': [_vp, _vp, _vp, _vp, _l, _vp, _vp],
+    's2e_shard_sum': [_i, _vp, _vp, _i, _l, _vp],
 }
 
 _lib = None

@@ -547,6 +547,7 @@ int wb_workgroups() {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         const char* e = getenv("S2E_WGRAD_BATCH_WGS");   // experiment switch: workgroups of the batched launch (default: one per CU)
         if (e && atoi(e) > 0) v = atoi(e);
+        if (v > WB_FIX_LIST) v = WB_FIX_LIST;            // (the fix-up's owner list holds WB_FIX_LIST workgroups per tile: ADVICE r5)
         return v;
     }();
     return n;

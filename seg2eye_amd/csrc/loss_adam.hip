@@ -210,3 +210,43 @@ extern "C" int s2e_adam_flat(float* p, const float* g, float* m, float* v, long 
     S2E_CHECK_LAUNCH("adam_tick_kernel");
     return S2E_OK;
 }
+
+// ---- data-parallel gradient exchange, 'direct' form (seg2eye_amd/distributed.py): the owner of a bucket shard adds the P copies the
+// all-to-all delivered, in rank order, fp32 accumulation, ONE rounding to the payload dtype -- every replica gets the same bits from the
+// all-gather that follows.  recv: [world][shard] elements; out: [shard].  One 16-byte vector per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void shard_sum_kernel(const T* __restrict__ recv, T* __restrict__ out, int world, long shard) {
+    constexpr int VEC = Vec<T>::N;
+    const long nv = shard / VEC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        float a[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a[j] = 0.f;
+        for (int r = 0; r < world; ++r) {
+            float f[VEC];
+            unpack16<T>(*(const u32x4_t*)(recv + (size_t)r * shard + i * VEC), f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[j] += f[j];
+        }
+        *(u32x4_t*)(out + i * VEC) = pack16<T>(a);
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * VEC + threadIdx.x; i < shard; i += blockDim.x) {
+            float a = 0.f;
+            for (int r = 0; r < world; ++r) a += load1<T>(recv + (size_t)r * shard + i);
+            store1<T>(out + i, a);
+        }
+}
+
+extern "C" int s2e_shard_sum(int dtype, const void* recv, void* out, int world, long shard, void* stream) {
+    if (!recv || !out || world <= 0 || shard <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_shard_sum: bad argument");
+    if ((((uintptr_t)recv | (uintptr_t)out) & 15) || (shard * (dtype == S2E_BF16 ? 2 : 4)) % 16 != 0)
+        S2E_FAIL(S2E_ERR_ARG, "s2e_shard_sum: buffers and the shard size must be 16-byte multiples");
+    const long nv = shard / (dtype == S2E_BF16 ? 8 : 4) + 1;
+    const int grid = (int)((nv + 255) / 256 < 2048 ? (nv + 255) / 256 : 2048);
+    if (dtype == S2E_BF16) shard_sum_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)recv, (bf16_t*)out, world, shard);
+    else if (dtype == S2E_F32) shard_sum_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)recv, (float*)out, world, shard);
+    else S2E_FAIL(S2E_ERR_ARG, "s2e_shard_sum: bad dtype %d", dtype);
+    S2E_CHECK_LAUNCH("shard_sum_kernel");
+    return S2E_OK;
+}

@@ -101,6 +101,8 @@ class FlatGradSync:
         'direct' spells the exchange out for the fully connected xGMI mesh of one node (a ring pushes 2 (P-1)/P S
         over ONE link, point-to-point pieces use all seven): all-to-all of the P bucket shards, each replica adds the P copies
         of ITS shard in rank order, all-gather of the sums -- one owner per element, so bit-identical replicas here too.
+    noop (attribute, bench.py's `exchange_ms_exposed`): launch / all_reduce start and wait for NOTHING and still return 1 / world --
+        the same step without its collectives; the replicas' gradients then differ, so only for timing.
     S2E_DEBUG_SYNC=1: `launch(i)` only records a copy of the group's slice; `all_reduce()` checks that the slice still holds those
         bits when the backward has ended -- i.e. that nothing wrote a group after it was declared final -- and then exchanges."""
 
@@ -121,6 +123,7 @@ class FlatGradSync:
         self._pending = []                                   # second halves of buckets in flight: callables run by all_reduce()
         self._stage = {}                                     # bucket start -> staging buffers (kept: no allocation per step)
         self._poisoned = False
+        self.noop = False
         self._debug = os.environ.get('S2E_DEBUG_SYNC', '0') == '1'
         self._final = {}                                     # S2E_DEBUG_SYNC: group -> copy of its slice when it was declared final
 
@@ -133,7 +136,7 @@ class FlatGradSync:
             n = e - s
             st = {}
             if self.algorithm == 'direct':
-                shard = (n + world - 1) // world
+                shard = ((n + world - 1) // world + 7) // 8 * 8                                  # (16-byte multiples: the owner-sum kernel's vectors)
                 st['send'] = torch.zeros(shard * world, dtype=dt, device=self.flat.device)       # (zero tail: padding adds nothing)
                 st['recv'] = torch.empty(shard * world, dtype=dt, device=self.flat.device)
                 st['sum'] = torch.empty(shard, dtype=dt, device=self.flat.device)
@@ -152,7 +155,7 @@ class FlatGradSync:
                 return
             st['send'].copy_(sl)                             # round to bf16 on the compute stream, behind the kernels that wrote sl
             self._handles.append(dist.all_reduce(st['send'], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self._pending.append(lambda: sl.copy_(st['send']))
+            self._pending.append(lambda: (sl.copy_(st['send']), None)[1])
             return
         # direct: shard r of every replica's bucket goes to replica r ...
         n, shard = e - s, st['shard']
@@ -162,13 +165,23 @@ class FlatGradSync:
         def finish():
             h.wait()                                         # (device-side dependency on RCCL's stream; a host wait under gloo)
             world = dist.get_world_size(self.group)
-            # ... which adds the P copies in rank order (fp32 accumulation, one rounding for a bf16 payload) ...
-            acc = st['recv'].view(world, shard).to(torch.float32).sum(dim=0) if self.payload == 'bf16' else \
-                st['recv'].view(world, shard).sum(dim=0)
-            st['sum'].copy_(acc)
-            # ... and hands the sums to everybody
-            dist.all_gather_into_tensor(st['send'], st['sum'], group=self.group)
-            sl.copy_(st['send'][:n])
+            # ... which adds the P copies in rank order (fp32 accumulation, one rounding for a bf16 payload): one launch on the GPU ...
+            if st['recv'].is_cuda:
+                from . import _lib as L
+                L.check(L.lib().s2e_shard_sum(L.S2E_BF16 if self.payload == 'bf16' else L.S2E_F32, st['recv'].data_ptr(), st['sum'].data_ptr(),
+                                              world, shard, torch.cuda.current_stream().cuda_stream), 's2e_shard_sum')
+            else:                                            # (CPU arenas: the gloo dry runs of tests/test_distributed_gloo.py)
+                acc = st['recv'].view(world, shard).to(torch.float32).sum(dim=0) if self.payload == 'bf16' else \
+                    st['recv'].view(world, shard).sum(dim=0)
+                st['sum'].copy_(acc)
+            # ... and hands the sums to everybody: asynchronously, every bucket's gather is in flight before the first is
+            # waited for; the copy back into the arena is the returned closure
+            h2 = dist.all_gather_into_tensor(st['send'], st['sum'], group=self.group, async_op=True)
+
+            def done():
+                h2.wait()
+                sl.copy_(st['send'][:n])
+            return done
         self._pending.append(finish)
 
     def _start(self, i):
@@ -189,6 +202,8 @@ class FlatGradSync:
 
     def launch(self, i):
         """Group i's gradients are final: start their exchange now (no-op on one process / when already started)."""
+        if self.noop:
+            return
         if exchange_active() and i not in self._launched:
             self._check_poison()
             self._start(i)
@@ -207,6 +222,8 @@ class FlatGradSync:
     def all_reduce(self):
         if not exchange_active():
             return 1.0
+        if self.noop:
+            return 1.0 / world_size()
         self._check_poison()
         if self._debug:
             stale = [i for i, snap in self._final.items() if not torch.equal(self.flat[self.groups[i][0]:self.groups[i][1]], snap)]
@@ -224,10 +241,35 @@ class FlatGradSync:
                 self._start(i)
         for h in self._handles:
             h.wait()
-        for fin in self._pending:
-            fin()
+        tails = [fin() for fin in self._pending]             # (second halves: a 'direct' bucket returns the closure that ends it)
+        for t in tails:
+            if t is not None:
+                t()
         self._launched, self._handles, self._pending = set(), [], []
         return 1.0 / world_size()
+
+    def time_groups(self):
+        """bench.py (--gpus N): the exchange of each group on its own -- started on an idle device, waited for, timed by the host
+        around a device synchronize -- in milliseconds.  Collective: every rank calls it.  The arena's contents are summed (garbage
+        in, garbage out: call it after the timed region)."""
+        import time
+        out = []
+        if not exchange_active():
+            return out
+        for i in range(len(self.groups)):
+            torch.cuda.synchronize() if self.flat.is_cuda else None
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            self._start(i)
+            for h in self._handles:
+                h.wait()
+            for t in [fin() for fin in self._pending]:
+                if t is not None:
+                    t()
+            torch.cuda.synchronize() if self.flat.is_cuda else None
+            out.append((time.perf_counter() - t0) * 1e3)
+            self._launched, self._handles, self._pending = set(), [], []
+        return out
 
     def describe(self):
         """What the bench line records about the exchange."""

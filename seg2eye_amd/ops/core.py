@@ -335,8 +335,22 @@ class GradSink:
         residual's gradient, and the block's first SPADE then adds its own dx into it IN PLACE -- ModulateFn's relay): the queue
         keeps a copy, the deferred launch must not see that sum."""
         pool = ZeroPool.active()
-        if pool is None or switches.WGRAD_BATCH_OFF or x.dtype != torch.bfloat16 or gy.dtype != torch.bfloat16:
+        if pool is None:
             return False
+        # FIRST, whatever the shape: a dW that already has a queued job receives another contribution before the flush -- that job must
+        # ADD, not store (ADVICE r5: the scan used to sit behind the early returns below, so a second use of the weight at a shape the
+        # batch does not take left the queued job's `fresh` flag set and the flush overwrote the immediate contribution)
+        for j in pool.sink.wg:
+            if j[2].data_ptr() == dw_rows.data_ptr():
+                j[6] = False
+                return False
+
+        def declined():
+            # the caller now accumulates into dw_rows at once: a job queued for it LATER in this scope must add as well
+            pool.sink.wg_done.add(dw_rows.data_ptr())
+            return False
+        if switches.WGRAD_BATCH_OFF or x.dtype != torch.bfloat16 or gy.dtype != torch.bfloat16:
+            return declined()
         n, h, w, cin = x.shape
         cout = gy.shape[-1]
         key = (n, h, w, cin, cout, rects is not None)
@@ -345,11 +359,7 @@ class GradSink:
             ok = _WGRAD_BATCH_OK[key] = bool(L.lib().s2e_wgrad_batch_supported(L.S2E_BF16, n, h, w, cin, cout)) and \
                 (rects is None or (h % 16 == 0 and w % 16 == 0))
         if not ok:
-            return False
-        for j in pool.sink.wg:
-            if j[2].data_ptr() == dw_rows.data_ptr():
-                j[6] = False                                 # (that dW receives another contribution before the flush: add, do not store)
-                return False
+            return declined()
         _need(x, gy, dw_rows, dbias)
         # a gradient arena that zero_grad cleared right before this step, and nothing queued for it yet: single-owner tiles are stored
         fresh = ZeroPool.grad_is_fresh(dw_rows) and dw_rows.data_ptr() not in pool.sink.wg_done
@@ -379,7 +389,7 @@ class GradSink:
         ws = self.__dict__.get('_wg_ws')
         wsb = L.lib().s2e_wgrad_batch_workspace_bytes()
         if ws is None or ws.device != dev or ws.numel() * 4 < wsb:
-            ws = self._wg_ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)     # (kept: the same 151 MB every flush)
+            ws = self._wg_ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)     # (kept: the same ~216 MiB every flush: 3 slots x 256 workgroups x 288 KB)
         LaunchProfiler.run('conv_wgrad_patch', flops, lambda: L.check(
             L.lib().s2e_wgrad_batch(L.S2E_BF16, C.byref(arr), len(jobs), _p(ws), wsb, _stream()), 's2e_wgrad_batch'),
             tag='W k3 s1 x%d batched' % len(jobs), nbytes=nbytes, executed=executed)

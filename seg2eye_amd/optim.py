@@ -139,7 +139,14 @@ class FlatAdam:
         return self.flat_m
 
     def state_dict(self):
-        return {'step': self.step_count, 'm': self._first_moment(), 'v': self.flat_v, 'lr': self.param_groups[0]['lr'], 'layout': self._layout()}
+        """`m_valid`: False when the saved first moment is NOT the optimizer's -- beta1 == 0 / no weight decay steps leave
+        flat_m untouched, and outside the window between step() and the next zero_grad() the gradient it would be formed from is
+        gone.  Harmless for a resume at beta1 == 0 (the next step overwrites m); a run resumed with another beta1 (--no_TTUR: 0.5)
+        must not trust an invalid m: load_state_dict then starts it from zeros."""
+        skipped = self.betas[0] == 0.0 and self._wd == 0.0 and self.step_count > 0
+        valid = (not skipped) or bool(self.__dict__.get('_g_is_last_step', False))
+        return {'step': self.step_count, 'm': self._first_moment(), 'v': self.flat_v, 'lr': self.param_groups[0]['lr'], 'layout': self._layout(),
+                'm_valid': valid}
 
     def load_state_dict(self, sd, trust_param_order=False):
         """Moments saved by another FlatAdam.  With a `layout` that carries `shapes` the parameter signature must match; the
@@ -176,6 +183,8 @@ class FlatAdam:
         self._finish_load(sd)
 
     def _finish_load(self, sd):
+        if not sd.get('m_valid', True) and not (self.betas[0] == 0.0 and self._wd == 0.0):
+            self.flat_m.zero_()                              # (saved by a beta1 == 0 run outside the step window: see state_dict)
         self.step_count = int(sd['step'])
         self.param_groups[0]['lr'] = float(sd['lr'])
         self.hyper[4:5].fill_(float(self.step_count))

@@ -104,14 +104,22 @@ class Pix2PixTrainer:
 
     def _train_mode(self):
         """model.train() -- when something put it or ANY of its modules into eval mode (a validation pass, a caller freezing one
-        SPADE block: spectral norm's power iteration and BatchNorm's running statistics stop there).  Reading ~260 flags costs
-        ~15 us; re-setting them every step cost 2 ms of host time per eager step."""
+        SPADE block: spectral norm's power iteration and BatchNorm's running statistics stop there).  Reading the ~260 cached
+        flags costs ~15 us; walking `modules()` to see whether the module LIST changed (a module added or replaced
+        later must be seen) costs a few hundred us, so that walk runs on the first call and then every 64th --
+        `invalidate_modules()` forces it at once."""
         mods = self.__dict__.get('_all_modules')
-        n = sum(1 for _ in self.pix2pix_model.modules())     # (a module added or replaced later must be seen: ADVICE r4)
-        if mods is None or len(mods) != n or any(a is not b for a, b in zip(mods, self.pix2pix_model.modules())):
-            mods = self.__dict__['_all_modules'] = list(self.pix2pix_model.modules())
+        tick = self.__dict__['_mode_tick'] = self.__dict__.get('_mode_tick', 0) + 1
+        if mods is None or tick % 64 == 1:
+            now = list(self.pix2pix_model.modules())
+            if mods is None or len(mods) != len(now) or any(a is not b for a, b in zip(mods, now)):
+                mods = self.__dict__['_all_modules'] = now
         if not all(x.training for x in mods):
             self.pix2pix_model.train()
+
+    def invalidate_modules(self):
+        """Call after adding / replacing a module of the model: the next step re-reads the module list."""
+        self.__dict__.pop('_all_modules', None)
 
     def _one(self):
         """d(total)/d(total) as a persistent device scalar (autograd would launch a ones_like per backward)."""

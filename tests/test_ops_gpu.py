@@ -908,6 +908,32 @@ def test_wgrad_batch_through_the_sink():
         assert float((db - k * rb).abs().max()) <= 2e-5 * float(rb.abs().max()) * k + 1e-6, i
 
 
+@pytest.mark.parametrize('order', ['queued_then_immediate', 'immediate_then_queued'])
+def test_wgrad_sink_fresh_arena_view_used_at_two_shapes(order):
+    """a dW that is a view of a gradient arena zero_grad has just cleared (`grad_is_fresh`: single-owner tiles of the batched
+    launch are STORED, not added) and whose weight is used twice in one scope, once at a shape the batch takes (queued) and once at
+    one it declines (the per-layer kernel accumulates at once) -- in either order the flush must ADD to what is there."""
+    from seg2eye_amd import ops
+    dev = _dev()
+    cin = cout = 64
+    a = (nhwc(_rnd((2, cin, 32, 32), 401, torch.bfloat16)).to(dev), nhwc(_rnd((2, cout, 32, 32), 402, torch.bfloat16)).to(dev))     # batch shape
+    b = (nhwc(_rnd((2, cin, 12, 20), 403, torch.bfloat16)).to(dev), nhwc(_rnd((2, cout, 12, 20), 404, torch.bfloat16)).to(dev))     # not 8 x 16 slabs
+    ref = torch.zeros(cout, 9 * cin, device=dev)
+    for x, gy in (a, b):                                        # no scope: both accumulate at once
+        ops.conv2d_wgrad_raw(x, gy, 3, 3, 1, 1, ops.ACT_NONE, False, None, dw_out=ref)
+    arena = torch.zeros(cout * 9 * cin + 64, device=dev)
+    ops.ZeroPool.arena_zeroed(arena)                            # (what optim.FlatAdam.zero_grad reports)
+    dw = arena[:cout * 9 * cin].view(cout, 9 * cin)
+    pool = ops.ZeroPool(dev)
+    with pool.scope('t'):
+        assert ops.ZeroPool.grad_is_fresh(dw)
+        for x, gy in ((a, b) if order == 'queued_then_immediate' else (b, a)):
+            ops.conv2d_wgrad_raw(x, gy, 3, 3, 1, 1, ops.ACT_NONE, False, None, dw_out=dw)
+        assert len(pool.sink.wg) == 1 and pool.sink.wg[0][6] is False        # queued, and told to add
+    torch.cuda.synchronize()
+    assert float((dw - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize('duo', ['512', '0'])
 def test_patch_conv_kernels_match_torch_at_bench_shapes(duo):
     """The two patch-resident 3x3 kernels at the bench's shapes against torch's own convolution in fp32 (tools/check_duo.py):
