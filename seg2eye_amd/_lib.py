@@ -41,6 +41,11 @@ class WgradBatchJob(C.Structure):
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('flags', C.c_int)]
 
 
+class WgradMultiJob(C.Structure):
+    """s2e_wgrad_multi_job"""
+    _fields_ = [('x', C.c_void_p), ('gy', C.c_void_p), ('dw', C.c_void_p), ('dbias', C.c_void_p), ('d', ConvDesc)]
+
+
 class LabelConvJob(C.Structure):
     _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('out_off', C.c_long), ('h', C.c_int), ('w', C.c_int),
                 ('cout', C.c_int), ('relu', C.c_int)]
@@ -123,6 +128,9 @@ SIGNATURES = {
     's2e_spade_uniform_grads': [_vp, _i, _vp],
     's2e_conv2d_wgrad_workspace_bytes': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
+    's2e_conv2d_wgrad_multi_supported': [_i, C.POINTER(ConvDesc)],
+    's2e_conv2d_wgrad_multi_workspace_bytes': [_i, _vp, _i],
+    's2e_conv2d_wgrad_multi': [_i, _vp, _i, _vp, C.c_size_t, _vp],
     's2e_in_stats_workspace_bytes': [_i, _i, _i, _i],
     's2e_modulate_bwd_workspace_bytes': [_i, _i, _i, _i],
     's2e_instance_norm_fwd': [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],

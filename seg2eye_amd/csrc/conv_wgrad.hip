@@ -37,8 +37,9 @@ __device__ __forceinline__ u32x2_t lds_tr16_b64(const char* p) {
 
 // VECPATH: Cin and Cout are multiples of the 16-B vector width (every real layer except the 1- and
 // 5-channel heads); the element-wise gather lives in its own instantiation.
+// One workgroup's tile: block `blk` of `nblk` of the launch described by p (a launch of its own, or one job of a multi-job launch).
 template <typename T, bool VECPATH, int BR>              // BR = pixels per chunk (one barrier per chunk)
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_tile(const WgradParams& p, int blk, int nblk, char* smem) {
     constexpr int VEC = Vec<T>::N;
     constexpr int ROW = WgLds<T>::ROW;
     constexpr int OP_BYTES = BR * ROW;                   // one operand tile
@@ -46,13 +47,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     constexpr int CPR = 128 / VEC;                       // 16-B chunks per row
     constexpr int RPT = 256 / CPR;                       // rows per pass
     constexpr int NI = BR / RPT;                         // vectors per thread per operand
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;             // 2x2 waves, each 64(co) x 64(k)
     // consecutive logical ids (= the (co,k) tiles of ONE pixel slice, which stream the same gy / x rows in
     // lockstep) are placed on one XCD so they share that XCD's L2 instead of each L2 re-fetching the slice
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(blk, nblk);
     const int tk = bid % p.tiles_k; bid /= p.tiles_k;
     const int tco = bid % p.tiles_co; const int split = bid / p.tiles_co;
     const int m_begin = split * p.m_per_split;
@@ -262,6 +262,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             }
 }
 
+template <typename T, bool VECPATH, int BR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * BR * WgLds<T>::ROW];
+    wgrad_tile<T, VECPATH, BR>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Every generic weight gradient of a backward pass in ONE launch (round 6): the 1x1 shortcuts, netE's stride-2 layers, the PatchGAN's
+// 4x4 layers, the 8x8 maps -- two dozen launches of 30-160 us that each fill the chip badly and each end with a tail -- run side by side:
+// workgroup b belongs to job k with first[k] <= b < first[k + 1] (first[] in steps of 8: a job's workgroups keep the XCD placement
+// xcd_remap assumes) and is that job's workgroup b - first[k] of nblk[k].  bf16, vector channel counts.
+constexpr int WGM_MAX_JOBS = 26;
+struct WgMulti { int n; int first[WGM_MAX_JOBS + 1]; int nblk[WGM_MAX_JOBS]; int splits[WGM_MAX_JOBS]; WgradParams j[WGM_MAX_JOBS]; };
+static_assert(sizeof(WgMulti) <= 4000, "kernel arguments");
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_multi_kernel(const WgMulti b) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 32 * WgLds<bf16_t>::ROW];
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.first[k + 1]) ++k;
+    const int blk = (int)blockIdx.x - b.first[k];
+    if (blk >= b.nblk[k]) return;                         // (padding to the next multiple of 8)
+    wgrad_tile<bf16_t, true, 32>(b.j[k], blk, b.nblk[k], smem);
+}
+
 // dw += sum over the pixel splits of a (co, k) tile's partial tiles, dbias += sum over splits and k-tile workgroups of the bias
 // partials -- in a FIXED order: the weight gradient is bit-reproducible run to run, which fp32 atomics were not (two
 // runs of a trainer drifted apart through Adam's sign flips of near-zero gradients).
@@ -269,11 +292,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 // by the four waves of a workgroup (wave g takes splits g, g + 4, ...; eight loads in flight), combined through LDS as
 // (g0 + g1) + (g2 + g3).  Workgroups stride over the items: at most 2048 of them however many tiles there are (a 128-tile dW
 // would otherwise launch 32768 tiny workgroups), and a ONE-tile dW with 512 splits still spreads over 256 items.
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradParams p, int splits, int items) {
-    __shared__ float red[4][64];
+__device__ __forceinline__ void wgrad_reduce_body(const WgradParams& p, int splits, int items, int blk, int nblk, float (*red)[64]) {
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const size_t stride = (size_t)p.tiles_co * p.tiles_k * 16384;   // one split further
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    for (int item = blk; item < items; item += nblk) {
         const int tile = item >> 8, frag = item & 255;              // frag = (wave * 4 + mi * 2 + ni) * 16 + r
         const float* src = p.partial + (size_t)tile * 16384 + frag * 64 + lane;
         float a = 0.f;
@@ -300,8 +322,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradParam
     }
     // bias: the first 2 * tiles_co workgroups take 64 channels each; the (split, k-tile) partials of a channel are walked by
     // the four waves like the splits above
-    if (p.dbias && blockIdx.x < 2 * p.tiles_co) {
-        const int tco = blockIdx.x >> 1, ch = (blockIdx.x & 1) * 64 + lane, co = tco * 128 + ch;
+    if (p.dbias && blk < 2 * p.tiles_co) {
+        const int tco = blk >> 1, ch = (blk & 1) * 64 + lane, co = tco * 128 + ch;
         const int P = splits * p.tiles_k;                           // partial j = (split j / tiles_k, k-tile j % tiles_k)
         auto at = [&](int j) __attribute__((always_inline)) -> float {
             const int sidx = j / p.tiles_k, t = j - sidx * p.tiles_k;
@@ -321,6 +343,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradParam
         __syncthreads();
         if (g == 0 && co < p.Cout) p.dbias[co] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradParams p, int splits, int items) {
+    __shared__ float red[4][64];
+    wgrad_reduce_body(p, splits, items, blockIdx.x, gridDim.x, red);
+}
+// the reductions of a multi-job launch's split jobs, side by side
+struct WgMultiRed { int n; int first[WGM_MAX_JOBS + 1]; int job[WGM_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_multi_kernel(const WgMulti b, const WgMultiRed r) {
+    __shared__ float red[4][64];
+    int k = 0;
+    while (k + 1 < r.n && (int)blockIdx.x >= r.first[k + 1]) ++k;
+    const int jb = r.job[k];
+    wgrad_reduce_body(b.j[jb], b.splits[jb], b.j[jb].tiles_k * b.j[jb].tiles_co * 256, (int)blockIdx.x - r.first[k], r.first[k + 1] - r.first[k], red);
 }
 
 // ------------------------------------------------------------------------------------ bf16 LDS-DMA variant
@@ -611,6 +647,73 @@ extern "C" int s2e_conv2d_wgrad(int dtype, const void* x, const void* gy, float*
         if (rgrid < 2 * p.tiles_co) rgrid = 2 * p.tiles_co;
         conv_wgrad_reduce_kernel<<<rgrid, 256, 0, st>>>(p, splits, items);
         S2E_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+    }
+    return S2E_OK;
+}
+
+// ---- every generic weight gradient of a backward pass in one launch (+ one for the partial-tile reductions): conv_wgrad_multi_kernel
+static bool wgrad_multi_ok(int dtype, const s2e_conv_desc* d) {
+    if (!d || dtype != S2E_BF16 || d->transposed || (d->stride != 1 && d->stride != 2)) return false;
+    if (d->Cin % 8 != 0 || d->Cout % 8 != 0) return false;
+    if ((long)d->N * d->Hi * d->Wi >= (1L << 31) || (long)d->N * d->Ho * d->Wo >= (1L << 31)) return false;
+    if (s2e_small_wgrad_kind(dtype, d) || s2e_wgrad_patch_plan(dtype, d) || s2e_wgrad_c8_plan(dtype, d)) return false;
+    return true;
+}
+extern "C" int s2e_conv2d_wgrad_multi_supported(int dtype, const s2e_conv_desc* d) { return wgrad_multi_ok(dtype, d) ? 1 : 0; }
+
+extern "C" size_t s2e_conv2d_wgrad_multi_workspace_bytes(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs) {
+    size_t total = 0;
+    for (int i = 0; jobs && i < n_jobs; ++i) total += (s2e_conv2d_wgrad_workspace_bytes(dtype, &jobs[i].d) + 255) & ~(size_t)255;
+    return total;
+}
+
+extern "C" int s2e_conv2d_wgrad_multi(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    if (!jobs || n_jobs <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad_multi: no jobs");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    size_t ws_left = workspace ? workspace_bytes : 0;
+    for (int base = 0; base < n_jobs; base += WGM_MAX_JOBS) {
+        const int n = n_jobs - base < WGM_MAX_JOBS ? n_jobs - base : WGM_MAX_JOBS;
+        WgMulti b{};
+        WgMultiRed r{};
+        b.n = n;
+        int blocks = 0, rblocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const s2e_wgrad_multi_job& J = jobs[base + i];
+            if (!J.x || !J.gy || !J.dw) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad_multi: null pointer in job %d", base + i);
+            if (!wgrad_multi_ok(dtype, &J.d)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad_multi: job %d is not a generic bf16 shape (s2e_conv2d_wgrad_multi_supported)", base + i);
+            WgradParams& p = b.j[i];
+            const s2e_conv_desc* d = &J.d;
+            p.x = J.x; p.gy = J.gy; p.dw = J.dw; p.dbias = J.dbias;
+            p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+            p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.in_act = d->in_act;
+            int splits;
+            generic_wgrad_plan(d, &p, &splits);
+            const int g = p.tiles_k * p.tiles_co * splits;
+            const size_t need = (size_t)g * (128 * 128 + 128) * sizeof(float);
+            if (wgrad_use_partial(splits) && ws && ws_left >= need) {
+                p.partial = (float*)ws;
+                p.bpartial = p.partial + (size_t)g * (128 * 128);
+                const size_t adv = (need + 255) & ~(size_t)255;
+                ws += adv; ws_left = ws_left > adv ? ws_left - adv : 0;
+                const int items = p.tiles_k * p.tiles_co * 256;
+                int rgrid = items < 2048 ? items : 2048;
+                if (rgrid < 2 * p.tiles_co) rgrid = 2 * p.tiles_co;
+                r.first[r.n] = rblocks; r.job[r.n] = i; ++r.n;
+                rblocks += rgrid;
+            }
+            b.first[i] = blocks; b.nblk[i] = g; b.splits[i] = splits;
+            blocks += (g + 7) & ~7;                       // (a job's first workgroup on a multiple of 8: xcd_remap's placement)
+        }
+        b.first[n] = blocks;
+        r.first[r.n] = rblocks;
+        conv_wgrad_multi_kernel<<<blocks, 256, 0, st>>>(b);
+        S2E_CHECK_LAUNCH("conv_wgrad_multi_kernel");
+        if (r.n) {
+            conv_wgrad_reduce_multi_kernel<<<rblocks, 256, 0, st>>>(b, r);
+            S2E_CHECK_LAUNCH("conv_wgrad_reduce_multi_kernel");
+        }
     }
     return S2E_OK;
 }

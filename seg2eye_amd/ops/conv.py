@@ -163,14 +163,17 @@ def conv2d_raw(x, wp, bias, residual, aux, out_hw_c, kh, kw, stride, pad, transp
     return y
 
 
-def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False, dbias_out=None, dw_out=None, gy_shared=False):
+def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=False, dbias_out=None, dw_out=None, gy_shared=False,
+                     defer_ok=False):
     """-> (dw, db): dw (Cout, KH*KW*Cin) fp32 in packed order; db (Cout) fp32 or None.  Both live in one
     zero-filled buffer (ZeroPool scratch when the bias gradient is not returned).  dbias_out: an fp32 (Cout) tensor to ACCUMULATE the bias
     gradient into instead (e.g. the parameter's slice of the gradient arena); then db is None.
     dw_out: an fp32 (Cout, KH*KW*Cin) row-major tensor to ACCUMULATE the weight gradient into instead of a fresh zeroed buffer
     (the gradient of a parameter stored channels-last: _cl_rows(p.grad)); returned as dw.
     Inside a trainer step the patch-resident 3x3 shapes are QUEUED (GradSink.push_wgrad): dw / dbias_out then receive the sums at
-    the step's next flush.  gy_shared: gy is also handed on as another tensor's gradient (see push_wgrad)."""
+    the step's next flush.  gy_shared: gy is also handed on as another tensor's gradient (see push_wgrad).
+    defer_ok: the caller reads dw / db only through jobs queued in the same GradSink (or not at all before the flush: an arena slice):
+    a generic shape may then be queued too (GradSink.push_gwg: every generic weight gradient of a backward as one launch)."""
     _need(x, gy, dbias_out, dw_out)
     n, hi, wi, cin = x.shape
     _, ho, wo, cout = gy.shape
@@ -189,6 +192,9 @@ def conv2d_wgrad_raw(x, gy, kh, kw, stride, pad, in_act=ACT_NONE, want_bias=Fals
     if (kh == 3 and kw == 3 and stride == 1 and pad == 1 and in_act == ACT_NONE and not own_b and ho == hi and wo == wi
             and GradSink.push_wgrad(x, gy, dw, dbp, gy_shared=gy_shared)):
         return dw, db                                        # accumulated at the step's next flush, with every other queued layer
+    if defer_ok and not own_b and GradSink.push_gwg(x, gy, dw, dbp, (n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE),
+                                                    gy_shared=gy_shared):
+        return dw, db
     d, wsb = _conv_plan(True, _dt(x), n, hi, wi, cin, ho, wo, cout, kh, kw, stride, pad, 0, in_act, ACT_NONE, AUX_NONE)
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     LaunchProfiler.run(lambda: _WGRAD_FAMILY[L.lib().s2e_conv2d_wgrad_kernel_kind(_dt(x), C.byref(d))],
@@ -355,14 +361,15 @@ class Conv2dFn(torch.autograd.Function):
             # weight is "channels-last" too, but the in-place kernels work on 16-byte groups of one tap): the kernel accumulates
             # straight into it; spectral norm's chain rule is then applied in place (queued: one launch pair per step)
             _, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, ctx.bdst if want_b else None, dw_out=_cl_rows(wdst),
-                                     gy_shared=shared)
+                                     gy_shared=shared, defer_ok=True)
             if sigma is not None:
                 GradSink.push_inplace(_cl_rows(wdst), weight, u, v, sigma, cout, cin, kh * kw)
         elif ctx.needs_input_grad[1]:
             bdst = ctx.bdst if want_b else None
-            dwp, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, bdst, gy_shared=shared)
             if wdst is not None and not wdst.is_contiguous():
                 wdst = None                                  # (a channels-last .grad fed a channel-padded input: through autograd)
+            # (with a .grad to accumulate into, the packed dW is read by jobs queued in the step's GradSink only: it may be queued itself)
+            dwp, gb = conv2d_wgrad_raw(x, g, kh, kw, stride, pad, in_act, want_b, bdst, gy_shared=shared, defer_ok=wdst is not None)
             w_oihw = weight.detach() if weight.is_contiguous() else weight.detach().contiguous()
             if sigma is None:
                 if wdst is not None:

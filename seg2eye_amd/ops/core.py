@@ -236,6 +236,7 @@ class _ZeroScope:
                 self.pool.sink.c8 = []
                 self.pool.sink.uni = []
                 self.pool.sink.wg = []
+                self.pool.sink.gwg = []
         finally:
             self.pool._end()
         return False
@@ -258,6 +259,7 @@ class GradSink:
         self.uni = []              # deferred label-sparse SPADE backward jobs (uniform rectangles' closed-form gradients): push_uniform
         self.wg = []               # deferred patch-resident 3x3 weight gradients (one persistent launch per flush): push_wgrad
         self.wg_done = set()       # dW slices a wgrad flush of the open scope has already written (a later job must ADD to them)
+        self.gwg = []              # deferred GENERIC weight gradients (one multi-job launch per flush): push_gwg
         self.tables = {}
         self.keepalive = None
         self.keep_c8 = None
@@ -396,6 +398,47 @@ class GradSink:
         self.keep_wg = jobs                                  # the tensors stay referenced until the next flush (stream order covers the rest)
 
     @staticmethod
+    def push_gwg(x, gy, dw, dbias, desc_key, gy_shared=False):
+        """Queue a GENERIC weight gradient (a shape s2e_conv2d_wgrad would run in its implicit-GEMM kernel: the 1x1 shortcuts, netE's
+        stride-2 layers, the PatchGAN's 4x4 layers, the 8x8 maps) to be accumulated into dw (Cout, KH*KW*Cin) / dbias at the next
+        flush, every queued job in ONE launch (s2e_conv2d_wgrad_multi).  desc_key: the ConvDesc fields of the forward conv.  False:
+        not queued (no trainer step open, not bf16, not a generic shape, a dW that already has a queued job, S2E_WGRAD_MULTI=0)."""
+        pool = ZeroPool.active()
+        if pool is None or switches.WGRAD_MULTI_OFF or x.dtype != torch.bfloat16 or gy.dtype != torch.bfloat16:
+            return False
+        ok = _WGRAD_MULTI_OK.get(desc_key)
+        if ok is None:
+            d = L.ConvDesc(*desc_key)
+            ok = _WGRAD_MULTI_OK[desc_key] = bool(L.lib().s2e_conv2d_wgrad_multi_supported(L.S2E_BF16, C.byref(d)))
+        if not ok or any(j[2].data_ptr() == dw.data_ptr() for j in pool.sink.gwg):      # (the reduction adds without atomics: one job per dW)
+            return False
+        _need(x, gy, dw, dbias)
+        pool.sink.gwg.append((x, gy.clone() if gy_shared else gy, dw, dbias, desc_key))
+        return True
+
+    def _flush_gwg(self):
+        jobs, self.gwg = self.gwg, []
+        dev = jobs[0][0].device
+        arr = (L.WgradMultiJob * len(jobs))()
+        flops = nbytes = 0.0
+        for a, (x, gy, dw, db, key) in zip(arr, jobs):
+            a.x, a.gy, a.dw, a.dbias = x.data_ptr(), gy.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+            a.d = L.ConvDesc(*key)
+            flops += 2.0 * key[0] * key[4] * key[5] * key[3] * key[6] * key[7] * key[8]
+            nbytes += (x.numel() + gy.numel()) * 2.0 + dw.numel() * 4.0
+        wsb = int(L.lib().s2e_conv2d_wgrad_multi_workspace_bytes(L.S2E_BF16, C.byref(arr), len(jobs)))
+        ws = self.__dict__.get('_gwg_ws')
+        if wsb and (ws is None or ws.device != dev or ws.numel() * 4 < wsb):
+            if ZeroPool._active is not None and ZeroPool._active.frozen:
+                ws, wsb = None, 0                            # (a captured graph must not start using new memory: those jobs add with atomics)
+            else:
+                ws = self._gwg_ws = torch.empty(wsb // 4 + 64, dtype=torch.float32, device=dev)
+        LaunchProfiler.run('conv_wgrad', flops, lambda: L.check(
+            L.lib().s2e_conv2d_wgrad_multi(L.S2E_BF16, C.byref(arr), len(jobs), _p(ws) if wsb else None, wsb, _stream()), 's2e_conv2d_wgrad_multi'),
+            tag='W generic x%d multi' % len(jobs), nbytes=nbytes)
+        self.keep_gwg = jobs                                 # the tensors stay referenced until the next flush (stream order covers the rest)
+
+    @staticmethod
     def push_c8(oh, dactv, dw, db, ncls):
         """Queue the weight / bias gradient of a 3x3 conv on the 8-channel one-hot map `oh` (N,h,w,8) with output gradient
         `dactv` (N,h,w,128), accumulated straight into dw (128,ncls,3,3) / db (128) fp32 at the next flush -- all queued layers
@@ -467,6 +510,8 @@ class GradSink:
     def flush(self):
         if self.wg:
             self._flush_wgrad()                              # first: the re-layout / chain-rule / rank-1 jobs below read or add to its results
+        if self.gwg:
+            self._flush_gwg()                                # (likewise: its dW buffers feed the re-layout / chain-rule jobs)
         if self.uni:
             self._flush_uniform()
         if self.c8:
@@ -512,6 +557,7 @@ class GradSink:
                                              dots.data_ptr(), _stream()), 's2e_weight_grads_batched'), nbytes=nbytes)
         self.keepalive = jobs                                # the tensors of this flush stay referenced until the next one
 _WGRAD_BATCH_OK = {}
+_WGRAD_MULTI_OK = {}
 
 
 def _cl_dense(t):

@@ -11,6 +11,8 @@ _DET = os.environ.get('S2E_DETERMINISTIC', '0') == '1'          # every gradient
 
 # 0 = every patch-resident weight gradient as its own launch (round 4); S2E_DETERMINISTIC keeps the fixed-order per-layer path
 WGRAD_BATCH_OFF = os.environ.get('S2E_WGRAD_BATCH', '1') == '0' or _DET
+# 0 = every generic weight gradient (1x1, stride-2, 4x4, small maps) as its own launch + reduction (rounds 1-5)
+WGRAD_MULTI_OFF = os.environ.get('S2E_WGRAD_MULTI', '1') == '0'
 # 0 = the dense SPADE backward of round 3 (the label-sparse one sums with float atomics: off under S2E_DETERMINISTIC)
 SPARSE_BWD_OFF = os.environ.get('S2E_SPADE_SPARSE_BWD', '1') == '0' or _DET
 # 0 = the dense fused launch everywhere (no label-uniform rectangles served from the class table)

@@ -1031,9 +1031,11 @@ def _load_teacher_state(tr, state):
             dst.copy_(src)
 
 
-def _one_iteration(tr, data, acts=None):
-    """One G + one D step; -> losses, generated image, the G / E / D parameter gradients (clones).  acts: a dict to fill with the
-    ResBlk outputs of the G step's forward (eager trainers only: a hipGraph replay runs no hooks)."""
+def _one_iteration(tr, data, acts=None, mid_state=None):
+    """One G + one D step; -> losses, generated image, the G / E / D parameter gradients (clones), and the state between the two steps.
+    acts: a dict to fill with the ResBlk outputs of the G step's forward (eager trainers only: a hipGraph replay runs no hooks).
+    mid_state: a teacher's state after ITS G step, loaded before this trainer's D step -- the D step then starts from the teacher's
+    weights too (its own G update, -lr * sign-like steps of Adam at beta1 = 0 on bf16 gradients, is not what is being compared)."""
     m = tr.pix2pix_model
     hs = []
     if acts is not None:
@@ -1048,10 +1050,14 @@ def _one_iteration(tr, data, acts=None):
     gg = {('G.' + k): p.grad.detach().clone() for k, p in m.netG.named_parameters() if p.grad is not None}
     gg.update({('E.' + k): p.grad.detach().clone() for k, p in m.netE.named_parameters() if p.grad is not None})
     fake = tr.get_latest_generated().detach().float().cpu()
+    if mid_state is not None:
+        _load_teacher_state(tr, mid_state)
+    mid = _teacher_state(tr)
     tr.run_discriminator_one_step(dict(data))
     torch.cuda.synchronize()
     gd = {('D.' + k): p.grad.detach().clone() for k, p in m.netD.named_parameters() if p.grad is not None}
-    return {'losses': {k: float(v.detach().float().mean()) for k, v in tr.get_latest_losses().items()}, 'fake': fake, 'grads_G': gg, 'grads_D': gd}
+    return {'losses': {k: float(v.detach().float().mean()) for k, v in tr.get_latest_losses().items()}, 'fake': fake, 'grads_G': gg, 'grads_D': gd,
+            'mid': mid}
 
 
 def test_bf16_step_teacher_forced_along_the_fp32_trajectory():
@@ -1059,8 +1065,8 @@ def test_bf16_step_teacher_forced_along_the_fp32_trajectory():
     fp32 one beyond a few iterations (the fixture's GAN is chaotic: fp32 does not track itself, see the test above), so here the
     fp32 eager run of trainers/pix2pix_trainer.py:26-45 is the TEACHER: at its iterations 0, 5, 10, 15 and 20 (four batches in
     rotation, ngf = ndf = 64, 256x256, batch 8) its parameters and spectral-norm u|v are copied into a bf16 trainer with hipGraphs on
-    (what bench.py times) and into a bf16 eager one, which then run ONE G+D step from exactly that state on the same batch; the
-    per-step bounds of test_cfg3_as_benched_matches_reference are held at all five states: losses 2 %, generated image rel-RMS < 3 %,
+    (what bench.py times) and into a bf16 eager one, which then run ONE G step from exactly that state on the same batch, take the
+    teacher's state after ITS G step, and run ONE D step; the per-step bounds of test_cfg3_as_benched_matches_reference are held at all five states: losses 2 %, generated image rel-RMS < 3 %,
     every ResBlk output < 2 % (eager bf16: a replay runs no hooks), the five largest G and three largest D weight gradients < 8 %."""
     from seg2eye_amd.pix2pix_trainer import Pix2PixTrainer
     z = load_golden('trainer_ngf64_256_n8')
@@ -1087,11 +1093,11 @@ def test_bf16_step_teacher_forced_along_the_fp32_trajectory():
         ta = {}
         t = _one_iteration(teacher, data, ta)                # (this IS the teacher's iteration `it`: its trajectory goes on from here)
         _load_teacher_state(graphed, state)
-        g = _one_iteration(graphed, data)
+        g = _one_iteration(graphed, data, mid_state=t['mid'])
         assert graphed.use_graphs and graphed.graph_G is not None, 'the bf16 step did not run as a hipGraph replay'
         _load_teacher_state(eager, state)
         ea = {}
-        e = _one_iteration(eager, data, ea)
+        e = _one_iteration(eager, data, ea, mid_state=t['mid'])
         big = sorted(t['grads_G'], key=lambda k: -t['grads_G'][k].numel())[:5]
         bigd = sorted(t['grads_D'], key=lambda k: -t['grads_D'][k].numel())[:3]
         for tag, r in (('graphs', g), ('eager', e)):

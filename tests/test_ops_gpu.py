@@ -908,6 +908,45 @@ def test_wgrad_batch_through_the_sink():
         assert float((db - k * rb).abs().max()) <= 2e-5 * float(rb.abs().max()) * k + 1e-6, i
 
 
+def test_generic_wgrad_multi_matches_per_layer_launches():
+    """Round 6: inside a trainer-step scope the GENERIC weight gradients (1x1, stride 2, 4x4, small maps) are queued too
+    (GradSink.push_gwg) and the flush runs them as one multi-job launch + one reduction launch (s2e_conv2d_wgrad_multi); the sums
+    must be those of the per-layer launches (s2e_conv2d_wgrad), job by job -- split jobs with partial tiles, unsplit ones, with and
+    without a bias gradient, a dW used twice (the second use runs at once)."""
+    from seg2eye_amd import ops
+    dev = _dev()
+    #        n   hi  wi  cin  cout k  s  p  bias
+    cfgs = [(4, 64, 64, 64, 128, 3, 2, 1, False), (2, 32, 32, 256, 128, 1, 1, 0, False), (2, 33, 33, 64, 128, 4, 2, 2, True),
+            (8, 8, 8, 128, 256, 3, 1, 1, True), (4, 17, 17, 128, 64, 4, 1, 2, False), (16, 128, 128, 64, 128, 3, 2, 1, False)]
+    ins = []
+    for i, (n, hi, wi, cin, cout, k, st, pd, bias) in enumerate(cfgs):
+        ho, wo = (hi + 2 * pd - k) // st + 1, (wi + 2 * pd - k) // st + 1
+        ins.append((nhwc(_rnd((n, cin, hi, wi), 500 + i, torch.bfloat16)).to(dev), nhwc(_rnd((n, cout, ho, wo), 520 + i, torch.bfloat16)).to(dev)))
+
+    def run(deferred):
+        outs = []
+        for (n, hi, wi, cin, cout, k, st, pd, bias), (x, gy) in zip(cfgs, ins):
+            dw = torch.zeros(cout, k * k * cin, device=dev)
+            db = torch.zeros(cout, device=dev) if bias else None
+            ops.conv2d_wgrad_raw(x, gy, k, k, st, pd, ops.ACT_NONE, bias, db, dw_out=dw, defer_ok=deferred)
+            outs.append((dw, db))
+        return outs
+    ref = run(False)
+    pool = ops.ZeroPool(dev)
+    with pool.scope('t'):
+        outs = run(True)
+        assert len(pool.sink.gwg) == len(cfgs) and float(outs[0][0].abs().max()) == 0.0          # queued, nothing written yet
+        x, gy = ins[1]
+        ops.conv2d_wgrad_raw(x, gy, 1, 1, 1, 0, ops.ACT_NONE, False, None, dw_out=outs[1][0], defer_ok=True)   # same dW again: at once
+        assert len(pool.sink.gwg) == len(cfgs) and float(outs[1][0].abs().max()) > 0.0
+    torch.cuda.synchronize()
+    for i, ((dw, db), (rw, rb)) in enumerate(zip(outs, ref)):
+        kf = 2.0 if i == 1 else 1.0
+        assert float((dw - kf * rw).abs().max()) <= 3e-5 * float(rw.abs().max()) * kf + 1e-6, (i, float((dw - kf * rw).abs().max()), float(rw.abs().max()))
+        if rb is not None:
+            assert float((db - rb).abs().max()) <= 3e-5 * float(rb.abs().max()) + 1e-6, i
+
+
 @pytest.mark.parametrize('order', ['queued_then_immediate', 'immediate_then_queued'])
 def test_wgrad_sink_fresh_arena_view_used_at_two_shapes(order):
     """a dW that is a view of a gradient arena zero_grad has just cleared (`grad_is_fresh`: single-owner tiles of the batched
