@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256, 2) void conv_plane_kernel(const PlaneParams p)
     // a ring of RING register sets: K-step j's weights are requested D = RING - 1 K-steps ahead (an L2 hit under load takes longer than
     // one 16-MFMA K-step).  RING divides the K-steps of every stage (pair of stages when odd), so every stage starts on set 0.
     constexpr int KS_MIN = S * (SO == 2 ? (MODE == PLANE_K3S2D ? 1 : 4) : TT);      // the shortest class's K-steps per stage
+    // (odd K-step counts run in pairs of stages, 18 K-steps: a ring of 3.  A ring of 6 -- five K-steps ahead -- measured 15-20 % SLOWER on
+    //  every 3x3 shape, round 6: 96 weight registers, spills in the stride-2 instantiation)
     constexpr int RING = (KS_MIN & 1) ? 3 : (KS_MIN % 4 == 0 ? 4 : 2), D = RING - 1;
     u32x4_t wf[RING][4];
     const int wlane = lane * 16;
@@ -177,35 +179,21 @@ __global__ __launch_bounds__(256, 2) void conv_plane_kernel(const PlaneParams p)
         const int c0 = q.tn * BN + wn * 64 + 8 * kq;
         const float neg = (p.aux_mode == S2E_AUX_RELU_MASK) ? 0.f : 0.2f;
         const bool has_res = resg != nullptr, has_aux = p.aux_mode != S2E_AUX_NONE;
-        u32x4_t opr[NPF][2];
-        int off[NPF]; bool ok[NPF];
-        f32x4_t bv[4];                                  // bias of this lane's channels 32 m + 8 kq + 4 hf + r (f = 2 m + hf)
+        // (operands are fetched pass by pass, not up front: the next tile's weight ring is already in flight and the registers are few)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            bv[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bv[f] = *(const f32x4_t*)(p.bias + c0 + 32 * (f >> 1) + 4 * (f & 1));
-        }
+        for (int m = 0; m < 2; ++m) {
+            f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;   // bias of this lane's channels 32 m + 8 kq .. + 7
+            if (p.bias) { b0 = *(const f32x4_t*)(p.bias + c0 + 32 * m); b1 = *(const f32x4_t*)(p.bias + c0 + 32 * m + 4); }
 #pragma unroll
-        for (int np = 0; np < NPF; ++np) {
-            const int oy = SO * (q.y0 + wm * NPF + np) + cy;
-            ok[np] = oy < p.Ho && ox < p.Wo;
-            off[np] = ((q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + c0;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                opr[np][m] = u32x4_t{0u, 0u, 0u, 0u};
-                if (ok[np] && (has_res || has_aux)) opr[np][m] = *(const u32x4_t*)((has_res ? resg : auxg) + off[np] + 32 * m);
-            }
-        }
-#pragma unroll
-        for (int np = 0; np < NPF; ++np) {
-            if (!ok[np]) continue;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const f32x4_t lo = acc[2 * m][np] + bv[2 * m], hi = acc[2 * m + 1][np] + bv[2 * m + 1];
+            for (int np = 0; np < NPF; ++np) {
+                const int oy = SO * (q.y0 + wm * NPF + np) + cy;
+                if (!(oy < p.Ho && ox < p.Wo)) continue;
+                const int off = ((q.n * p.Ho + oy) * p.Wo + ox) * p.Cout + c0 + 32 * m;
+                const f32x4_t lo = acc[2 * m][np] + b0, hi = acc[2 * m + 1][np] + b1;
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 if (has_res) {
                     float t[8];
-                    unpack16<T>(opr[np][m], t);
+                    unpack16<T>(*(const u32x4_t*)(resg + off), t);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += t[j];
                 }
@@ -215,11 +203,11 @@ __global__ __launch_bounds__(256, 2) void conv_plane_kernel(const PlaneParams p)
                 }
                 if (has_aux && !has_res) {
                     float t[8];
-                    unpack16<T>(opr[np][m], t);
+                    unpack16<T>(*(const u32x4_t*)(auxg + off), t);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] *= (t[j] > 0.f ? 1.f : neg);
                 }
-                *(u32x4_t*)(yg + off[np] + 32 * m) = u32x4_t{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+                *(u32x4_t*)(yg + off) = u32x4_t{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
             }
         }
     };
@@ -393,7 +381,7 @@ int plane_launch(const PlaneParams& p, hipStream_t st) {
     const long items = (long)p.rects * p.tiles_n * (m_so(MODE) == 2 ? 4 : 1);
     const int cap = 2 * plane_cu_count();
     const int grid = items < cap ? (int)items : cap;
-    if (p.Cout % 128 == 0) conv_plane_kernel<MODE, 128, 8, S><<<grid, 256, 0, st>>>(p);
+    if (p.tiles_n * 128 == p.Cout) conv_plane_kernel<MODE, 128, 8, S><<<grid, 256, 0, st>>>(p);
     else conv_plane_kernel<MODE, 64, 8, S><<<grid, 256, 0, st>>>(p);
     S2E_CHECK_LAUNCH("conv_plane_kernel");
     return S2E_OK;
@@ -403,6 +391,16 @@ int plane_launch(const PlaneParams& p, hipStream_t st) {
 constexpr int plane_stage_chunks(int mode, int nch = 4) { return mode == PLANE_K1 ? (nch % 4 == 0 ? 4 : 2) : mode == PLANE_K3S2D || mode == PLANE_K4S2D ? 2 : 1; }
 
 }  // namespace
+
+// Channels per tile: 128, or 64 for a 64-channel layer.  S2E_PLANE_BN64=<k> (experiment; default 0 = off): 64-channel tiles also for
+// layers whose 128-channel tiles give the chip's workgroup slots fewer than k items each -- measured slower at k = 1, 2, 4 on every
+// shape of the step (twice the weight traffic per MFMA costs more than the fuller chip gains): kept for A/B runs only.
+static int plane_bn(const s2e_conv_desc* d, int mode, long rects) {
+    if (d->Cout % 128 != 0) return 64;
+    static const int per_slot = [] { const char* e = getenv("S2E_PLANE_BN64"); return e ? atoi(e) : 0; }();      // (measured: 64-channel tiles lose everywhere, 0 = never)
+    const long items128 = rects * (d->Cout / 128) * ((mode == PLANE_K3S2D || mode == PLANE_K4S2D) ? 4 : 1);
+    return items128 < (long)per_slot * 2 * plane_cu_count() ? 64 : 128;
+}
 
 // S2E_CONV_PLANE: bit mask of the modes this kernel may take (default: 1x1 and the 3x3 stride-2 pair); 0 = never (A/B runs)
 static int plane_mask() {
@@ -433,7 +431,8 @@ int s2e_conv_plane_mode(int dtype, const s2e_conv_desc* d) {
     if ((mode == PLANE_K3S1 || mode == PLANE_K3S2F) && (d->Cin / 32 / plane_stage_chunks(mode)) % 2 != 0) return PLANE_NONE;
     // rectangles of 8 x 16: the map must be at least one rectangle wide and tall, and the launch must give the chip something to do
     if (rw < 16 || rh < 8) return PLANE_NONE;
-    const long items = (long)d->N * ceil_div(rh, 8) * ceil_div(rw, 16) * ceil_div(d->Cout, d->Cout % 128 == 0 ? 128 : 64) * (mode == PLANE_K3S2D ? 4 : 1);
+    const long rects = (long)d->N * ceil_div(rh, 8) * ceil_div(rw, 16);
+    const long items = rects * ceil_div(d->Cout, plane_bn(d, mode, rects)) * (mode == PLANE_K3S2D ? 4 : 1);
     static const int min_items = [] { const char* e = getenv("S2E_CONV_PLANE_MIN"); return e ? atoi(e) : 128; }();
     if (items < min_items) return PLANE_NONE;
     return mode;
@@ -451,8 +450,8 @@ int s2e_conv_plane_launch(int mode, const void* x, const void* w, const float* b
     const bool dg = mode == PLANE_K3S2D || mode == PLANE_K4S2D;
     const int rh = dg ? d->Hi : d->Ho, rw = dg ? d->Wi : d->Wo;
     p.tiles_x = ceil_div(rw, 16); p.tiles_y = ceil_div(rh, 8);
-    p.tiles_n = ceil_div(d->Cout, d->Cout % 128 == 0 ? 128 : 64);
     p.rects = d->N * p.tiles_y * p.tiles_x;
+    p.tiles_n = ceil_div(d->Cout, plane_bn(d, mode, p.rects));
     p.nch = d->Cin / 32;
     p.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Cin * 2);
     p.w_bytes = (unsigned)((long)ceil_div(d->Cout, 64) * 64 * d->KH * d->KW * d->Cin * 2);

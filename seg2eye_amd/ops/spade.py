@@ -239,7 +239,7 @@ class LabelConvFn(torch.autograd.Function):
             raise NotImplementedError('use SpadeParamFn for the ReLU variant (mask fused into the dgrad)')
         cout, ncls = weight.shape[0], weight.shape[1]
         oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
-        dwp, gb = conv2d_wgrad_raw(oh, g, 3, 3, 1, 1, ACT_NONE, True, ctx.bdst)
+        dwp, gb = conv2d_wgrad_raw(oh, g, 3, 3, 1, 1, ACT_NONE, True, ctx.bdst, defer_ok=ctx.wdst is not None and ctx.bdst is not None)
         if ctx.wdst is not None:
             unpack_weight_grad_into(dwp, ctx.wdst, cout, ncls, 3, 3, 8)
             return None, None, gb, None, None, None, None
@@ -397,9 +397,9 @@ def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
     if sp is not None and ctx.gb_dst is not None and _cl_dense(ctx.gb_dst[0]) and _sparse_wgrad(g, actv, ctx.gb_dst, sp):
         uni_gb = ctx.gb_dst
     elif ctx.gb_dst is not None and _cl_dense(ctx.gb_dst[0]):     # channels-last arena: straight into [dW_gamma; dW_beta]
-        conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1], dw_out=_cl_rows(ctx.gb_dst[0]))
+        conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1], dw_out=_cl_rows(ctx.gb_dst[0]), defer_ok=True)
     elif ctx.gb_dst is not None:
-        dwp, _ = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1])
+        dwp, _ = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True, ctx.gb_dst[1], defer_ok=True)
         unpack_weight_grad_into(dwp, ctx.gb_dst[0], c2, nh, 3, 3, nh)
     else:
         dwp, gb_gb = conv2d_wgrad_raw(actv, g, 3, 3, 1, 1, ACT_NONE, True)
@@ -441,7 +441,7 @@ def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
     wdst, bdst = ctx.sh_dst
     if GradSink.push_c8(oh, dactv, wdst, bdst, ncls):        # inside a trainer step: all mlp_shared gradients in one launch, later
         return gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b
-    dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True, bdst)
+    dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True, bdst, defer_ok=wdst is not None and bdst is not None)
     if wdst is not None:
         unpack_weight_grad_into(dwp, wdst, nh, ncls, 3, 3, 8)
     else:

@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \
         SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -o sq -- python3 bench.py \
         --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
-    python3 tools/pmc_sq.py /tmp/pmc_sq profiles/r05/pmc/sq_counters_patch_kernels.txt
+    python3 tools/pmc_sq.py /tmp/pmc_sq profiles/r06/pmc/sq_counters_patch_kernels.txt
 
 Per kernel (all dispatches of the run summed): SQ_WAIT_ANY (parked in s_waitcnt / barrier), SQ_WAIT_INST_ANY (issue-stalled)
 and SQ_ACTIVE_INST_ANY as fractions of SQ_WAVE_CYCLES (the three are disjoint, MI355X_MICROARCH.md); matrix-pipe utilisation =
@@ -16,7 +16,7 @@ import os
 import sys
 from collections import defaultdict
 
-WANT = ('conv_duo_kernel', 'conv_patch_kernel', 'conv_wgrad_batch_kernel', 'conv_wgrad_patch_kernel', 'conv_igemm_kernel', 'conv_stream_kernel', 'conv_wgrad_kernel', 'conv_wgrad_stream_kernel')
+WANT = ('conv_plane_kernel', 'conv_wgrad_multi_kernel', 'conv_duo_kernel', 'conv_patch_kernel', 'conv_wgrad_batch_kernel', 'conv_wgrad_patch_kernel', 'conv_igemm_kernel', 'conv_stream_kernel', 'conv_wgrad_kernel', 'conv_wgrad_stream_kernel')
 
 
 def main():

@@ -4,7 +4,7 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline --no-kernel-events
-    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r05/pmc [steps-profiled]
+    python3 tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w profiles/r06/pmc [steps-profiled]
 
 Counters are in KB; FETCH_SIZE is doubled (gfx950 counts a 128-B request as 64 B: MI355X_MICROARCH.md, HBM section).
 Families are seg2eye_amd.ops.LaunchProfiler's -- one per C-ABI entry point (the conv entry points split by
@@ -72,6 +72,8 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'style_fc_fwd_kernel': ('style_fc', True), 'style_fc_bwd_kernel': ('style_fc', True), 'style_fc_dw_fold_kernel': ('style_fc', False),
     'sn_gemvT_chain_kernel': ('spectral_norm', True), 'sn_gemv_chain_kernel': ('spectral_norm', False), 'sn_finalize_chain_kernel': ('spectral_norm', False),
     'conv_wgrad_reduce_kernel': ('conv_wgrad', False),
+    # (round 6: every generic weight gradient of a backward as one multi-job launch + one reduction launch)
+    'conv_wgrad_multi_kernel': ('conv_wgrad', True), 'conv_wgrad_reduce_multi_kernel': ('conv_wgrad', False),
     'sn_gemvT_kernel': ('spectral_norm', True), 'sn_gemv_kernel': ('spectral_norm', False),     # launches = power ITERATIONS
     'sn_norm_v_kernel': ('spectral_norm', False), 'sn_finalize_kernel': ('spectral_norm', False),
     'upsample2x_fwd_kernel': ('resample', True), 'upsample2x_bwd_kernel': ('resample', True),

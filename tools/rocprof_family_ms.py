@@ -2,7 +2,7 @@
 """Per-family GPU time per G+D step from a `rocprofv3 --kernel-trace --stats` summary of `python bench.py ...` (the
 bench line quotes it beside its own HIP-event figure -- the events of an eager re-run carry ~12 us of dispatch per launch).
 
-    python3 tools/rocprof_family_ms.py <..._kernel_stats.csv> profiles/r05/kernel_ms_per_step.json
+    python3 tools/rocprof_family_ms.py <..._kernel_stats.csv> profiles/r06/kernel_ms_per_step.json
 
 Families are tools/pmc_traffic.py's (= seg2eye_amd.ops.LaunchProfiler's).  Step BODIES profiled = adam_flat_kernel calls / 2 (every
 timed, warm-up and per-step-timed G+D step ends with two Adam launches) + 2: the two eager G+D bodies the trainer runs before
