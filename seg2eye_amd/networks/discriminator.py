@@ -10,6 +10,9 @@ from ..spectral import sn_begin
 from .base_network import BaseNetwork, compute_dtype_of
 from .normalization import apply_nonspade_norm, get_nonspade_norm_layer
 
+import os
+_TWO_STREAMS = os.environ.get('S2E_D_STREAMS', '1') == '1'      # round 6: the two scales of netD on two streams (0: one after the other)
+
 D_CPAD = 8          # the 5-channel input cat([one-hot seg, image]) is stored as 8 NHWC channels (16-B vectors)
 
 
@@ -108,6 +111,12 @@ class MultiscaleDiscriminator(BaseNetwork):
         for i in range(opt.num_D):
             self.add_module('discriminator_%d' % i, NLayerDiscriminator(opt))
 
+    def _side_stream(self, device):
+        st = self.__dict__.get('_side')
+        if st is None or st.device != device:
+            st = self.__dict__['_side'] = torch.cuda.Stream(device=device)
+        return st
+
     def forward(self, input, feat_lambda=None):
         """input: (2N, label_nc+output_nc, H, W) as in the reference call (pix2pix_model.py:338), or
         the already-built (2N,H,W,8) NHWC tensor.  Returns list[num_D] of list[n_layers_D+1] tensors,
@@ -128,11 +137,35 @@ class MultiscaleDiscriminator(BaseNetwork):
             # (not with BatchNorm in D: batch statistics couple the samples, the real half's activations then DO carry gradient)
             coupled = any(isinstance(m, nn.BatchNorm2d) for m in self.modules())
             with ops.LivePrefix.of(x.shape[0] // 2 if (terms is not None and not coupled) else None):
-                for name, D in self.named_children():
-                    raw = D.forward_nhwc(x, terms, (feat_lambda or 0.0) / num_D)
-                    feats = [f.permute(0, 3, 1, 2) for f in raw]
-                    result.append(feats if keep_all else [feats[-1]])
-                    x = ops.avgpool3x3s2(x)                    # F.avg_pool2d(3, 2, 1, count_include_pad=False)
+                children = list(self.named_children())
+                if _TWO_STREAMS and len(children) == 2 and x.is_cuda:
+                    # The two scales are independent chains (reference discriminator.py:53-63 runs them one after the other): the
+                    # half-resolution one -- 65^2 ... 18^2 maps, launches of a few dozen workgroups -- runs on a SECOND stream beside
+                    # the full-resolution one (its ~30 small launches per pass no longer queue behind each other's
+                    # tails).  Autograd runs each node's backward on its forward's stream and joins the streams when a gradient
+                    # crosses; inside a hipGraph capture the fork / join become parallel branches of the graph.
+                    main, side = torch.cuda.current_stream(), self._side_stream(x.device)
+                    x2 = ops.avgpool3x3s2(x)                   # F.avg_pool2d(3, 2, 1, count_include_pad=False)
+                    side.wait_stream(main)
+                    terms2 = [] if terms is not None else None
+                    with torch.cuda.stream(side):
+                        raw2 = children[1][1].forward_nhwc(x2, terms2, (feat_lambda or 0.0) / num_D)
+                    raw1 = children[0][1].forward_nhwc(x, terms, (feat_lambda or 0.0) / num_D)
+                    main.wait_stream(side)
+                    x2.record_stream(side)
+                    for t in raw2 + (terms2 or []):
+                        t.record_stream(main)                  # (allocated on the side stream, consumed by the loss code on this one)
+                    if terms is not None:
+                        terms += terms2
+                    for raw in (raw1, raw2):
+                        feats = [f.permute(0, 3, 1, 2) for f in raw]
+                        result.append(feats if keep_all else [feats[-1]])
+                else:
+                    for name, D in children:
+                        raw = D.forward_nhwc(x, terms, (feat_lambda or 0.0) / num_D)
+                        feats = [f.permute(0, 3, 1, 2) for f in raw]
+                        result.append(feats if keep_all else [feats[-1]])
+                        x = ops.avgpool3x3s2(x)                # F.avg_pool2d(3, 2, 1, count_include_pad=False)
             if terms is None:
                 return result
             return result, torch.stack(terms).sum().view(1)
