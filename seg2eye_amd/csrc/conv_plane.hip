@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_plane_kernel(const PlaneParams p)
     constexpr int KS_MIN = S * (SO == 2 ? (MODE == PLANE_K3S2D ? 1 : 4) : TT);      // the shortest class's K-steps per stage
     // (odd K-step counts run in pairs of stages, 18 K-steps: a ring of 3.  A ring of 6 -- five K-steps ahead -- measured 15-20 % SLOWER on
     //  every 3x3 shape, round 6: 96 weight registers, spills in the stride-2 instantiation)
-    constexpr int RING = (KS_MIN & 1) ? 3 : (KS_MIN % 4 == 0 ? 4 : 2), D = RING - 1;
+    constexpr int RING = (KS_MIN & 1) ? 3 : ((KS_MIN % 4 == 0 && MODE != PLANE_K4S2F && MODE != PLANE_K4S2D) ? 4 : 2), D = RING - 1;      // (the 4x4 stride-2 modes: registers)
     u32x4_t wf[RING][4];
     const int wlane = lane * 16;
     auto load_w = [&](int set, int tn64, int c, int wt) __attribute__((always_inline)) {
@@ -402,11 +402,12 @@ static int plane_bn(const s2e_conv_desc* d, int mode, long rects) {
     return items128 < (long)per_slot * 2 * plane_cu_count() ? 64 : 128;
 }
 
-// S2E_CONV_PLANE: bit mask of the modes this kernel may take (default: 1x1 and the 3x3 stride-2 pair); 0 = never (A/B runs)
+// S2E_CONV_PLANE: bit mask of the modes this kernel may take (default: 1x1, the 3x3 and the 4x4 stride-2 pairs; the stride-1 modes
+// lose to conv_duo.hip on the large maps and stay off); 0 = never (A/B runs)
 static int plane_mask() {
     static const int m = [] {
         const char* e = getenv("S2E_CONV_PLANE");
-        return e ? atoi(e) : (1 << PLANE_K1) | (1 << PLANE_K3S2F) | (1 << PLANE_K3S2D);
+        return e ? atoi(e) : (1 << PLANE_K1) | (1 << PLANE_K3S2F) | (1 << PLANE_K3S2D) | (1 << PLANE_K4S2F) | (1 << PLANE_K4S2D);
     }();
     return m;
 }
@@ -421,6 +422,10 @@ int s2e_conv_plane_mode(int dtype, const s2e_conv_desc* d) {
     if (d->KH == 1 && d->stride == 1 && d->pad == 0 && d->Ho == d->Hi && d->Wo == d->Wi) mode = PLANE_K1;
     else if (d->KH == 3 && d->stride == 2 && d->pad == 1 && !d->transposed && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo) mode = PLANE_K3S2F;
     else if (d->KH == 3 && d->stride == 2 && d->pad == 1 && d->transposed && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi) { mode = PLANE_K3S2D; rh = d->Hi; rw = d->Wi; }
+    else if (d->KH == 4 && d->stride == 2 && d->pad == 2 && !d->transposed && d->Ho == d->Hi / 2 + 1 && d->Wo == d->Wi / 2 + 1) mode = PLANE_K4S2F;
+    else if (d->KH == 4 && d->stride == 2 && d->pad == 2 && d->transposed && d->Hi == d->Ho / 2 + 1 && d->Wi == d->Wo / 2 + 1) {
+        mode = PLANE_K4S2D; rh = (d->Ho + 1) / 2; rw = (d->Wo + 1) / 2;
+    }
     else if (d->KH == 3 && d->stride == 1) {
         const int grow = d->transposed ? 2 - 2 * d->pad : 2 * d->pad - 2;
         if (d->Ho == d->Hi + grow && d->Wo == d->Wi + grow) mode = PLANE_K3S1;
@@ -432,7 +437,7 @@ int s2e_conv_plane_mode(int dtype, const s2e_conv_desc* d) {
     // rectangles of 8 x 16: the map must be at least one rectangle wide and tall, and the launch must give the chip something to do
     if (rw < 16 || rh < 8) return PLANE_NONE;
     const long rects = (long)d->N * ceil_div(rh, 8) * ceil_div(rw, 16);
-    const long items = rects * ceil_div(d->Cout, plane_bn(d, mode, rects)) * (mode == PLANE_K3S2D ? 4 : 1);
+    const long items = rects * ceil_div(d->Cout, plane_bn(d, mode, rects)) * ((mode == PLANE_K3S2D || mode == PLANE_K4S2D) ? 4 : 1);
     static const int min_items = [] { const char* e = getenv("S2E_CONV_PLANE_MIN"); return e ? atoi(e) : 128; }();
     if (items < min_items) return PLANE_NONE;
     return mode;
@@ -448,7 +453,7 @@ int s2e_conv_plane_launch(int mode, const void* x, const void* w, const float* b
     p.flip = d->transposed ? 1 : 0;
     p.out_act = d->out_act; p.aux_mode = d->aux_mode;
     const bool dg = mode == PLANE_K3S2D || mode == PLANE_K4S2D;
-    const int rh = dg ? d->Hi : d->Ho, rw = dg ? d->Wi : d->Wo;
+    const int rh = mode == PLANE_K4S2D ? (d->Ho + 1) / 2 : dg ? d->Hi : d->Ho, rw = mode == PLANE_K4S2D ? (d->Wo + 1) / 2 : dg ? d->Wi : d->Wo;
     p.tiles_x = ceil_div(rw, 16); p.tiles_y = ceil_div(rh, 8);
     p.rects = d->N * p.tiles_y * p.tiles_x;
     p.tiles_n = ceil_div(d->Cout, plane_bn(d, mode, p.rects));
@@ -460,6 +465,8 @@ int s2e_conv_plane_launch(int mode, const void* x, const void* w, const float* b
     case PLANE_K3S1: return plane_launch<PLANE_K3S1, plane_stage_chunks(PLANE_K3S1)>(p, st);
     case PLANE_K3S2F: return plane_launch<PLANE_K3S2F, plane_stage_chunks(PLANE_K3S2F)>(p, st);
     case PLANE_K3S2D: return plane_launch<PLANE_K3S2D, plane_stage_chunks(PLANE_K3S2D)>(p, st);
+    case PLANE_K4S2F: return plane_launch<PLANE_K4S2F, plane_stage_chunks(PLANE_K4S2F)>(p, st);
+    case PLANE_K4S2D: return plane_launch<PLANE_K4S2D, plane_stage_chunks(PLANE_K4S2D)>(p, st);
     default: break;
     }
     S2E_FAIL(S2E_ERR_UNSUPPORTED, "conv_plane: mode %d", mode);

@@ -508,6 +508,19 @@ class GradSink:
         self.keep_uni = jobs                                 # the tensors stay referenced until the next flush
 
     def flush(self):
+        if (self.wg and self.gwg and switches.FLUSH_STREAMS and self.gwg[0][0].is_cuda
+                and not ({j[2].data_ptr() for j in self.wg} & {j[2].data_ptr() for j in self.gwg})):      # (never a dW in both launches)
+            # the two big launches of a flush -- the batched patch-resident weight gradients (one persistent workgroup per CU) and the
+            # multi-job generic ones -- share no output and leave half of each CU's registers / LDS free: side by side (16.35 -> 16.29 ms, two same-box pairs)
+            main = torch.cuda.current_stream()
+            side = self.__dict__.get('_side')
+            if side is None or side.device != main.device:
+                side = self._side = torch.cuda.Stream(device=main.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._flush_gwg()
+            self._flush_wgrad()
+            main.wait_stream(side)
         if self.wg:
             self._flush_wgrad()                              # first: the re-layout / chain-rule / rank-1 jobs below read or add to its results
         if self.gwg:

@@ -19,3 +19,5 @@ SPARSE_BWD_OFF = os.environ.get('S2E_SPADE_SPARSE_BWD', '1') == '0' or _DET
 SPARSE_OFF = os.environ.get('S2E_SPADE_SPARSE', '1') == '0'
 # 0 = the two-launch path ([gamma | beta] conv, then the modulation) everywhere
 FUSED_OFF = os.environ.get('S2E_SPADE_FUSED', '1') == '0'
+# 0 = a flush runs its two big weight-gradient launches one after the other (round 6: on two streams)
+FLUSH_STREAMS = os.environ.get('S2E_FLUSH_STREAMS', '1') == '1'

@@ -111,13 +111,18 @@ def main():
     run(3, 48, 64, 128, 64, 3, 2, 1, res=True)
     run(2, 32, 32, 256, 512, 3, 2, 1)
     run(5, 36, 44, 64, 64, 3, 2, 1, mask=True)
+    run(2, 64, 64, 64, 128, 4, 2, 2)
+    run(3, 65, 65, 64, 128, 4, 2, 2, bias=True, lrelu=True, cl=True)
+    run(2, 33, 33, 128, 64, 4, 2, 2, mask=True)
+    run(2, 129, 129, 64, 128, 4, 2, 2)
     if os.environ.get('S2E_CONV_PLANE') and (int(os.environ['S2E_CONV_PLANE']) >> 2) & 1:
         run(2, 32, 32, 64, 128, 3, 1, 1, bias=True)
         run(2, 24, 40, 128, 64, 3, 1, 1, res=True)
     print('parity ok')
     if bench:
         # netE (batch 32) and the learned shortcuts at the benchmark's sizes
-        for (n, h, cin, cout, k, s, p) in [(32, 128, 64, 128, 3, 2, 1), (32, 64, 128, 256, 3, 2, 1), (32, 32, 256, 512, 3, 2, 1), (32, 16, 512, 512, 3, 2, 1),
+        for (n, h, cin, cout, k, s, p) in [(16, 129, 64, 128, 4, 2, 2), (16, 65, 128, 256, 4, 2, 2), (16, 65, 64, 128, 4, 2, 2), (16, 33, 128, 256, 4, 2, 2),
+                                           (32, 128, 64, 128, 3, 2, 1), (32, 64, 128, 256, 3, 2, 1), (32, 32, 256, 512, 3, 2, 1), (32, 16, 512, 512, 3, 2, 1),
                                            (8, 256, 128, 64, 1, 1, 0), (8, 128, 256, 128, 1, 1, 0), (8, 64, 512, 256, 1, 1, 0), (8, 32, 1024, 512, 1, 1, 0)]:
             run(n, h, h, cin, cout, k, s, p, bench=True, check=False)
         if os.environ.get('S2E_CONV_PLANE') and (int(os.environ['S2E_CONV_PLANE']) >> 2) & 1:
