@@ -21,7 +21,7 @@ torch.cuda.synchronize(); ops.LaunchProfiler.install(None)
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for fam, fl, s, e, tag, _nb, _ex in prof.records:
     a = agg[(fam, tag)]; a[0] += 1; a[1] += s.elapsed_time(e); a[2] += fl
-for fam in ('conv_patch', 'conv_igemm', 'conv_small', 'conv_wgrad_patch', 'conv_wgrad', 'conv_wgrad_small'):
+for fam in ('conv_patch', 'conv_plane', 'conv_igemm', 'conv_small', 'conv_wgrad_patch', 'conv_wgrad', 'conv_wgrad_small'):
     items = sorted(((k, v) for k, v in agg.items() if k[0] == fam), key=lambda kv: -kv[1][1])
     tot = sum(v[1] for _, v in items) / N
     print('== %s total %.2f ms/step' % (fam, tot))
