@@ -513,17 +513,19 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_glds_kernel(const WgradPara
 // So: aim for S2E_WGRAD_WG (2048) workgroups, keep >= 32 pixel chunks per split (64 when dW is large), never more
 // than 512 splits -- unless that leaves the chip under-filled (< 512 workgroups), then allow 16-chunk splits
 // (8-chunk splits for a 1-2 tile dW).
-static void generic_wgrad_plan(const s2e_conv_desc* d, WgradParams* p, int* splits_out) {
+static void generic_wgrad_plan(const s2e_conv_desc* d, WgradParams* p, int* splits_out, int target_override = 0) {
     p->Ktot = d->KH * d->KW * d->Cin;
     p->M = d->N * d->Ho * d->Wo;
     p->tiles_k = ceil_div(p->Ktot, 128);
     p->tiles_co = ceil_div(d->Cout, 128);
     const int tiles = p->tiles_k * p->tiles_co;
-    const int target_wg = 2048;                      // (c128->256 @256^2: 476 / 497 / 558 TFLOP/s at 512 / 1024 / 2048 workgroups)
+    // (c128->256 @256^2: 476 / 497 / 558 TFLOP/s at 512 / 1024 / 2048 workgroups; a job of a multi-job launch gets its share of the
+    //  launch's workgroups instead: it does not have to fill the chip alone)
+    const int target_wg = target_override > 0 ? target_override : 2048;
     int splits = ceil_div(target_wg, tiles);
     int max_splits = p->M / (tiles >= 64 ? 2048 : 1024);
     if (max_splits > 512) max_splits = 512;
-    if ((long)tiles * max_splits < 512) {
+    if (target_override <= 0 && (long)tiles * max_splits < 512) {
         const int fill = ceil_div(512, tiles), cap = p->M / (tiles <= 2 ? 256 : 512);
         max_splits = fill < cap ? fill : cap;
     }
@@ -661,9 +663,38 @@ static bool wgrad_multi_ok(int dtype, const s2e_conv_desc* d) {
 }
 extern "C" int s2e_conv2d_wgrad_multi_supported(int dtype, const s2e_conv_desc* d) { return wgrad_multi_ok(dtype, d) ? 1 : 0; }
 
+// The plan of jobs [base, base + n) of a multi-job launch: a job's share of the launch's workgroups (S2E_WGRAD_MULTI_WGS in all, default
+// 6144: 12 per workgroup slot of the chip) goes by its MFMA work -- planned alone (2048 workgroups each) two dozen jobs made 30-40 k
+// workgroups and ~1 GB of partial tiles per step.  Fills ps[i] (shape, tiling, m_per_split) and splits[i].
+static void wgrad_multi_plan(const s2e_wgrad_multi_job* jobs, int base, int n, WgradParams* ps, int* splits) {
+    static const int total_wg = [] { const char* e = getenv("S2E_WGRAD_MULTI_WGS"); return e ? atoi(e) : 6144; }();
+    double work[WGM_MAX_JOBS], work_sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const s2e_conv_desc* d = &jobs[base + i].d;
+        work[i] = (double)ceil_div(d->Cout, 128) * ceil_div(d->KH * d->KW * d->Cin, 128) * ((double)d->N * d->Ho * d->Wo);
+        work_sum += work[i];
+    }
+    for (int i = 0; i < n; ++i) {
+        const s2e_conv_desc* d = &jobs[base + i].d;
+        WgradParams& p = ps[i];
+        p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+        p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.in_act = d->in_act;
+        generic_wgrad_plan(d, &p, &splits[i], total_wg > 0 ? (int)(total_wg * work[i] / work_sum) + 1 : 0);
+    }
+}
+
 extern "C" size_t s2e_conv2d_wgrad_multi_workspace_bytes(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs) {
     size_t total = 0;
-    for (int i = 0; jobs && i < n_jobs; ++i) total += (s2e_conv2d_wgrad_workspace_bytes(dtype, &jobs[i].d) + 255) & ~(size_t)255;
+    for (int base = 0; jobs && base < n_jobs; base += WGM_MAX_JOBS) {
+        const int n = n_jobs - base < WGM_MAX_JOBS ? n_jobs - base : WGM_MAX_JOBS;
+        WgradParams ps[WGM_MAX_JOBS];
+        int splits[WGM_MAX_JOBS];
+        for (int i = 0; i < n; ++i) if (!wgrad_multi_ok(dtype, &jobs[base + i].d)) return 0;
+        wgrad_multi_plan(jobs, base, n, ps, splits);
+        for (int i = 0; i < n; ++i)
+            if (wgrad_use_partial(splits[i]))
+                total += ((size_t)ps[i].tiles_k * ps[i].tiles_co * splits[i] * (128 * 128 + 128) * sizeof(float) + 255) & ~(size_t)255;
+    }
     return total;
 }
 
@@ -679,17 +710,16 @@ extern "C" int s2e_conv2d_wgrad_multi(int dtype, const s2e_wgrad_multi_job* jobs
         WgMultiRed r{};
         b.n = n;
         int blocks = 0, rblocks = 0;
+        int splits_of[WGM_MAX_JOBS];
+        for (int i = 0; i < n; ++i)
+            if (!wgrad_multi_ok(dtype, &jobs[base + i].d)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad_multi: job %d is not a generic bf16 shape (s2e_conv2d_wgrad_multi_supported)", base + i);
+        wgrad_multi_plan(jobs, base, n, b.j, splits_of);
         for (int i = 0; i < n; ++i) {
             const s2e_wgrad_multi_job& J = jobs[base + i];
             if (!J.x || !J.gy || !J.dw) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad_multi: null pointer in job %d", base + i);
-            if (!wgrad_multi_ok(dtype, &J.d)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad_multi: job %d is not a generic bf16 shape (s2e_conv2d_wgrad_multi_supported)", base + i);
             WgradParams& p = b.j[i];
-            const s2e_conv_desc* d = &J.d;
             p.x = J.x; p.gy = J.gy; p.dw = J.dw; p.dbias = J.dbias;
-            p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
-            p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.in_act = d->in_act;
-            int splits;
-            generic_wgrad_plan(d, &p, &splits);
+            const int splits = splits_of[i];
             const int g = p.tiles_k * p.tiles_co * splits;
             const size_t need = (size_t)g * (128 * 128 + 128) * sizeof(float);
             if (wgrad_use_partial(splits) && ws && ws_left >= need) {

@@ -11,7 +11,7 @@ from .base_network import BaseNetwork, compute_dtype_of
 from .normalization import apply_nonspade_norm, get_nonspade_norm_layer
 
 import os
-_TWO_STREAMS = os.environ.get('S2E_D_STREAMS', '1') == '1'      # round 6: the two scales of netD on two streams (0: one after the other)
+_TWO_STREAMS = os.environ.get('S2E_D_STREAMS', '0') == '1'      # round 6 experiment: the two scales of netD on two streams (measured neutral: off)
 
 D_CPAD = 8          # the 5-channel input cat([one-hot seg, image]) is stored as 8 NHWC channels (16-B vectors)
 

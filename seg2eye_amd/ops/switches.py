@@ -19,5 +19,6 @@ SPARSE_BWD_OFF = os.environ.get('S2E_SPADE_SPARSE_BWD', '1') == '0' or _DET
 SPARSE_OFF = os.environ.get('S2E_SPADE_SPARSE', '1') == '0'
 # 0 = the two-launch path ([gamma | beta] conv, then the modulation) everywhere
 FUSED_OFF = os.environ.get('S2E_SPADE_FUSED', '1') == '0'
-# 0 = a flush runs its two big weight-gradient launches one after the other (round 6: on two streams)
-FLUSH_STREAMS = os.environ.get('S2E_FLUSH_STREAMS', '1') == '1'
+# 1 = a flush runs its two big weight-gradient launches on two streams (round 6 experiment: 16.35 -> 16.29 ms, but the persistent batched launch
+# holds the CUs and the small reduction launch behind it then shows 0.7 ms in the kernel trace: off, the accounting stays readable)
+FLUSH_STREAMS = os.environ.get('S2E_FLUSH_STREAMS', '0') == '1'
