@@ -309,6 +309,10 @@ int s2e_modulate_bwd(int dtype, int mode, const void* g, const void* x, const vo
 typedef struct s2e_wgrad_c8_job {
     const void* x; const void* gy; float* dw_oihw; float* dbias;
     int H, W, ncls;
+    /* round 6, both or neither (H, W multiples of 16): only the pixels of the 16 x 16 rectangles rect_list[0 .. *rect_count) (device
+     * memory; rectangle r = (n * (H/16) + ty) * (W/16) + tx) contribute -- the label-sparse SPADE backward, whose d(actv) exists
+     * on those rectangles only: gy outside them is never read (it need not be initialised) */
+    const int* rect_list; const int* rect_count;
 } s2e_wgrad_c8_job;
 int s2e_wgrad_c8_batch_supported(int dtype, int H, int W, int cout);
 size_t s2e_wgrad_c8_batch_workspace_bytes(int N, const s2e_wgrad_c8_job* jobs, int n_jobs);

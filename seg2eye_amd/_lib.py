@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
 
 class WgradC8Job(C.Structure):
     _fields_ = [('x', C.c_void_p), ('gy', C.c_void_p), ('dw_oihw', C.c_void_p), ('dbias', C.c_void_p),
-                ('H', C.c_int), ('W', C.c_int), ('ncls', C.c_int)]
+                ('H', C.c_int), ('W', C.c_int), ('ncls', C.c_int), ('rect_list', C.c_void_p), ('rect_count', C.c_void_p)]
 
 
 class WgradBatchJob(C.Structure):

@@ -295,6 +295,9 @@ struct WcParams {
     const void* x; const void* gy; float* ws;
     int N, H, W, Cout;
     int sx, sy, nslabs, per_split;
+    // label-sparse form (8 x 16 slabs only): the slabs are the halves of the 16 x 16 rectangles rect_list[0 .. *rect_count) of a
+    // (tiles_y x tiles_x) rectangle grid per sample; `splits` workgroups share them evenly (the count lives on the device)
+    const int* rect_list; const int* rect_count; int tiles_x, tiles_y, splits;
 };
 
 // two bf16 from two LDS addresses into one register: the low half by ds_read_u16 (zero-extended), the high half by
@@ -316,7 +319,11 @@ __device__ __forceinline__ void conv_wgrad_c8_body(const WcParams& p, int split,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave;                              // 32-co block of this wave
-    const int s0 = split * p.per_split, s1 = min(p.nslabs, s0 + p.per_split);
+    int s0 = split * p.per_split, s1 = min(p.nslabs, s0 + p.per_split);
+    if (p.rect_list) {
+        const int nsl = 2 * *p.rect_count, per = (nsl + p.splits - 1) / p.splits;
+        s0 = split * per; s1 = min(nsl, s0 + per);
+    }
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ gg = (const T*)p.gy;
     const int hh = lane >> 5, l31 = lane & 31;
@@ -347,6 +354,13 @@ __device__ __forceinline__ void conv_wgrad_c8_body(const WcParams& p, int split,
         struct Slab { int n, y0, x0; };
         auto decode = [&](int s) __attribute__((always_inline)) -> Slab {
             Slab q;
+            if (p.rect_list) {                         // (TWS = 4: a rectangle is two 8 x 16 slabs)
+                int r = p.rect_list[s >> 1];
+                q.x0 = (r % p.tiles_x) * 16; r /= p.tiles_x;
+                q.y0 = (r % p.tiles_y) * 16 + (s & 1) * 8;
+                q.n = r / p.tiles_y;
+                return q;
+            }
             q.x0 = (s % p.sx) << TWS; s /= p.sx;
             q.y0 = (s % p.sy) * TH;
             q.n = s / p.sy;
@@ -452,7 +466,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c8_kernel(const WcParams p)
 // The 8-channel weight gradients of MANY layers (a generator's 19 mlp_shared convs: the one-hot label map against d actv) in one
 // launch.  The jobs travel BY VALUE in the kernel arguments (no device table to upload, and a hipGraph node keeps them):
 // block b belongs to the job whose [first, first + splits) range of blocks holds it.  Cout = 128 for every job.
-struct WcJob { const void* x; const void* gy; float* dw; float* dbias; int H, W, sx, sy, nslabs, per_split, first, splits, ws_tile, ncls; };
+struct WcJob { const void* x; const void* gy; float* dw; float* dbias; const int* rect_list; const int* rect_count;
+               int H, W, sx, sy, nslabs, per_split, first, splits, ws_tile, ncls; };
 constexpr int WC_MAX_JOBS = 24;
 struct WcBatch { int n, N; WcJob j[WC_MAX_JOBS]; };
 
@@ -465,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c8_batch_kernel(const WcBat
     WcParams p;
     p.x = J.x; p.gy = J.gy; p.ws = ws; p.N = b.N; p.H = J.H; p.W = J.W; p.Cout = 128;
     p.sx = J.sx; p.sy = J.sy; p.nslabs = J.nslabs; p.per_split = J.per_split;
+    p.rect_list = J.rect_list; p.rect_count = J.rect_count; p.tiles_x = J.W >> 4; p.tiles_y = J.H >> 4; p.splits = J.splits;
     const int split = blockIdx.x - J.first;
     conv_wgrad_c8_body<TWS>(p, split, 0, ws + (size_t)(J.ws_tile + split) * (128 * 80), smem);
 }
@@ -690,8 +706,9 @@ extern "C" int s2e_wgrad_c8_batch_supported(int dtype, int H, int W, int cout) {
     return dtype == S2E_BF16 && cout == 128 && wc_best_slab(H, W) != 0;
 }
 static void wc_job_plan(int N, const s2e_wgrad_c8_job& h, WcJob& J, int& slab_w) {
-    slab_w = wc_best_slab(h.H, h.W);
+    slab_w = h.rect_list ? 16 : wc_best_slab(h.H, h.W);         // (a rectangle list: its 16 x 16 rectangles as 8 x 16 slabs)
     J.x = h.x; J.gy = h.gy; J.dw = h.dw_oihw; J.dbias = h.dbias; J.H = h.H; J.W = h.W; J.ncls = h.ncls;
+    J.rect_list = h.rect_list; J.rect_count = h.rect_count;
     J.sx = ceil_div(h.W, slab_w); J.sy = ceil_div(h.H, 128 / slab_w); J.nslabs = N * J.sy * J.sx;
     int splits = ceil_div(J.nslabs, 8);               // ~8 slabs (1024 pixels) per workgroup
     if (splits > 512) splits = 512;
@@ -723,7 +740,8 @@ extern "C" int s2e_wgrad_c8_batch(int dtype, int N, const s2e_wgrad_c8_job* jobs
         int ws_tile = 0;
         for (int i = 0; i < cnt; ++i) {
             const s2e_wgrad_c8_job& h = jobs[base + i];
-            if (!h.x || !h.gy || !h.dw_oihw || h.ncls <= 0 || h.ncls > 8 || !wc_best_slab(h.H, h.W))
+            if (!h.x || !h.gy || !h.dw_oihw || h.ncls <= 0 || h.ncls > 8 || !wc_best_slab(h.H, h.W) || (h.rect_list != nullptr) != (h.rect_count != nullptr)
+                || (h.rect_list && ((h.H | h.W) & 15)))
                 S2E_FAIL(S2E_ERR_ARG, "s2e_wgrad_c8_batch: bad job %d", base + i);
             wc_job_plan(N, h, all.j[i], slab[i]);
             all.j[i].ws_tile = ws_tile;

@@ -439,17 +439,27 @@ class GradSink:
         self.keep_gwg = jobs                                 # the tensors stay referenced until the next flush (stream order covers the rest)
 
     @staticmethod
-    def push_c8(oh, dactv, dw, db, ncls):
+    def c8_would_queue(dtype, h, w, dw, db):
+        """Would push_c8 take this layer (so that its caller may leave d(actv) undefined outside the rectangle list it passes)?"""
+        return (ZeroPool.active() is not None and dw is not None and db is not None and dtype == torch.bfloat16
+                and bool(L.lib().s2e_wgrad_c8_batch_supported(L.S2E_BF16, h, w, 128)))
+
+    @staticmethod
+    def push_c8(oh, dactv, dw, db, ncls, rects=None):
         """Queue the weight / bias gradient of a 3x3 conv on the 8-channel one-hot map `oh` (N,h,w,8) with output gradient
         `dactv` (N,h,w,128), accumulated straight into dw (128,ncls,3,3) / db (128) fp32 at the next flush -- all queued layers
-        in one launch per slab shape (s2e_wgrad_c8_batch).  False: not queued (no scope, or a shape the batch does not take)."""
+        in one launch per slab shape (s2e_wgrad_c8_batch).  rects = (rect_list, counts): only the pixels of those 16 x 16 rectangles
+        contribute (the label-sparse backward: dactv is defined there only).  False: not queued (no scope, or a shape the batch
+        does not take)."""
         pool = ZeroPool.active()
         if pool is None or dw is None or db is None or oh.dtype != torch.bfloat16:
             return False
         n, h, w, _ = oh.shape
         if dactv.shape[-1] != 128 or not L.lib().s2e_wgrad_c8_batch_supported(L.S2E_BF16, h, w, 128):
             return False
-        pool.sink.c8.append((oh, dactv, dw, db, int(ncls)))
+        if rects is not None and ((h | w) & 15):
+            return False
+        pool.sink.c8.append((oh, dactv, dw, db, int(ncls), rects))
         return True
 
     def _flush_c8(self):
@@ -460,9 +470,11 @@ class GradSink:
             c8 = [j for j in c8 if j[0].shape[0] == n]
             self.c8 = rest
         arr = (L.WgradC8Job * len(c8))()
-        for i, (oh, dactv, dw, db, ncls) in enumerate(c8):
+        for i, (oh, dactv, dw, db, ncls, rects) in enumerate(c8):
             arr[i].x, arr[i].gy, arr[i].dw_oihw, arr[i].dbias = oh.data_ptr(), dactv.data_ptr(), dw.data_ptr(), db.data_ptr()
             arr[i].H, arr[i].W, arr[i].ncls = oh.shape[1], oh.shape[2], ncls
+            if rects is not None:
+                arr[i].rect_list, arr[i].rect_count = rects[0].data_ptr(), rects[1].data_ptr()
         wsb = L.lib().s2e_wgrad_c8_batch_workspace_bytes(n, C.byref(arr), len(c8))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=c8[0][0].device)
         flops = sum(2.0 * n * j[0].shape[1] * j[0].shape[2] * 8 * 128 * 9 for j in c8)

@@ -412,7 +412,12 @@ def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
         # shifted sums of dgb per class, folded into mlp_shared's gradients when the step's sink flushes
         cls, work_list, ui_list, counts = sp
         n = g.shape[0]
-        dactv = ZeroPool.take(n * h * w * nh, g.dtype, g.device).view(n, h, w, nh)       # (zero where no conv runs)
+        # d(actv) exists on the work rectangles only.  When its one reader -- mlp_shared's weight gradient -- is queued with the same
+        # rectangle list (round 6) the rest is never read: no zero-fill (0.5 GB per G step at the bench's size).  Otherwise zeros.
+        lazy = not switches.C8_SPARSE_OFF and nh == 128 and GradSink.c8_would_queue(g.dtype, h, w, ctx.sh_dst[0], ctx.sh_dst[1]) and not ((h | w) & 15)
+        dactv = torch.empty(n, h, w, nh, dtype=g.dtype, device=g.device) if lazy else \
+            ZeroPool.take(n * h * w * nh, g.dtype, g.device).view(n, h, w, nh)               # (zero where no conv runs)
+        c8_rects = (work_list, counts) if lazy else None
         d, _ = _conv_plan(False, _dt(g), n, h, w, c2, h, w, nh, 3, 3, 1, 1, 1, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
         flops = 2.0 * n * h * w * c2 * nh * 9
         frac = 1.0
@@ -433,14 +438,17 @@ def _spade_param_grads(ctx, g, label, w_sh, w_gb, actv):
                                            uni_gb[0] if uni_gb is not None else None, uni_gb[1] if uni_gb is not None else None, c2, nh, ncls,
                                            int(g.dtype == torch.bfloat16)))
     else:
+        c8_rects = None
         dactv = conv2d_raw(g, wpt, None, None, actv, (h, w, nh), 3, 3, 1, 1, True, ACT_NONE, ACT_NONE, AUX_RELU_MASK)
     # (a streaming class-bucket kernel for this gradient was tried twice -- LDS float atomics, then per-wave
     # queues of boundary pixels -- and lost to the MFMA wgrad against the 8-channel one-hot map: 1.7 vs 0.75 ms
     # per step; see DESIGN.md "tried and dropped")
     oh = onehot_nhwc_raw(label, None, h, w, ncls, 8, g.dtype)
     wdst, bdst = ctx.sh_dst
-    if GradSink.push_c8(oh, dactv, wdst, bdst, ncls):        # inside a trainer step: all mlp_shared gradients in one launch, later
+    if GradSink.push_c8(oh, dactv, wdst, bdst, ncls, c8_rects):    # inside a trainer step: all mlp_shared gradients in one launch, later
         return gw_sh, gb_sh, gw_g, gb_g, gw_b, gb_b
+    if c8_rects is not None:
+        raise L.Seg2EyeHipError('label-sparse SPADE backward: d(actv) was left undefined outside the work rectangles but the 8-channel weight gradient was not queued')
     dwp, gb_sh = conv2d_wgrad_raw(oh, dactv, 3, 3, 1, 1, ACT_NONE, True, bdst, defer_ok=wdst is not None and bdst is not None)
     if wdst is not None:
         unpack_weight_grad_into(dwp, wdst, nh, ncls, 3, 3, 8)

@@ -22,3 +22,5 @@ FUSED_OFF = os.environ.get('S2E_SPADE_FUSED', '1') == '0'
 # 1 = a flush runs its two big weight-gradient launches on two streams (round 6 experiment: 16.35 -> 16.29 ms, but the persistent batched launch
 # holds the CUs and the small reduction launch behind it then shows 0.7 ms in the kernel trace: off, the accounting stays readable)
 FLUSH_STREAMS = os.environ.get('S2E_FLUSH_STREAMS', '0') == '1'
+# 0 = mlp_shared's weight gradient of a label-sparse SPADE backward walks the whole map (and d(actv) is zero-filled outside the work rectangles)
+C8_SPARSE_OFF = os.environ.get('S2E_C8_SPARSE', '1') == '0'
