@@ -70,6 +70,47 @@ def test_argument_errors_are_reported_without_a_gpu():
         _lib.check(-1, 'x')
 
 
+def test_round6_planners_are_host_only():
+    """The shape planners of round 6's kernels answer without a GPU: which launches conv_plane.hip takes (and in which mode), the
+    size of a PLANE-layout weight, which weight gradients the multi-job launch takes; argument errors before any launch."""
+    from seg2eye_amd import _lib
+    L = _lib.lib()
+    bf, f32 = _lib.S2E_BF16, _lib.S2E_F32
+    mode = lambda *a: L.s2e_conv2d_plane_supported(bf, ctypes.byref(_lib.ConvDesc(*a)))
+    # netE at the benchmark's size: batch 32, 3x3 stride 2 pad 1 (forward = mode 3, data gradient = mode 4)
+    assert mode(32, 128, 128, 64, 64, 64, 128, 3, 3, 2, 1, 0, 0, 0, 0) == 3
+    assert mode(32, 64, 64, 128, 128, 128, 64, 3, 3, 2, 1, 1, 0, 0, 0) == 4
+    assert mode(32, 16, 16, 512, 8, 8, 512, 3, 3, 2, 1, 0, 0, 0, 0) == 0                # an 8 x 8 map: no 8 x 16 rectangle
+    # the learned 1x1 shortcuts (mode 1), forward and data gradient
+    assert mode(8, 256, 256, 128, 256, 256, 64, 1, 1, 1, 0, 0, 0, 0, 0) == 1
+    assert mode(8, 256, 256, 64, 256, 256, 128, 1, 1, 1, 0, 1, 0, 0, 0) == 1
+    # the PatchGAN's 4x4 stride-2 pad-2 layers on ragged maps (modes 5 / 6); its 8-channel first layer stays generic
+    assert mode(16, 129, 129, 64, 65, 65, 128, 4, 4, 2, 2, 0, 0, 0, 0) == 5
+    assert mode(8, 65, 65, 128, 129, 129, 64, 4, 4, 2, 2, 1, 0, 0, 0) == 6
+    assert mode(16, 256, 256, 8, 129, 129, 64, 4, 4, 2, 2, 0, 0, 1, 0) == 0
+    # 3x3 stride 1 stays in conv_duo.hip by default; fp32 never runs here
+    assert mode(8, 128, 128, 256, 128, 128, 128, 3, 3, 1, 1, 0, 0, 0, 0) == 0
+    assert L.s2e_conv2d_plane_supported(f32, ctypes.byref(_lib.ConvDesc(8, 256, 256, 128, 256, 256, 64, 1, 1, 1, 0, 0, 0, 0, 0))) == 0
+    d = _lib.ConvDesc(32, 128, 128, 64, 64, 64, 200, 3, 3, 2, 1, 0, 0, 0, 0)
+    assert L.s2e_conv_plane_weight_elems(ctypes.byref(d)) == 256 * 9 * 64                # rows padded to 64
+    assert L.s2e_conv2d_plane(bf, 1, 1, None, None, None, 1, ctypes.byref(_lib.ConvDesc(8, 8, 8, 64, 8, 8, 64, 3, 3, 1, 1, 0, 0, 0, 0)), None) == -3
+    assert b's2e_conv2d_plane' in L.s2e_last_error()
+    assert L.s2e_conv2d_plane(bf, None, 1, None, None, None, 1, ctypes.byref(d), None) == -1
+    # multi-job generic weight gradient: generic bf16 shapes only
+    multi = lambda *a: L.s2e_conv2d_wgrad_multi_supported(bf, ctypes.byref(_lib.ConvDesc(*a)))
+    assert multi(32, 128, 128, 64, 64, 64, 128, 3, 3, 2, 1, 0, 0, 0, 0) == 1             # netE stride 2
+    assert multi(8, 256, 256, 128, 256, 256, 64, 1, 1, 1, 0, 0, 0, 0, 0) == 1            # 1x1 shortcut
+    assert multi(8, 256, 256, 128, 256, 256, 256, 3, 3, 1, 1, 0, 0, 0, 0) == 0           # patch-resident: the batched launch's
+    assert multi(8, 256, 256, 64, 256, 256, 1, 3, 3, 1, 1, 0, 0, 0, 0) == 0              # 1-channel stream kernel's
+    assert L.s2e_conv2d_wgrad_multi(bf, None, 0, None, 0, None) == -1
+    jobs = (_lib.WgradMultiJob * 2)()
+    for j, a in zip(jobs, ((32, 128, 128, 64, 64, 64, 128, 3, 3, 2, 1, 0, 0, 0, 0), (8, 256, 256, 128, 256, 256, 64, 1, 1, 1, 0, 0, 0, 0, 0))):
+        j.d = _lib.ConvDesc(*a)
+    assert L.s2e_conv2d_wgrad_multi_workspace_bytes(bf, ctypes.byref(jobs), 2) % 256 == 0
+    assert L.s2e_conv2d_wgrad_multi(bf, ctypes.byref(jobs), 2, None, 0, None) == -1      # null operand pointers
+    assert L.s2e_shard_sum(bf, 1, 1, 8, 100, None) == -1                                  # shard bytes not a multiple of 16
+
+
 def test_pack_block_map_is_host_only():
     """s2e_pack_block_map is pure host code: grid of a forward pack = rows_pad/4 x ceil(cin_pad/64), of a
     transposed pack = ceil(cout/64) x ceil(rows_pad/8); triples are {job, bx, by}."""

@@ -908,6 +908,153 @@ def test_wgrad_batch_through_the_sink():
         assert float((db - k * rb).abs().max()) <= 2e-5 * float(rb.abs().max()) * k + 1e-6, i
 
 
+# (n, hi, wi, cin, cout, k, stride, pad, bias, residual, lrelu): every mode of conv_plane.hip at >= 128 work items, ragged maps included
+_PLANE_CFGS = [(4, 64, 64, 128, 256, 1, 1, 0, False, True, False), (5, 48, 80, 256, 64, 1, 1, 0, True, False, True),
+               (8, 128, 128, 64, 128, 3, 2, 1, False, False, False), (8, 72, 104, 128, 64, 3, 2, 1, True, False, True),
+               (4, 64, 64, 256, 512, 3, 2, 1, False, False, False),
+               (8, 129, 129, 64, 128, 4, 2, 2, False, False, False), (16, 65, 65, 128, 256, 4, 2, 2, True, False, False),
+               (16, 66, 50, 64, 64, 4, 2, 2, False, False, False)]
+
+
+@pytest.mark.parametrize('cfg', _PLANE_CFGS)
+def test_plane_conv_forward_and_gradients_match_fp64(cfg):
+    """Round 6: netE's 3x3 stride-2 convs (reference models/networks/encoder.py:23-39), the PatchGAN's 4x4
+    stride-2 convs (discriminator.py:84-96) and the learned 1x1 shortcuts (architecture.py:26-27,53-56) run in csrc/conv_plane.hip --
+    parity-plane patch in LDS, weights in the PLANE pack layout straight into registers -- forward AND data gradient, through the
+    same ops.conv2d the networks call (autograd included: the weight gradient goes through the multi-job / per-layer generic kernel).
+    Against torch fp64 on the bf16-rounded operands."""
+    from seg2eye_amd import ops
+    from seg2eye_amd.ops import conv as oc
+    n, hi, wi, cin, cout, k, st, pd, bias, res, lrelu = cfg
+    dev, dt = _dev(), torch.bfloat16
+    ho, wo = (hi + 2 * pd - k) // st + 1, (wi + 2 * pd - k) // st + 1
+    act = ops.ACT_LRELU if lrelu else ops.ACT_NONE
+    assert oc.plane_mode(dt, n, hi, wi, cin, ho, wo, cout, k, k, st, pd, False, ops.ACT_NONE, act, ops.AUX_NONE, res) > 0, 'forward not a plane shape'
+    assert oc.plane_mode(dt, n, ho, wo, cout, hi, wi, cin, k, k, st, pd, True) > 0, 'data gradient not a plane shape'
+    x = nhwc(_rnd((n, cin, hi, wi), 700, dt)).to(dev).requires_grad_(True)
+    w = (_rnd((cout, cin, k, k), 701, torch.float32) / (cin * k * k) ** 0.5).to(dev).requires_grad_(True)
+    b = _rnd((cout,), 702, torch.float32).to(dev).requires_grad_(True) if bias else None
+    r = nhwc(_rnd((n, cout, ho, wo), 703, dt)).to(dev) if res else None
+    proj = nhwc(_rnd((n, cout, ho, wo), 704, dt)).to(dev)
+    y = ops.conv2d(x, w, b, r, st, pd, ops.ACT_NONE, act)
+    (y.float() * proj.float()).sum().backward()
+    xr = x.detach().double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.detach().to(dt).double().requires_grad_(True)
+    br = b.detach().double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, st, pd)
+    if res:
+        yr = yr + r.double().permute(0, 3, 1, 2)
+    if lrelu:
+        yr = F.leaky_relu(yr, 0.2)
+    (yr * proj.double().permute(0, 3, 1, 2)).sum().backward()
+    _close(y.permute(0, 3, 1, 2), yr, dt, what='plane forward')
+    _close_kink(x.grad.permute(0, 3, 1, 2), xr.grad, dt, what='plane data gradient') if lrelu else _close(x.grad.permute(0, 3, 1, 2), xr.grad, dt, what='plane data gradient')
+    _close_kink(w.grad, wr.grad, dt, what='weight gradient') if lrelu else _close(w.grad, wr.grad, dt, what='weight gradient')
+    if bias:
+        _close(b.grad, br.grad, dt, what='bias gradient')
+
+
+@pytest.mark.parametrize('shape', [(128, 64, 3, 3), (192, 256, 1, 1), (64, 128, 4, 4), (200, 96, 3, 3)])
+def test_plane_pack_layout(shape):
+    """The PLANE weight layout (csrc/conv_plane.h): per (64 rows, 32-element K chunk, tap) a 4-KB block of four 16x16x32 fragments in
+    register order with the row permutation that makes a lane's accumulators 8 consecutive channels.  Checked element by element
+    against the definition, forward and transposed, from torch-order and from channels-last masters (the batched pack of a PackPlan
+    uses the same device function)."""
+    from seg2eye_amd import ops
+    from seg2eye_amd.ops import conv as oc
+    dev = _dev()
+    cout, cin, kh, kw = shape
+    taps = kh * kw
+    w = _rnd(shape, 710, torch.float32).to(dev)
+    wcl = w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    sg = torch.tensor([1.7], device=dev)
+    for tr in (False, True):
+        rows, kd = (cin, cout) if tr else (cout, cin)
+        if kd % 32:
+            continue
+        a = oc.pack_weight(w, torch.bfloat16, None, tr, sg, plane=True)
+        b = oc.pack_weight(wcl, torch.bfloat16, None, tr, sg, plane=True)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), 'the two source layouts must pack to the same bytes'
+        # definition: unit = ((g * nch + c) * taps + t) * 256 + f * 64 + L holds k = 32 c + 8 (L >> 4) .. + 7 of row
+        # 64 g + 32 (f >> 1) + 8 ((L & 15) >> 2) + 4 (f & 1) + (L & 3)
+        g64, nch = (rows + 63) // 64, kd // 32
+        flat = a.reshape(-1).float().cpu().view(g64, nch, taps, 4, 64, 8)
+        wd = (w / sg).to(torch.bfloat16).float().cpu()
+        L = torch.arange(64)
+        for f in range(4):
+            row_in = 32 * (f >> 1) + 8 * ((L & 15) >> 2) + 4 * (f & 1) + (L & 3)                  # (64,)
+            for g in range(g64):
+                row = 64 * g + row_in
+                ok = row < rows
+                for c in range(nch):
+                    k = 32 * c + 8 * (L >> 4)[:, None] + torch.arange(8)[None, :]             # (64, 8)
+                    rr = row.clamp(max=rows - 1)[:, None].expand(64, 8)
+                    ref = (wd[k, rr] if tr else wd[rr, k]).reshape(64, 8, taps).permute(2, 0, 1)   # (taps, 64, 8)
+                    ref = ref * ok[None, :, None]
+                    got = flat[g, c, :, f]
+                    assert torch.equal(got, ref), (tr, f, g, c)
+
+
+def test_c8_batch_rect_list_form():
+    """Round 6: mlp_shared's weight gradient of a label-sparse SPADE backward (reference models/networks/normalization.py:85-89
+    differentiated) walks the backward's work rectangles only: the rect-list form of s2e_wgrad_c8_batch must give the dense form's
+    sums when gy is zero outside the listed rectangles -- and must not READ gy there (NaNs outside the list change nothing)."""
+    import ctypes as C
+    from seg2eye_amd import _lib as L
+    dev = _dev()
+    n, h, w, ncls = 4, 64, 64, 4
+    g = torch.Generator().manual_seed(720)
+    lab = torch.randint(0, ncls, (n, h, w), generator=g)
+    oh = torch.zeros(n, h, w, 8)
+    oh.scatter_(3, lab[..., None], 1.0)
+    oh = oh.to(dev).to(torch.bfloat16)
+    rects_all = n * (h // 16) * (w // 16)
+    pick = torch.randperm(rects_all, generator=g)[:rects_all // 3].sort().values.to(torch.int32)
+    mask = torch.zeros(rects_all, dtype=torch.bool)
+    mask[pick.long()] = True
+    pm = mask.view(n, h // 16, w // 16).repeat_interleave(16, 1).repeat_interleave(16, 2)
+    gy = torch.randn(n, h, w, 128, generator=g) * pm[..., None]
+    gy_d = gy.to(dev).to(torch.bfloat16)
+    gy_nan = gy_d.clone()
+    gy_nan[~pm.to(dev)] = float('nan')
+    lst, cnt = pick.to(dev), torch.tensor([pick.numel(), 0], dtype=torch.int32, device=dev)
+    outs = []
+    for gyt, use_list in ((gy_d, False), (gy_d, True), (gy_nan, True)):
+        dw = torch.zeros(128, ncls, 3, 3, device=dev)
+        db = torch.zeros(128, device=dev)
+        job = (L.WgradC8Job * 1)()
+        job[0].x, job[0].gy, job[0].dw_oihw, job[0].dbias = oh.data_ptr(), gyt.data_ptr(), dw.data_ptr(), db.data_ptr()
+        job[0].H, job[0].W, job[0].ncls = h, w, ncls
+        if use_list:
+            job[0].rect_list, job[0].rect_count = lst.data_ptr(), cnt.data_ptr()
+        wsb = L.lib().s2e_wgrad_c8_batch_workspace_bytes(n, C.byref(job), 1)
+        ws = torch.empty(wsb // 4, device=dev)
+        L.check(L.lib().s2e_wgrad_c8_batch(L.S2E_BF16, n, C.byref(job), 1, ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream), 's2e_wgrad_c8_batch')
+        outs.append((dw, db))
+    torch.cuda.synchronize()
+    ref = F.conv2d(oh[..., :ncls].double().permute(3, 0, 1, 2), gy_d.double().permute(3, 0, 1, 2), None, 1, 1).permute(1, 0, 2, 3)     # (128, ncls, 3, 3)
+    for dw, db in outs:
+        assert torch.isfinite(dw).all() and torch.isfinite(db).all()
+        assert float((dw.double() - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-5
+        assert float((db.double() - gy_d.double().sum((0, 1, 2))).abs().max()) <= 2e-4 * float(gy_d.double().sum((0, 1, 2)).abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_shard_sum_matches_torch(dtype):
+    """The owner sum of the 'direct' gradient exchange (seg2eye_amd/distributed.py): fp32 accumulation in rank order, one rounding."""
+    from seg2eye_amd import _lib as L
+    dev = _dev()
+    world, shard = 8, 4096 + 8
+    recv = _rnd((world, shard), 730, dtype).to(dev)
+    out = torch.empty(shard, dtype=dtype, device=dev)
+    L.check(L.lib().s2e_shard_sum(L.S2E_BF16 if dtype == torch.bfloat16 else L.S2E_F32, recv.data_ptr(), out.data_ptr(), world, shard,
+                                  torch.cuda.current_stream().cuda_stream), 's2e_shard_sum')
+    acc = torch.zeros(shard, dtype=torch.float32, device=dev)
+    for r in range(world):
+        acc += recv[r].float()
+    assert torch.equal(out, acc.to(dtype))
+
+
 def test_generic_wgrad_multi_matches_per_layer_launches():
     """Round 6: inside a trainer-step scope the GENERIC weight gradients (1x1, stride 2, 4x4, small maps) are queued too
     (GradSink.push_gwg) and the flush runs them as one multi-job launch + one reduction launch (s2e_conv2d_wgrad_multi); the sums
