@@ -165,6 +165,12 @@ typedef struct s2e_wgrad_multi_job {
 int s2e_conv2d_wgrad_multi_supported(int dtype, const s2e_conv_desc* d);
 size_t s2e_conv2d_wgrad_multi_workspace_bytes(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs);
 int s2e_conv2d_wgrad_multi(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs, void* workspace, size_t workspace_bytes, void* stream);
+/* Which kernel a job of s2e_conv2d_wgrad_multi runs in: 0 = the generic 128 x 128 tile kernel (partial tiles in the workspace + one reduction);
+ * 1..5 = the flat-slab patch-resident kernel of csrc/conv_wgrad_flat.hip (round 6: 1 = 1x1, 2 = 3x3 stride 1, 3 = 3x3 stride 2 pad 1,
+ * 4 = 4x4 stride 1 pad 2, 5 = 4x4 stride 2 pad 2; Cin a multiple of 64, no input activation; fp32 atomics into dW, no workspace) -- the
+ * weight-gradient half of encoder.py:26-40 and discriminator.py:78-93's stride-2 / 4x4 layers; -1 = not a job of that call.
+ * S2E_WGRAD_FLAT (environment, bit k = kind k) selects the kinds that leave the generic kernel. */
+int s2e_conv2d_wgrad_multi_kind(int dtype, const s2e_conv_desc* d);
 
 /* ------------------------------------------------------------------ spectral normalisation
  * torch.nn.utils.spectral_norm as applied at architecture.py:30-34 and normalization.py:25-26

@@ -129,6 +129,7 @@ SIGNATURES = {
     's2e_conv2d_wgrad_workspace_bytes': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_wgrad': [_i, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_size_t, _vp],
     's2e_conv2d_wgrad_multi_supported': [_i, C.POINTER(ConvDesc)],
+    's2e_conv2d_wgrad_multi_kind': [_i, C.POINTER(ConvDesc)],
     's2e_conv2d_wgrad_multi_workspace_bytes': [_i, _vp, _i],
     's2e_conv2d_wgrad_multi': [_i, _vp, _i, _vp, C.c_size_t, _vp],
     's2e_in_stats_workspace_bytes': [_i, _i, _i, _i],

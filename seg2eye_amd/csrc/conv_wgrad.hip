@@ -15,6 +15,7 @@
 #include "common.h"
 #include "conv_small.h"
 #include "conv_wgrad_patch.h"
+#include "conv_wgrad_flat.h"
 #include <stdlib.h>
 
 struct WgradParams {
@@ -666,16 +667,16 @@ extern "C" int s2e_conv2d_wgrad_multi_supported(int dtype, const s2e_conv_desc* 
 // The plan of jobs [base, base + n) of a multi-job launch: a job's share of the launch's workgroups (S2E_WGRAD_MULTI_WGS in all, default
 // 6144: 12 per workgroup slot of the chip) goes by its MFMA work -- planned alone (2048 workgroups each) two dozen jobs made 30-40 k
 // workgroups and ~1 GB of partial tiles per step.  Fills ps[i] (shape, tiling, m_per_split) and splits[i].
-static void wgrad_multi_plan(const s2e_wgrad_multi_job* jobs, int base, int n, WgradParams* ps, int* splits) {
+static void wgrad_multi_plan(const s2e_wgrad_multi_job* jobs, const int* idx, int n, WgradParams* ps, int* splits) {
     static const int total_wg = [] { const char* e = getenv("S2E_WGRAD_MULTI_WGS"); return e ? atoi(e) : 6144; }();
     double work[WGM_MAX_JOBS], work_sum = 0.0;
     for (int i = 0; i < n; ++i) {
-        const s2e_conv_desc* d = &jobs[base + i].d;
+        const s2e_conv_desc* d = &jobs[idx[i]].d;
         work[i] = (double)ceil_div(d->Cout, 128) * ceil_div(d->KH * d->KW * d->Cin, 128) * ((double)d->N * d->Ho * d->Wo);
         work_sum += work[i];
     }
     for (int i = 0; i < n; ++i) {
-        const s2e_conv_desc* d = &jobs[base + i].d;
+        const s2e_conv_desc* d = &jobs[idx[i]].d;
         WgradParams& p = ps[i];
         p.N = d->N; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
         p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.in_act = d->in_act;
@@ -683,14 +684,28 @@ static void wgrad_multi_plan(const s2e_wgrad_multi_job* jobs, int base, int n, W
     }
 }
 
+// the jobs of a multi-job call that stay in the generic kernel (the others: conv_wgrad_flat.hip); returns their count
+static int wgrad_multi_generic_jobs(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs, int* idx, int* flat_idx, int* n_flat) {
+    int n = 0, nf = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (s2e_wgrad_flat_kind(dtype, &jobs[i].d)) { if (flat_idx) flat_idx[nf] = i; ++nf; }
+        else idx[n++] = i;
+    }
+    if (n_flat) *n_flat = nf;
+    return n;
+}
+
 extern "C" size_t s2e_conv2d_wgrad_multi_workspace_bytes(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs) {
     size_t total = 0;
-    for (int base = 0; jobs && base < n_jobs; base += WGM_MAX_JOBS) {
-        const int n = n_jobs - base < WGM_MAX_JOBS ? n_jobs - base : WGM_MAX_JOBS;
+    if (!jobs || n_jobs <= 0 || n_jobs > 4096) return 0;
+    for (int i = 0; i < n_jobs; ++i) if (!wgrad_multi_ok(dtype, &jobs[i].d)) return 0;
+    int idx_all[4096];
+    const int n_gen = wgrad_multi_generic_jobs(dtype, jobs, n_jobs, idx_all, nullptr, nullptr);
+    for (int base = 0; base < n_gen; base += WGM_MAX_JOBS) {
+        const int n = n_gen - base < WGM_MAX_JOBS ? n_gen - base : WGM_MAX_JOBS;
         WgradParams ps[WGM_MAX_JOBS];
         int splits[WGM_MAX_JOBS];
-        for (int i = 0; i < n; ++i) if (!wgrad_multi_ok(dtype, &jobs[base + i].d)) return 0;
-        wgrad_multi_plan(jobs, base, n, ps, splits);
+        wgrad_multi_plan(jobs, idx_all + base, n, ps, splits);
         for (int i = 0; i < n; ++i)
             if (wgrad_use_partial(splits[i]))
                 total += ((size_t)ps[i].tiles_k * ps[i].tiles_co * splits[i] * (128 * 128 + 128) * sizeof(float) + 255) & ~(size_t)255;
@@ -700,23 +715,29 @@ extern "C" size_t s2e_conv2d_wgrad_multi_workspace_bytes(int dtype, const s2e_wg
 
 extern "C" int s2e_conv2d_wgrad_multi(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs, void* workspace, size_t workspace_bytes,
                                       void* stream) {
-    if (!jobs || n_jobs <= 0) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad_multi: no jobs");
+    if (!jobs || n_jobs <= 0 || n_jobs > 4096) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad_multi: no jobs (or more than 4096)");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     size_t ws_left = workspace ? workspace_bytes : 0;
-    for (int base = 0; base < n_jobs; base += WGM_MAX_JOBS) {
-        const int n = n_jobs - base < WGM_MAX_JOBS ? n_jobs - base : WGM_MAX_JOBS;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!wgrad_multi_ok(dtype, &jobs[i].d)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad_multi: job %d is not a generic bf16 shape (s2e_conv2d_wgrad_multi_supported)", i);
+        if (!jobs[i].x || !jobs[i].gy || !jobs[i].dw) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad_multi: null pointer in job %d", i);
+    }
+    int idx_all[4096], flat_idx[4096], n_flat = 0;
+    const int n_gen = wgrad_multi_generic_jobs(dtype, jobs, n_jobs, idx_all, flat_idx, &n_flat);
+    // the stride-2 / 4x4 / 1x1 layers: the flat-slab patch-resident kernel (atomics into dW; no workspace)
+    if (n_flat) if (int rc = s2e_wgrad_flat_launch(jobs, flat_idx, n_flat, st)) return rc;
+    for (int base = 0; base < n_gen; base += WGM_MAX_JOBS) {
+        const int n = n_gen - base < WGM_MAX_JOBS ? n_gen - base : WGM_MAX_JOBS;
+        const int* idx = idx_all + base;
         WgMulti b{};
         WgMultiRed r{};
         b.n = n;
         int blocks = 0, rblocks = 0;
         int splits_of[WGM_MAX_JOBS];
-        for (int i = 0; i < n; ++i)
-            if (!wgrad_multi_ok(dtype, &jobs[base + i].d)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad_multi: job %d is not a generic bf16 shape (s2e_conv2d_wgrad_multi_supported)", base + i);
-        wgrad_multi_plan(jobs, base, n, b.j, splits_of);
+        wgrad_multi_plan(jobs, idx, n, b.j, splits_of);
         for (int i = 0; i < n; ++i) {
-            const s2e_wgrad_multi_job& J = jobs[base + i];
-            if (!J.x || !J.gy || !J.dw) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad_multi: null pointer in job %d", base + i);
+            const s2e_wgrad_multi_job& J = jobs[idx[i]];
             WgradParams& p = b.j[i];
             p.x = J.x; p.gy = J.gy; p.dw = J.dw; p.dbias = J.dbias;
             const int splits = splits_of[i];
@@ -746,4 +767,11 @@ extern "C" int s2e_conv2d_wgrad_multi(int dtype, const s2e_wgrad_multi_job* jobs
         }
     }
     return S2E_OK;
+}
+
+// which kernel a job of s2e_conv2d_wgrad_multi runs in: 0 = the generic tile kernel, 1..5 = conv_wgrad_flat.hip's kinds (1x1, 3x3 stride 1,
+// 3x3 stride 2, 4x4 stride 1, 4x4 stride 2), -1 = not a job of that call
+extern "C" int s2e_conv2d_wgrad_multi_kind(int dtype, const s2e_conv_desc* d) {
+    if (!wgrad_multi_ok(dtype, d)) return -1;
+    return s2e_wgrad_flat_kind(dtype, d);
 }

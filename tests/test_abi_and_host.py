@@ -103,6 +103,15 @@ def test_round6_planners_are_host_only():
     assert multi(8, 256, 256, 128, 256, 256, 256, 3, 3, 1, 1, 0, 0, 0, 0) == 0           # patch-resident: the batched launch's
     assert multi(8, 256, 256, 64, 256, 256, 1, 3, 3, 1, 1, 0, 0, 0, 0) == 0              # 1-channel stream kernel's
     assert L.s2e_conv2d_wgrad_multi(bf, None, 0, None, 0, None) == -1
+    # ... and which of them leave the generic tile kernel for the flat-slab patch-resident one (default: the PatchGAN's 4x4 layers)
+    if 'S2E_WGRAD_FLAT' not in os.environ:
+        kind = lambda *a: L.s2e_conv2d_wgrad_multi_kind(bf, ctypes.byref(_lib.ConvDesc(*a)))
+        assert kind(16, 129, 129, 64, 65, 65, 128, 4, 4, 2, 2, 0, 0, 0, 0) == 5          # 4x4 stride 2 on a ragged map
+        assert kind(16, 33, 33, 256, 34, 34, 512, 4, 4, 1, 2, 0, 0, 0, 0) == 4           # 4x4 stride 1
+        assert kind(32, 128, 128, 64, 64, 64, 128, 3, 3, 2, 1, 0, 0, 0, 0) == 0          # netE: stays generic by default
+        assert kind(16, 256, 256, 8, 129, 129, 64, 4, 4, 2, 2, 0, 0, 0, 0) == 0          # 8 input channels: generic
+        assert kind(16, 33, 33, 256, 34, 34, 512, 4, 4, 1, 2, 0, 1, 0, 0) == 0           # an input activation: generic
+        assert kind(8, 256, 256, 128, 256, 256, 256, 3, 3, 1, 1, 0, 0, 0, 0) == -1       # not a job of the multi call at all
     jobs = (_lib.WgradMultiJob * 2)()
     for j, a in zip(jobs, ((32, 128, 128, 64, 64, 64, 128, 3, 3, 2, 1, 0, 0, 0, 0), (8, 256, 256, 128, 256, 256, 64, 1, 1, 1, 0, 0, 0, 0, 0))):
         j.d = _lib.ConvDesc(*a)

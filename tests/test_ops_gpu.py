@@ -1,6 +1,7 @@
 """Op-level parity of every HIP kernel (through the C-ABI / ctypes path) against plain
 PyTorch fp64 CPU references of the same op.  fp32 kernels: tight tolerance; bf16 kernels:
 both sides start from the same bf16-rounded inputs, tolerance = bf16 output rounding."""
+import os
 import numpy as np
 import pytest
 from conftest import load_golden
@@ -1092,6 +1093,21 @@ def test_generic_wgrad_multi_matches_per_layer_launches():
         assert float((dw - kf * rw).abs().max()) <= 3e-5 * float(rw.abs().max()) * kf + 1e-6, (i, float((dw - kf * rw).abs().max()), float(rw.abs().max()))
         if rb is not None:
             assert float((db - rb).abs().max()) <= 3e-5 * float(rb.abs().max()) + 1e-6, i
+
+
+def test_flat_wgrad_kinds_against_fp64():
+    """conv_wgrad_flat.hip, every kind (1x1, 3x3 stride 1 / 2, 4x4 stride 1 / 2) on small, ragged and multi-tile shapes, with bias
+    gradients: dW and db through s2e_conv2d_wgrad_multi against torch fp64 on the bf16-rounded operands (tools/check_wgrad_flat.py; the
+    kinds that are off by default are switched on through S2E_WGRAD_FLAT, which the library reads once -- hence the child process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, S2E_WGRAD_FLAT='62')
+    env.pop('S2E_WF_NOEPI', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_wgrad_flat.py')], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'parity ok' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    kinds = [int(l.split('kind')[1].split()[0]) for l in r.stdout.splitlines() if ' kind ' in l]
+    assert sorted(set(kinds)) == [1, 2, 3, 4, 5], kinds
 
 
 @pytest.mark.parametrize('order', ['queued_then_immediate', 'immediate_then_queued'])
