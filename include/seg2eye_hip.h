@@ -105,7 +105,7 @@ int s2e_pack_conv_weights(int dtype, const s2e_pack_job* jobs, const int* block_
 size_t s2e_conv2d_workspace_bytes(int dtype, const s2e_conv_desc* d);
 /* Which kernel s2e_conv2d / s2e_conv2d_wgrad run for this shape (for profilers and tests; the choice is made inside the
  * library from the shape alone): S2E_KERNEL_GENERIC = implicit GEMM (conv_igemm.hip / conv_wgrad.hip),
- * S2E_KERNEL_SMALL = the 1-channel streaming kernels, S2E_KERNEL_PATCH = the patch-resident kernels (3x3 / 4x4 stride 1, and the
+ * S2E_KERNEL_SMALL = the 1-channel streaming kernels and the 8-channel first layer of the PatchGAN (conv_c8.hip), S2E_KERNEL_PATCH = the patch-resident kernels (3x3 / 4x4 stride 1, and the
  * 4x4 stride-2 pad-2 layers through the space-to-depth view). */
 enum { S2E_KERNEL_GENERIC = 0, S2E_KERNEL_SMALL = 1, S2E_KERNEL_PATCH = 2 };
 int s2e_conv2d_kernel_kind(int dtype, const s2e_conv_desc* d);
@@ -168,7 +168,8 @@ int s2e_conv2d_wgrad_multi(int dtype, const s2e_wgrad_multi_job* jobs, int n_job
 /* Which kernel a job of s2e_conv2d_wgrad_multi runs in: 0 = the generic 128 x 128 tile kernel (partial tiles in the workspace + one reduction);
  * 1..5 = the flat-slab patch-resident kernel of csrc/conv_wgrad_flat.hip (round 6: 1 = 1x1, 2 = 3x3 stride 1, 3 = 3x3 stride 2 pad 1,
  * 4 = 4x4 stride 1 pad 2, 5 = 4x4 stride 2 pad 2; Cin a multiple of 64, no input activation; fp32 atomics into dW, no workspace) -- the
- * weight-gradient half of encoder.py:26-40 and discriminator.py:78-93's stride-2 / 4x4 layers; -1 = not a job of that call.
+ * weight-gradient half of encoder.py:26-40 and discriminator.py:78-93's stride-2 / 4x4 layers; 6 = the 8-channel 4x4 stride-2 kernel of
+ * csrc/conv_c8.hip (the PatchGAN's first layer, discriminator.py:78-85; fp32 atomics, no workspace); -1 = not a job of that call.
  * S2E_WGRAD_FLAT (environment, bit k = kind k) selects the kinds that leave the generic kernel. */
 int s2e_conv2d_wgrad_multi_kind(int dtype, const s2e_conv_desc* d);
 

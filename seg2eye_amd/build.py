@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libseg2eye_hip.so')
-SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'norm_modulate.hip', 'label_ops.hip', 'loss_adam.hip', 'spectral.hip', 'conv_small.hip', 'conv_patch.hip', 'conv_duo.hip', 'conv_plane.hip', 'conv_stream.hip', 'conv_wgrad_patch.hip', 'conv_wgrad_batch.hip', 'conv_wgrad_flat.hip', 'metric.hip', 'style_fc.hip', 'spade_sparse_bwd.hip']
+SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'norm_modulate.hip', 'label_ops.hip', 'loss_adam.hip', 'spectral.hip', 'conv_small.hip', 'conv_c8.hip', 'conv_patch.hip', 'conv_duo.hip', 'conv_plane.hip', 'conv_stream.hip', 'conv_wgrad_patch.hip', 'conv_wgrad_batch.hip', 'conv_wgrad_flat.hip', 'metric.hip', 'style_fc.hip', 'spade_sparse_bwd.hip']
 
 
 def _hipcc():

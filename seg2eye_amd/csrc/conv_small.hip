@@ -682,6 +682,8 @@ static int small_fwd(const SmallConvParams& p, int kind, hipStream_t st) {
 int s2e_small_conv_kind(int dtype, const s2e_conv_desc* d) {
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     if (!small_ks(d)) return SMALL_NONE;
+    if (s2e_c8s2_fwd_ok(dtype, d)) return SMALL_FWD_C8S2;
+    if (s2e_c8s2_dgrad_ok(dtype, d)) return SMALL_DGRAD_C8S2;
     if (!d->transposed && d->Cout == 1 && d->Cin % vec == 0 && pow2_le64(d->Cin / vec) && d->aux_mode == S2E_AUX_NONE)
         return SMALL_FWD_COUT1;
     if (!d->transposed && d->Cin == 1 && d->Cout % vec == 0 && pow2_le64(d->Cout / vec) && d->aux_mode == S2E_AUX_NONE)
@@ -694,6 +696,8 @@ int s2e_small_conv_kind(int dtype, const s2e_conv_desc* d) {
 
 int s2e_small_conv_launch(int dtype, int kind, const SmallConvParams& p, hipStream_t st) {
     int t, wk, nkw;
+    if (kind == SMALL_FWD_C8S2) return s2e_c8s2_fwd_launch(p, st);
+    if (kind == SMALL_DGRAD_C8S2) return s2e_c8s2_dgrad_launch(p, st);
     if (kind == SMALL_FWD_COUT1 && dtype == S2E_BF16 && cout1_mfma_plan(p, &t, &wk, &nkw))
         return p.KH == 3 ? cout1_mfma_go<3>(p, t, wk, nkw, st) : cout1_mfma_go<4>(p, t, wk, nkw, st);
     if (p.KH == 3) return dtype == S2E_BF16 ? small_fwd<bf16_t, 3>(p, kind, st) : small_fwd<float, 3>(p, kind, st);

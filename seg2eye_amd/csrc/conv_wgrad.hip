@@ -684,14 +684,16 @@ static void wgrad_multi_plan(const s2e_wgrad_multi_job* jobs, const int* idx, in
     }
 }
 
-// the jobs of a multi-job call that stay in the generic kernel (the others: conv_wgrad_flat.hip); returns their count
-static int wgrad_multi_generic_jobs(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs, int* idx, int* flat_idx, int* n_flat) {
-    int n = 0, nf = 0;
+// the jobs of a multi-job call that stay in the generic kernel (the others: conv_wgrad_flat.hip, conv_c8.hip); returns their count
+static int wgrad_multi_generic_jobs(int dtype, const s2e_wgrad_multi_job* jobs, int n_jobs, int* idx, int* flat_idx, int* n_flat, int* c8_idx, int* n_c8) {
+    int n = 0, nf = 0, nc = 0;
     for (int i = 0; i < n_jobs; ++i) {
         if (s2e_wgrad_flat_kind(dtype, &jobs[i].d)) { if (flat_idx) flat_idx[nf] = i; ++nf; }
+        else if (s2e_c8s2_wgrad_ok(dtype, &jobs[i].d)) { if (c8_idx) c8_idx[nc] = i; ++nc; }
         else idx[n++] = i;
     }
     if (n_flat) *n_flat = nf;
+    if (n_c8) *n_c8 = nc;
     return n;
 }
 
@@ -700,7 +702,9 @@ extern "C" size_t s2e_conv2d_wgrad_multi_workspace_bytes(int dtype, const s2e_wg
     if (!jobs || n_jobs <= 0 || n_jobs > 4096) return 0;
     for (int i = 0; i < n_jobs; ++i) if (!wgrad_multi_ok(dtype, &jobs[i].d)) return 0;
     int idx_all[4096];
-    const int n_gen = wgrad_multi_generic_jobs(dtype, jobs, n_jobs, idx_all, nullptr, nullptr);
+    int n_c8w = 0;
+    const int n_gen = wgrad_multi_generic_jobs(dtype, jobs, n_jobs, idx_all, nullptr, nullptr, nullptr, &n_c8w);
+    if (n_c8w) total += (s2e_c8s2_wgrad_workspace_bytes(n_c8w) + 255) & ~(size_t)255;
     for (int base = 0; base < n_gen; base += WGM_MAX_JOBS) {
         const int n = n_gen - base < WGM_MAX_JOBS ? n_gen - base : WGM_MAX_JOBS;
         WgradParams ps[WGM_MAX_JOBS];
@@ -723,10 +727,17 @@ extern "C" int s2e_conv2d_wgrad_multi(int dtype, const s2e_wgrad_multi_job* jobs
         if (!wgrad_multi_ok(dtype, &jobs[i].d)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_conv2d_wgrad_multi: job %d is not a generic bf16 shape (s2e_conv2d_wgrad_multi_supported)", i);
         if (!jobs[i].x || !jobs[i].gy || !jobs[i].dw) S2E_FAIL(S2E_ERR_ARG, "s2e_conv2d_wgrad_multi: null pointer in job %d", i);
     }
-    int idx_all[4096], flat_idx[4096], n_flat = 0;
-    const int n_gen = wgrad_multi_generic_jobs(dtype, jobs, n_jobs, idx_all, flat_idx, &n_flat);
+    int idx_all[4096], flat_idx[4096], c8_idx[4096], n_flat = 0, n_c8 = 0;
+    const int n_gen = wgrad_multi_generic_jobs(dtype, jobs, n_jobs, idx_all, flat_idx, &n_flat, c8_idx, &n_c8);
     // the stride-2 / 4x4 / 1x1 layers: the flat-slab patch-resident kernel (atomics into dW; no workspace)
     if (n_flat) if (int rc = s2e_wgrad_flat_launch(jobs, flat_idx, n_flat, st)) return rc;
+    // the PatchGAN's 8-channel first layers (conv_c8.hip)
+    if (n_c8) {
+        const size_t need = (s2e_c8s2_wgrad_workspace_bytes(n_c8) + 255) & ~(size_t)255;
+        const bool have = ws && ws_left >= need;
+        if (int rc = s2e_c8s2_wgrad_launch(jobs, c8_idx, n_c8, have ? ws : nullptr, have ? need : 0, st)) return rc;
+        if (have) { ws += need; ws_left -= need; }
+    }
     for (int base = 0; base < n_gen; base += WGM_MAX_JOBS) {
         const int n = n_gen - base < WGM_MAX_JOBS ? n_gen - base : WGM_MAX_JOBS;
         const int* idx = idx_all + base;
@@ -770,8 +781,9 @@ extern "C" int s2e_conv2d_wgrad_multi(int dtype, const s2e_wgrad_multi_job* jobs
 }
 
 // which kernel a job of s2e_conv2d_wgrad_multi runs in: 0 = the generic tile kernel, 1..5 = conv_wgrad_flat.hip's kinds (1x1, 3x3 stride 1,
-// 3x3 stride 2, 4x4 stride 1, 4x4 stride 2), -1 = not a job of that call
+// 3x3 stride 2, 4x4 stride 1, 4x4 stride 2), 6 = conv_c8.hip's 8-channel 4x4 stride-2 kernel, -1 = not a job of that call
 extern "C" int s2e_conv2d_wgrad_multi_kind(int dtype, const s2e_conv_desc* d) {
     if (!wgrad_multi_ok(dtype, d)) return -1;
-    return s2e_wgrad_flat_kind(dtype, d);
+    if (const int k = s2e_wgrad_flat_kind(dtype, d)) return k;
+    return s2e_c8s2_wgrad_ok(dtype, d) ? 6 : 0;
 }

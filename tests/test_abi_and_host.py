@@ -109,7 +109,10 @@ def test_round6_planners_are_host_only():
         assert kind(16, 129, 129, 64, 65, 65, 128, 4, 4, 2, 2, 0, 0, 0, 0) == 5          # 4x4 stride 2 on a ragged map
         assert kind(16, 33, 33, 256, 34, 34, 512, 4, 4, 1, 2, 0, 0, 0, 0) == 4           # 4x4 stride 1
         assert kind(32, 128, 128, 64, 64, 64, 128, 3, 3, 2, 1, 0, 0, 0, 0) == 0          # netE: stays generic by default
-        assert kind(16, 256, 256, 8, 129, 129, 64, 4, 4, 2, 2, 0, 0, 0, 0) == 0          # 8 input channels: generic
+        if 'S2E_CONV_C8' not in os.environ:
+            assert kind(16, 256, 256, 8, 129, 129, 64, 4, 4, 2, 2, 0, 0, 0, 0) == 6      # the PatchGAN's first layer: conv_c8.hip
+            assert L.s2e_conv2d_kernel_kind(bf, ctypes.byref(_lib.ConvDesc(16, 256, 256, 8, 129, 129, 64, 4, 4, 2, 2, 0, 0, 1, 0))) == 1   # S2E_KERNEL_SMALL
+        assert kind(16, 256, 256, 16, 129, 129, 64, 4, 4, 2, 2, 0, 0, 0, 0) == 0         # 16 input channels: generic
         assert kind(16, 33, 33, 256, 34, 34, 512, 4, 4, 1, 2, 0, 1, 0, 0) == 0           # an input activation: generic
         assert kind(8, 256, 256, 128, 256, 256, 256, 3, 3, 1, 1, 0, 0, 0, 0) == -1       # not a job of the multi call at all
     jobs = (_lib.WgradMultiJob * 2)()

@@ -1095,6 +1095,20 @@ def test_generic_wgrad_multi_matches_per_layer_launches():
             assert float((db - rb).abs().max()) <= 3e-5 * float(rb.abs().max()) + 1e-6, i
 
 
+def test_c8_first_layer_kernels_against_fp64():
+    """conv_c8.hip: the PatchGAN's first layer (8 -> 64 channels, 4x4 stride 2 pad 2) forward (bias / LeakyReLU / residual), data gradient and
+    weight + bias gradient on even, odd and ragged maps against torch fp64 on the bf16-rounded operands, through s2e_conv2d and
+    s2e_conv2d_wgrad_multi (tools/check_c8.py asserts; the padding channels of the data gradient must be exactly zero)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop('S2E_CONV_C8', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_c8.py')], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'parity ok' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout.count('kind 6') == 5, r.stdout
+
+
 def test_flat_wgrad_kinds_against_fp64():
     """conv_wgrad_flat.hip, every kind (1x1, 3x3 stride 1 / 2, 4x4 stride 1 / 2) on small, ragged and multi-tile shapes, with bias
     gradients: dW and db through s2e_conv2d_wgrad_multi against torch fp64 on the bf16-rounded operands (tools/check_wgrad_flat.py; the
