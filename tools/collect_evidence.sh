@@ -35,4 +35,9 @@ python3 tools/check_wgrad_batch.py --bench 2>&1 | grep -v amdgpu.ids > "$O/${P}_
 python3 tools/bench_small.py 2>&1 | grep -v amdgpu.ids > "$O/${P}_degenerate_channel_convs_microbench.log"
 python3 tools/bench_sn.py 2>&1 | grep " bank " > "$O/${P}_spectral_norm_chain_microbench.log"
 python3 tools/check_plane.py --bench 2>&1 | grep -v amdgpu.ids > "$O/${P}_plane_conv_microbench.log"
+S2E_WGRAD_FLAT=62 python3 tools/check_wgrad_flat.py --bench --each 2>&1 | grep -v amdgpu.ids > "$O/${P}_wgrad_flat_microbench_all_kinds_on.log"
+S2E_WGRAD_FLAT=0 python3 tools/check_wgrad_flat.py --bench --each 2>&1 | grep -v amdgpu.ids > "$O/${P}_wgrad_flat_microbench_generic_side.log"
+python3 tools/check_c8.py --bench 2>&1 | grep -v amdgpu.ids > "$O/${P}_c8_first_layer_microbench.log"
+S2E_CONV_C8=0 python3 tools/check_c8.py --bench 2>&1 | grep -v amdgpu.ids > "$O/${P}_c8_first_layer_microbench_generic_side.log"
+bash tools/kt_wgrad.sh "0 48" > "$O/${P}_wgrad_launches_in_step_flat_off_on.log" 2>&1
 tail -c 1500 "$O/${P}_bench.json"

@@ -74,6 +74,10 @@ FAMILIES = {  # kernel-name substring -> (family, counts as a launch of the fami
     'conv_wgrad_reduce_kernel': ('conv_wgrad', False),
     # (round 6: every generic weight gradient of a backward as one multi-job launch + one reduction launch)
     'conv_wgrad_multi_kernel': ('conv_wgrad', True), 'conv_wgrad_reduce_multi_kernel': ('conv_wgrad', False),
+    # (round 6, after milestone b: the PatchGAN's 4x4 weight gradients in the flat-slab kernel -- the D step's call has no generic job left --
+    #  and its 8-channel first layer in conv_c8.hip)
+    'conv_wgrad_flat_kernel': ('conv_wgrad', True), 'conv_c8s2_wgrad_kernel': ('conv_wgrad', False), 'conv_c8s2_wgrad_reduce_kernel': ('conv_wgrad', False),
+    'conv_c8s2_fwd_kernel': ('conv_small', True), 'conv_c8s2_dgrad_kernel': ('conv_small', True),
     'sn_gemvT_kernel': ('spectral_norm', True), 'sn_gemv_kernel': ('spectral_norm', False),     # launches = power ITERATIONS
     'sn_norm_v_kernel': ('spectral_norm', False), 'sn_finalize_kernel': ('spectral_norm', False),
     'upsample2x_fwd_kernel': ('resample', True), 'upsample2x_bwd_kernel': ('resample', True),
