@@ -501,8 +501,14 @@ def main():
                 if rp:
                     #  the summary is of a committed run -- another commit and another box unless its git_head is the code
                     # being measured now (S2E_GIT_HEAD on the GPU box, git HEAD here): say so instead of letting the figure pass as live
+                    # ... judged by the digest of the sources the profile was taken from (tools/pmc_traffic.py source_digest: there is no
+                    # .git on a GPU box), else by the commit
                     here = os.environ.get('S2E_GIT_HEAD') or _git_head()
                     same = bool(here) and str(kj.get('git_head', '?')).startswith(here[:7])
+                    if kj.get('source_digest'):
+                        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                        from pmc_traffic import source_digest
+                        same = source_digest() == kj['source_digest']
                     out['roofline'].update({'rocprof_ms_per_step': rp, 'rocprof_frac': d['executed_flops'] / prof_steps / (rp * 1e-3) / 1e12 / peak,
                                             'rocprof_source': '%s @ %s' % (os.path.relpath(kms[-1], ROOT), kj.get('git_head', '?')),
                                             'rocprof_stale': not same})

@@ -116,6 +116,19 @@ def read(dirname, counter):
     return per_kernel
 
 
+def source_digest():
+    """sha1 over the kernel sources and the host package (what a profile is a profile OF): bench.py recomputes it on the box it runs on
+    -- there is no .git there -- and marks a quoted profile `rocprof_stale` when it differs."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    for pat in ('seg2eye_amd/csrc/*', 'seg2eye_amd/*.py', 'seg2eye_amd/*/*.py', 'include/*.h'):
+        for f in sorted(glob.glob(os.path.join(root, pat))):
+            if os.path.isfile(f):
+                h.update(os.path.relpath(f, root).encode()); h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def git_head():
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -146,7 +159,7 @@ def main():
         if counts:
             fams[fam]['launches'] += n
     # the head is passed in by the caller when the tool runs on the GPU box (no .git there)
-    out = {'git_head': os.environ.get('S2E_GIT_HEAD') or git_head(), 'steps_profiled': steps,
+    out = {'git_head': os.environ.get('S2E_GIT_HEAD') or git_head(), 'source_digest': source_digest(), 'steps_profiled': steps,
            '_how': __doc__.split('\n\n')[1].strip() + ' | counters KB -> bytes, FETCH_SIZE doubled (gfx950); per-family: '
            'total bytes of every kernel launched inside the C-ABI call / number of calls', 'kernels': {}}
     for fam, v in fams.items():

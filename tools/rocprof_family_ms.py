@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from pmc_traffic import classify, git_head      # noqa: E402
+from pmc_traffic import classify, git_head, source_digest      # noqa: E402
 
 
 def main():
@@ -33,7 +33,7 @@ def main():
         fams[fam][1] += ns
         if counts:
             fams[fam][0] += int(r['Calls'])
-    out = {'git_head': os.environ.get('S2E_GIT_HEAD') or git_head(), 'steps_profiled': steps, 'source': os.path.basename(src),
+    out = {'git_head': os.environ.get('S2E_GIT_HEAD') or git_head(), 'source_digest': source_digest(), 'steps_profiled': steps, 'source': os.path.basename(src),
            'kernel_ms_per_step_total': total / 1e6 / steps, 'unclassified_ms_per_step': other / 1e6 / steps,
            'families': {k: {'ms_per_step': v[1] / 1e6 / steps, 'launches_per_step': v[0] / steps} for k, v in sorted(fams.items())}}
     os.makedirs(os.path.dirname(os.path.abspath(dst)), exist_ok=True)
