@@ -441,6 +441,13 @@ int s2e_modulate_bwd_staged(int dtype, int mode, const void* g, const void* x, c
                             const float* stats, const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                             int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, int x_up_w,
                             int dx_quad, void* stream);
+/* The same with the accumulated-into tensor and the result apart: dx = dx_add + this layer's gradient (mode carries
+ * S2E_NORM_ACCUMULATE_DX; dx_add NULL or == dx: in place).  For a relayed gradient (architecture.py:53-60: the block input feeds both
+ * SPADEs and the shortcut) whose tensor a queued weight-gradient job still has to read (round 6: no copy of it). */
+int s2e_modulate_bwd_relay(int dtype, int mode, const void* g, const void* x, const void* gb, const void* out,
+                           const float* stats, const float* style, void* dx, const void* dx_add, void* dgb, float* dstyle, double* ws,
+                           int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, int x_up_w,
+                           int dx_quad, void* stream);
 /* out[c] += sum_m g[m][c]  (conv bias gradient).  g (M, C); out fp32 (C). */
 int s2e_colsum(int dtype, const void* g, long M, int C, float* out, void* stream);
 

@@ -142,6 +142,7 @@ SIGNATURES = {
     's2e_modulate_bwd': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     's2e_modulate_bwd_gamma': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     's2e_modulate_bwd_staged': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_double, _i, _i, _vp],
+    's2e_modulate_bwd_relay': [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_double, _i, _i, _vp],
     's2e_spade_conv_modulate_rect': [_i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     's2e_label_rect_classify': [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     's2e_spade_conv_modulate_sparse': [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],

@@ -799,7 +799,7 @@ __global__ void modulate_bwd_coef_kernel(double* __restrict__ ws, const float* _
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __restrict__ gin, const T* __restrict__ x,
-        const T* __restrict__ gb, const T* __restrict__ dgb, const f32x4_t* __restrict__ coef, T* __restrict__ dx,
+        const T* __restrict__ gb, const T* __restrict__ dgb, const f32x4_t* __restrict__ coef, T* dx, const T* dxa,
         int vps, int HW, int C, int cg, int cg_shift, int lrelu, int acc, int gst, int xw, float inv_xw) {
     constexpr int VEC = Vec<T>::N;
     const int n = blockIdx.y;                              // one sample per grid row: 32-bit indices, no 64-bit division
@@ -842,9 +842,9 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
                 o[j] = K[j][1] * go - K[j][2] - f[j] * K[j][3];
             }
         }
-        if (acc) {                                         // dx already holds another consumer's gradient of the same x
+        if (acc) {                                         // dxa (= dx, or the tensor the relay must leave alone) holds another consumer's gradient of the same x
             float prev[VEC];
-            unpack16<T>(*(const u32x4_t*)(dx + row * C + c0), prev);
+            unpack16<T>(*(const u32x4_t*)(dxa + row * C + c0), prev);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] += prev[j];
         }
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_kernel(const T* __rest
 // the full-resolution dx never exists).  One thread per low-resolution 16-byte vector; acc adds into dx_low.
 template <typename T>
 __global__ __launch_bounds__(256) void modulate_bwd_apply_quad_kernel(const T* __restrict__ x, const T* __restrict__ gb, const T* __restrict__ dgb,
-        const f32x4_t* __restrict__ coef, T* __restrict__ dx, int HW, int C, int cg, int acc, int gst, int xw, float inv_wl) {
+        const f32x4_t* __restrict__ coef, T* dx, const T* dxa, int HW, int C, int cg, int acc, int gst, int xw, float inv_wl) {
     constexpr int VEC = Vec<T>::N;
     const int n = blockIdx.y, wl = xw >> 1, hwl = HW >> 2;
     const int vps = hwl * cg;
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_quad_kernel(const T* _
         }
         if (acc) {
             float prev[VEC];
-            unpack16<T>(*(const u32x4_t*)(dx + lrow * C + c0), prev);
+            unpack16<T>(*(const u32x4_t*)(dxa + lrow * C + c0), prev);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] += prev[j];
         }
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_apply_quad_kernel(const T* _
 // the compute dtype for pass 2; here go is recomputed from g, so dx differs from it by that rounding only.
 template <typename T, int G>
 __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x, const T* __restrict__ gamma,
-        const T* __restrict__ fout, const float* __restrict__ stats, const float* __restrict__ style, T* __restrict__ dx, T* __restrict__ dgb,
+        const T* __restrict__ fout, const float* __restrict__ stats, const float* __restrict__ style, T* dx, const T* dxa, T* __restrict__ dgb,
         float* __restrict__ dstyle, int HW, int C, int lrelu, int sld, int acc, int xw, float inv_xw, int quad) {
     constexpr int VEC = Vec<T>::N, CH = G * VEC, RL = 256 / G;
     constexpr int UR = 2;                                    // rows in flight per thread and tensor (see in_small_bwd_kernel)
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
             }
             if (acc) {
                 float prev[VEC];
-                unpack16<T>(*(const u32x4_t*)(dx + lo), prev);
+                unpack16<T>(*(const u32x4_t*)(dxa + lo), prev);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o[j] += prev[j];
             }
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
             rg[k] = *(const u32x4_t*)(g + o); ra[k] = *(const u32x4_t*)(gamma + o);
             rx[k] = *(const u32x4_t*)(x + mod_x_row(n, min(r + RL * k, HW - 1), HW, xw, inv_xw) * C + c0);
             ro[k] = lrelu ? *(const u32x4_t*)(fout + o) : u32x4_t{0u, 0u, 0u, 0u};
-            rp[k] = acc ? *(const u32x4_t*)(dx + o) : u32x4_t{0u, 0u, 0u, 0u};
+            rp[k] = acc ? *(const u32x4_t*)(dxa + o) : u32x4_t{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int k = 0; k < UR; ++k) {
@@ -1043,7 +1043,8 @@ __global__ __launch_bounds__(256) void spade_small_bwd_kernel(const T* __restric
 static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, const void* gb, const void* fout, const float* stats,
                              const float* style, void* dx, void* dgb, float* dstyle, double* ws,
                              int N, int HW, int C, int lrelu, int style_ld, void* stream, int stage = 0, double batch_count = 0.0,
-                             int xw = 0, int quad = 0) {
+                             int xw = 0, int quad = 0, const void* dx_add = nullptr) {
+    if (!dx_add) dx_add = dx;                              // S2E_NORM_ACCUMULATE_DX: dx = dx_add + this layer's gradient (in place unless told otherwise)
     const int sld = style_ld > 0 ? style_ld : 2 * C;
     const int gst = fout ? C : 2 * C;
     const int acc = (mode & S2E_NORM_ACCUMULATE_DX) != 0;
@@ -1063,9 +1064,9 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
     if (quad && (!xw || mode != S2E_NORM_SPADE_STYLE)) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd: dx_quad goes with x_up_w (SPADE_STYLE mode)");
     if (fout && mode == S2E_NORM_SPADE_STYLE && !batch && stage == 0 && HW <= in_small_hw()) {     // small map: one launch
         if (dtype == S2E_BF16) S2E_SMALL_LAUNCH(spade_small_bwd_kernel, bf16_t, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)gb, (const bf16_t*)fout,
-                                                 stats, style, (bf16_t*)dx, (bf16_t*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw, quad);
+                                                 stats, style, (bf16_t*)dx, (const bf16_t*)dx_add, (bf16_t*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw, quad);
         else S2E_SMALL_LAUNCH(spade_small_bwd_kernel, float, (const float*)g, (const float*)x, (const float*)gb, (const float*)fout,
-                              stats, style, (float*)dx, (float*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw, quad);
+                              stats, style, (float*)dx, (const float*)dx_add, (float*)dgb, dstyle, HW, C, lrelu, sld, acc, xw, inv_xw, quad);
         S2E_CHECK_LAUNCH("spade_small_bwd_kernel");
         return S2E_OK;
     }
@@ -1092,8 +1093,8 @@ static int modulate_bwd_impl(int dtype, int mode, const void* g, const void* x, 
         if (sums_first) modulate_bwd_sums_kernel<MM><<<gridc, 256, 0, st>>>(part, ws, N, C, P); } \
     if (stage != 1) { modulate_bwd_coef_kernel<MM><<<gridc, 256, 0, st>>>(ws, (stage == 2 || sums_first) ? nullptr : part, P, coef, stats, style, dstyle, N, C, HW, sld, batch, batch_count); \
     if (quad) { const int gq = ((HW >> 2) * rg.cg + 255) / 256; \
-        modulate_bwd_apply_quad_kernel<TT><<<dim3(gq < gx_cap ? gq : gx_cap, N), 256, 0, st>>>((const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, HW, C, rg.cg, acc, gst, xw, 2.f * inv_xw); } \
-    else modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst, xw, inv_xw); } } while (0)
+        modulate_bwd_apply_quad_kernel<TT><<<dim3(gq < gx_cap ? gq : gx_cap, N), 256, 0, st>>>((const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, (const TT*)dx_add, HW, C, rg.cg, acc, gst, xw, 2.f * inv_xw); } \
+    else modulate_bwd_apply_kernel<TT, MM><<<grid2, 256, 0, st>>>((const TT*)g, (const TT*)x, (const TT*)gb, (const TT*)dgb, coef, (TT*)dx, (const TT*)dx_add, vps, HW, C, rg.cg, cg_shift, lrelu, acc, gst, xw, inv_xw); } } while (0)
     if (dtype == S2E_BF16) { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(bf16_t, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(bf16_t, S2E_NORM_PLAIN_IN); }
     else { if (mode == S2E_NORM_SPADE_STYLE) S2E_LAUNCH_BWD(float, S2E_NORM_SPADE_STYLE); else S2E_LAUNCH_BWD(float, S2E_NORM_PLAIN_IN); }
 #undef S2E_LAUNCH_BWD
@@ -1123,6 +1124,18 @@ extern "C" int s2e_modulate_bwd_staged(int dtype, int mode, const void* g, const
     if (stage < 0 || stage > 2) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_staged: stage %d", stage);
     return modulate_bwd_impl(dtype, mode, g, x, gb, out, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream, stage, batch_count,
                              x_up_w, dx_quad);
+}
+
+// s2e_modulate_bwd_staged with the accumulated-into tensor and the result apart: dx = dx_add + this layer's gradient (mode must carry
+// S2E_NORM_ACCUMULATE_DX; dx_add == dx or NULL is the in-place form)
+extern "C" int s2e_modulate_bwd_relay(int dtype, int mode, const void* g, const void* x, const void* gb, const void* out,
+                                      const float* stats, const float* style, void* dx, const void* dx_add, void* dgb, float* dstyle, double* ws,
+                                      int N, int HW, int C, int lrelu, int style_ld, int stage, double batch_count, int x_up_w,
+                                      int dx_quad, void* stream) {
+    if (stage < 0 || stage > 2) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_relay: stage %d", stage);
+    if (!(mode & S2E_NORM_ACCUMULATE_DX)) S2E_FAIL(S2E_ERR_ARG, "s2e_modulate_bwd_relay: mode without S2E_NORM_ACCUMULATE_DX");
+    return modulate_bwd_impl(dtype, mode, g, x, gb, out, stats, style, dx, dgb, dstyle, ws, N, HW, C, lrelu, style_ld, stream, stage, batch_count,
+                             x_up_w, dx_quad, dx_add);
 }
 
 extern "C" size_t s2e_modulate_bwd_workspace_bytes(int dtype, int N, int HW, int C) {

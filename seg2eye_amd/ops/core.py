@@ -334,8 +334,9 @@ class GradSink:
         queued -- no trainer step open, a shape the batch does not take, a dW already queued in this flush (single-owner tiles are
         added without atomics), or S2E_WGRAD_BATCH=0 / S2E_DETERMINISTIC=1.
         gy_shared: the caller hands the SAME tensor on as somebody's gradient (a conv with a residual input returns it as the
-        residual's gradient, and the block's first SPADE then adds its own dx into it IN PLACE -- ModulateFn's relay): the queue
-        keeps a copy, the deferred launch must not see that sum."""
+        residual's gradient, and the block's first SPADE then adds its own dx to it -- ModulateFn's relay): the deferred launch must not
+        see that sum.  Rounds 4-5 queued a COPY (135 MB of copies per G step); since round 6 the relay asks is_pinned() and writes its
+        sum to a new tensor instead of in place when the one it was handed is still to be read by a queued job."""
         pool = ZeroPool.active()
         if pool is None:
             return False
@@ -365,7 +366,7 @@ class GradSink:
         _need(x, gy, dw_rows, dbias)
         # a gradient arena that zero_grad cleared right before this step, and nothing queued for it yet: single-owner tiles are stored
         fresh = ZeroPool.grad_is_fresh(dw_rows) and dw_rows.data_ptr() not in pool.sink.wg_done
-        pool.sink.wg.append([x, gy.clone() if gy_shared else gy, dw_rows, dbias, rects, tag, fresh])
+        pool.sink.wg.append([x, gy, dw_rows, dbias, rects, tag, fresh])          # (gy_shared: see is_pinned)
         return True
 
     def _flush_wgrad(self):
@@ -398,6 +399,16 @@ class GradSink:
         self.keep_wg = jobs                                  # the tensors stay referenced until the next flush (stream order covers the rest)
 
     @staticmethod
+    def is_pinned(t):
+        """Is `t` the output gradient of a weight-gradient job queued in the open trainer step (not launched yet)?  Whoever would
+        modify it in place (ModulateFn's relay) must write elsewhere: the queue holds the tensor itself, not a copy."""
+        pool = ZeroPool.active()
+        if pool is None or t is None:
+            return False
+        p = t.data_ptr()
+        return any(j[1].data_ptr() == p for j in pool.sink.wg) or any(j[1].data_ptr() == p for j in pool.sink.gwg)
+
+    @staticmethod
     def push_gwg(x, gy, dw, dbias, desc_key, gy_shared=False):
         """Queue a GENERIC weight gradient (a shape s2e_conv2d_wgrad would run in its implicit-GEMM kernel: the 1x1 shortcuts, netE's
         stride-2 layers, the PatchGAN's 4x4 layers, the 8x8 maps) to be accumulated into dw (Cout, KH*KW*Cin) / dbias at the next
@@ -413,7 +424,7 @@ class GradSink:
         if not ok or any(j[2].data_ptr() == dw.data_ptr() for j in pool.sink.gwg):      # (the reduction adds without atomics: one job per dW)
             return False
         _need(x, gy, dw, dbias)
-        pool.sink.gwg.append((x, gy.clone() if gy_shared else gy, dw, dbias, desc_key))
+        pool.sink.gwg.append((x, gy, dw, dbias, desc_key))                          # (gy_shared: see is_pinned)
         return True
 
     def _flush_gwg(self):

@@ -508,7 +508,10 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     quad = int(getattr(ctx, 'x_up_w', 0) != 0)
     g = g.contiguous()
     acc = g_relay is not None and g_relay.is_contiguous() and g_relay.dtype == x.dtype
-    dx = g_relay if acc else torch.empty_like(x)
+    # (a relayed gradient that a queued weight-gradient job still has to read -- the block's conv_1 with the identity shortcut handed
+    #  its gy on as the residual's gradient -- is added to OUT of place: dx = g_relay + this layer's gradient, g_relay untouched)
+    apart = acc and GradSink.is_pinned(g_relay)
+    dx = g_relay if (acc and not apart) else torch.empty_like(x)
     dgb = torch.empty(n, h, w, 2 * c, dtype=x.dtype, device=x.device)
     if ctx.off is None:
         dstyle = ZeroPool.take(style.numel(), torch.float32, x.device).view(style.shape)
@@ -528,6 +531,11 @@ def _modulate_grads(ctx, g, g_relay, x, gb, fout, style, stats):
     world = sdist.sync_world_size() if ctx.batch else 1
 
     def launch(stage, count):
+        if apart:
+            return L.check(L.lib().s2e_modulate_bwd_relay(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx), _p(g_relay), _p(dgb), dsp,
+                                                          _p(ws), n, h * w, c, int(ctx.lrelu), ld, stage, float(count),
+                                                          int(getattr(ctx, 'x_up_w', 0)), quad, _stream()),
+                           's2e_modulate_bwd_relay')
         return L.check(L.lib().s2e_modulate_bwd_staged(_dt(x), mode, _p(g), _p(x), _p(gb), _p(fout), _p(stats), sp, _p(dx), _p(dgb), dsp,
                                                        _p(ws), n, h * w, c, int(ctx.lrelu), ld, stage, float(count),
                                                        int(getattr(ctx, 'x_up_w', 0)), quad, _stream()),
