@@ -239,6 +239,13 @@ class Pix2PixTrainer:
         # capturing threads may invalidate the capture (the collectives themselves stay outside the graphs).
         multi = torch.distributed.is_available() and torch.distributed.is_initialized()
         mode = {'capture_error_mode': 'thread_local'} if multi else {}
+        # No CYCLIC garbage collection while capturing: a collection that happens to start inside the captured body may destroy
+        # objects of an earlier trainer (hipGraph executables, streams) -- runtime calls a capture does not survive: the full test suite
+        # aborted once in "Garbage-collecting" under _g_body.  Reference counting frees everything else as always.
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         try:
             if m.netG.__dict__.get('grad_ready') is not None:
                 graph_G = self._capture_segmented(self._g_body, mode.get('capture_error_mode', 'global'))
@@ -252,6 +259,8 @@ class Pix2PixTrainer:
                 self._d_body(self._static)
             self.graph_G, self.graph_D = graph_G, graph_D
         finally:
+            if gc_was:
+                gc.enable()
             with torch.no_grad():
                 for b, s0 in zip(banks, snap):
                     b.uv_arena.copy_(s0)
