@@ -93,6 +93,9 @@ typedef struct s2e_pack_job {
     void* out;               /* packed matrix, compute dtype, s2e_conv_cout_pad(rows) x s2e_conv_k_pad(...) */
     int sigma_index;         /* or -1 */
     int cout, cin, taps, cin_pad, transposed;
+    void* out_fwd;           /* transposed == 3 jobs (channels-last source, transposed pack) only, or NULL: the forward pack of the same
+                              * weight ([co][tap * cin + ci], row pitch s2e_conv_k_pad(taps * cin)) is written from the same read of the
+                              * master (round 6).  Only the weight's own elements: zero that matrix's padding once yourself. */
 } s2e_pack_job;
 long s2e_pack_block_map(int dtype, const s2e_pack_job* jobs_host, int n_jobs, int* block_map_host);
 int s2e_pack_conv_weights(int dtype, const s2e_pack_job* jobs, const int* block_map, int n_blocks, int max_taps,

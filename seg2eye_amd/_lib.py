@@ -65,7 +65,7 @@ class SnLayer(C.Structure):
 class PackJob(C.Structure):
     """s2e_pack_job"""
     _fields_ = [('w', C.c_void_p), ('out', C.c_void_p), ('sigma_index', C.c_int), ('cout', C.c_int), ('cin', C.c_int),
-                ('taps', C.c_int), ('cin_pad', C.c_int), ('transposed', C.c_int)]
+                ('taps', C.c_int), ('cin_pad', C.c_int), ('transposed', C.c_int), ('out_fwd', C.c_void_p)]
 
 
 class GradJob(C.Structure):

@@ -446,9 +446,13 @@ __device__ __forceinline__ void pack_fwd_cl_block(const float* __restrict__ w, T
 
 // transposed pack from a CHANNELS-LAST source w[co][tap][ci] (cin_pad == cin): one block = 64 co x 64 ci of ONE tap, a plain
 // tile transpose -- rows of 64 consecutive ci in, rows of 64 consecutive co out.  by = tap * ceil(rows_pad / 64) + ci chunk.
+// out_fwd != NULL (round 6): the FORWARD pack of the same weight, [co][tap * cin + ci] with row pitch kpad_f, is written from the same
+// tile -- the fp32 master is read once for both layouts (a G step packs 93 M parameters both ways: 372 MB of reads saved).  Only the
+// weight's own elements are written there: the padding rows / K tail of that matrix are the caller's to zero, once.
 template <typename T>
 __device__ __forceinline__ void pack_tr_cl_block(const float* __restrict__ w, T* __restrict__ out, const float* __restrict__ sigma,
-                                                 int cout, int cin, int taps, int rows_pad, int kpad, int bx, int by, float* lds) {
+                                                 int cout, int cin, int taps, int rows_pad, int kpad, int bx, int by, float* lds,
+                                                 T* __restrict__ out_fwd = nullptr, int kpad_f = 0) {
     // lds: [64 co][65]
     const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gyc = (rows_pad + 63) / 64;
@@ -459,6 +463,9 @@ __device__ __forceinline__ void pack_tr_cl_block(const float* __restrict__ w, T*
         lds[m * 65 + lane] = (co < cout && ci < cin) ? w[((size_t)co * taps + tap) * cin + ci] * inv : 0.f;
     }
     __syncthreads();
+    if (out_fwd && ci0 + lane < cin)
+        for (int m = q; m < 64; m += 4)
+            if (co0 + m < cout) out_fwd[(size_t)(co0 + m) * kpad_f + (size_t)tap * cin + ci0 + lane] = (T)lds[m * 65 + lane];
     if (co0 + lane < cout)
         for (int cil = q; cil < 64; cil += 4)
             if (ci0 + cil < rows_pad) out[(size_t)(ci0 + cil) * kpad + (size_t)tap * cout + co0 + lane] = (T)lds[lane * 65 + cil];
@@ -515,7 +522,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const s2e_pack_job* __r
     } else if (J.transposed & 2) {                           // ... transposed
         const int kpad = (J.taps * J.cout + (dtype == S2E_BF16 ? 63 : 31)) / (dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
         const int rows = J.cin_pad <= 32 ? 32 : (J.cin_pad <= 64 ? 64 : (J.cin_pad + 127) / 128 * 128);
-        pack_tr_cl_block<T>(J.w, (T*)J.out, sg, J.cout, J.cin, J.taps, rows, kpad, bm[1], bm[2], lds);
+        const int kpad_f = (J.taps * J.cin + (dtype == S2E_BF16 ? 63 : 31)) / (dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
+        pack_tr_cl_block<T>(J.w, (T*)J.out, sg, J.cout, J.cin, J.taps, rows, kpad, bm[1], bm[2], lds, (T*)J.out_fwd, kpad_f);
     } else if (!J.transposed) {
         const int kpad = (J.taps * J.cin_pad + (dtype == S2E_BF16 ? 63 : 31)) / (dtype == S2E_BF16 ? 64 : 32) * (dtype == S2E_BF16 ? 64 : 32);
         pack_fwd_block<T>(J.w, (T*)J.out, sg, J.cout, J.cin, J.taps, J.cin_pad, kpad, bm[1], bm[2], lds);

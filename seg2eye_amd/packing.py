@@ -74,7 +74,20 @@ class PackPlan:
             by_dtype.setdefault(j['dtype'], []).append(j)
         self.tables = {}
         for dtype, jobs in by_dtype.items():
-            jobs.sort(key=lambda j: j['transposed'])          # forward packs first: a prefix of the block map
+            # A forward pack whose weight ALSO has a transposed pack from a channels-last master (both row-major layouts) is written by
+            # the transposed job's blocks when both are wanted (one read of the fp32 master): such "covered" forward jobs come first,
+            # a launch with autograd on starts behind them.
+            def wkey(j):
+                return (j['w'].data_ptr(), tuple(j['w'].shape), tuple(j['w'].stride()), j['cin_pad'])
+            tr_of = {wkey(j): j for j in jobs if j['transposed'] and j['cl'] and not j['plane']}
+            for j in jobs:
+                j['dual'] = None
+                j['covered'] = False
+            for j in jobs:
+                if not j['transposed'] and j['cl'] and not j['plane'] and wkey(j) in tr_of:
+                    j['covered'] = True
+                    tr_of[wkey(j)]['dual'] = j
+            jobs.sort(key=lambda j: (j['transposed'], not j['covered']))     # covered forward packs, the other forward packs, transposed packs
             dt = L.S2E_BF16 if dtype == torch.bfloat16 else L.S2E_F32
             dev = jobs[0]['w'].device
             arr = (L.PackJob * len(jobs))()
@@ -86,18 +99,29 @@ class PackPlan:
                     rows = ((j['cin_pad'] if j['transposed'] else cout) + 63) // 64 * 64
                     kpad = kh * kw * (cout if j['transposed'] else j['cin_pad'])
                 if j['out'] is None:
-                    j['out'] = torch.empty(rows, kpad, dtype=dtype, device=dev)
+                    # (a covered forward pack's padding rows / K tail are written by its own job only: zero once)
+                    j['out'] = (torch.zeros if j['covered'] else torch.empty)(rows, kpad, dtype=dtype, device=dev)
                 j['stale'] = True
                 arr[i].w, arr[i].out, arr[i].sigma_index = j['w'].data_ptr(), j['out'].data_ptr(), j['sigma_index']
                 arr[i].cout, arr[i].cin, arr[i].taps, arr[i].cin_pad = cout, cin, kh * kw, j['cin_pad']
                 arr[i].transposed = int(j['transposed']) | (2 if j['cl'] else 0) | (4 if j['plane'] else 0)     # bit 1: the source is stored channels-last; bit 2: PLANE layout
+            for i, j in enumerate(jobs):
+                if j['dual'] is not None:
+                    arr[i].out_fwd = j['dual']['out'].data_ptr()
             n_fwd = sum(1 for j in jobs if not j['transposed'])
+            n_cov = sum(1 for j in jobs if j['covered'])
             nb_fwd = lib.s2e_pack_block_map(dt, C.byref(arr), n_fwd, None) if n_fwd else 0
-            nb_all = lib.s2e_pack_block_map(dt, C.byref(arr), len(jobs), None)
-            bm = np.zeros(3 * nb_all, dtype=np.int32)
-            lib.s2e_pack_block_map(dt, C.byref(arr), len(jobs), bm.ctypes.data)
+            bm = np.zeros(3 * max(nb_fwd, 1), dtype=np.int32)
+            if n_fwd:
+                lib.s2e_pack_block_map(dt, C.byref(arr), n_fwd, bm.ctypes.data)
+            # with autograd on: the jobs behind the covered ones (job indices of that map count from arr[n_cov])
+            rest = (L.PackJob * (len(jobs) - n_cov)).from_buffer(arr, n_cov * C.sizeof(L.PackJob)) if len(jobs) > n_cov else None
+            nb_all = lib.s2e_pack_block_map(dt, C.byref(rest), len(jobs) - n_cov, None) if rest is not None else 0
+            bm_all = np.zeros(3 * max(nb_all, 1), dtype=np.int32)
+            if nb_all:
+                lib.s2e_pack_block_map(dt, C.byref(rest), len(jobs) - n_cov, bm_all.ctypes.data)
             jobs_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
-            map_dev = torch.from_numpy(bm).to(dev)
+            map_dev = (torch.from_numpy(bm).to(dev), torch.from_numpy(bm_all).to(dev), n_cov * C.sizeof(L.PackJob))
             max_taps = max(j['w'].shape[2] * j['w'].shape[3] for j in jobs)
             self.tables[dt] = (jobs_dev, map_dev, nb_fwd, nb_all, max_taps, jobs, n_fwd)
         self.dirty = False
@@ -116,13 +140,17 @@ class PackPlan:
             nb = nb_all if want_tr else nb_fwd
             if nb == 0:
                 continue
+            map_fwd, map_all, skip = map_dev
+            jobs_ptr = jobs_dev.data_ptr() + (skip if want_tr else 0)
+            map_ptr = (map_all if want_tr else map_fwd).data_ptr()
             if any(j['sigma_index'] >= 0 for j in jobs) and sigma_base is None:
                 raise L.Seg2EyeHipError('PackPlan: spectral-normed weights but no sigma array')
             from .ops import LaunchProfiler
             esz = 2 if dt == L.S2E_BF16 else 4
-            nbytes = float(sum(j['w'].numel() * (4 + esz) for i, j in enumerate(jobs) if want_tr or i < n_fwd))
+            # (algorithmic: the fp32 master read, the packed copy written; a covered forward pack costs its write only)
+            nbytes = float(sum(j['w'].numel() * ((esz if (want_tr and j['covered']) else 4 + esz)) for i, j in enumerate(jobs) if want_tr or i < n_fwd))
             LaunchProfiler.run('weight_pack', 0.0, lambda: L.check(
-                L.lib().s2e_pack_conv_weights(dt, jobs_dev.data_ptr(), map_dev.data_ptr(), nb, max_taps,
+                L.lib().s2e_pack_conv_weights(dt, jobs_ptr, map_ptr, nb, max_taps,
                                               None if sigma_base is None else sigma_base.data_ptr(), st),
                 's2e_pack_conv_weights'), nbytes=nbytes)                # fp32 master read, packed copy written
             for i, j in enumerate(jobs):
