@@ -408,11 +408,27 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             ops.LaunchProfiler.install(prof)
+        # FOUR eager steps, each summed per family on its own; the family's time is the MEDIAN of the four, counted twice (the summary
+        # keeps the "two profiled steps" form below): an eager step now and then contains one launch that sits 30-60 ms behind a
+        # runtime stall (seen twice in round 6: a family at ten times its time), which a mean over two steps hands to the roofline
         prof_steps = 2
-        for _ in range(prof_steps):
+        per_step = []
+        for _ in range(4):
+            prof.reset()
             step()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            if rank == 0:
+                per_step.append(prof.summary())
         ops.LaunchProfiler.install(None)
+        if per_step:
+            fams = per_step[0]
+            for fam, d in fams.items():
+                ms = sorted(ps[fam]['ms'] for ps in per_step if fam in ps)
+                med = 0.5 * (ms[(len(ms) - 1) // 2] + ms[len(ms) // 2])
+                for k in ('launches', 'flops', 'executed_flops', 'bytes'):
+                    d[k] *= prof_steps
+                d['ms'] = med * prof_steps
+            prof.summary = lambda: fams
     losses = {k: float(v.detach().float().mean()) for k, v in trainer.get_latest_losses().items()}
     if not all(np.isfinite(list(losses.values()))):
         raise SystemExit('non-finite losses: %s' % losses)
