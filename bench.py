@@ -412,18 +412,18 @@ def main():
         # keeps the "two profiled steps" form below): an eager step now and then contains one launch that sits 30-60 ms behind a
         # runtime stall (seen twice in round 6: a family at ten times its time), which a mean over two steps hands to the roofline
         prof_steps = 2
-        per_step = []
+        fam_steps = []
         for _ in range(4):
             prof.reset()
             step()
             torch.cuda.synchronize()
             if rank == 0:
-                per_step.append(prof.summary())
+                fam_steps.append(prof.summary())
         ops.LaunchProfiler.install(None)
-        if per_step:
-            fams = per_step[0]
+        if fam_steps:
+            fams = fam_steps[0]
             for fam, d in fams.items():
-                ms = sorted(ps[fam]['ms'] for ps in per_step if fam in ps)
+                ms = sorted(ps[fam]['ms'] for ps in fam_steps if fam in ps)
                 med = 0.5 * (ms[(len(ms) - 1) // 2] + ms[len(ms) // 2])
                 for k in ('launches', 'flops', 'executed_flops', 'bytes'):
                     d[k] *= prof_steps
