@@ -1,5 +1,6 @@
 // Label-map and resampling kernels (all HBM-bound, NHWC, 16-byte channel groups per thread).
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ label conv3x3
 // conv3x3(one_hot(nearest_down(label))) == sum over the 9 taps of one table row selected by the
@@ -9,33 +10,53 @@
 template <typename T>
 __device__ __forceinline__ void label_conv3x3_body(const uint8_t* __restrict__ label, const float* __restrict__ weight,
         const float* __restrict__ bias, T* __restrict__ out, int N, int H, int W, int h, int w, int ncls, int Cout, int relu,
-        int bx, int nbx, int by, float* tab) {
+        int bx, int nbx, int by, float* tab, int fast_min = 65536) {
     constexpr int VEC = Vec<T>::N;
-    constexpr int CT = 128;                               // channels per block
+    constexpr int CT = 128, CTP = CT + 4;                 // channels per block; LDS row pitch in floats (see the table fill)
     const int cbase = by * CT;
     const int cw = min(CT, Cout - cbase);
     const int rows = 9 * ncls;
-    // gather table straight from the OIHW conv weight: tab[(tap*ncls + cls)][cc] = weight[cbase+cc][cls][tap]
-    // (lanes walk the channel: LDS writes are conflict-free; walking the source-contiguous index instead puts all 64
-    // lanes of a write on one bank and made this preamble, not the pixel loop, the cost of the small launches)
-    for (int i = threadIdx.x; i < rows * CT; i += blockDim.x) {
-        const int r = i / CT, cc = i - r * CT;            // r = cls*9 + tap in the OIHW weight
+    // the table straight from the OIHW conv weight: tab[(tap*ncls + cls)][cc] = weight[cbase+cc][cls][tap].  Lanes walk the SOURCE (the
+    // block's [cw][rows] slice is one contiguous run: coalesced 4-byte loads); the rows of the LDS table are CTP = CT + 4 floats apart, so
+    // consecutive lanes (r, r + 1, ...: 132 floats further each) spread over eight banks -- with a pitch of CT they all met on one, which
+    // is why rounds 1-5 walked the channel instead and paid for it with one cache line per lane: that preamble, not the pixel loop, was the
+    // cost of the batched launch (155 us at up to 1024 blocks a layer; fewer blocks for the small layers alone: 124 us)
+    for (int i = threadIdx.x; i < cw * rows; i += blockDim.x) {
+        const int cc = i / rows, r = i - cc * rows;       // r = cls*9 + tap in the OIHW weight
         const int cls = r / 9, tap = r - cls * 9;
-        tab[(tap * ncls + cls) * CT + cc] = cc < cw ? weight[(size_t)(cbase + cc) * rows + r] : 0.f;
+        tab[(tap * ncls + cls) * CTP + cc] = weight[(size_t)cbase * rows + i];
     }
-    for (int i = threadIdx.x; i < CT; i += blockDim.x) tab[rows * CT + i] = (bias && i < cw) ? bias[cbase + i] : 0.f;
+    if (cw < CT)
+        for (int i = threadIdx.x; i < rows * (CT - cw); i += blockDim.x) {
+            const int r = i / (CT - cw), cc = cw + i - r * (CT - cw);
+            tab[r * CTP + cc] = 0.f;
+        }
+    for (int i = threadIdx.x; i < CT; i += blockDim.x) tab[rows * CTP + i] = (bias && i < cw) ? bias[cbase + i] : 0.f;
     __syncthreads();
     // Label maps are piecewise constant: for an interior pixel whose 3x3 neighbourhood is ONE class the sum is a
     // per-class constant.  uni[cls][cc] = bias + sum_tap tab[tap][cls] (same order as the general path below, so
     // both paths give the same bits); such pixels cost one LDS vector read instead of nine.
-    float* uni = tab + (rows + 1) * CT;                   // [ncls][CT]
+    float* uni = tab + (rows + 1) * CTP;                  // [ncls][CT]
     for (int i = threadIdx.x; i < ncls * CT; i += blockDim.x) {
         const int cl = i / CT, cc = i - cl * CT;
-        float a = tab[rows * CT + cc];
-        for (int t = 0; t < 9; ++t) a += tab[(t * ncls + cl) * CT + cc];
+        float a = tab[rows * CTP + cc];
+        for (int t = 0; t < 9; ++t) a += tab[(t * ncls + cl) * CTP + cc];
         uni[i] = a;
     }
     __syncthreads();
+    // ... and for bf16 outputs that constant AS IT IS STORED (ReLU applied, rounded): nine pixels in ten of a label map are
+    // interior to a class, and the general path below spends ~70 instructions per 16-byte vector on them (two LDS reads, eight
+    // max, the conversions, the address).  With the stored form the uniform path is one 16-byte LDS read and one store (150 -> 148 us a
+    // launch: the launch was not bound there -- ablations: 125 us without its stores, 133 without its label loads; what paid was fewer
+    // blocks for the small layers, label_conv_blocks).
+    uint16_t* unib = (uint16_t*)(uni + ncls * CT);         // [ncls][CT] bf16 bits
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        for (int i = threadIdx.x; i < ncls * CT; i += blockDim.x) {
+            const float a = relu ? fmaxf(uni[i], 0.f) : uni[i];
+            unib[i] = (uint16_t)f32_to_bf16_bits(a);
+        }
+        __syncthreads();
+    }
 
     const int cgb = (cw + VEC - 1) / VEC;                 // lanes per pixel
     const int sy = H / h, sx = W / w;
@@ -60,6 +81,12 @@ __device__ __forceinline__ void label_conv3x3_body(const uint8_t* __restrict__ l
     };
     // emit one pixel's 16-byte channel group given its word
     auto emit = [&](unsigned word, int pix, int tx) __attribute__((always_inline)) {
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            if ((word & (1u << 27)) && (Cout % VEC) == 0) {
+                *(u32x4_t*)(out + (size_t)pix * Cout + cbase + tx * VEC) = *(const u32x4_t*)(unib + (word & 7u) * CT + tx * VEC);
+                return;
+            }
+        }
         float acc[VEC];
         if (word & (1u << 27)) {
             const float* u = uni + (word & 7u) * CT + tx * VEC;
@@ -67,12 +94,12 @@ __device__ __forceinline__ void label_conv3x3_body(const uint8_t* __restrict__ l
             for (int j = 0; j < VEC; ++j) acc[j] = u[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) acc[j] = tab[rows * CT + tx * VEC + j];
+            for (int j = 0; j < VEC; ++j) acc[j] = tab[rows * CTP + tx * VEC + j];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const unsigned c = (word >> (3 * t)) & 7u;
                 if (c != 7u) {
-                    const float* trow = tab + (t * ncls + c) * CT + tx * VEC;
+                    const float* trow = tab + (t * ncls + c) * CTP + tx * VEC;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) acc[j] += trow[j];
                 }
@@ -87,12 +114,14 @@ __device__ __forceinline__ void label_conv3x3_body(const uint8_t* __restrict__ l
         else for (int j = 0; j < VEC && cbase + tx * VEC + j < Cout; ++j) store1<T>(o + j, acc[j]);
     };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((64 % cgb) == 0 && npix >= 65536) {               // (small maps: too few 256-pixel blocks to fill the chip)
+    if ((64 % cgb) == 0 && npix >= fast_min) {            // (small maps of a launch of their own: too few 256-pixel blocks to fill the chip)
         // A wave owns 64 consecutive pixels per pass: every lane fetches the word of ITS pixel (nine byte loads, no
         // redundancy across the pixel's lanes), then the wave emits the 64 pixels in cgb sub-steps of 64/cgb pixels,
         // each lane pulling the word it needs with one shuffle.  The coordinate arithmetic and the label loads are
         // thus paid once per 64 pixels instead of once per 64/cgb: the loop was VALU-issue-bound (~150 wave
         // instructions per KB stored), not HBM-bound.
+        // (tried: the one-in-ten pixels of the nine-tap path queued per wave and emitted densely behind the uniform ones, so that they do not
+        //  drag the other pixels of their sub-step along: 119 -> 121 us per launch, not kept)
         const int ppw = 64 / cgb;
         const int tx = lane % cgb, sub = lane / cgb;
         for (int base = (bx * 4 + wave) * 64; base < npix; base += nbx * 256) {
@@ -119,6 +148,7 @@ __global__ __launch_bounds__(256) void label_conv3x3_kernel(const uint8_t* __res
     label_conv3x3_body<T>(label, weight, bias, out, N, H, W, h, w, ncls, Cout, relu, blockIdx.x, gridDim.x, blockIdx.y, tab);
 }
 
+constexpr int LABEL_FAST_MIN_BATCH = 2048;             // (see label_conv_blocks)
 // all label convs of a generator forward in ONE launch (19 mlp_shared convs, most of them a few microseconds of work behind a
 // ~5-us launch): block_map[b] = {job, bx, nbx}; outputs at out_base + job.out_off (one buffer per forward)
 template <typename T>
@@ -127,17 +157,20 @@ __global__ __launch_bounds__(256) void label_conv3x3_batch_kernel(const uint8_t*
     extern __shared__ __attribute__((aligned(16))) float tab[];
     const int* bm = block_map + 3 * blockIdx.x;
     const s2e_label_conv_job J = jobs[bm[0]];
-    label_conv3x3_body<T>(label, J.weight, J.bias, (T*)(out_base + J.out_off), N, H, W, J.h, J.w, ncls, J.cout, J.relu, bm[1], bm[2], 0, tab);
+    label_conv3x3_body<T>(label, J.weight, J.bias, (T*)(out_base + J.out_off), N, H, W, J.h, J.w, ncls, J.cout, J.relu, bm[1], bm[2], 0, tab, LABEL_FAST_MIN_BATCH);
 }
 
 // blocks along the pixels of one layer (the single launch's grid.x)
-static long label_conv_blocks(int dtype, long npix, int Cout) {
+// fast_min: the wave-per-64-pixels path from this many pixels on -- 65536 for a layer launched alone (fewer 256-pixel blocks would not
+// fill the chip), 2048 inside the batched launch, where the other layers' blocks do: a 64^2 x 8 layer then has 128 blocks instead of 1024,
+// each of which builds the layer's 18-KB table first
+static long label_conv_blocks(int dtype, long npix, int Cout, int fast_min = 65536) {
     const int vec = dtype == S2E_BF16 ? 8 : 4;
     const int cw = Cout < 128 ? Cout : 128;
     const int cgb_h = (cw + vec - 1) / vec;
-    const int ppb = ((64 % cgb_h) == 0 && npix >= 65536) ? 256 : 256 / cgb_h;       // pixels per block per pass
+    const int ppb = ((64 % cgb_h) == 0 && npix >= fast_min) ? 256 : 256 / cgb_h;       // pixels per block per pass
     const long gx = (npix + ppb - 1) / ppb;
-    const long cap = 1024;                           // (the optimum of 256 ... 2048, measured)
+    static const long cap = [] { const char* e = getenv("S2E_LABEL_CONV_CAP"); return e ? atol(e) : 1024L; }();   // (the optimum of 256 ... 2048, measured)
     return gx > cap ? cap : gx;
 }
 
@@ -151,7 +184,7 @@ extern "C" int s2e_label_conv3x3(int dtype, const uint8_t* label, const float* w
     if (npix >= (1L << 31)) S2E_FAIL(S2E_ERR_UNSUPPORTED, "s2e_label_conv3x3: too many pixels for 32-bit indices");
     const long gx = label_conv_blocks(dtype, npix, Cout);
     dim3 grid((unsigned)gx, ceil_div(Cout, 128));
-    const size_t lds = (size_t)(9 * ncls + 1 + ncls) * 128 * sizeof(float);
+    const size_t lds = ((size_t)(9 * ncls + 1) * 132 + (size_t)ncls * 128) * sizeof(float) + (size_t)ncls * 128 * 2;     // table rows at a pitch of 132 floats, uniform rows, the same as stored bf16
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16) label_conv3x3_kernel<bf16_t><<<grid, 256, lds, st>>>(label, weight, bias, (bf16_t*)out, N, H, W, h, w, ncls, Cout, relu);
     else label_conv3x3_kernel<float><<<grid, 256, lds, st>>>(label, weight, bias, (float*)out, N, H, W, h, w, ncls, Cout, relu);
@@ -167,7 +200,7 @@ extern "C" long s2e_label_conv_block_map(int dtype, const s2e_label_conv_job* jo
     for (int j = 0; j < n_jobs; ++j) {
         const s2e_label_conv_job& J = jobs_host[j];
         if (J.cout <= 0 || J.cout > 128 || J.h <= 0 || J.w <= 0) return S2E_ERR_ARG;
-        const long gx = label_conv_blocks(dtype, (long)N * J.h * J.w, J.cout);
+        const long gx = label_conv_blocks(dtype, (long)N * J.h * J.w, J.cout, LABEL_FAST_MIN_BATCH);
         for (long b = 0; b < gx; ++b, ++nb)
             if (block_map_host) { int* e = block_map_host + 3 * nb; e[0] = j; e[1] = (int)b; e[2] = (int)gx; }
     }
@@ -178,7 +211,7 @@ extern "C" int s2e_label_conv3x3_batch(int dtype, const uint8_t* label, const s2
     if (!label || !jobs || !block_map || !out_base || n_blocks <= 0 || N <= 0 || ncls <= 0 || ncls > 7)
         S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3_batch: bad argument");
     if (dtype != S2E_BF16 && dtype != S2E_F32) S2E_FAIL(S2E_ERR_ARG, "s2e_label_conv3x3_batch: bad dtype %d", dtype);
-    const size_t lds = (size_t)(9 * ncls + 1 + ncls) * 128 * sizeof(float);
+    const size_t lds = ((size_t)(9 * ncls + 1) * 132 + (size_t)ncls * 128) * sizeof(float) + (size_t)ncls * 128 * 2;     // table rows at a pitch of 132 floats, uniform rows, the same as stored bf16
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2E_BF16) label_conv3x3_batch_kernel<bf16_t><<<n_blocks, 256, lds, st>>>(label, jobs, block_map, (char*)out_base, N, H, W, ncls);
     else label_conv3x3_batch_kernel<float><<<n_blocks, 256, lds, st>>>(label, jobs, block_map, (char*)out_base, N, H, W, ncls);
