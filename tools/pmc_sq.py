@@ -16,7 +16,7 @@ import os
 import sys
 from collections import defaultdict
 
-WANT = ('conv_plane_kernel', 'conv_wgrad_multi_kernel', 'conv_duo_kernel', 'conv_patch_kernel', 'conv_wgrad_batch_kernel', 'conv_wgrad_patch_kernel', 'conv_igemm_kernel', 'conv_stream_kernel', 'conv_wgrad_kernel', 'conv_wgrad_stream_kernel', 'conv_wgrad_flat_kernel', 'conv_c8s2_fwd_kernel', 'conv_c8s2_dgrad_kernel', 'conv_c8s2_wgrad_kernel')
+WANT = ('conv_plane_kernel', 'conv_wgrad_multi_kernel', 'conv_duo_kernel', 'conv_patch_kernel', 'conv_wgrad_batch_kernel', 'conv_wgrad_patch_kernel', 'conv_igemm_kernel', 'conv_stream_kernel', 'conv_wgrad_kernel', 'conv_wgrad_stream_kernel', 'conv_wgrad_flat_kernel', 'conv_c8s2_fwd_kernel', 'conv_c8s2_dgrad_kernel', 'conv_c8s2_wgrad_kernel', 'label_conv3x3_batch_kernel', 'spade_modulate_uniform_kernel', 'modulate_bwd_reduce_kernel', 'in_small_bwd_kernel')
 
 
 def main():
